@@ -1,0 +1,222 @@
+// TEST INFRASTRUCTURE ONLY — C API over the CPU oracle (oracle/taylor_oracle.hpp) so that
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive it via ctypes.
+// The entry points deliberately mirror include/gftaylor.h name-for-name (prefix `orc_` for
+// f64, `orci_` for Interval<f64>) so one Python wrapper class serves both libraries.
+//
+// Scalars cross the boundary as `const double*` pointing at WIDTH doubles (1 for f64,
+// {lo,hi} for intervals); coefficient data is plane-major: WIDTH planes of numel doubles.
+#include <chrono>
+#include <cstdio>
+#include <string>
+
+#include "taylor_oracle.hpp"
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+template <class S> struct Tr;
+template <> struct Tr<F64> {
+    static constexpr int W = 1;
+    static F64 load(const double* p) { return F64(p[0]); }
+    static void store(F64 s, double* p) { p[0] = s.v; }
+    static F64 load_plane(const double* d, usize n, usize i) { (void)n; return F64(d[i]); }
+    static void store_plane(F64 s, double* d, usize n, usize i) { (void)n; d[i] = s.v; }
+};
+template <> struct Tr<Interval> {
+    static constexpr int W = 2;
+    static Interval load(const double* p) { return Interval(p[0], p[1]); }
+    static void store(Interval s, double* p) { p[0] = s.lo; p[1] = s.hi; }
+    static Interval load_plane(const double* d, usize n, usize i) { return Interval(d[i], d[n + i]); }
+    static void store_plane(Interval s, double* d, usize n, usize i) { d[i] = s.lo; d[n + i] = s.hi; }
+};
+
+template <class S> using P = TaylorPoly<S>;
+
+static std::vector<usize> vec(const size_t* p, size_t n) { return std::vector<usize>(p, p + n); }
+
+#define ORC_TRY(expr)                         \
+    try {                                     \
+        return (expr);                        \
+    } catch (const std::exception& e) {       \
+        g_err = e.what();                     \
+        return 0;                             \
+    }
+
+template <class S>
+static P<S>* from_host(const double* data, const size_t* shape, const size_t* degs, size_t ndim) {
+    Arr<S> a;
+    a.shape = vec(shape, ndim);
+    usize n = numel(a.shape);
+    a.data.resize(n);
+    for (usize i = 0; i < n; ++i) a.data[i] = Tr<S>::load_plane(data, n, i);
+    return new P<S>(std::move(a), vec(degs, ndim));
+}
+
+#define DEFINE_API(PFX, S)                                                                                 \
+    extern "C" {                                                                                           \
+    const char* PFX##last_error() { return g_err.c_str(); }                                                \
+    int PFX##width() { return Tr<S>::W; }                                                                  \
+    void* PFX##from_host(const double* d, const size_t* sh, const size_t* dg, size_t nd) {                 \
+        ORC_TRY((void*)from_host<S>(d, sh, dg, nd))                                                        \
+    }                                                                                                      \
+    void* PFX##scalar(const double* s) { ORC_TRY((void*)new P<S>(P<S>::from_scalar(Tr<S>::load(s)))) }     \
+    void* PFX##from_u32(uint32_t c) { ORC_TRY((void*)new P<S>(P<S>::from_u32_with(c, {}))) }               \
+    void* PFX##zero_with(const size_t* dg, size_t nd) { ORC_TRY((void*)new P<S>(P<S>::zero_with(vec(dg, nd)))) } \
+    void* PFX##var(size_t v, const double* x, size_t len) {                                                \
+        ORC_TRY((void*)new P<S>(P<S>::var(v, Tr<S>::load(x), len)))                                        \
+    }                                                                                                      \
+    void* PFX##var_at_zero(size_t v, size_t len) { ORC_TRY((void*)new P<S>(P<S>::var_at_zero(v, len))) }   \
+    void* PFX##var_with_degrees_p1(size_t v, const double* x, const size_t* dg, size_t nd) {               \
+        ORC_TRY((void*)new P<S>(P<S>::var_with_degrees_p1(v, Tr<S>::load(x), vec(dg, nd))))                \
+    }                                                                                                      \
+    void* PFX##clone(const void* p) { ORC_TRY((void*)new P<S>(*(const P<S>*)p)) }                          \
+    void PFX##free(void* p) { delete (P<S>*)p; }                                                           \
+    size_t PFX##num_vars(const void* p) { return ((const P<S>*)p)->num_vars(); }                           \
+    size_t PFX##numel(const void* p) { return ((const P<S>*)p)->coeffs.len(); }                            \
+    void PFX##shape(const void* p, size_t* out) {                                                          \
+        const auto& s = ((const P<S>*)p)->coeffs.shape;                                                    \
+        for (usize i = 0; i < s.size(); ++i) out[i] = s[i];                                                \
+    }                                                                                                      \
+    void PFX##degrees_p1(const void* p, size_t* out) {                                                     \
+        const auto& s = ((const P<S>*)p)->degrees_p1;                                                      \
+        for (usize i = 0; i < s.size(); ++i) out[i] = s[i];                                                \
+    }                                                                                                      \
+    int PFX##to_host(const void* p, double* out) {                                                         \
+        const auto& d = ((const P<S>*)p)->coeffs.data;                                                     \
+        for (usize i = 0; i < d.size(); ++i) Tr<S>::store_plane(d[i], out, d.size(), i);                   \
+        return 0;                                                                                          \
+    }                                                                                                      \
+    size_t PFX##len_of(const void* p, size_t v) { return ((const P<S>*)p)->len_of(v); }                    \
+    int PFX##is_constant(const void* p) { return ((const P<S>*)p)->is_constant(); }                        \
+    int PFX##is_zero(const void* p) { return ((const P<S>*)p)->is_zero(); }                                \
+    int PFX##is_one(const void* p) { return ((const P<S>*)p)->is_one(); }                                  \
+    int PFX##equal(const void* a, const void* b) { return *(const P<S>*)a == *(const P<S>*)b; }            \
+    int PFX##constant_term(const void* p, double* out) {                                                   \
+        Tr<S>::store(((const P<S>*)p)->constant_term(), out);                                              \
+        return 0;                                                                                          \
+    }                                                                                                      \
+    int PFX##extract_constant(const void* p, double* out) {                                                \
+        S c;                                                                                               \
+        if (!((const P<S>*)p)->extract_constant(c)) return 0;                                              \
+        Tr<S>::store(c, out);                                                                              \
+        return 1;                                                                                          \
+    }                                                                                                      \
+    int PFX##extract_linear(const void* p, double* c_out, double* m_out, size_t* v_out) {                  \
+        S c, m;                                                                                            \
+        usize v;                                                                                           \
+        if (!((const P<S>*)p)->extract_linear(c, m, v)) return 0;                                          \
+        Tr<S>::store(c, c_out);                                                                            \
+        Tr<S>::store(m, m_out);                                                                            \
+        *v_out = v;                                                                                        \
+        return 1;                                                                                          \
+    }                                                                                                      \
+    int PFX##coefficient(const void* p, const size_t* idx, size_t n, double* out) {                        \
+        try {                                                                                              \
+            Tr<S>::store(((const P<S>*)p)->coefficient(vec(idx, n)), out);                                 \
+            return 0;                                                                                      \
+        } catch (const std::exception& e) {                                                                \
+            g_err = e.what();                                                                              \
+            return -1;                                                                                     \
+        }                                                                                                  \
+    }                                                                                                      \
+    void* PFX##add(const void* a, const void* b) { ORC_TRY((void*)new P<S>(P<S>::add(*(const P<S>*)a, *(const P<S>*)b))) } \
+    void* PFX##sub(const void* a, const void* b) { ORC_TRY((void*)new P<S>(P<S>::sub(*(const P<S>*)a, *(const P<S>*)b))) } \
+    void* PFX##mul(const void* a, const void* b) { ORC_TRY((void*)new P<S>(P<S>::mul(*(const P<S>*)a, *(const P<S>*)b))) } \
+    void* PFX##div(const void* a, const void* b) { ORC_TRY((void*)new P<S>(P<S>::div(*(const P<S>*)a, *(const P<S>*)b))) } \
+    void* PFX##neg(const void* a) { ORC_TRY((void*)new P<S>(P<S>::neg(*(const P<S>*)a))) }                \
+    void* PFX##exp(const void* a) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->exp())) }                    \
+    void* PFX##log(const void* a) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->log())) }                    \
+    void* PFX##pow(const void* a, uint32_t e) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->pow(e))) }       \
+    void* PFX##derivative(const void* a, size_t v, size_t n) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->derivative(v, n))) } \
+    void* PFX##taylor_expansion_of_coeff(const void* a, size_t v, size_t n) {                              \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->taylor_expansion_of_coeff(v, n)))                        \
+    }                                                                                                      \
+    void* PFX##shift_down(const void* a, size_t v, size_t n) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->shift_down(v, n))) } \
+    void* PFX##subst_var(const void* a, size_t v, const void* s) {                                         \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->subst_var(v, *(const P<S>*)s)))                          \
+    }                                                                                                      \
+    void* PFX##coefficients_of_term(const void* a, size_t v, size_t o) {                                   \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->coefficients_of_term(v, o)))                             \
+    }                                                                                                      \
+    void* PFX##taylor_polynomial_terms(const void* a, size_t v, const size_t* orders, size_t n) {          \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->taylor_polynomial_terms(v, vec(orders, n))))             \
+    }                                                                                                      \
+    void* PFX##truncate_to_degree_p1(const void* a, size_t d) {                                            \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->truncate_to_degree_p1(d)))                               \
+    }                                                                                                      \
+    void* PFX##remove_last_variable(const void* a) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->remove_last_variable())) } \
+    void* PFX##extend_to_dim(const void* a, size_t nd, size_t d) {                                         \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->extend_to_dim(nd, d)))                                   \
+    }                                                                                                      \
+    void* PFX##extend(const void* a, const size_t* ns, size_t n) {                                         \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->extend(vec(ns, n))))                                     \
+    }                                                                                                      \
+    void* PFX##mul_var(const void* a, const double* m, size_t v, const size_t* sh, const size_t* dg, size_t n) { \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->mul_var(Tr<S>::load(m), v, vec(sh, n), vec(dg, n))))     \
+    }                                                                                                      \
+    void* PFX##mul_linear(const void* a, const double* c, const double* m, size_t v, const size_t* sh,     \
+                          const size_t* dg, size_t n) {                                                    \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->mul_linear(Tr<S>::load(c), Tr<S>::load(m), v, vec(sh, n), vec(dg, n)))) \
+    }                                                                                                      \
+    }
+
+DEFINE_API(orc_, F64)
+DEFINE_API(orci_, Interval)
+
+// ---------------------------------------------------------------------------------------
+// Raw array entry points (no handles): the reference's general product `mul`
+// (mt:984-1012) on caller-owned row-major buffers, and a timed variant used ONLY as
+// bench.py's `cpu_baseline` leg.
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+// res[k] += sum_j xs[j]*ys[k-j], identical loop nest / summation order to mt:971-1012.
+int orc_mul_raw(const double* xs, const size_t* xshape, const double* ys, const size_t* yshape, double* res,
+                const size_t* rshape, size_t ndim) {
+    try {
+        static_assert(sizeof(F64) == sizeof(double), "F64 must be layout-compatible with double");
+        View<const F64> xv{reinterpret_cast<const F64*>(xs), vec(xshape, ndim), c_strides(vec(xshape, ndim))};
+        View<const F64> yv{reinterpret_cast<const F64*>(ys), vec(yshape, ndim), c_strides(vec(yshape, ndim))};
+        View<F64> rv{reinterpret_cast<F64*>(res), vec(rshape, ndim), c_strides(vec(rshape, ndim))};
+        mul_rec<F64>(xv, yv, rv);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Same product restricted to the leading-axis output slabs [k_lo, k_hi) (each slab is
+// independent, mt:1001-1011), timed with a steady clock.  Returns seconds; writes the number of
+// multiply-accumulates performed to *macs.  `res` must hold the full result shape.
+double orc_mul_slabs_timed(const double* xs, const size_t* xshape, const double* ys, const size_t* yshape, double* res,
+                           const size_t* rshape, size_t ndim, size_t k_lo, size_t k_hi, double* macs) {
+    View<const F64> xv{reinterpret_cast<const F64*>(xs), vec(xshape, ndim), c_strides(vec(xshape, ndim))};
+    View<const F64> yv{reinterpret_cast<const F64*>(ys), vec(yshape, ndim), c_strides(vec(yshape, ndim))};
+    View<F64> rv{reinterpret_cast<F64*>(res), vec(rshape, ndim), c_strides(vec(rshape, ndim))};
+    // MAC count of slab k: prod over axes of #valid j.
+    auto pairs_1d = [](usize sx, usize sy, usize k) -> double {
+        usize lo = sat_sub(k + 1, sy), hi = std::min(k + 1, sx);
+        return hi > lo ? (double)(hi - lo) : 0.0;
+    };
+    double inner = 1.0;
+    for (usize a = 1; a < ndim; ++a) {
+        double s = 0.0;
+        for (usize k = 0; k < rshape[a]; ++k) s += pairs_1d(xshape[a], yshape[a], k);
+        inner *= s;
+    }
+    double total = 0.0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (usize k = k_lo; k < k_hi && k < rshape[0]; ++k) {
+        View<F64> z = rv.index0(k);
+        usize lo = sat_sub(k + 1, yv.len_of(0));
+        usize hi = std::min(k + 1, xv.len_of(0));
+        for (usize j = lo; j < hi; ++j) mul_rec<F64>(xv.index0(j), yv.index0(k - j), z);
+        total += pairs_1d(xshape[0], yshape[0], k) * inner;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    *macs = total;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+}
