@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: TaylorPoly mul f64 (dense truncated N-d
+polynomial product, src/multivariate_taylor.rs:971-1072) in GMAC/s on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|small]
+
+A "step" is one full product z = x (*) y of the workload with x, y already resident in HBM
+(synthetic splitmix64 inputs).  N > 1: one process per GPU (torchrun / RANK env);
+the product's leading output axis is sharded with the folded slab assignment
+(gft_plan_slabs), operands replicated, result slabs exchanged with RCCL all-gather inside the
+timed region => "strong" scaling of one product.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the product kernel
+against the gfx950 FP64 FMA peak — the product is compute-bound, SURVEY §8d — with the
+algorithmic-HBM figure beside it) and `cpu_baseline` (the oracle = scalar restatement of the
+reference loop nest, timed on this box's host cores on a bounded sample; N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X vendor FP64 peak, vector == matrix (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (shape, description)  — c2 is BASELINE.json configs[1], the config the metric is quoted on
+    "c2": ([128, 128, 128], "synthetic 3-var TaylorPoly mul, order 128 each (128^3 f64 coeffs)"),
+    "c4": ([64, 64, 64, 64], "4-var order-64 mul (64^4 coeffs)"),
+    "small": ([32, 32, 32], "3-var order-32 mul (debug size)"),
+}
+
+
+def splitmix64_uniform(seed, n):
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def cpu_baseline(shape, x, y, budget_hint_s=20.0):
+    """Time the oracle (oracle/liborc.so: same loop nest / summation order as mt:971-1012, one
+    thread, -O2 -ffp-contract=off) on a bounded sample of the SAME product: a few leading-axis
+    output slabs, chosen so that the sample is ~10-30 s of CPU work."""
+    import subprocess
+
+    so = os.path.join(ROOT, "oracle", "liborc.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    lib.orc_mul_slabs_timed.restype = ctypes.c_double
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    lib.orc_mul_slabs_timed.argtypes = [ctypes.c_void_p, szp, ctypes.c_void_p, szp, ctypes.c_void_p, szp,
+                                        ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_double)]
+    nd = len(shape)
+    sz = (ctypes.c_size_t * nd)(*shape)
+    res = np.zeros(shape)
+    macs = ctypes.c_double(0.0)
+    n0 = shape[0]
+    # calibrate on the cheapest slab, then pick slabs {mid, top} if they fit the budget
+    t = lib.orc_mul_slabs_timed(x.ctypes.data_as(ctypes.c_void_p), sz, y.ctypes.data_as(ctypes.c_void_p), sz,
+                                res.ctypes.data_as(ctypes.c_void_p), sz, nd, 0, 1, ctypes.byref(macs))
+    rate = macs.value / max(t, 1e-9)
+    per_slab_unit = macs.value  # MACs of slab 0; slab k costs (k+1)x
+    slabs = []
+    spent = 0.0
+    for k in (n0 - 1, n0 // 2 - 1, n0 // 4 - 1):
+        if k < 0:
+            continue
+        cost = per_slab_unit * (k + 1) / rate
+        if spent + cost <= budget_hint_s or not slabs:
+            slabs.append(k)
+            spent += cost
+    total_macs, total_t = 0.0, 0.0
+    for k in slabs:
+        res[k] = 0.0
+        t = lib.orc_mul_slabs_timed(x.ctypes.data_as(ctypes.c_void_p), sz, y.ctypes.data_as(ctypes.c_void_p), sz,
+                                    res.ctypes.data_as(ctypes.c_void_p), sz, nd, k, k + 1, ctypes.byref(macs))
+        total_macs += macs.value
+        total_t += t
+    return {
+        "value": total_macs / total_t / 1e9,
+        "unit": "GMAC/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"leading-axis output slabs k0 in {sorted(slabs)} of the same product "
+                  f"({total_macs:.3e} of {per_slab_unit * n0 * (n0 + 1) / 2:.3e} MACs, {total_t:.1f} s, "
+                  f"host has {os.cpu_count()} cores; reference is single-threaded, src/main.rs:101-105)",
+    }, res, slabs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-mode", type=int, default=0, help="0 auto, 1 reference-order kernel, 2 tiled kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import genfer_amd
+
+    genfer_amd.init(local_rank)
+    L = genfer_amd.lib()
+    L.gft_set_conv_mode(args.conv_mode)
+    # all kernels go to torch's current stream so that collectives and kernels are ordered together
+    stream = torch.cuda.current_stream()
+    L.gft_set_stream(ctypes.c_void_p(stream.cuda_stream))
+
+    shape, desc = WORKLOADS[args.workload]
+    n = int(np.prod(shape))
+    xh = splitmix64_uniform(1 if args.workload != "c4" else 3, n).reshape(shape)
+    yh = splitmix64_uniform(2 if args.workload != "c4" else 4, n).reshape(shape)
+    x = torch.from_numpy(xh).cuda()
+    y = torch.from_numpy(yh).cuda()
+    z = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    total_macs = genfer_amd.conv_macs(shape, shape, shape)
+    alg_bytes = 3 * n * 8  # read x, read y, write z once
+
+    (lo0, hi0), (lo1, hi1), even = genfer_amd.plan_slabs(shape[0], world, rank)
+    groups = [(lo0, hi0), (lo1, hi1)]
+    local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in groups if b > a)
+    plans = [genfer_amd.plan_slabs(shape[0], world, r) for r in range(world)]
+
+    kern_ms = []
+
+    def step(timed):
+        if world > 1 and not even:
+            z.zero_()
+        if timed:
+            L.gft_event_record(0)
+        for a, b in groups:
+            if b > a:
+                genfer_amd.conv_raw(x.data_ptr(), shape, y.data_ptr(), shape, z.data_ptr(), shape, a, b)
+        if timed:
+            L.gft_event_record(1)
+        if world > 1:
+            if even:
+                for g in (0, 1):
+                    outs = [z[plans[r][g][0]:plans[r][g][1]] for r in range(world)]
+                    dist.all_gather(outs, z[groups[g][0]:groups[g][1]])
+            else:
+                dist.all_reduce(z)  # every rank wrote only its own slabs into a zeroed tensor
+        if timed:
+            kern_ms.append(L.gft_event_elapsed_ms(0, 1))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_macs * args.steps / elapsed / 1e9
+    k_ms = float(np.mean(kern_ms))
+    achieved_tflops = 2.0 * local_macs / (k_ms * 1e-3) / 1e12
+    out = {
+        "metric": "TaylorPoly mul f64 GMAC/s",
+        "value": value,
+        "unit": "GMAC/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (splitmix64 uniform [0,1), seeds 1/2, row-major; SURVEY §8d)",
+        "config": {
+            "workload": f"{args.workload}: {desc}; z = x (*) y truncated at degrees_p1 = shape",
+            "shape": shape,
+            "macs": total_macs,
+            "parallelism": "single GPU" if world == 1 else f"leading output axis folded-sharded over {world} GPUs, "
+                           f"operands replicated, RCCL {'all-gather' if even else 'all-reduce'} of result slabs",
+        },
+        "roofline": {
+            "bound": "mfma",
+            "achieved": achieved_tflops,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved_tflops / FP64_PEAK_TFLOPS,
+            "traffic": None,
+            "note": "FP64 FMA roof (vector == matrix FP64 peak on gfx950, 78.6 TFLOP/s); flops = 2*MACs of the "
+                    "slabs this rank computes / mean HIP-event duration of the product launch(es) on its stream",
+            "kernel_ms": k_ms,
+            "hbm_algorithmic": {
+                "achieved": alg_bytes * (local_macs / total_macs) / (k_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": alg_bytes * (local_macs / total_macs) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "bytes": alg_bytes,
+            },
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, ref_slabs, slabs = cpu_baseline(shape, xh, yh)
+        out["cpu_baseline"] = base
+        # the timed sample doubles as an end-of-run parity check of the full-size result
+        zh = z.cpu().numpy()
+        worst = 0.0
+        for k in slabs:
+            err = np.abs(zh[k] - ref_slabs[k]) / np.abs(ref_slabs[k])
+            worst = max(worst, float(err.max()))
+        out["parity_max_rel_err_vs_oracle_sample"] = worst
+        if worst > 1e-10:
+            out["parity_failed"] = True
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

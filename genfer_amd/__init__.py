@@ -1,0 +1,121 @@
+"""genfer_amd — MI355X-native multivariate-Taylor arithmetic core for Genfer.
+
+The package is a thin host-side mirror of the reference's ``TaylorPoly<F64>`` /
+``TaylorPoly<Interval<F64>>`` surface (src/multivariate_taylor.rs) over the C ABI of
+``include/gftaylor.h`` implemented by ``genfer_amd/csrc/libgftaylor.so`` (hand-written HIP
+kernels for gfx950).  There is no CPU fallback: importing the handle classes without the built
+library, or using them without a gfx950 device, fails loudly.
+
+    >>> from genfer_amd import TaylorPoly
+    >>> f = TaylorPoly.taylor([[1.0, 2.0], [3.0, 4.0]])
+    >>> (f * f).array()
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .taylor import USIZE_MAX, TaylorError, bind  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgftaylor.so")
+
+_lib = None
+_classes = {}
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded C-ABI library (raises if it has not been built: see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing — build it with `make -C genfer_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+        # libhsa-runtime64 and load them by path.  If libgftaylor pulled in /opt/rocm's copy first,
+        # a later `import torch` would bring up a second runtime that cannot open the GPU
+        # ("No HIP GPUs are available").  Importing torch first makes our DT_NEEDED resolve (by
+        # soname) to the copy torch already loaded.  torch is plumbing here (streams,
+        # torch.distributed), never a compute fallback; without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare_runtime(_lib)
+    return _lib
+
+
+def _declare_runtime(L):
+    c = ctypes
+    sz = c.POINTER(c.c_size_t)
+    dp = c.POINTER(c.c_double)
+    L.gft_init.restype, L.gft_init.argtypes = c.c_int, [c.c_int]
+    L.gft_shutdown.restype, L.gft_shutdown.argtypes = None, []
+    L.gft_set_stream.restype, L.gft_set_stream.argtypes = c.c_int, [c.c_void_p]
+    L.gft_get_stream.restype, L.gft_get_stream.argtypes = c.c_void_p, []
+    L.gft_synchronize.restype, L.gft_synchronize.argtypes = c.c_int, []
+    L.gft_last_error.restype, L.gft_last_error.argtypes = c.c_char_p, []
+    L.gft_pool_stats.restype, L.gft_pool_stats.argtypes = None, [sz]
+    L.gft_event_record.restype, L.gft_event_record.argtypes = c.c_int, [c.c_int]
+    L.gft_event_elapsed_ms.restype, L.gft_event_elapsed_ms.argtypes = c.c_float, [c.c_int, c.c_int]
+    L.gft_set_conv_mode.restype, L.gft_set_conv_mode.argtypes = c.c_int, [c.c_int]
+    L.gft_conv_raw.restype = c.c_int
+    L.gft_conv_raw.argtypes = [c.c_void_p, sz, c.c_void_p, sz, c.c_void_p, sz, c.c_size_t, c.c_size_t, c.c_size_t, c.c_int]
+    L.gft_conv_macs.restype = c.c_double
+    L.gft_conv_macs.argtypes = [sz, sz, sz, c.c_size_t, c.c_size_t, c.c_size_t]
+    L.gft_plan_slabs.restype = c.c_int
+    L.gft_plan_slabs.argtypes = [c.c_size_t, c.c_int, c.c_int, sz]
+
+
+def init(device: int = -1) -> None:
+    """Select the HIP device (default: LOCAL_RANK or 0) and create stream + memory pool."""
+    L = lib()
+    if L.gft_init(device) != 0:
+        raise TaylorError((L.gft_last_error() or b"gft_init failed").decode())
+
+
+def _cls(prefix: str):
+    if prefix not in _classes:
+        _classes[prefix] = bind(lib(), prefix)
+    return _classes[prefix]
+
+
+def __getattr__(name):  # lazy: `from genfer_amd import TaylorPoly` loads the library on first use
+    if name == "TaylorPoly":
+        return _cls("gft_")
+    if name == "IntervalTaylorPoly":
+        return _cls("gfti_")
+    raise AttributeError(name)
+
+
+def _sz(seq):
+    seq = [int(s) for s in seq]
+    return (ctypes.c_size_t * max(len(seq), 1))(*seq)
+
+
+def conv_raw(x_ptr: int, xshape, y_ptr: int, yshape, z_ptr: int, zshape, slab_lo=0, slab_hi=None, accumulate=False):
+    """``gft_conv_raw`` on caller-owned device buffers (e.g. ``torch.Tensor.data_ptr()``)."""
+    L = lib()
+    nd = len(zshape)
+    if slab_hi is None:
+        slab_hi = zshape[0] if nd else 1
+    rc = L.gft_conv_raw(x_ptr, _sz(xshape), y_ptr, _sz(yshape), z_ptr, _sz(zshape), nd, slab_lo, slab_hi, int(accumulate))
+    if rc != 0:
+        raise TaylorError((L.gft_last_error() or b"").decode())
+
+
+def conv_macs(xshape, yshape, zshape, slab_lo=0, slab_hi=None) -> float:
+    nd = len(zshape)
+    if slab_hi is None:
+        slab_hi = zshape[0] if nd else 1
+    return float(lib().gft_conv_macs(_sz(xshape), _sz(yshape), _sz(zshape), nd, slab_lo, slab_hi))
+
+
+def plan_slabs(n0: int, world: int, rank: int):
+    """Folded leading-axis slab assignment: ((lo0, hi0), (lo1, hi1), balanced_for_all_gather)."""
+    out = (ctypes.c_size_t * 4)()
+    even = lib().gft_plan_slabs(n0, world, rank, out)
+    return (int(out[0]), int(out[1])), (int(out[2]), int(out[3])), bool(even)

@@ -1,0 +1,1288 @@
+// Host side of libgftaylor: runtime (device, stream, memory pool), the TaylorPoly bookkeeping
+// of src/multivariate_taylor.rs (compact shapes, degrees_p1, broadcast, shortcut dispatch) and
+// the C ABI of include/gftaylor.h.  All VALUE arithmetic is done by the kernels in
+// gft_kernels.hip / gft_conv_tiled.hip; the host never computes a coefficient.  There is no CPU
+// fallback: without a usable gfx950 device every entry point fails with an error message.
+//
+// Citations `mt:<lines>` refer to /root/reference/src/multivariate_taylor.rs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gftaylor.h"
+#include "gft_kernels.hpp"
+
+using namespace gft;
+typedef std::vector<size_t> Dims;
+static const size_t UMAX = SIZE_MAX;
+
+// ------------------------------------------------------------------------------------------
+// runtime
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+thread_local std::string g_err;
+
+#define HIP_OK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            throw Error(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #call);           \
+    } while (0)
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // size-class pool: freed blocks are reused immediately — legal because every kernel, memset and
+    // copy of this library is ordered on the one stream.
+    std::multimap<size_t, void*> free_blocks;
+    size_t in_use = 0, cached = 0, peak = 0;
+    unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
+    double* h_pinned = nullptr;  // pinned staging for small D2H reads
+    hipEvent_t events[16] = {};
+    int conv_mode = 0;
+    void* conv_ws = nullptr;
+    size_t conv_ws_bytes = 0;
+};
+Runtime R;
+
+static size_t size_class(size_t bytes) {
+    if (bytes < 256) return 256;
+    if (bytes <= (1u << 20)) {  // next power of two up to 1 MiB
+        size_t c = 256;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    const size_t g = 2u << 20;  // 2 MiB granules above
+    return (bytes + g - 1) / g * g;
+}
+
+static void* pool_alloc(size_t bytes, size_t* cls_out) {
+    size_t cls = size_class(bytes);
+    *cls_out = cls;
+    auto it = R.free_blocks.find(cls);
+    void* p;
+    if (it != R.free_blocks.end()) {
+        p = it->second;
+        R.free_blocks.erase(it);
+        R.cached -= cls;
+    } else {
+        hipError_t e = hipMalloc(&p, cls);
+        if (e != hipSuccess) {  // release the cache and retry once
+            for (auto& kv : R.free_blocks) (void)hipFree(kv.second);
+            R.free_blocks.clear();
+            R.cached = 0;
+            HIP_OK(hipMalloc(&p, cls));
+        }
+    }
+    R.in_use += cls;
+    R.peak = std::max(R.peak, R.in_use);
+    return p;
+}
+
+static void pool_free(void* p, size_t cls) {
+    R.in_use -= cls;
+    R.cached += cls;
+    R.free_blocks.emplace(cls, p);
+}
+
+struct Buf {
+    double* p = nullptr;
+    size_t cls = 0;
+    bool borrowed = false;
+    ~Buf() {
+        if (p && !borrowed && R.ready) pool_free(p, cls);
+    }
+};
+
+static std::shared_ptr<Buf> alloc_doubles(size_t n) {
+    auto b = std::make_shared<Buf>();
+    b->p = (double*)pool_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
+    return b;
+}
+
+static void require_ready() {
+    if (!R.ready) {
+        if (gft_init(-1) != 0) throw Error("gftaylor: no usable HIP device (" + g_err + "); there is no CPU fallback");
+    }
+}
+
+static void read_back(void* dst, const void* dev_src, size_t bytes) {
+    HIP_OK(hipMemcpyAsync(R.h_pinned, dev_src, bytes, hipMemcpyDeviceToHost, R.stream));
+    HIP_OK(hipStreamSynchronize(R.stream));
+    std::memcpy(dst, R.h_pinned, bytes);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// polynomial handle
+// ------------------------------------------------------------------------------------------
+struct gft_poly {
+    int width = 1;              // 1: F64, 2: Interval (lo plane, hi plane)
+    Dims shape;                 // stored (compact) coefficient shape
+    Dims deg;                   // degrees_p1
+    std::shared_ptr<Buf> buf;   // width * numel doubles, plane stride == numel
+    size_t numel = 1;
+    // host cache of the value when numel == 1 (filled on construction from host scalars or lazily)
+    mutable bool cached = false;
+    mutable double cv[2] = {0, 0};
+};
+
+namespace {
+
+static size_t prod(const Dims& s) {
+    size_t n = 1;
+    for (size_t x : s) n *= x;
+    return n;
+}
+
+static void check_invariants(const Dims& shape, const Dims& deg) {  // mt:23-31
+    if (shape.size() != deg.size()) throw Error("invariant violated: coeffs.ndim() != degrees_p1.len()");
+    for (size_t v = 0; v < shape.size(); ++v)
+        if (!(0 < shape[v] && shape[v] <= deg[v])) throw Error("invariant violated: 0 < shape[v] <= degrees_p1[v]");
+    if (shape.size() > 32) throw Error("more than 32 variables are not supported");
+}
+
+static Shape to_shape(const Dims& s) {
+    // drop nothing: callers collapse when they need to; MAXD bounds the kernel-side rank
+    if (s.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
+    Shape r;
+    r.nd = (int)s.size();
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (s[i] > 0xffffffffull) throw Error("axis length exceeds 2^32");
+        r.d[i] = (unsigned)s[i];
+    }
+    return r;
+}
+
+// Remove unit axes so that ranks up to 32 with few non-trivial axes fit MAXD.  `keep0` keeps axis 0.
+static Dims collapse_mask(const std::vector<const Dims*>& shapes, bool keep0) {
+    Dims keep;
+    size_t nd = shapes[0]->size();
+    for (size_t a = 0; a < nd; ++a) {
+        bool all1 = true;
+        for (auto s : shapes)
+            if ((*s)[a] != 1) all1 = false;
+        if (!all1 || (keep0 && a == 0)) keep.push_back(a);
+    }
+    return keep;
+}
+static Dims pick(const Dims& s, const Dims& keep) {
+    Dims r;
+    for (size_t a : keep) r.push_back(s[a]);
+    return r;
+}
+static Dims c_strides(const Dims& s) {
+    Dims st(s.size(), 1);
+    for (size_t i = s.size(); i-- > 1;) st[i - 1] = st[i] * s[i];
+    return st;
+}
+
+template <class E>
+struct Ops {
+    typedef gft_poly P;
+    static constexpr int W = E::W;
+
+    // A contiguous device view used inside the recurrences.
+    struct HV {
+        double* p;
+        size_t plane;
+        Dims shape;
+        size_t numel() const { return prod(shape); }
+        HV index0(size_t k) const {
+            HV r;
+            Dims sub(shape.begin() + 1, shape.end());
+            r.p = p + k * prod(sub);
+            r.plane = plane;
+            r.shape = sub;
+            return r;
+        }
+    };
+    static HV view(const P& p) { return HV{p.buf->p, p.numel, p.shape}; }
+    static DView dview(const HV& v, const Dims* keep = nullptr) {
+        DView d;
+        d.p = v.p;
+        d.plane = v.plane;
+        d.sh = to_shape(keep ? pick(v.shape, *keep) : v.shape);
+        return d;
+    }
+
+    // ---- allocation ------------------------------------------------------------------------
+    static P make(const Dims& shape, const Dims& deg) {
+        check_invariants(shape, deg);
+        P r;
+        r.width = W;
+        r.shape = shape;
+        r.deg = deg;
+        r.numel = prod(shape);
+        r.buf = alloc_doubles(r.numel * W);
+        return r;
+    }
+    static P with_meta(const P& src, const Dims& shape, const Dims& deg) {  // metadata-only reshape
+        check_invariants(shape, deg);
+        P r = src;
+        r.shape = shape;
+        r.deg = deg;
+        return r;
+    }
+    static P from_host_scalar(const double* x, const Dims& shape, const Dims& deg) {
+        P r = make(shape, deg);
+        HIP_OK(hipMemcpyAsync(r.buf->p, x, sizeof(double) * W, hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));  // x may be a caller stack temporary
+        r.cached = true;
+        r.cv[0] = x[0];
+        r.cv[1] = W == 2 ? x[1] : 0.0;
+        return r;
+    }
+    static P copy_of(const P& a) {
+        P r = make(a.shape, a.deg);
+        HIP_OK(hipMemcpyAsync(r.buf->p, a.buf->p, sizeof(double) * a.numel * W, hipMemcpyDeviceToDevice, R.stream));
+        return r;
+    }
+
+    // ---- value inspection (the only host syncs) ---------------------------------------------
+    static void first_value(const P& p, double out[2]) {
+        if (p.numel == 1 && p.cached) {
+            out[0] = p.cv[0];
+            out[1] = p.cv[1];
+            return;
+        }
+        double tmp[2] = {0, 0};
+        read_back(&tmp[0], p.buf->p, sizeof(double));
+        if (W == 2) read_back(&tmp[1], p.buf->p + p.numel, sizeof(double));
+        out[0] = tmp[0];
+        out[1] = tmp[1];
+        if (p.numel == 1) {
+            p.cached = true;
+            p.cv[0] = tmp[0];
+            p.cv[1] = tmp[1];
+        }
+    }
+    static bool val_is_zero(const double v[2]) { return W == 1 ? v[0] == 0.0 : (v[0] == 0.0 && v[1] == 0.0); }
+    static bool val_is_one(const double v[2]) { return W == 1 ? v[0] == 1.0 : (v[0] == 1.0 && v[1] == 1.0); }
+    static bool is_zero(const P& p) {  // mt:643-645
+        if (p.numel != 1) return false;
+        double v[2];
+        first_value(p, v);
+        return val_is_zero(v);
+    }
+    static bool is_one(const P& p) {  // mt:653-655
+        if (p.numel != 1) return false;
+        double v[2];
+        first_value(p, v);
+        return val_is_one(v);
+    }
+
+    // ---- shape helpers (mt:114-204, 832-852) ---------------------------------------------------
+    static Dims min_degrees(const P& a, const P& b) {
+        Dims d(std::max(a.deg.size(), b.deg.size()), UMAX);
+        for (size_t v = 0; v < d.size(); ++v) {
+            if (v < a.deg.size()) d[v] = std::min(d[v], a.deg[v]);
+            if (v < b.deg.size()) d[v] = std::min(d[v], b.deg[v]);
+        }
+        return d;
+    }
+    static Dims max_shape(const P& a, const P& b) {
+        Dims s(std::max(a.shape.size(), b.shape.size()), 1);
+        for (size_t v = 0; v < s.size(); ++v) {
+            if (v < a.shape.size()) s[v] = std::max(s[v], a.shape[v]);
+            if (v < b.shape.size()) s[v] = std::max(s[v], b.shape[v]);
+            if (v < a.deg.size()) s[v] = std::min(s[v], a.deg[v]);
+            if (v < b.deg.size()) s[v] = std::min(s[v], b.deg[v]);
+        }
+        return s;
+    }
+    static Dims sum_shape(const P& a, const P& b) {
+        Dims s(std::max(a.shape.size(), b.shape.size()), 0);
+        for (size_t v = 0; v < s.size(); ++v) {
+            if (v < a.shape.size()) s[v] += a.shape[v] - 1;
+            if (v < b.shape.size()) s[v] += b.shape[v] - 1;
+            s[v] += 1;
+            if (v < a.deg.size()) s[v] = std::min(s[v], a.deg[v]);
+            if (v < b.deg.size()) s[v] = std::min(s[v], b.deg[v]);
+        }
+        return s;
+    }
+    static void broadcast(P& x, P& y) {
+        if (x.deg.size() < y.deg.size()) x.deg.insert(x.deg.end(), y.deg.begin() + x.deg.size(), y.deg.end());
+        else if (y.deg.size() < x.deg.size()) y.deg.insert(y.deg.end(), x.deg.begin() + y.deg.size(), x.deg.end());
+        while (x.shape.size() < y.shape.size()) x.shape.push_back(1);
+        while (y.shape.size() < x.shape.size()) y.shape.push_back(1);
+    }
+
+    // ---- structured copies -----------------------------------------------------------------------
+    // General gather of `src` into a fresh tensor of shape `out_shape`; per-axis shift and valid length.
+    static P gather(const P& src, const Dims& out_shape, const Dims& out_deg, const std::vector<long long>& shift,
+                    const Dims& src_len, int op = OP_COPY, const double* s = nullptr, int tab_axis = -1,
+                    const double* tab = nullptr, size_t tab_plane = 0, const unsigned char* keep = nullptr) {
+        P out = make(out_shape, out_deg);
+        if (out.numel == 0) return out;
+        Dims sst = c_strides(src.shape);
+        // collapse axes that are trivial in the output and read index 0 (+shift) of the source
+        GatherArgs a;
+        std::memset(&a, 0, sizeof(a));
+        int nd = 0;
+        size_t base = 0;
+        a.tab_axis = -1;
+        for (size_t ax = 0; ax < out_shape.size(); ++ax) {
+            if (out_shape[ax] == 1 && (int)ax != tab_axis) {
+                long long si = shift[ax];
+                if (si < 0 || (size_t)si >= src_len[ax]) {  // whole output is outside the source box
+                    HIP_OK(hipMemsetAsync(out.buf->p, 0, sizeof(double) * out.numel * W, R.stream));
+                    return out;
+                }
+                base += (size_t)si * sst[ax];
+                continue;
+            }
+            if (nd >= MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
+            a.out.d[nd] = (unsigned)out_shape[ax];
+            a.shift[nd] = (int)shift[ax];
+            a.src_len[nd] = (unsigned)std::min<size_t>(src_len[ax], 0xffffffffu);
+            a.src_stride[nd] = sst[ax];
+            if ((int)ax == tab_axis) a.tab_axis = nd;
+            nd++;
+        }
+        a.out.nd = nd;
+        a.op = op;
+        if (s) {
+            a.s.a = s[0];
+            a.s.b = W == 2 ? s[1] : 0.0;
+        }
+        a.tab = tab;
+        a.tab_plane = tab_plane;
+        a.keep = keep;
+        K<E>::gather(R.stream, src.buf->p + base, src.numel, out.buf->p, out.numel, a);
+        return out;
+    }
+    static P lead_block(const P& p, const Dims& lens, const Dims& deg) {  // slice 0..lens per axis
+        if (lens == p.shape) return with_meta(p, p.shape, deg);
+        std::vector<long long> shift(lens.size(), 0);
+        return gather(p, lens, deg, shift, p.shape);
+    }
+    static P slab_range(const P& p, size_t v, size_t lo, size_t hi, const Dims& deg, int op = OP_COPY,
+                        int tab_axis = -1, const double* tab = nullptr, size_t tab_plane = 0) {
+        Dims out = p.shape;
+        out[v] = hi - lo;
+        std::vector<long long> shift(out.size(), 0);
+        shift[v] = (long long)lo;
+        return gather(p, out, deg, shift, p.shape, op, nullptr, tab_axis, tab, tab_plane);
+    }
+    static P truncate_degrees(const P& p, const Dims& degs) {  // mt:195-204
+        Dims nd = p.deg, lens = p.shape;
+        for (size_t v = 0; v < p.deg.size(); ++v) {
+            nd[v] = std::min(nd[v], degs[v]);
+            if (v < lens.size() && lens[v] > degs[v]) lens[v] = degs[v];
+        }
+        return lead_block(p, lens, nd);
+    }
+    static P map_copy(const P& p, int op, const double* s) {  // fresh tensor = f(p) elementwise
+        std::vector<long long> shift(p.shape.size(), 0);
+        return gather(p, p.shape, p.deg, shift, p.shape, op, s);
+    }
+
+    // ---- constructors (mt:208-259) ------------------------------------------------------------------
+    static P zero_with(const Dims& deg) {
+        double z[2] = {0, 0};
+        return from_host_scalar(z, Dims(deg.size(), 1), deg);
+    }
+    static P scalar(const double* x) { return from_host_scalar(x, {}, {}); }
+    static P var_like(size_t v, const double* x, bool have_x, size_t len_v_shape, bool second_is_one, const Dims& deg) {
+        Dims shape(deg.size(), 1);
+        shape[v] = len_v_shape;
+        P r = make(shape, deg);
+        double host[4] = {0, 0, 0, 0};  // [lo plane: e0, e1][hi plane: e0, e1]
+        size_t n = r.numel;             // 1 or 2
+        if (have_x) {
+            host[0] = x[0];
+            if (W == 2) host[n] = x[1];
+        }
+        if (n == 2 && second_is_one) {
+            host[1] = 1.0;
+            if (W == 2) host[n + 1] = 1.0;
+        }
+        HIP_OK(hipMemcpyAsync(r.buf->p, host, sizeof(double) * n * W, hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        if (n == 1) {
+            r.cached = true;
+            r.cv[0] = host[0];
+            r.cv[1] = W == 2 ? host[1] : 0.0;
+        }
+        return r;
+    }
+
+    // ---- Add / Sub / Neg (mt:854-937) -----------------------------------------------------------------
+    static P addsub(P self, P other, bool subtract) {
+        Dims rd = min_degrees(self, other);
+        broadcast(self, other);
+        self = truncate_degrees(self, rd);
+        other = truncate_degrees(other, rd);
+        if (other.numel == 1) {
+            P out = copy_of(self);
+            K<E>::first_elem(R.stream, out.buf->p, out.numel, subtract ? FIRST_SUB : FIRST_ADD, other.buf->p, other.numel);
+            out.deg = rd;
+            return out;
+        }
+        if (self.numel == 1) {
+            P out = copy_of(other);
+            K<E>::first_elem(R.stream, out.buf->p, out.numel, subtract ? FIRST_SUB : FIRST_ADD, self.buf->p, self.numel);
+            if (subtract) K<E>::map_inplace(R.stream, out.buf->p, out.numel, out.numel, MAP_NEG, 0, Scalar2{0, 0});
+            out.deg = rd;
+            return out;
+        }
+        Dims shape = max_shape(self, other);
+        P out = make(shape, rd);
+        Dims keep = collapse_mask({&shape}, false);
+        HV vo = view(out), va = view(self), vb = view(other);
+        K<E>::addsub_padded(R.stream, dview(vo, &keep), dview(va, &keep), dview(vb, &keep), subtract ? 1 : 0);
+        return out;
+    }
+    static P neg(const P& a) { return map_copy(a, OP_NEG, nullptr); }
+
+    // ---- extract_linear (mt:275-294) --------------------------------------------------------------------
+    static bool extract_linear(const P& p, double c[2], double m[2], size_t* var) {
+        unsigned mask = 0;
+        for (size_t v = 0; v < p.shape.size(); ++v)
+            if (p.shape[v] >= 2) mask |= 1u << v;
+        if (!mask) return false;
+        // kernel works on the collapsed view; map collapsed axis bits back to real axes
+        Dims keep = collapse_mask({&p.shape}, false);
+        unsigned cmask = 0;
+        for (size_t i = 0; i < keep.size(); ++i)
+            if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
+        HIP_OK(hipMemcpyAsync(R.d_flag, &cmask, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+        HV v = view(p);
+        K<E>::linear_mask(R.stream, dview(v, &keep), R.d_flag);
+        unsigned got = 0;
+        read_back(&got, R.d_flag, sizeof(unsigned));
+        if (!got) return false;
+        size_t ci = 0;
+        while (!((got >> ci) & 1u)) ci++;
+        size_t ax = keep[ci];
+        Dims st = c_strides(p.shape);
+        read_back(&c[0], p.buf->p, sizeof(double));
+        read_back(&m[0], p.buf->p + st[ax], sizeof(double));
+        c[1] = m[1] = 0.0;
+        if (W == 2) {
+            read_back(&c[1], p.buf->p + p.numel, sizeof(double));
+            read_back(&m[1], p.buf->p + p.numel + st[ax], sizeof(double));
+        }
+        *var = ax;
+        return true;
+    }
+
+    // ---- the product (mt:971-1072) --------------------------------------------------------------------------
+    // conv: z[slab range] (+)= x (*) y in the reference's summation structure.  `slab_mode` marks a
+    // recurrence step (axis 0 is always an "outer" axis, see gft_kernels.hip).
+    static void conv(const HV& x, const HV& y, const HV& z, size_t slab_lo, size_t slab_hi, bool accumulate,
+                     bool slab_mode, int j0_min, int j0_excl, int j0_desc) {
+        Dims keep = collapse_mask({&z.shape}, slab_mode);
+        Dims xs = pick(x.shape, keep), ys = pick(y.shape, keep), zs = pick(z.shape, keep);
+        if (zs.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.nd = (int)zs.size();
+        Dims xst = c_strides(xs), yst = c_strides(ys), zst = c_strides(zs);
+        for (int i = 0; i < a.nd; ++i) {
+            a.xs[i] = (unsigned)xs[i];
+            a.ys[i] = (unsigned)ys[i];
+            a.zs[i] = (unsigned)zs[i];
+            a.xstr[i] = xst[i];
+            a.ystr[i] = yst[i];
+            a.zstr[i] = zst[i];
+        }
+        if (!z.shape.empty() && slab_hi <= slab_lo) return;  // empty slab range
+        const bool axis0_kept = !keep.empty() && keep[0] == 0;
+        if (a.nd == 0) {
+            a.slab_lo = 0;
+            a.slab_hi = 1;
+        } else if (!axis0_kept) {  // the (unit) leading axis was collapsed away: its only slab is everything
+            a.slab_lo = 0;
+            a.slab_hi = a.zs[0];
+        } else {
+            a.slab_lo = (unsigned)slab_lo;
+            a.slab_hi = (unsigned)slab_hi;
+        }
+        a.accumulate = accumulate ? 1 : 0;
+        a.j0_min = j0_min;
+        a.j0_excl = j0_excl;
+        a.j0_desc = j0_desc;
+        // number of non-unit axes that take part in the reference's "1-d like" inner product
+        int first_inner_axis = slab_mode ? 1 : 0;
+        int nonunit = 0;
+        for (int i = first_inner_axis; i < a.nd; ++i)
+            if (a.zs[i] != 1) nonunit++;
+        a.inner_from_zero = nonunit >= 1 ? 1 : 0;
+
+        bool want_tiled = (W == 1) && R.conv_mode != 1;
+        if (want_tiled) {
+            size_t need = 0;
+            bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, a, nullptr, 0, &need);
+            if (ok && R.conv_mode == 0) {
+                // auto: only worth it when the product is large (the naive kernel is exact-order)
+                double macs = 1.0;
+                for (int i = 0; i < a.nd; ++i) macs *= 0.5 * (double)a.zs[i] * (double)std::min(a.xs[i], a.ys[i]);
+                if (macs < 5.0e7) ok = false;
+            }
+            if (ok) {
+                if (need > R.conv_ws_bytes) {
+                    if (R.conv_ws) HIP_OK(hipFree(R.conv_ws));
+                    R.conv_ws = nullptr;
+                    HIP_OK(hipMalloc(&R.conv_ws, need));
+                    R.conv_ws_bytes = need;
+                }
+                if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need))
+                    throw Error("tiled convolution launch failed");
+                return;
+            }
+            if (R.conv_mode == 2) throw Error("conv_mode=2 (tiled) requested but the shape is not supported by the tiled kernel");
+        }
+        K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
+    }
+
+    static P mul_var(const P& self, const double* m, size_t v, const Dims& shape, const Dims& deg) {  // mt:589-608
+        if (v >= self.shape.size() || shape.size() != self.shape.size()) throw Error("mul_var: bad axis/shape");
+        size_t upper = std::min(shape[v] - 1, self.shape[v]);
+        std::vector<long long> shift(shape.size(), 0);
+        shift[v] = -1;
+        Dims src_len = self.shape;
+        src_len[v] = upper;
+        return gather(self, shape, deg, shift, src_len, OP_MUL_S, m);
+    }
+    static P mul_linear(const P& self, const double* c, const double* m, size_t v, const Dims& shape, const Dims& deg) {  // mt:611-623
+        if (val_is_zero(c)) return mul_var(self, m, v, shape, deg);
+        return addsub(mul_var(self, m, v, shape, deg), mul(self, scalar(c)), false);
+    }
+
+    static P mul(P self, P other) {  // mt:1014-1072
+        Dims deg = min_degrees(self, other);
+        if (is_zero(self) || is_zero(other)) return zero_with(deg);
+        broadcast(self, other);
+        Dims shape = sum_shape(self, other);
+        self = truncate_degrees(self, deg);
+        other = truncate_degrees(other, deg);
+        if (is_one(self)) return other;
+        if (is_one(other)) return self;
+        double c[2], m[2];
+        if (self.numel == 1) {
+            first_value(self, c);
+            return map_copy(other, OP_LMUL_S, c);
+        }
+        if (other.numel == 1) {
+            first_value(other, c);
+            return map_copy(self, OP_LMUL_S, c);
+        }
+        size_t v;
+        if (extract_linear(self, c, m, &v)) {
+            Dims sh = other.shape;
+            sh[v] = std::min(deg[v], sh[v] + 1);
+            return mul_linear(other, c, m, v, sh, deg);
+        }
+        if (extract_linear(other, c, m, &v)) {
+            Dims sh = self.shape;
+            sh[v] = std::min(deg[v], sh[v] + 1);
+            return mul_linear(self, c, m, v, sh, deg);
+        }
+        P out = make(shape, deg);
+        conv(view(self), view(other), view(out), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
+        return out;
+    }
+
+    // ---- division (mt:1162-1231) -----------------------------------------------------------------------------
+    static int nonunit_axes(const Dims& s) {
+        int n = 0;
+        for (size_t x : s)
+            if (x != 1) n++;
+        return n;
+    }
+    static void div_rec(const HV& xs, const HV& ys, const HV& res) {
+        if (xs.numel() == 0) return;
+        if (res.shape.empty()) {
+            K<E>::scalar_op(R.stream, SC_DIV, xs.p, xs.plane, ys.p, ys.plane, res.p, res.plane);
+            return;
+        }
+        if (res.shape.size() == 1) {  // last level: fused sequential recurrence
+            K<E>::div_1d(R.stream, xs.p, xs.plane, (unsigned)xs.shape[0], ys.p, ys.plane, (unsigned)ys.shape[0], res.p,
+                         res.plane, (unsigned)res.shape[0]);
+            return;
+        }
+        size_t n0 = res.shape[0];
+        HV y0 = ys.index0(0);
+        for (size_t k = 0; k < n0; ++k) {
+            HV cur = res.index0(k);
+            conv(res, ys, res, k, k + 1, false, true, 0, 1, 0);  // cur = sum_{j<k} res[j] (*) ys[k-j]
+            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_NEG, 0, Scalar2{0, 0});
+            if (k < xs.shape[0]) {
+                HV xk = xs.index0(k);
+                Dims keep = collapse_mask({&cur.shape}, false);
+                K<E>::block_op(R.stream, dview(cur, &keep), dview(xk, &keep), BLK_ADD, 0);
+            }
+            std::shared_ptr<Buf> tmp = alloc_doubles(cur.numel() * W);
+            HV copy{tmp->p, cur.numel(), cur.shape};
+            HIP_OK(hipMemcpyAsync(copy.p, cur.p, sizeof(double) * cur.numel(), hipMemcpyDeviceToDevice, R.stream));
+            if (W == 2)
+                HIP_OK(hipMemcpyAsync(copy.p + copy.plane, cur.p + cur.plane, sizeof(double) * cur.numel(),
+                                      hipMemcpyDeviceToDevice, R.stream));
+            div_rec(copy, y0, cur);
+        }
+    }
+    static P div(P self, P other) {
+        broadcast(self, other);
+        Dims deg = min_degrees(self, other);
+        self = truncate_degrees(self, deg);
+        other = truncate_degrees(other, deg);
+        if (is_one(other)) return self;
+        if (other.numel == 1) {
+            double c[2];
+            first_value(other, c);
+            return map_copy(self, OP_DIV_S, c);
+        }
+        Dims rs = deg;
+        for (size_t i = 0; i < rs.size(); ++i)
+            if (other.shape[i] == 1) rs[i] = self.shape[i];
+        for (size_t i = 0; i < rs.size(); ++i)
+            if (rs[i] == UMAX) throw Error("div: untruncated result shape (degrees_p1 == usize::MAX)");
+        P out = make(rs, deg);
+        div_rec(view(self), view(other), view(out));
+        return out;
+    }
+
+    // ---- exp / log (mt:406-430, 1270-1386) ---------------------------------------------------------------------
+    // xs scaled slab-wise by T::from(j) along axis 0 (mt:1308-1310): xs[j] * j
+    static std::shared_ptr<Buf> scaled_by_index(const HV& xs, HV* out) {
+        std::shared_ptr<Buf> buf = alloc_doubles(xs.numel() * W);
+        std::shared_ptr<Buf> tab = alloc_doubles(xs.shape[0] * W);
+        K<E>::factor_table(R.stream, TAB_INDEX, 0, (unsigned)xs.shape[0], nullptr, 0, tab->p, xs.shape[0]);
+        GatherArgs a;
+        std::memset(&a, 0, sizeof(a));
+        size_t inner = xs.numel() / std::max<size_t>(xs.shape[0], 1);
+        a.out.nd = 2;
+        a.out.d[0] = (unsigned)xs.shape[0];
+        a.out.d[1] = (unsigned)inner;
+        a.src_len[0] = a.out.d[0];
+        a.src_len[1] = a.out.d[1];
+        a.src_stride[0] = inner;
+        a.src_stride[1] = 1;
+        a.op = OP_MUL_TAB;
+        a.tab_axis = 0;
+        a.tab = tab->p;
+        a.tab_plane = xs.shape[0];
+        *out = HV{buf->p, xs.numel(), xs.shape};
+        K<E>::gather(R.stream, xs.p, xs.plane, buf->p, xs.numel(), a);
+        return buf;
+    }
+    static void exp_rec(const HV& xs, const HV& res) {
+        if (xs.numel() == 0) return;
+        if (res.shape.empty()) {
+            K<E>::scalar_op(R.stream, SC_EXP, xs.p, xs.plane, nullptr, 0, res.p, res.plane);
+            return;
+        }
+        if (nonunit_axes(res.shape) == 1) {
+            K<E>::exp_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel());
+            return;
+        }
+        exp_rec(xs.index0(0), res.index0(0));
+        if (res.shape[0] <= 1) return;
+        HV xsc;
+        std::shared_ptr<Buf> hold = scaled_by_index(xs, &xsc);
+        for (size_t k = 1; k < res.shape[0]; ++k) {
+            HV cur = res.index0(k);
+            conv(xsc, res, res, k, k + 1, false, true, 1, 0, 0);
+            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_DIV_U32, (unsigned)k, Scalar2{0, 0});
+        }
+    }
+    static Dims explog_shape(const P& a) {
+        Dims rs = a.deg;
+        for (size_t i = 0; i < rs.size(); ++i) {
+            if (a.shape[i] == 1) rs[i] = 1;
+            if (rs[i] == UMAX) throw Error("exp/log: untruncated result shape (degrees_p1 == usize::MAX)");
+        }
+        return rs;
+    }
+    static P exp(const P& a) {
+        P out = make(explog_shape(a), a.deg);
+        exp_rec(view(a), view(out));
+        return out;
+    }
+
+    static void log_rec(const HV& xs, const HV& res) {
+        if (xs.numel() == 0) return;
+        if (res.shape.empty()) {
+            K<E>::scalar_op(R.stream, SC_LOG, xs.p, xs.plane, nullptr, 0, res.p, res.plane);
+            return;
+        }
+        if (nonunit_axes(xs.shape) == 1) {
+            if (nonunit_axes(res.shape) != 1) throw Error("log: called `Option::unwrap()` on a `None` value (mt:1346)");
+            K<E>::log_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel());
+            return;
+        }
+        log_rec(xs.index0(0), res.index0(0));
+        size_t n0 = res.shape[0];
+        if (n0 <= 1) return;
+        // rs[j] = res[j] * j, filled slab by slab as res becomes known (mt:1362-1365)
+        std::shared_ptr<Buf> rsbuf = alloc_doubles(res.numel() * W);
+        HV rs{rsbuf->p, res.numel(), res.shape};
+        HIP_OK(hipMemsetAsync(rs.p, 0, sizeof(double) * res.numel() * W, R.stream));
+        Dims sub(res.shape.begin() + 1, res.shape.end());
+        HV x0 = xs.index0(0);
+        for (size_t k = 1; k < n0; ++k) {
+            HV cur = res.index0(k);
+            conv(xs, rs, res, k, k + 1, false, true, 1, 1, 1);  // sum_{j} xs[k-j] (*) (res[j]*j), j ascending
+            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_NEG, 0, Scalar2{0, 0});
+            if (k < xs.shape[0]) {
+                HV xk = xs.index0(k);
+                Dims keep = collapse_mask({&cur.shape}, false);
+                K<E>::block_op(R.stream, dview(cur, &keep), dview(xk, &keep), BLK_ADD_U32_TIMES, (unsigned)k);
+            }
+            // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
+            P num = make(sub, sub), den = make(x0.shape, sub);
+            copy_planes(num.buf->p, num.numel, cur.p, cur.plane, cur.numel());
+            copy_planes(den.buf->p, den.numel, x0.p, x0.plane, x0.numel());
+            P q = div(num, den);
+            if (q.shape != sub) throw Error("log: internal shape mismatch after division");
+            copy_planes(cur.p, cur.plane, q.buf->p, q.numel, cur.numel());
+            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_DIV_U32, (unsigned)k, Scalar2{0, 0});
+            HV rk = rs.index0(k);
+            copy_planes(rk.p, rk.plane, cur.p, cur.plane, cur.numel());
+            K<E>::map_inplace(R.stream, rk.p, rk.plane, rk.numel(), MAP_MUL_U32, (unsigned)k, Scalar2{0, 0});
+        }
+    }
+    static void copy_planes(double* dst, size_t dplane, const double* src, size_t splane, size_t n) {
+        HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
+        if (W == 2) HIP_OK(hipMemcpyAsync(dst + dplane, src + splane, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
+    }
+    static P log(const P& a) {
+        P out = make(explog_shape(a), a.deg);
+        log_rec(view(a), view(out));
+        return out;
+    }
+
+    static P pow(const P& a, uint32_t e) {  // mt:433-451
+        double one[2] = {1.0, 1.0};
+        if (e == 0) return scalar(one);
+        if (e == 1) return a;
+        P res = scalar(one);
+        P base = a;
+        while (e > 0) {
+            if (e & 1) res = mul(res, base);
+            base = mul(base, base);  // includes the reference's redundant final squaring
+            e >>= 1;
+        }
+        return res;
+    }
+
+    // ---- derivative-like slab scalings (mt:457-509) ---------------------------------------------------------------
+    static P deriv_like(const P& a, size_t v, size_t n, int table_op, const char* what) {
+        size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+        if (!(v < a.deg.size() && n < len_of)) throw Error(std::string(what) + ": assertion failed: v < num_vars && n < len_of(v)");
+        if (v >= a.shape.size()) return n == 0 ? a : zero_with(a.deg);
+        Dims d = a.deg;
+        d[v] = d[v] > n ? d[v] - n : 0;
+        if (n >= a.shape[v]) return zero_with(d);
+        size_t len = a.shape[v] - n;
+        std::shared_ptr<Buf> tab = alloc_doubles(len * W);
+        K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len);
+    }
+
+    // ---- shift_down (mt:514-536) -------------------------------------------------------------------------------------
+    static void sum_axis_into(const P& a, size_t v, size_t upto, double* out, size_t out_plane) {
+        size_t outer = 1, inner = 1;
+        for (size_t i = 0; i < v; ++i) outer *= a.shape[i];
+        for (size_t i = v + 1; i < a.shape.size(); ++i) inner *= a.shape[i];
+        int mode = SUM_SEQ;
+        // ndarray 0.15.6 sum_axis: 2-d array whose summed axis has unit stride => per-lane 8-way fold
+        if (a.shape.size() == 2 && inner == 1) mode = SUM_UNROLL8;
+        if (W == 1 && inner == 1 && upto >= 128) mode = SUM_WAVE;  // long rows: wavefront-shuffle reduction
+        K<E>::sum_axis(R.stream, a.buf->p, a.numel, (unsigned)outer, (unsigned)upto, (unsigned)inner,
+                       a.shape[v] * inner, out, out_plane, mode);
+    }
+    static P shift_down(const P& a, size_t v, size_t n) {
+        size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+        if (!(v < a.deg.size() && n < len_of)) throw Error("shift_down: assertion failed: v < num_vars && n < len_of(v)");
+        if (v >= a.shape.size()) return a;
+        Dims d = a.deg;
+        d[v] = d[v] > n ? d[v] - n : 0;
+        if (a.shape[v] <= n + 1) {
+            Dims rs = a.shape;
+            rs[v] = 1;
+            P out = make(rs, d);
+            sum_axis_into(a, v, a.shape[v], out.buf->p, out.numel);
+            return out;
+        }
+        P out = slab_range(a, v, n, a.shape[v], d);
+        Dims ss = a.shape;
+        ss[v] = 1;
+        std::shared_ptr<Buf> s = alloc_doubles(prod(ss) * W);
+        sum_axis_into(a, v, n, s->p, prod(ss));
+        Dims keep = collapse_mask({&out.shape}, false);
+        HV vo = view(out), vs{s->p, prod(ss), ss};
+        K<E>::block_op(R.stream, dview(vo, &keep), dview(vs, &keep), BLK_ADD, 0);
+        return out;
+    }
+
+    // ---- subst_var (mt:540-580) -----------------------------------------------------------------------------------------
+    static P subst_var(const P& a, size_t v, const P& subst) {
+        if (v >= a.shape.size()) return a;
+        Dims deg = min_degrees(a, subst);
+        if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
+        double c[2], m[2];
+        size_t w;
+        if (extract_linear(subst, c, m, &w)) {
+            if (v == w && val_is_zero(c)) {
+                Dims lens = a.shape;
+                for (size_t i = 0; i < lens.size(); ++i) lens[i] = std::min(lens[i], deg[i]);
+                std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
+                Dims sst = c_strides(subst.shape);
+                K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], subst.buf->p + sst[w], subst.numel, tab->p, lens[v]);
+                std::vector<long long> shift(lens.size(), 0);
+                return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v]);
+            }
+        }
+        P res = zero_with(deg);
+        Dims cshape = a.shape;
+        while (cshape.size() < deg.size()) cshape.push_back(1);
+        P ca = with_meta_unchecked(a, cshape);
+        for (size_t i = cshape[v]; i-- > 0;) {
+            Dims out = cshape;
+            out[v] = 1;
+            for (size_t ax = 0; ax < out.size(); ++ax) out[ax] = std::min(out[ax], deg[ax]);
+            std::vector<long long> shift(out.size(), 0);
+            shift[v] = (long long)i;
+            P coeff = gather(ca, out, deg, shift, cshape);
+            res = addsub(mul(res, subst), coeff, false);
+        }
+        return res;
+    }
+    static P with_meta_unchecked(const P& src, const Dims& shape) {
+        P r = src;
+        r.shape = shape;
+        return r;
+    }
+
+    // ---- slab extraction (mt:341-404) --------------------------------------------------------------------------------------
+    static P coefficients_of_term(const P& a, size_t v, size_t order) {
+        if (v >= a.shape.size()) return order == 0 ? a : zero_with(a.deg);
+        if (order >= a.shape[v]) return zero_with(a.deg);
+        return slab_range(a, v, order, order + 1, a.deg);
+    }
+    static P taylor_polynomial_terms(const P& a, size_t v, const Dims& orders) {
+        size_t max_order_p1 = 1;
+        for (size_t o : orders) max_order_p1 = std::max(max_order_p1, o + 1);
+        bool has0 = std::find(orders.begin(), orders.end(), (size_t)0) != orders.end();
+        if (v >= a.shape.size()) return has0 ? a : zero_with(a.deg);
+        size_t upper = std::min(a.shape[v], max_order_p1);
+        std::vector<unsigned char> keep(max_order_p1, 0);
+        for (size_t o : orders) keep[o] = 1;
+        std::shared_ptr<Buf> kb = alloc_doubles((upper + 7) / 8 + 1);
+        HIP_OK(hipMemcpyAsync(kb->p, keep.data(), upper, hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        Dims out = a.shape;
+        out[v] = upper;
+        std::vector<long long> shift(out.size(), 0);
+        return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, (const unsigned char*)kb->p);
+    }
+
+    // ---- metadata ops (mt:81-112, 172-193) -------------------------------------------------------------------------------------
+    static P extend_to_dim(const P& a, size_t ndim, size_t degree_p1) {
+        if (a.shape.size() > ndim) throw Error("extend_to_dim: ndim smaller than current");
+        Dims s = a.shape, d = a.deg;
+        while (s.size() < ndim) s.push_back(1);
+        d.resize(ndim, degree_p1);
+        return with_meta(a, s, d);
+    }
+    static P extend(const P& a, const Dims& ns) {
+        if (a.deg.size() > ns.size()) throw Error("extend: too few dims");
+        Dims s = a.shape;
+        while (s.size() < ns.size()) s.push_back(1);
+        for (size_t v = 0; v < s.size(); ++v)
+            if (s[v] > ns[v]) throw Error("extend: shape exceeds new size");
+        P src = with_meta_unchecked(a, s);
+        std::vector<long long> shift(ns.size(), 0);
+        return gather(src, ns, ns, shift, s);
+    }
+    static P remove_last_variable(const P& a) {
+        if (a.deg.empty()) throw Error("remove_last_variable: attempt to subtract with overflow (no variables)");
+        size_t v = a.deg.size() - 1;
+        Dims d = a.deg;
+        d.pop_back();
+        Dims s = a.shape;
+        if (v < s.size()) {
+            if (s[v] != 1) {
+                Dims lens = s;
+                lens[v] = 1;
+                P blk = lead_block(with_meta_unchecked(a, s), lens, a.deg);
+                lens.pop_back();
+                return with_meta(blk, lens, d);
+            }
+            s.pop_back();
+        }
+        return with_meta(a, s, d);
+    }
+    static P truncate_to_degree_p1(const P& a, size_t degree_p1) {
+        return truncate_degrees(a, Dims(a.deg.size(), degree_p1));
+    }
+
+    // ---- coefficient (mt:314-339) ------------------------------------------------------------------------------------------------
+    static void coefficient(const P& a, const Dims& index, double out[2]) {
+        size_t consumed = 0, off = 0;
+        Dims st = c_strides(a.shape);
+        for (size_t v = 0; v < index.size(); ++v) {
+            size_t idx = index[v];
+            size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+            if (!(idx < len_of)) throw Error("index out of bounds");
+            if (v >= a.shape.size()) {
+                if (idx != 0) {
+                    out[0] = out[1] = 0.0;
+                    return;
+                }
+            } else if (idx >= a.shape[v]) {
+                out[0] = out[1] = 0.0;
+                return;
+            } else {
+                off += idx * st[v];
+                consumed++;
+            }
+        }
+        if (consumed != a.shape.size()) throw Error("index is too short");
+        out[1] = 0.0;
+        read_back(&out[0], a.buf->p + off, sizeof(double));
+        if (W == 2) read_back(&out[1], a.buf->p + a.numel + off, sizeof(double));
+    }
+
+    static bool equal(const P& a, const P& b) {
+        if (a.deg != b.deg || a.shape != b.shape) return false;
+        unsigned zero = 0;
+        HIP_OK(hipMemcpyAsync(R.d_flag + 1, &zero, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+        K<E>::count_neq(R.stream, a.buf->p, a.numel, b.buf->p, b.numel, a.numel, R.d_flag + 1);
+        unsigned cnt = 0;
+        read_back(&cnt, R.d_flag + 1, sizeof(unsigned));
+        return cnt == 0;
+    }
+};
+
+static Dims dims(const size_t* p, size_t n) { return Dims(p, p + n); }
+
+template <class F>
+static gft_poly* guard(F&& f) {
+    try {
+        require_ready();
+        return new gft_poly(f());
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+template <class F>
+static int guard_int(F&& f) {
+    try {
+        require_ready();
+        return f();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI — runtime
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int gft_init(int device) {
+    if (R.ready) return 0;
+    try {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0) throw Error("no HIP device visible");
+        if (device < 0) {
+            const char* lr = getenv("LOCAL_RANK");
+            device = lr ? atoi(lr) % n : 0;
+        }
+        HIP_OK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+            throw Error(std::string("device is ") + prop.gcnArchName + ", but libgftaylor is built for gfx950 only");
+        HIP_OK(hipStreamCreateWithFlags(&R.own_stream, hipStreamNonBlocking));
+        R.stream = R.own_stream;
+        HIP_OK(hipMalloc((void**)&R.d_flag, 256));
+        HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
+        for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
+        R.device = device;
+        R.ready = true;
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+void gft_shutdown(void) {
+    if (!R.ready) return;
+    (void)hipStreamSynchronize(R.stream);
+    for (auto& kv : R.free_blocks) (void)hipFree(kv.second);
+    R.free_blocks.clear();
+    R.cached = 0;
+    if (R.conv_ws) (void)hipFree(R.conv_ws);
+    R.conv_ws = nullptr;
+    R.conv_ws_bytes = 0;
+    (void)hipFree(R.d_flag);
+    (void)hipHostFree(R.h_pinned);
+    for (auto& ev : R.events) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(R.own_stream);
+    R.ready = false;
+}
+
+int gft_set_stream(void* s) {
+    return guard_int([&] {
+        HIP_OK(hipStreamSynchronize(R.stream));
+        R.stream = s ? (hipStream_t)s : R.own_stream;
+        return 0;
+    });
+}
+void* gft_get_stream(void) { return (void*)R.stream; }
+int gft_synchronize(void) {
+    return guard_int([&] {
+        HIP_OK(hipStreamSynchronize(R.stream));
+        return 0;
+    });
+}
+const char* gft_last_error(void) { return g_err.c_str(); }
+const char* gfti_last_error(void) { return g_err.c_str(); }
+void gft_pool_stats(size_t out[3]) {
+    out[0] = R.in_use;
+    out[1] = R.cached;
+    out[2] = R.peak;
+}
+int gft_event_record(int slot) {
+    return guard_int([&] {
+        if (slot < 0 || slot >= 16) throw Error("event slot out of range");
+        HIP_OK(hipEventRecord(R.events[slot], R.stream));
+        return 0;
+    });
+}
+float gft_event_elapsed_ms(int a, int b) {
+    try {
+        require_ready();
+        HIP_OK(hipEventSynchronize(R.events[b]));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, R.events[a], R.events[b]));
+        return ms;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1.0f;
+    }
+}
+int gft_set_conv_mode(int mode) {
+    if (mode < 0 || mode > 2) return -1;
+    R.conv_mode = mode;
+    return 0;
+}
+
+// ---- raw entry points ------------------------------------------------------------------------
+int gft_conv_raw(const double* x, const size_t* xshape, const double* y, const size_t* yshape, double* res,
+                 const size_t* rshape, size_t ndim, size_t slab_lo, size_t slab_hi, int accumulate) {
+    return guard_int([&] {
+        typedef Ops<EF64> O;
+        O::HV xv{const_cast<double*>(x), 0, dims(xshape, ndim)};
+        O::HV yv{const_cast<double*>(y), 0, dims(yshape, ndim)};
+        O::HV zv{res, 0, dims(rshape, ndim)};
+        for (size_t i = 0; i < ndim; ++i)
+            if (xshape[i] > rshape[i] || yshape[i] > rshape[i] || xshape[i] == 0 || yshape[i] == 0)
+                throw Error("conv_raw: operand shapes must be non-empty and not exceed the result shape");
+        if (ndim > 0 && (slab_lo > slab_hi || slab_hi > rshape[0])) throw Error("conv_raw: bad slab range");
+        // Whole-product semantics on the selected slabs: same summation structure as Mul's general path.
+        O::conv(xv, yv, zv, slab_lo, slab_hi, accumulate != 0, false, 0, 0, 0);
+        return 0;
+    });
+}
+
+double gft_conv_macs(const size_t* xs, const size_t* ys, const size_t* rs, size_t ndim, size_t slab_lo,
+                     size_t slab_hi) {
+    auto pairs = [](size_t sx, size_t sy, size_t k) -> double {
+        size_t lo = k + 1 > sy ? k + 1 - sy : 0, hi = std::min(k + 1, sx);
+        return hi > lo ? (double)(hi - lo) : 0.0;
+    };
+    double inner = 1.0;
+    for (size_t a = 1; a < ndim; ++a) {
+        double s = 0;
+        for (size_t k = 0; k < rs[a]; ++k) s += pairs(xs[a], ys[a], k);
+        inner *= s;
+    }
+    if (ndim == 0) return 1.0;
+    double total = 0;
+    for (size_t k = slab_lo; k < slab_hi && k < rs[0]; ++k) total += pairs(xs[0], ys[0], k) * inner;
+    return total;
+}
+
+int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
+    // Folded assignment: work(k) ~ k+1, so pair low slab group r with the mirrored high
+    // group.  Boundaries are ceil-split so any n0 / world works; groups may be empty.
+    if (world < 1 || rank < 0 || rank >= world) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        return 0;
+    }
+    size_t half = n0 / 2;            // low half [0, half), high half [half, n0) mirrored
+    size_t G = (size_t)world;
+    auto cut = [&](size_t len, size_t i) { return (len * i) / G; };
+    size_t lo_len = half, hi_len = n0 - half;
+    out[0] = cut(lo_len, (size_t)rank);
+    out[1] = cut(lo_len, (size_t)rank + 1);
+    // mirrored: rank r takes the r-th chunk counted from the top
+    out[2] = n0 - cut(hi_len, (size_t)rank + 1);
+    out[3] = n0 - cut(hi_len, (size_t)rank);
+    return (lo_len % G == 0 && hi_len % G == 0) ? 1 : 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// C ABI — handle API, generated for both element types
+// ------------------------------------------------------------------------------------------
+#define GFT_API(PFX, E)                                                                                       \
+    extern "C" {                                                                                              \
+    int PFX##width(void) { return E::W; }                                                                     \
+    gft_poly* PFX##from_host(const double* c, const size_t* sh, const size_t* dg, size_t nd) {                \
+        return guard([&] {                                                                                    \
+            gft_poly r = Ops<E>::make(dims(sh, nd), dims(dg, nd));                                            \
+            HIP_OK(hipMemcpyAsync(r.buf->p, c, sizeof(double) * r.numel * E::W, hipMemcpyHostToDevice, R.stream)); \
+            HIP_OK(hipStreamSynchronize(R.stream));                                                           \
+            return r;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    gft_poly* PFX##scalar(const double* x) { return guard([&] { return Ops<E>::scalar(x); }); }               \
+    gft_poly* PFX##from_u32(uint32_t c) {                                                                     \
+        return guard([&] {                                                                                    \
+            double v[2] = {(double)c, (double)c};                                                             \
+            return Ops<E>::scalar(v);                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    gft_poly* PFX##zero_with(const size_t* dg, size_t nd) { return guard([&] { return Ops<E>::zero_with(dims(dg, nd)); }); } \
+    gft_poly* PFX##var(size_t v, const double* x, size_t len) {                                               \
+        return guard([&] { return Ops<E>::var_like(v, x, true, std::min<size_t>(len, 2), len > 1, Dims(v + 1, len)); }); \
+    }                                                                                                         \
+    gft_poly* PFX##var_at_zero(size_t v, size_t len) {                                                        \
+        return guard([&] { return Ops<E>::var_like(v, nullptr, false, 2, len > 1, Dims(v + 1, len)); });      \
+    }                                                                                                         \
+    gft_poly* PFX##var_with_degrees_p1(size_t v, const double* x, const size_t* dg, size_t nd) {              \
+        return guard([&] {                                                                                    \
+            Dims d = dims(dg, nd);                                                                            \
+            if (v >= nd) throw Error("var_with_degrees_p1: index out of bounds");                             \
+            return Ops<E>::var_like(v, x, true, 2, d[v] > 1, d);                                              \
+        });                                                                                                   \
+    }                                                                                                         \
+    gft_poly* PFX##clone(const gft_poly* p) { return guard([&] { return *p; }); }                             \
+    void PFX##free(gft_poly* p) { delete p; }                                                                 \
+    size_t PFX##num_vars(const gft_poly* p) { return p->deg.size(); }                                         \
+    size_t PFX##numel(const gft_poly* p) { return p->numel; }                                                 \
+    void PFX##shape(const gft_poly* p, size_t* out) { std::copy(p->shape.begin(), p->shape.end(), out); }     \
+    void PFX##degrees_p1(const gft_poly* p, size_t* out) { std::copy(p->deg.begin(), p->deg.end(), out); }    \
+    int PFX##to_host(const gft_poly* p, double* out) {                                                        \
+        return guard_int([&] {                                                                                \
+            HIP_OK(hipMemcpyAsync(out, p->buf->p, sizeof(double) * p->numel * E::W, hipMemcpyDeviceToHost, R.stream)); \
+            HIP_OK(hipStreamSynchronize(R.stream));                                                           \
+            return 0;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    size_t PFX##len_of(const gft_poly* p, size_t v) { return v < p->deg.size() ? p->deg[v] : UMAX; }          \
+    int PFX##is_constant(const gft_poly* p) { return p->numel == 1; }                                         \
+    int PFX##is_zero(const gft_poly* p) { return guard_int([&] { return (int)Ops<E>::is_zero(*p); }); }       \
+    int PFX##is_one(const gft_poly* p) { return guard_int([&] { return (int)Ops<E>::is_one(*p); }); }         \
+    int PFX##equal(const gft_poly* a, const gft_poly* b) { return guard_int([&] { return (int)Ops<E>::equal(*a, *b); }); } \
+    int PFX##constant_term(const gft_poly* p, double* out) {                                                  \
+        return guard_int([&] {                                                                                \
+            double v[2];                                                                                      \
+            Ops<E>::first_value(*p, v);                                                                       \
+            for (int i = 0; i < E::W; ++i) out[i] = v[i];                                                     \
+            return 0;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    int PFX##extract_constant(const gft_poly* p, double* out) {                                               \
+        return guard_int([&] {                                                                                \
+            if (p->numel != 1) return 0;                                                                      \
+            double v[2];                                                                                      \
+            Ops<E>::first_value(*p, v);                                                                       \
+            for (int i = 0; i < E::W; ++i) out[i] = v[i];                                                     \
+            return 1;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    int PFX##extract_linear(const gft_poly* p, double* c, double* m, size_t* v) {                             \
+        return guard_int([&] {                                                                                \
+            double cc[2], mm[2];                                                                              \
+            if (!Ops<E>::extract_linear(*p, cc, mm, v)) return 0;                                             \
+            for (int i = 0; i < E::W; ++i) {                                                                  \
+                c[i] = cc[i];                                                                                 \
+                m[i] = mm[i];                                                                                 \
+            }                                                                                                 \
+            return 1;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    int PFX##coefficient(const gft_poly* p, const size_t* idx, size_t n, double* out) {                       \
+        return guard_int([&] {                                                                                \
+            double v[2];                                                                                      \
+            Ops<E>::coefficient(*p, dims(idx, n), v);                                                         \
+            for (int i = 0; i < E::W; ++i) out[i] = v[i];                                                     \
+            return 0;                                                                                         \
+        });                                                                                                   \
+    }                                                                                                         \
+    gft_poly* PFX##add(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::addsub(*a, *b, false); }); } \
+    gft_poly* PFX##sub(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::addsub(*a, *b, true); }); } \
+    gft_poly* PFX##neg(const gft_poly* a) { return guard([&] { return Ops<E>::neg(*a); }); }                  \
+    gft_poly* PFX##mul(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::mul(*a, *b); }); } \
+    gft_poly* PFX##div(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::div(*a, *b); }); } \
+    gft_poly* PFX##exp(const gft_poly* a) { return guard([&] { return Ops<E>::exp(*a); }); }                  \
+    gft_poly* PFX##log(const gft_poly* a) { return guard([&] { return Ops<E>::log(*a); }); }                  \
+    gft_poly* PFX##pow(const gft_poly* a, uint32_t e) { return guard([&] { return Ops<E>::pow(*a, e); }); }   \
+    gft_poly* PFX##derivative(const gft_poly* a, size_t v, size_t n) {                                        \
+        return guard([&] { return Ops<E>::deriv_like(*a, v, n, TAB_DERIV, "derivative"); });                  \
+    }                                                                                                         \
+    gft_poly* PFX##taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n) {                         \
+        return guard([&] { return Ops<E>::deriv_like(*a, v, n, TAB_COEFF, "taylor_expansion_of_coeff"); });   \
+    }                                                                                                         \
+    gft_poly* PFX##shift_down(const gft_poly* a, size_t v, size_t n) { return guard([&] { return Ops<E>::shift_down(*a, v, n); }); } \
+    gft_poly* PFX##subst_var(const gft_poly* a, size_t v, const gft_poly* s) {                                \
+        return guard([&] { return Ops<E>::subst_var(*a, v, *s); });                                           \
+    }                                                                                                         \
+    gft_poly* PFX##coefficients_of_term(const gft_poly* a, size_t v, size_t o) {                              \
+        return guard([&] { return Ops<E>::coefficients_of_term(*a, v, o); });                                 \
+    }                                                                                                         \
+    gft_poly* PFX##taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders, size_t n) {     \
+        return guard([&] { return Ops<E>::taylor_polynomial_terms(*a, v, dims(orders, n)); });                \
+    }                                                                                                         \
+    gft_poly* PFX##truncate_to_degree_p1(const gft_poly* a, size_t d) {                                       \
+        return guard([&] { return Ops<E>::truncate_to_degree_p1(*a, d); });                                   \
+    }                                                                                                         \
+    gft_poly* PFX##remove_last_variable(const gft_poly* a) { return guard([&] { return Ops<E>::remove_last_variable(*a); }); } \
+    gft_poly* PFX##extend_to_dim(const gft_poly* a, size_t nd, size_t d) {                                    \
+        return guard([&] { return Ops<E>::extend_to_dim(*a, nd, d); });                                       \
+    }                                                                                                         \
+    gft_poly* PFX##extend(const gft_poly* a, const size_t* ns, size_t n) {                                    \
+        return guard([&] { return Ops<E>::extend(*a, dims(ns, n)); });                                        \
+    }                                                                                                         \
+    gft_poly* PFX##mul_var(const gft_poly* a, const double* m, size_t v, const size_t* sh, const size_t* dg, size_t n) { \
+        return guard([&] { return Ops<E>::mul_var(*a, m, v, dims(sh, n), dims(dg, n)); });                    \
+    }                                                                                                         \
+    gft_poly* PFX##mul_linear(const gft_poly* a, const double* c, const double* m, size_t v, const size_t* sh, \
+                              const size_t* dg, size_t n) {                                                   \
+        return guard([&] { return Ops<E>::mul_linear(*a, c, m, v, dims(sh, n), dims(dg, n)); });              \
+    }                                                                                                         \
+    }
+
+GFT_API(gft_, EF64)
+GFT_API(gfti_, EIv)

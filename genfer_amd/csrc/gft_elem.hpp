@@ -1,0 +1,125 @@
+// Element types of the Taylor tensors on the device: F64 (src/number/f64.rs) and
+// Interval<F64> (src/interval.rs) with identical static interfaces, so every structural kernel
+// is written once.  Interval tensors are stored as two planes (lo, hi) `plane` doubles apart.
+//
+// The whole library is compiled with -ffp-contract=off: the reference never fuses a*b+c and
+// Interval widening assumes separately rounded operations.  FMA is used only where a kernel
+// asks for it explicitly (the tiled f64 convolution).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace gft {
+
+struct Scalar2 {  // a scalar crossing the host->kernel boundary: {v,unused} or {lo,hi}
+    double a, b;
+};
+
+struct EF64 {
+    typedef double V;
+    static constexpr int W = 1;
+    __device__ static V ld(const double* p, size_t, size_t i) { return p[i]; }
+    __device__ static void st(double* p, size_t, size_t i, V v) { p[i] = v; }
+    __device__ static V from(Scalar2 s) { return s.a; }
+    __device__ static V zero() { return 0.0; }
+    __device__ static V one() { return 1.0; }
+    __device__ static V from_u32(unsigned u) { return (double)u; }  // f64.rs:19-24
+    __device__ static bool is_zero(V x) { return x == 0.0; }        // f64.rs:181-183
+    __device__ static bool eq(V a, V b) { return a == b; }
+    __device__ static V neg(V a) { return -a; }
+    __device__ static V add(V a, V b) { return a + b; }
+    __device__ static V sub(V a, V b) { return a - b; }
+    __device__ static V mul(V a, V b) { return a * b; }
+    __device__ static V div(V a, V b) { return a / b; }
+    __device__ static V exp(V a) { return ::exp(a); }  // f64.rs:54-56
+    __device__ static V log(V a) { return ::log(a); }  // f64.rs:59-61
+};
+
+// f64.rs:127-171 — integer arithmetic on the bits.
+__device__ inline double next_up(double x) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    if (x != x || bits == 0x7ff0000000000000ULL) return x;
+    unsigned long long a = bits & 0x7fffffffffffffffULL;
+    unsigned long long nx = (a == 0) ? 0x1ULL : (bits == a ? bits + 1 : bits - 1);
+    return __longlong_as_double((long long)nx);
+}
+__device__ inline double next_down(double x) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    if (x != x || bits == 0xfff0000000000000ULL) return x;
+    unsigned long long a = bits & 0x7fffffffffffffffULL;
+    unsigned long long nx = (a == 0) ? 0x8000000000000001ULL : (bits == a ? bits - 1 : bits + 1);
+    return __longlong_as_double((long long)nx);
+}
+__device__ inline double fmin_ref(double a, double b) { return a < b ? a : b; }  // f64.rs:68-74
+__device__ inline double fmax_ref(double a, double b) { return a > b ? a : b; }  // f64.rs:77-83
+__device__ inline bool finite_d(double x) { return (x - x) == 0.0; }
+
+struct Iv {
+    double lo, hi;
+};
+
+struct EIv {
+    typedef Iv V;
+    static constexpr int W = 2;
+    __device__ static V ld(const double* p, size_t plane, size_t i) { return Iv{p[i], p[plane + i]}; }
+    __device__ static void st(double* p, size_t plane, size_t i, V v) {
+        p[i] = v.lo;
+        p[plane + i] = v.hi;
+    }
+    __device__ static V from(Scalar2 s) { return Iv{s.a, s.b}; }
+    __device__ static V zero() { return Iv{0.0, 0.0}; }
+    __device__ static V one() { return Iv{1.0, 1.0}; }
+    __device__ static V from_u32(unsigned u) { return Iv{(double)u, (double)u}; }  // interval.rs:80-85
+    __device__ static V widen(double lo, double hi) { return Iv{next_down(lo), next_up(hi)}; }  // :28-31
+    __device__ static bool is_zero(V x) { return x.lo == 0.0 && x.hi == 0.0; }   // :100-103
+    __device__ static bool is_one(V x) { return x.lo == 1.0 && x.hi == 1.0; }    // :112-115
+    __device__ static bool is_finite(V x) { return finite_d(x.lo) && finite_d(x.hi); }
+    __device__ static bool is_nan(V x) { return x.lo != x.lo || x.hi != x.hi; }
+    __device__ static bool eq(V a, V b) { return a.lo == b.lo && a.hi == b.hi; }
+    __device__ static V neg(V a) { return Iv{-a.hi, -a.lo}; }                     // :117-124
+    __device__ static V add(V a, V b) {                                           // :126-139
+        if (is_zero(a)) return b;
+        if (is_zero(b)) return a;
+        return widen(a.lo + b.lo, a.hi + b.hi);
+    }
+    __device__ static V sub(V a, V b) { return add(a, neg(b)); }                  // :148-155
+    __device__ static V mul(V a, V b) {                                           // :164-190
+        if ((is_zero(a) && is_finite(b)) || (is_finite(a) && is_zero(b))) return zero();
+        if (is_one(a)) return b;
+        if (is_one(b)) return a;
+        if (is_one(neg(a))) return neg(b);
+        if (is_one(neg(b))) return neg(a);
+        double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
+        return widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
+    }
+    __device__ static V div(V a, V b) {                                           // :199-234
+        if (is_nan(a) || is_nan(b)) {
+            double n = __longlong_as_double(0x7ff8000000000000LL);
+            return Iv{n, n};
+        }
+        if (is_zero(a) && !is_zero(b)) return a;
+        if (is_one(b)) return a;
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        double lo = inf, hi = -inf;
+        if (b.lo <= 0.0 && 0.0 <= b.hi) {
+            if (0.0 <= a.lo) hi = inf; else lo = -inf;
+            if (a.hi <= 0.0) lo = -inf; else hi = inf;
+        }
+        double p = a.lo / b.lo, q = a.lo / b.hi, r = a.hi / b.lo, s = a.hi / b.hi;
+        lo = fmin_ref(fmin_ref(fmin_ref(fmin_ref(lo, p), q), r), s);
+        hi = fmax_ref(fmax_ref(fmax_ref(fmax_ref(hi, p), q), r), s);
+        return widen(lo, hi);
+    }
+    __device__ static V exp(V a) {                                                // :264-269
+        if (is_zero(a)) return one();
+        return widen(::exp(a.lo), ::exp(a.hi));
+    }
+    __device__ static V log(V a) {                                                // :271-276
+        if (is_one(a)) return zero();
+        return widen(::log(a.lo), ::log(a.hi));
+    }
+};
+
+}  // namespace gft

@@ -1,0 +1,543 @@
+// Structural / streaming / reduction kernels and the reference-order convolution for gfx950.
+// All of these are HBM- or latency-bound index/copy work: coalesced along the innermost axis,
+// grid-stride loops capped at 2048 workgroups of 256 threads (4 waves), no LDS needed.  The
+// compute-bound product lives in gft_conv_tiled.hip.
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+static inline unsigned grid_for(size_t n, unsigned block = 256) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 blocks; the rest is grid-strided
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather: structured strided copy with optional scaling / per-slab table / keep-mask
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, size_t src_plane,
+                                                double* __restrict__ out, size_t out_plane, GatherArgs a,
+                                                size_t total) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin;
+        size_t soff = 0;
+        bool valid = true;
+        unsigned kaxis = 0;
+#pragma unroll 1
+        for (int ax = a.out.nd - 1; ax >= 0; --ax) {
+            unsigned d = a.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            long long si = (long long)k + a.shift[ax];
+            if (si < 0 || si >= (long long)a.src_len[ax]) valid = false;
+            soff += (size_t)(si < 0 ? 0 : si) * a.src_stride[ax];
+            if (ax == a.tab_axis) kaxis = k;
+        }
+        if (valid && a.keep && !a.keep[kaxis]) valid = false;
+        V v = E::zero();
+        if (valid) {
+            v = E::ld(src, src_plane, soff);
+            switch (a.op) {
+                case OP_MUL_S: v = E::mul(v, E::from(a.s)); break;
+                case OP_DIV_S: v = E::div(v, E::from(a.s)); break;
+                case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
+                case OP_NEG: v = E::neg(v); break;
+                case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                default: break;
+            }
+        }
+        E::st(out, out_plane, lin, v);
+    }
+}
+
+template <class E>
+void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* out, size_t out_plane,
+                  const GatherArgs& a) {
+    size_t total = 1;
+    for (int i = 0; i < a.out.nd; ++i) total *= a.out.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_gather<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, a,
+                       total);
+}
+
+// ------------------------------------------------------------------------------------------
+// add / sub of two leading blocks into a zero tensor (mt:873-880, 927-934)
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void __launch_bounds__(256) k_addsub_padded(DView out, DView a, DView b, int subtract, size_t total) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, aoff = 0, boff = 0, astr = 1, bstr = 1;
+        bool ina = true, inb = true;
+#pragma unroll 1
+        for (int ax = out.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = out.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k >= a.sh.d[ax]) ina = false;
+            if (k >= b.sh.d[ax]) inb = false;
+            aoff += k * astr;
+            boff += k * bstr;
+            astr *= a.sh.d[ax];
+            bstr *= b.sh.d[ax];
+        }
+        V v = E::zero();
+        if (ina) v = E::add(v, E::ld(a.p, a.plane, aoff));
+        if (inb) {
+            V w = E::ld(b.p, b.plane, boff);
+            v = subtract ? E::sub(v, w) : E::add(v, w);
+        }
+        E::st(out.p, out.plane, lin, v);
+    }
+}
+
+template <class E>
+void K<E>::addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract) {
+    size_t total = 1;
+    for (int i = 0; i < out.sh.nd; ++i) total *= out.sh.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_addsub_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, subtract, total);
+}
+
+// ------------------------------------------------------------------------------------------
+// tiny scalar kernels
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void k_first_elem(double* p, size_t plane, int op, const double* s, size_t s_plane) {
+    typename E::V x = E::ld(p, plane, 0), y = E::ld(s, s_plane, 0);
+    E::st(p, plane, 0, op == FIRST_ADD ? E::add(x, y) : E::sub(x, y));
+}
+template <class E>
+void K<E>::first_elem(hipStream_t st, double* p, size_t plane, int op, const double* s, size_t s_plane) {
+    hipLaunchKernelGGL(k_first_elem<E>, dim3(1), dim3(1), 0, st, p, plane, op, s, s_plane);
+}
+
+template <class E>
+__global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b, size_t bp, double* out,
+                            size_t op_plane) {
+    typename E::V x = E::ld(a, ap, 0);
+    typename E::V r;
+    if (op == SC_EXP) r = E::exp(x);
+    else if (op == SC_LOG) r = E::log(x);
+    else r = E::div(x, E::ld(b, bp, 0));
+    E::st(out, op_plane, 0, r);
+}
+template <class E>
+void K<E>::scalar_op(hipStream_t st, int op, const double* a, size_t a_plane, const double* b, size_t b_plane,
+                     double* out, size_t out_plane) {
+    hipLaunchKernelGGL(k_scalar_op<E>, dim3(1), dim3(1), 0, st, op, a, a_plane, b, b_plane, out, out_plane);
+}
+
+template <class E>
+__device__ inline typename E::V apply_map(typename E::V x, int op, unsigned u, typename E::V s) {
+    switch (op) {
+        case MAP_NEG: return E::neg(x);
+        case MAP_DIV_U32: return E::div(x, E::from_u32(u));
+        case MAP_MUL_U32: return E::mul(x, E::from_u32(u));
+        case MAP_MUL_S: return E::mul(x, s);
+        case MAP_DIV_S: return E::div(x, s);
+        case MAP_LMUL_S: return E::mul(s, x);
+        default: return x;
+    }
+}
+
+template <class E>
+__global__ void __launch_bounds__(256) k_map_inplace(double* p, size_t plane, size_t n, int op, unsigned u,
+                                                     Scalar2 s, const double* s_ptr, size_t s_plane) {
+    typename E::V sv = s_ptr ? E::ld(s_ptr, s_plane, 0) : E::from(s);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        E::st(p, plane, i, apply_map<E>(E::ld(p, plane, i), op, u, sv));
+}
+template <class E>
+void K<E>::map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, u, s,
+                       (const double*)nullptr, (size_t)0);
+}
+template <class E>
+void K<E>::map_inplace_dev(hipStream_t st, double* p, size_t plane, size_t n, int op, const double* s_ptr,
+                           size_t s_plane) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, 0u, Scalar2{0, 0},
+                       s_ptr, s_plane);
+}
+
+// ------------------------------------------------------------------------------------------
+// block_op: dst[leading block of src's shape] (op)= src
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void __launch_bounds__(256) k_block_op(DView dst, DView src, int op, unsigned u, size_t total) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, doff = 0, dstr = 1;
+#pragma unroll 1
+        for (int ax = src.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = src.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            doff += k * dstr;
+            dstr *= dst.sh.d[ax];
+        }
+        V x = E::ld(src.p, src.plane, lin);
+        V rv;
+        if (op == BLK_ASSIGN) rv = x;
+        else {
+            V cur = E::ld(dst.p, dst.plane, doff);
+            rv = (op == BLK_ADD) ? E::add(cur, x) : E::add(cur, E::mul(E::from_u32(u), x));
+        }
+        E::st(dst.p, dst.plane, doff, rv);
+    }
+}
+template <class E>
+void K<E>::block_op(hipStream_t st, const DView& dst, const DView& src, int op, unsigned u) {
+    size_t total = 1;
+    for (int i = 0; i < src.sh.nd; ++i) total *= src.sh.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_block_op<E>, dim3(grid_for(total)), dim3(256), 0, st, dst, src, op, u, total);
+}
+
+// ------------------------------------------------------------------------------------------
+// sequential 1-D recurrences (one lane; n is a few hundred at most in the reference's workloads)
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void k_exp_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n) {
+    typedef typename E::V V;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    E::st(res, rp, 0, E::exp(E::ld(xs, xp, 0)));
+    for (unsigned k = 1; k < n; ++k) {
+        V sum = E::zero();
+        unsigned hi = nx < k + 1 ? nx : k + 1;
+        for (unsigned j = 1; j < hi; ++j)
+            sum = E::add(sum, E::mul(E::mul(E::ld(xs, xp, j), E::from_u32(j)), E::ld(res, rp, k - j)));
+        E::st(res, rp, k, E::div(sum, E::from_u32(k)));
+    }
+}
+template <class E>
+void K<E>::exp_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
+                  unsigned n) {
+    hipLaunchKernelGGL(k_exp_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n);
+}
+
+template <class E>
+__global__ void k_log_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n) {
+    typedef typename E::V V;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V x0 = E::ld(xs, xp, 0);
+    E::st(res, rp, 0, E::log(x0));
+    for (unsigned k = 1; k < n; ++k) {
+        V sum = E::zero();
+        unsigned lo = (k + 1 > nx) ? (k + 1 - nx) : 0;
+        if (lo < 1) lo = 1;
+        for (unsigned j = lo; j < k; ++j)
+            sum = E::add(sum, E::mul(E::mul(E::ld(xs, xp, k - j), E::ld(res, rp, j)), E::from_u32(j)));
+        V xk = k < nx ? E::ld(xs, xp, k) : E::zero();
+        V num = E::sub(E::mul(xk, E::from_u32(k)), sum);
+        E::st(res, rp, k, E::div(E::div(num, x0), E::from_u32(k)));
+    }
+}
+template <class E>
+void K<E>::log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
+                  unsigned n) {
+    hipLaunchKernelGGL(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n);
+}
+
+template <class E>
+__global__ void k_div_1d(const double* xs, size_t xp, unsigned nx, const double* ys, size_t yp, unsigned ny,
+                         double* res, size_t rp, unsigned n) {
+    typedef typename E::V V;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V y0 = E::ld(ys, yp, 0);
+    for (unsigned k = 0; k < n; ++k) {
+        V cur = E::zero();
+        unsigned lo = (k + 1 > ny) ? (k + 1 - ny) : 0;
+        for (unsigned j = lo; j < k; ++j) cur = E::add(cur, E::mul(E::ld(res, rp, j), E::ld(ys, yp, k - j)));
+        cur = E::neg(cur);
+        if (k < nx) cur = E::add(cur, E::ld(xs, xp, k));
+        E::st(res, rp, k, E::div(cur, y0));
+    }
+}
+template <class E>
+void K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys, size_t y_plane,
+                  unsigned ny, double* res, size_t r_plane, unsigned n) {
+    hipLaunchKernelGGL(k_div_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
+}
+
+template <class E>
+__global__ void k_factor_table(int op, unsigned n, unsigned len, const double* m, size_t mp, double* tab,
+                               size_t tp) {
+    typedef typename E::V V;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (op == TAB_DERIV) {  // mt:472-478
+        V ff = E::one();
+        for (unsigned i = 1; i <= n; ++i) ff = E::mul(ff, E::from_u32(i));
+        for (unsigned k = 0; k < len; ++k) {
+            E::st(tab, tp, k, ff);
+            ff = E::mul(ff, E::div(E::from_u32(n + k + 1), E::from_u32(k + 1)));
+        }
+    } else if (op == TAB_COEFF) {  // mt:499-506 (slab 0 is left untouched: factor one)
+        V f = E::one();
+        E::st(tab, tp, 0, f);
+        for (unsigned k = 1; k < len; ++k) {
+            f = E::mul(f, E::div(E::from_u32(n + k), E::from_u32(k)));
+            E::st(tab, tp, k, f);
+        }
+    } else if (op == TAB_POW) {  // mt:557-565
+        V f = E::one();
+        V mv = E::ld(m, mp, 0);
+        for (unsigned k = 0; k < len; ++k) {
+            E::st(tab, tp, k, f);
+            f = E::mul(f, mv);
+        }
+    } else {  // TAB_INDEX: tab[k] = T::from(k)  (exp/log pre-scaling, mt:1309, 1364)
+        for (unsigned k = 0; k < len; ++k) E::st(tab, tp, k, E::from_u32(k));
+    }
+}
+template <class E>
+void K<E>::factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
+                        double* tab, size_t tab_plane) {
+    hipLaunchKernelGGL(k_factor_table<E>, dim3(1), dim3(64), 0, st, op, n, len, m, m_plane, tab, tab_plane);
+}
+
+// ------------------------------------------------------------------------------------------
+// extract_linear predicate (mt:275-294) for all axes at once
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void __launch_bounds__(256) k_linear_mask(DView t, unsigned* mask, size_t total) {
+    unsigned local = 0xffffffffu;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
+        // a non-zero entry at multi-index I is compatible with "linear in axis a" iff I == 0 or I == e_a
+        size_t r = lin;
+        int nonzero_axes = 0, which = -1;
+        bool unit = true;
+#pragma unroll 1
+        for (int ax = t.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = t.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k != 0) {
+                nonzero_axes++;
+                which = ax;
+                if (k != 1) unit = false;
+            }
+        }
+        if (nonzero_axes == 0) continue;
+        if (nonzero_axes == 1 && unit) local &= (1u << which);
+        else local = 0;
+    }
+    // wave-level AND, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local != 0xffffffffu) atomicAnd(mask, local);
+}
+template <class E>
+void K<E>::linear_mask(hipStream_t st, const DView& t, unsigned* mask) {
+    size_t total = 1;
+    for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_linear_mask<E>, dim3(grid_for(total)), dim3(256), 0, st, t, mask, total);
+}
+
+// ------------------------------------------------------------------------------------------
+// axis sums (shift_down, mt:514-536)
+// ------------------------------------------------------------------------------------------
+// One thread per output (o, i): coalesced across i; sequential ascending k == ndarray's
+// slab-by-slab `res = res + view` order.  SUM_UNROLL8 reproduces ndarray's 8-accumulator fold.
+template <class E>
+__global__ void __launch_bounds__(256) k_sum_axis_seq(const double* __restrict__ in, size_t ip, unsigned outer,
+                                                      unsigned len, unsigned inner, size_t outer_stride,
+                                                      double* __restrict__ out, size_t op, int mode) {
+    typedef typename E::V V;
+    size_t total = (size_t)outer * inner;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        unsigned i = (unsigned)(lin % inner);
+        size_t o = lin / inner;
+        const size_t base = o * outer_stride + i;
+        V acc = E::zero();
+        if (mode == SUM_UNROLL8) {
+            V p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = E::zero();
+            unsigned k = 0;
+            for (; k + 8 <= len; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = E::add(p[u], E::ld(in, ip, base + (size_t)(k + u) * inner));
+            }
+            acc = E::add(acc, E::add(p[0], p[4]));
+            acc = E::add(acc, E::add(p[1], p[5]));
+            acc = E::add(acc, E::add(p[2], p[6]));
+            acc = E::add(acc, E::add(p[3], p[7]));
+            for (; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
+        } else {
+            for (unsigned k = 0; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
+        }
+        E::st(out, op, lin, acc);
+    }
+}
+
+// Innermost-axis sum of f64 rows: one 64-lane wave per row, coalesced loads, butterfly reduction
+// with wavefront shuffles.  (Different summation order than the reference: 1e-10 parity row A13.)
+__global__ void __launch_bounds__(256) k_sum_last_axis_wave(const double* __restrict__ in, unsigned rows,
+                                                            unsigned len, size_t row_stride,
+                                                            double* __restrict__ out) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave_in_block = threadIdx.x >> 6;
+    const unsigned waves_per_block = blockDim.x >> 6;
+    for (size_t row = (size_t)blockIdx.x * waves_per_block + wave_in_block; row < rows;
+         row += (size_t)gridDim.x * waves_per_block) {
+        const double* p = in + row * row_stride;
+        double acc = 0.0;
+        for (unsigned k = lane; k < len; k += 64) acc += p[k];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) out[row] = acc;
+    }
+}
+
+template <class E>
+void K<E>::sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
+                    unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode) {
+    size_t total = (size_t)outer * inner;
+    if (total == 0) return;
+    if (mode == SUM_WAVE && E::W == 1 && inner == 1) {
+        size_t blocks = (outer + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_sum_last_axis_wave, dim3((unsigned)blocks), dim3(256), 0, st, in, outer, len,
+                           axis_stride_outer, out);
+        return;
+    }
+    hipLaunchKernelGGL(k_sum_axis_seq<E>, dim3(grid_for(total)), dim3(256), 0, st, in, in_plane, outer, len, inner,
+                       axis_stride_outer, out, out_plane, mode == SUM_WAVE ? SUM_SEQ : mode);
+}
+
+// ------------------------------------------------------------------------------------------
+// equality
+// ------------------------------------------------------------------------------------------
+template <class E>
+__global__ void __launch_bounds__(256) k_count_neq(const double* a, size_t ap, const double* b, size_t bp, size_t n,
+                                                   unsigned* count) {
+    unsigned local = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (!E::eq(E::ld(a, ap, i), E::ld(b, bp, i))) local++;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+template <class E>
+void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const double* b, size_t b_plane, size_t n,
+                     unsigned* count) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
+}
+
+// ------------------------------------------------------------------------------------------
+// Reference-order convolution: one thread per output element, loops in exactly the reference's
+// order (outer axes lexicographic ascending, innermost partial sum from zero), separate
+// multiply and add => bit-identical to the CPU algorithm for f64.  Used for small tensors, for
+// interval tensors, for rank > 4 and as the on-device cross-check of the tiled kernel.
+// ------------------------------------------------------------------------------------------
+template <class E, int AX, int ND, bool INNER0>
+struct ConvLoop {
+    __device__ static inline void run(const ConvArgs& a, const unsigned* k, const double* x, size_t xp,
+                                      const double* y, size_t yp, size_t xoff, size_t yoff,
+                                      typename E::V& acc) {
+        typedef typename E::V V;
+        const unsigned kk = k[AX];
+        unsigned lo = (kk + 1 > a.ys[AX]) ? (kk + 1 - a.ys[AX]) : 0;
+        unsigned hi = (kk + 1 < a.xs[AX]) ? (kk + 1) : a.xs[AX];
+        bool desc = false;
+        if (AX == 0) {
+            if (lo < (unsigned)a.j0_min) lo = (unsigned)a.j0_min;
+            if (a.j0_excl && hi > kk) hi = kk;
+            desc = a.j0_desc != 0;
+        }
+        if (hi <= lo) return;
+        if constexpr (AX == ND - 1) {
+            if (INNER0) {
+                V inner = E::zero();
+                for (unsigned j = lo; j < hi; ++j)
+                    inner = E::add(inner, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[AX]),
+                                                 E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[AX])));
+                acc = E::add(acc, inner);
+            } else {
+                const unsigned cnt = hi - lo;
+                for (unsigned t = 0; t < cnt; ++t) {
+                    unsigned j = desc ? (hi - 1 - t) : (lo + t);
+                    acc = E::add(acc, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[AX]),
+                                             E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[AX])));
+                }
+            }
+        } else {
+            const unsigned cnt = hi - lo;
+            for (unsigned t = 0; t < cnt; ++t) {
+                unsigned j = desc ? (hi - 1 - t) : (lo + t);
+                ConvLoop<E, (AX + 1 < ND ? AX + 1 : AX), ND, INNER0>::run(
+                    a, k, x, xp, y, yp, xoff + (size_t)j * a.xstr[AX], yoff + (size_t)(kk - j) * a.ystr[AX], acc);
+            }
+        }
+    }
+};
+
+template <class E, int ND, bool INNER0>
+__global__ void __launch_bounds__(256) k_conv_naive(const double* __restrict__ x, size_t xp,
+                                                    const double* __restrict__ y, size_t yp,
+                                                    double* __restrict__ z, size_t zp, ConvArgs a, size_t total,
+                                                    size_t slab_elems) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t zlin = lin + (size_t)a.slab_lo * slab_elems;
+        unsigned k[ND > 0 ? ND : 1];
+        size_t r = zlin;
+#pragma unroll
+        for (int ax = ND - 1; ax >= 0; --ax) {
+            unsigned d = a.zs[ax];
+            k[ax] = (unsigned)(r % d);
+            r /= d;
+        }
+        V acc = a.accumulate ? E::ld(z, zp, zlin) : E::zero();
+        if (ND == 0) {
+            acc = E::add(acc, E::mul(E::ld(x, xp, 0), E::ld(y, yp, 0)));
+        } else {
+            ConvLoop<E, 0, (ND > 0 ? ND : 1), INNER0>::run(a, k, x, xp, y, yp, 0, 0, acc);
+        }
+        E::st(z, zp, zlin, acc);
+    }
+}
+
+template <class E, bool INNER0>
+static void launch_conv_naive(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z,
+                              size_t zp, const ConvArgs& a) {
+    size_t slab = 1;
+    for (int i = 1; i < a.nd; ++i) slab *= a.zs[i];
+    size_t total = (a.nd == 0) ? 1 : (size_t)(a.slab_hi - a.slab_lo) * slab;
+    if (total == 0) return;
+    dim3 g(grid_for(total)), b(256);
+#define GFT_CASE(N)                                                                                         \
+    case N:                                                                                                 \
+        hipLaunchKernelGGL((k_conv_naive<E, N, INNER0>), g, b, 0, st, x, xp, y, yp, z, zp, a, total, slab); \
+        break;
+    switch (a.nd) {
+        GFT_CASE(0) GFT_CASE(1) GFT_CASE(2) GFT_CASE(3) GFT_CASE(4) GFT_CASE(5) GFT_CASE(6) GFT_CASE(7)
+        GFT_CASE(8) GFT_CASE(9) GFT_CASE(10) GFT_CASE(11) GFT_CASE(12)
+        default: break;
+    }
+#undef GFT_CASE
+}
+
+template <class E>
+void K<E>::conv_naive(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z,
+                      size_t z_plane, const ConvArgs& a) {
+    if (a.inner_from_zero) launch_conv_naive<E, true>(st, x, x_plane, y, y_plane, z, z_plane, a);
+    else launch_conv_naive<E, false>(st, x, x_plane, y, y_plane, z, z_plane, a);
+}
+
+template struct K<EF64>;
+template struct K<EIv>;
+
+}  // namespace gft

@@ -1,0 +1,113 @@
+// Launcher declarations for the HIP kernels (definitions in gft_kernels.hip / gft_conv_tiled.hip).
+// Everything operates on contiguous row-major device tensors ("views") of f64 or interval
+// (two-plane) elements.  No launcher synchronises the stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "gft_elem.hpp"
+
+namespace gft {
+
+constexpr int MAXD = 12;  // max tensor rank after unit-axis collapsing (reference programs: <= 8 vars)
+
+struct Shape {
+    int nd;
+    unsigned d[MAXD];
+};
+
+// A contiguous row-major tensor (or sub-block starting at p) in device memory.  For interval
+// tensors the hi plane lives `plane` doubles after the lo plane.
+struct DView {
+    double* p;
+    size_t plane;
+    Shape sh;
+};
+
+enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB = 4, OP_LMUL_S = 5 };
+enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_DIV_S = 4, MAP_LMUL_S = 5 };
+enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1 };
+enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
+enum ScalarOp { SC_EXP = 0, SC_LOG = 1, SC_DIV = 2 };
+enum TableOp { TAB_DERIV = 0, TAB_COEFF = 1, TAB_POW = 2, TAB_INDEX = 3 };
+
+struct GatherArgs {
+    Shape out;                  // output (contiguous) shape
+    int shift[MAXD];            // src index along axis a = k_a + shift[a]
+    unsigned src_len[MAXD];     // valid src index range [0, src_len[a]); outside -> zero
+    size_t src_stride[MAXD];    // src element strides
+    int op;                     // GatherOp
+    Scalar2 s;
+    int tab_axis;               // axis whose OUTPUT index selects tab[] / keep[]
+    const double* tab;          // OP_MUL_TAB: x * tab[k_axis]  (interval: two planes, tab_plane apart)
+    size_t tab_plane;
+    const unsigned char* keep;  // optional: keep[k_axis] == 0 -> write zero
+};
+
+struct ConvArgs {
+    int nd;
+    unsigned xs[MAXD], ys[MAXD], zs[MAXD];
+    size_t xstr[MAXD], ystr[MAXD], zstr[MAXD];
+    unsigned slab_lo, slab_hi;  // output range on axis 0
+    int accumulate;             // 0: start from zero, 1: start from the stored value
+    int j0_min;                 // exp/log recurrences start at j = 1
+    int j0_excl;                // 1: exclude j0 == k0 (div/log: res[k] is not known yet)
+    int j0_desc;                // iterate j0 downwards (log's summation order)
+    int inner_from_zero;        // last axis' partial sum is formed from zero, then added (mul_1d, mt:971-982)
+};
+
+template <class E>
+struct K {
+    // out[k] = f(src[k + shift]) or zero outside the source box
+    static void gather(hipStream_t st, const double* src, size_t src_plane, double* out, size_t out_plane,
+                       const GatherArgs& a);
+    // out[k] = ((0 + a[k]?) +/- b[k]?) with a, b leading blocks of out's shape  (mt:873-880, 927-934)
+    static void addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract);
+    // p[0] = p[0] (+|-) s
+    static void first_elem(hipStream_t st, double* p, size_t plane, int op, const double* s, size_t s_plane);
+    // in-place elementwise map over n contiguous elements
+    static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
+    // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])
+    static void map_inplace_dev(hipStream_t st, double* p, size_t plane, size_t n, int op, const double* s_ptr,
+                                size_t s_plane);
+    // dst (contiguous, shape D) leading block of src's shape: BLK_ADD r += x ; BLK_ADD_U32_TIMES r += u*x ; BLK_ASSIGN r = x
+    static void block_op(hipStream_t st, const DView& dst, const DView& src, int op, unsigned u);
+    // 0-dim ops: out = exp(a) | log(a) | a / b
+    static void scalar_op(hipStream_t st, int op, const double* a, size_t a_plane, const double* b, size_t b_plane,
+                          double* out, size_t out_plane);
+    // sequential 1-D recurrences (mt:1270-1283, 1319-1333)
+    static void exp_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
+                       unsigned n);
+    static void log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
+                       unsigned n);
+    // last-axis level of the division recurrence (mt:1162-1192 with 0-dim base): res = xs / ys, 1-D
+    static void div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys,
+                       size_t y_plane, unsigned ny, double* res, size_t r_plane, unsigned n);
+    // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
+    static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
+                             double* tab, size_t tab_plane);
+    // bit a of *mask stays set iff the tensor is "linear in axis a" (mt:275-294); *mask pre-set by the host
+    static void linear_mask(hipStream_t st, const DView& t, unsigned* mask);
+    // out[o, i] = sum_k in[o, k, i] (sequential ascending k; unrolled8 = ndarray's 8-way fold for the lane)
+    static void sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
+                         unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode);
+    // *count += number of positions where a != b  (n contiguous elements)
+    static void count_neq(hipStream_t st, const double* a, size_t a_plane, const double* b, size_t b_plane,
+                          size_t n, unsigned* count);
+    // reference-order truncated N-d Cauchy product, one thread per output element (mt:984-1012)
+    static void conv_naive(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane,
+                           double* z, size_t z_plane, const ConvArgs& a);
+};
+
+enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
+
+// LDS-tiled f64 convolution (gft_conv_tiled.hip).  Returns false if the shape is not supported
+// by the tiled kernel (caller falls back to conv_naive).  `ws`/`ws_bytes`: workspace for
+// split-J partial tiles (may be null to query the needed size via *ws_needed).
+bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
+                    size_t ws_bytes, size_t* ws_needed);
+
+}  // namespace gft

@@ -1,0 +1,188 @@
+/* gftaylor — C ABI of the MI355X-native multivariate-Taylor arithmetic core.
+ *
+ * This is the drop-in boundary for the hot path of fzaiser/genfer: the `TaylorPoly<T>` type of
+ * src/multivariate_taylor.rs, instantiated at T = F64 (prefix gft_) and T = Interval<F64>
+ * (prefix gfti_, `--bounds`).  The reference has no FFI today (the boundary is a Rust generic
+ * used only by src/generating_function.rs:8); each entry point below replaces one Rust item and
+ * cites it as `mt:<lines>` (= src/multivariate_taylor.rs).  INTEGRATION.md shows the Rust
+ * `extern "C"` block + newtype shim a maintainer would add.
+ *
+ * Model
+ *   - A polynomial is an opaque handle (`gft_poly*`).  Its coefficient tensor lives in HBM as a
+ *     contiguous row-major f64 array of the *compact* stored shape (mt:13-19); `degrees_p1`
+ *     (conceptual truncation orders, SIZE_MAX = untruncated) lives on the host.
+ *   - All value arithmetic runs in HIP kernels on gfx950.  There is no CPU fallback: if no
+ *     device / code object is available every call fails and gft_last_error() says why.
+ *   - The ABI is NON-consuming: `out = op(a, b)` never frees or mutates its inputs (the Rust
+ *     operators consume by value, mt:857,914,1017,1197; a shim maps that to "call, then drop").
+ *     Handles are immutable values; gft_clone is O(1) (shared device buffer).
+ *   - Single calling thread per process; one HIP stream (gft_set_stream to adopt the caller's).
+ *     The host only synchronises when a VALUE is inspected (to_host, coefficient, constant_term,
+ *     is_zero/is_one/extract_*, equal) — and data-dependent dispatch inside mul/div/subst_var
+ *     (mt:1021-1061), which the reference also performs.
+ *   - Errors: functions returning a handle return NULL, functions returning int return a
+ *     negative value; gft_last_error() holds the message.  Reference panics (assert!/unwrap,
+ *     `panic = "abort"`, Cargo.toml:29) map to such errors; IEEE inf/NaN propagate as values.
+ *   - Scalars cross the boundary as `const double*` pointing at WIDTH doubles: 1 for gft_
+ *     (the f64), 2 for gfti_ ({lo, hi}).  Coefficient data is plane-major: WIDTH planes of
+ *     numel doubles each (SoA (lo,hi) planes for intervals).
+ */
+#ifndef GFTAYLOR_H
+#define GFTAYLOR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gft_poly gft_poly;
+
+/* ---- runtime ------------------------------------------------------------------------- */
+/* Select the HIP device and create the stream + memory pool.  Idempotent. 0 on success. */
+int gft_init(int device);
+void gft_shutdown(void);
+/* Adopt an existing hipStream_t (e.g. torch's current stream); NULL restores the library's own. */
+int gft_set_stream(void* hip_stream);
+void* gft_get_stream(void);
+int gft_synchronize(void);
+const char* gft_last_error(void);
+/* Device-memory pool statistics in bytes: {in_use, cached, peak_in_use}. */
+void gft_pool_stats(size_t out[3]);
+/* hipEvent timing on the library's stream: record into slot 0..15, elapsed in ms (syncs on b). */
+int gft_event_record(int slot);
+float gft_event_elapsed_ms(int slot_a, int slot_b);
+/* Which convolution kernel `mul` may use: 0 = auto, 1 = force the simple one-thread-per-output
+ * kernel, 2 = force the LDS-tiled kernel (errors if the shape is unsupported).  Test/bench knob. */
+int gft_set_conv_mode(int mode);
+
+/* ---- raw device-pointer entry points (no handles) ---------------------------------------- */
+/* res[k] (+)= sum_j x[j]*y[k-j] for k0 in [slab_lo, slab_hi): the truncated N-d Cauchy product
+ * `mul` of mt:984-1012 on caller-owned contiguous row-major device buffers (e.g. torch tensors),
+ * restricted to a range of leading-axis output slabs — the unit of multi-GPU sharding and of the
+ * div/exp/log recurrences.  accumulate=0 overwrites the slabs, 1 adds to them.  Runs on the
+ * current stream; does not synchronise. */
+int gft_conv_raw(const double* x, const size_t* xshape, const double* y, const size_t* yshape, double* res,
+                 const size_t* rshape, size_t ndim, size_t slab_lo, size_t slab_hi, int accumulate);
+/* Exact multiply-accumulate count of those slabs (sum_k prod_v #{valid j_v}). */
+double gft_conv_macs(const size_t* xshape, const size_t* yshape, const size_t* rshape, size_t ndim,
+                     size_t slab_lo, size_t slab_hi);
+/* Leading-axis slab assignment for `world` ranks (work of slab k is proportional to the number
+ * of valid j0, i.e. triangular): writes for `rank` up to 2 half-open ranges
+ * {lo0,hi0,lo1,hi1} (folded: low group + mirrored high group).  Pure integer logic; needs no GPU.
+ * Returns 1 if every rank's two groups have equal sizes (all-gather friendly), 0 otherwise. */
+int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]);
+
+/* ---- constructors ------------------------------------------------------------------------- */
+gft_poly* gft_from_host(const double* coeffs, const size_t* shape, const size_t* degrees_p1,
+                        size_t ndim);                                   /* TaylorPoly::new        mt:33-41   */
+gft_poly* gft_scalar(const double* x);                                  /* From<T>                mt:626-630 */
+gft_poly* gft_from_u32(uint32_t c);                                     /* from_u32               mt:219-225 */
+gft_poly* gft_zero_with(const size_t* degrees_p1, size_t ndim);         /* zero_with              mt:208-216 */
+gft_poly* gft_var(size_t v, const double* x, size_t len);               /* var                    mt:239-248 */
+gft_poly* gft_var_at_zero(size_t v, size_t len);                        /* var_at_zero            mt:228-237 */
+gft_poly* gft_var_with_degrees_p1(size_t v, const double* x, const size_t* degrees_p1,
+                                  size_t ndim);                         /* var_with_degrees_p1    mt:250-259 */
+gft_poly* gft_clone(const gft_poly* p);                                 /* Clone                  mt:10      */
+void gft_free(gft_poly* p);                                             /* Drop                              */
+
+/* ---- queries ------------------------------------------------------------------------------ */
+int gft_width(void);                                                    /* 1 (gfti_width() = 2)              */
+size_t gft_num_vars(const gft_poly* p);                                 /* num_vars               mt:48-51   */
+size_t gft_numel(const gft_poly* p);                                    /* coeffs.len()                      */
+void gft_shape(const gft_poly* p, size_t* out);                         /* coeffs.shape() (compact)          */
+void gft_degrees_p1(const gft_poly* p, size_t* out);                    /* shape()                mt:53-56   */
+int gft_to_host(const gft_poly* p, double* out);                        /* array()/into_array     mt:58-66   */
+size_t gft_len_of(const gft_poly* p, size_t v);                         /* len_of                 mt:72-79   */
+int gft_is_constant(const gft_poly* p);                                 /* is_constant            mt:68-70   */
+int gft_is_zero(const gft_poly* p);                                     /* Zero::is_zero          mt:643-645 */
+int gft_is_one(const gft_poly* p);                                      /* One::is_one            mt:653-655 */
+int gft_equal(const gft_poly* a, const gft_poly* b);                    /* PartialEq              mt:10      */
+int gft_constant_term(const gft_poly* p, double* out);                  /* constant_term          mt:296-299 */
+int gft_extract_constant(const gft_poly* p, double* out);               /* extract_constant       mt:262-269 */
+int gft_extract_linear(const gft_poly* p, double* c, double* m, size_t* v); /* extract_linear     mt:275-294 */
+int gft_coefficient(const gft_poly* p, const size_t* index, size_t n, double* out); /* coefficient mt:314-339 */
+
+/* ---- algebra ------------------------------------------------------------------------------ */
+gft_poly* gft_add(const gft_poly* a, const gft_poly* b);                /* Add                    mt:854-882 */
+gft_poly* gft_sub(const gft_poly* a, const gft_poly* b);                /* Sub                    mt:911-937 */
+gft_poly* gft_neg(const gft_poly* a);                                   /* Neg                    mt:902-909 */
+gft_poly* gft_mul(const gft_poly* a, const gft_poly* b);                /* Mul + mul/mul_1d       mt:971-1072 */
+gft_poly* gft_div(const gft_poly* a, const gft_poly* b);                /* Div + div              mt:1162-1231 */
+gft_poly* gft_exp(const gft_poly* a);                                   /* exp                    mt:406-417,1270-1317 */
+gft_poly* gft_log(const gft_poly* a);                                   /* log                    mt:419-430,1319-1386 */
+gft_poly* gft_pow(const gft_poly* a, uint32_t e);                       /* pow                    mt:433-451 */
+
+/* ---- structure ---------------------------------------------------------------------------- */
+gft_poly* gft_derivative(const gft_poly* a, size_t v, size_t n);        /* derivative             mt:457-481 */
+gft_poly* gft_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n); /*                mt:484-509 */
+gft_poly* gft_shift_down(const gft_poly* a, size_t v, size_t n);        /* shift_down (axis sum)  mt:514-536 */
+gft_poly* gft_subst_var(const gft_poly* a, size_t v, const gft_poly* subst); /* subst_var (Taylor shift / marginalize / Horner) mt:540-580 */
+gft_poly* gft_coefficients_of_term(const gft_poly* a, size_t v, size_t order); /*                 mt:341-358 */
+gft_poly* gft_taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders,
+                                      size_t n);                        /*                        mt:380-404 */
+gft_poly* gft_truncate_to_degree_p1(const gft_poly* a, size_t degree_p1); /*                      mt:183-193 */
+gft_poly* gft_remove_last_variable(const gft_poly* a);                  /*                        mt:172-181 */
+gft_poly* gft_extend_to_dim(const gft_poly* a, size_t ndim, size_t degree_p1); /* extend          mt:81-89   */
+gft_poly* gft_extend(const gft_poly* a, const size_t* new_size, size_t n); /* (test-only) extend  mt:91-112  */
+gft_poly* gft_mul_var(const gft_poly* a, const double* m, size_t v, const size_t* shape,
+                      const size_t* degrees_p1, size_t n);              /* mul_var                mt:589-608 */
+gft_poly* gft_mul_linear(const gft_poly* a, const double* c, const double* m, size_t v,
+                         const size_t* shape, const size_t* degrees_p1, size_t n); /* mul_linear  mt:611-623 */
+
+/* ---- Interval<F64> twins (src/interval.rs; `--bounds`, main.rs:115-127) -------------------- */
+/* Same functions with prefix gfti_; scalars are {lo,hi}, data is two planes (lo then hi).      */
+#define GFT_DECLARE_INTERVAL_TWINS 1
+const char* gfti_last_error(void);
+int gfti_width(void);
+gft_poly* gfti_from_host(const double* planes, const size_t* shape, const size_t* degrees_p1, size_t ndim);
+gft_poly* gfti_scalar(const double* x);
+gft_poly* gfti_from_u32(uint32_t c);
+gft_poly* gfti_zero_with(const size_t* degrees_p1, size_t ndim);
+gft_poly* gfti_var(size_t v, const double* x, size_t len);
+gft_poly* gfti_var_at_zero(size_t v, size_t len);
+gft_poly* gfti_var_with_degrees_p1(size_t v, const double* x, const size_t* degrees_p1, size_t ndim);
+gft_poly* gfti_clone(const gft_poly* p);
+void gfti_free(gft_poly* p);
+size_t gfti_num_vars(const gft_poly* p);
+size_t gfti_numel(const gft_poly* p);
+void gfti_shape(const gft_poly* p, size_t* out);
+void gfti_degrees_p1(const gft_poly* p, size_t* out);
+int gfti_to_host(const gft_poly* p, double* out);
+size_t gfti_len_of(const gft_poly* p, size_t v);
+int gfti_is_constant(const gft_poly* p);
+int gfti_is_zero(const gft_poly* p);
+int gfti_is_one(const gft_poly* p);
+int gfti_equal(const gft_poly* a, const gft_poly* b);
+int gfti_constant_term(const gft_poly* p, double* out);
+int gfti_extract_constant(const gft_poly* p, double* out);
+int gfti_extract_linear(const gft_poly* p, double* c, double* m, size_t* v);
+int gfti_coefficient(const gft_poly* p, const size_t* index, size_t n, double* out);
+gft_poly* gfti_add(const gft_poly* a, const gft_poly* b);
+gft_poly* gfti_sub(const gft_poly* a, const gft_poly* b);
+gft_poly* gfti_neg(const gft_poly* a);
+gft_poly* gfti_mul(const gft_poly* a, const gft_poly* b);
+gft_poly* gfti_div(const gft_poly* a, const gft_poly* b);
+gft_poly* gfti_exp(const gft_poly* a);
+gft_poly* gfti_log(const gft_poly* a);
+gft_poly* gfti_pow(const gft_poly* a, uint32_t e);
+gft_poly* gfti_derivative(const gft_poly* a, size_t v, size_t n);
+gft_poly* gfti_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n);
+gft_poly* gfti_shift_down(const gft_poly* a, size_t v, size_t n);
+gft_poly* gfti_subst_var(const gft_poly* a, size_t v, const gft_poly* subst);
+gft_poly* gfti_coefficients_of_term(const gft_poly* a, size_t v, size_t order);
+gft_poly* gfti_taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders, size_t n);
+gft_poly* gfti_truncate_to_degree_p1(const gft_poly* a, size_t degree_p1);
+gft_poly* gfti_remove_last_variable(const gft_poly* a);
+gft_poly* gfti_extend_to_dim(const gft_poly* a, size_t ndim, size_t degree_p1);
+gft_poly* gfti_extend(const gft_poly* a, const size_t* new_size, size_t n);
+gft_poly* gfti_mul_var(const gft_poly* a, const double* m, size_t v, const size_t* shape,
+                       const size_t* degrees_p1, size_t n);
+gft_poly* gfti_mul_linear(const gft_poly* a, const double* c, const double* m, size_t v, const size_t* shape,
+                          const size_t* degrees_p1, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFTAYLOR_H */

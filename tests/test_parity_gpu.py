@@ -1,0 +1,242 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar (north_star): integer bookkeeping (stored shape, degrees_p1, support/index
+queries) bit-exact; values within 1e-10 relative — and bit-exact wherever the HIP path keeps the
+reference's operation order (everything except libm seeds, wave-shuffle axis sums and the
+tiled FMA convolution)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import splitmix64_uniform
+
+pytestmark = pytest.mark.gpu
+
+UMAX = 2**64 - 1
+
+
+def both(OTP, GTP, arr, deg=None):
+    arr = np.asarray(arr, dtype=np.float64)
+    deg = list(arr.shape) if deg is None else deg
+    return OTP.new(arr, deg), GTP.new(arr, deg)
+
+
+def same_meta(o, g):
+    assert g.degrees_p1() == o.degrees_p1()
+    assert g.coeffs_shape() == o.coeffs_shape()
+
+
+def check(o, g, exact=True, rel=1e-10, scale=None):
+    same_meta(o, g)
+    a, b = o.array(), g.array()
+    if exact:
+        assert np.array_equal(a, b, equal_nan=True), (a, b)
+    else:
+        ref = np.abs(a) if scale is None else scale
+        assert np.all((np.abs(a - b) <= rel * ref) | (a == b)), (a, b)
+
+
+def rand(shape, seed, lo=0.0, hi=1.0):
+    n = int(np.prod(shape)) if len(shape) else 1
+    return (lo + (hi - lo) * splitmix64_uniform(seed, n)).reshape(shape)
+
+
+SHAPES = [
+    ((5,), (7,), (8,)),
+    ((1,), (6,), (6,)),
+    ((3, 4), (4, 2), (5, 5)),
+    ((4, 4), (4, 4), (4, 4)),
+    ((2, 5), (5, 1), (6, 5)),
+    ((1, 5), (5, 1), (6, 5)),
+    ((3, 3, 3), (3, 3, 3), (4, 5, 3)),
+    ((4, 1, 3), (2, 3, 3), (5, 3, 4)),
+    ((6, 5, 7), (4, 5, 6), (8, 7, 9)),
+    ((2, 3, 2, 3), (3, 2, 2, 2), (4, 4, 3, 4)),
+    ((2, 2, 2, 2, 2), (2, 2, 2, 2, 2), (3, 2, 3, 2, 3)),
+    ((9, 1, 1, 8), (1, 1, 1, 8), (12, 2, 2, 12)),
+]
+
+
+@pytest.mark.parametrize("xs,ys,deg", SHAPES)
+def test_binary_ops_bit_exact(OTP, GTP, xs, ys, deg):
+    """add/sub/mul/div keep the reference's operation order on device => bit-exact (f64 + - * / are
+    IEEE-exact on gfx950; no FMA contraction: library built with -ffp-contract=off)."""
+    x, y = rand(xs, 1, -1, 1), rand(ys, 2, 0.5, 1.5)
+    ox, gx = both(OTP, GTP, x, deg)
+    oy, gy = both(OTP, GTP, y, deg)
+    check(ox + oy, gx + gy)
+    check(ox - oy, gx - gy)
+    check(oy - ox, gy - gx)
+    check(ox * oy, gx * gy)
+    check(oy * ox, gy * gx)
+    check(ox / oy, gx / gy)
+    check(-ox, -gx)
+
+
+@pytest.mark.parametrize("xs,ys,deg", SHAPES[:9])
+def test_exp_log_pow(OTP, GTP, xs, ys, deg):
+    x = rand(xs, 3, 0.5, 1.5)
+    ox, gx = both(OTP, GTP, x, deg)
+    # exp/log seeds come from the device libm (may differ from glibc in the last ulp): 1e-10 bar,
+    # measured against the size of the terms the recurrence sums
+    oe, ge = ox.exp(), gx.exp()
+    check(oe, ge, exact=False, scale=np.abs(oe.array()).max())
+    ol, gl = ox.log(), gx.log()
+    check(ol, gl, exact=False, scale=max(1.0, np.abs(ol.array()).max()))
+    for e in (0, 1, 2, 3, 5):
+        check(ox.pow(e), gx.pow(e))
+
+
+@pytest.mark.parametrize("xs,ys,deg", SHAPES)
+def test_structural_ops_bit_exact(OTP, GTP, xs, ys, deg):
+    x = rand(xs, 4, -1, 1)
+    ox, gx = both(OTP, GTP, x, deg)
+    nd = len(xs)
+    for v in range(nd):
+        for n in range(0, min(deg[v], 4)):
+            check(ox.derivative(v, n), gx.derivative(v, n))
+            check(ox.taylor_expansion_of_coeff(v, n), gx.taylor_expansion_of_coeff(v, n))
+            check(ox.shift_down(v, n), gx.shift_down(v, n))
+            check(ox.coefficients_of_term(v, n), gx.coefficients_of_term(v, n))
+        check(ox.taylor_polynomial_terms(v, [0, 2]), gx.taylor_polynomial_terms(v, [0, 2]))
+        check(ox.taylor_polynomial_terms(v, [1]), gx.taylor_polynomial_terms(v, [1]))
+        check(ox.taylor_polynomial_terms(v, []), gx.taylor_polynomial_terms(v, []))
+    check(ox.truncate_to_degree_p1(2), gx.truncate_to_degree_p1(2))
+    check(ox.truncate_to_degree_p1(1), gx.truncate_to_degree_p1(1))
+    check(ox.extend_to_dim(nd + 2, 5), gx.extend_to_dim(nd + 2, 5))
+    check(ox.remove_last_variable(), gx.remove_last_variable())
+    check(ox.extend(list(deg)), gx.extend(list(deg)))
+    assert gx.clone() == gx
+    assert gx.constant_term() == ox.constant_term()
+    assert gx.extract_constant() == ox.extract_constant()
+    assert gx.extract_linear() == ox.extract_linear()
+    assert gx.is_constant() == ox.is_constant() and gx.num_vars() == ox.num_vars()
+    for v in range(nd + 1):
+        assert gx.len_of(v) == ox.len_of(v)
+    for idx in itertools.islice(itertools.product(*[range(d) for d in deg]), 0, None, 7):
+        assert gx.coefficient(idx) == ox.coefficient(idx)
+
+
+@pytest.mark.parametrize("xs,ys,deg", SHAPES[:10])
+def test_subst_var(OTP, GTP, xs, ys, deg):
+    x, s = rand(xs, 5, -1, 1), rand(ys, 6, -0.5, 0.5)
+    ox, gx = both(OTP, GTP, x, deg)
+    os_, gs = both(OTP, GTP, s, deg)
+    for v in range(len(xs)):
+        check(ox.subst_var(v, os_), gx.subst_var(v, gs))  # general Horner: mul + add, bit-exact
+        check(ox.subst_var(v, OTP.zero()), gx.subst_var(v, GTP.zero()))  # marginalize
+        lin_o = OTP.from_scalar(0.3) * OTP.var_at_zero(v, deg[v])
+        lin_g = GTP.from_scalar(0.3) * GTP.var_at_zero(v, deg[v])
+        check(ox.subst_var(v, lin_o), gx.subst_var(v, lin_g))  # m*x_v scaling path
+        sh_o, sh_g = OTP.var(v, 0.25, deg[v]), GTP.var(v, 0.25, deg[v])
+        check(ox.subst_var(v, sh_o), gx.subst_var(v, sh_g))  # Taylor shift x0 + eps_v
+
+
+def test_shortcut_dispatch_and_scalars(OTP, GTP):
+    f = [[1.0, 2.0], [3.0, 4.0]]
+    of, gf = both(OTP, GTP, f)
+    for mk in ("zero", "one"):
+        check(getattr(OTP, mk)() * of, getattr(GTP, mk)() * gf)
+        check(of * getattr(OTP, mk)(), gf * getattr(GTP, mk)())
+        check(of + getattr(OTP, mk)(), gf + getattr(GTP, mk)())
+        check(getattr(OTP, mk)() - of, getattr(GTP, mk)() - gf)
+    check(of / OTP.one(), gf / GTP.one())
+    check(of / OTP.from_scalar(3.0), gf / GTP.from_scalar(3.0))
+    check(OTP.from_scalar(2.0) + OTP.from_scalar(3.0), GTP.from_scalar(2.0) + GTP.from_scalar(3.0))
+    check(OTP.from_scalar(2.0) * OTP.from_scalar(3.0), GTP.from_scalar(2.0) * GTP.from_scalar(3.0))
+    check(OTP.from_u32(7).exp().log(), GTP.from_u32(7).exp().log(), exact=False)
+    check(OTP.zero_with([3, 4]) * of, GTP.zero_with([3, 4]) * gf)
+    # linear factor on either side (mt:1052-1061)
+    ol = OTP.from_scalar(3.0) + OTP.from_scalar(2.0) * OTP.var_at_zero(1, 2)
+    gl = GTP.from_scalar(3.0) + GTP.from_scalar(2.0) * GTP.var_at_zero(1, 2)
+    assert gl.extract_linear() == ol.extract_linear() == (3.0, 2.0, 1)
+    check(ol * of, gl * gf)
+    check(of * ol, gf * gl)
+    # untruncated degrees (usize::MAX, used by simplify: generating_function.rs:485,569)
+    ou, gu = both(OTP, GTP, f, [UMAX, UMAX])
+    check(ou * ou, gu * gu)
+    check(ou + of, gu + gf)
+    assert (gu * gu).degrees_p1() == (UMAX, UMAX)
+    check(ou.subst_var(0, OTP.var(0, 0.5, 3)), gu.subst_var(0, GTP.var(0, 0.5, 3)))
+    # 0-dim and all-ones shapes
+    check(OTP.from_scalar(2.0).extend_to_dim(3, 4) * OTP.from_scalar(5.0), GTP.from_scalar(2.0).extend_to_dim(3, 4) * GTP.from_scalar(5.0))
+    check(OTP.from_scalar(2.0).exp(), GTP.from_scalar(2.0).exp(), exact=False)
+
+
+def test_error_behaviour_matches(OTP, GTP):
+    from genfer_amd import TaylorError
+
+    f = [[1.0, 2.0], [3.0, 4.0]]
+    of, gf = both(OTP, GTP, f)
+    for P in (of, gf):
+        with pytest.raises(TaylorError):
+            P.coefficient([2, 0])  # index out of bounds (mt:318-322)
+        with pytest.raises(TaylorError):
+            P.coefficient([1])  # index too short (mt:333-337)
+        with pytest.raises(TaylorError):
+            P.derivative(2, 0)  # bad variable (mt:459)
+        with pytest.raises(TaylorError):
+            P.shift_down(0, 2)  # n >= len_of(v) (mt:516)
+    with pytest.raises(TaylorError):
+        GTP.new([[1.0, 2.0]], [1, 1])  # shape exceeds degrees (mt:35-39)
+
+
+def test_conv_raw_naive_bit_exact_vs_oracle(oracle_lib, GTP):
+    """gft_conv_raw (reference-order kernel) on torch device buffers == oracle's orc_mul_raw bitwise,
+    including slab ranges and accumulation."""
+    import ctypes as C
+
+    import torch
+
+    import genfer_amd
+
+    genfer_amd.lib().gft_set_conv_mode(1)
+    try:
+        sz = lambda s: (C.c_size_t * len(s))(*s)
+        oracle_lib.orc_mul_raw.restype = C.c_int
+        szp = C.POINTER(C.c_size_t)
+        oracle_lib.orc_mul_raw.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t]
+        for xs, ys, zs in [((9, 8, 7), (6, 8, 5), (12, 9, 10)), ((17,), (9,), (20,)), ((5, 6, 3, 4), (4, 3, 3, 2), (6, 6, 4, 4))]:
+            x, y = rand(xs, 7, -1, 1), rand(ys, 8, -1, 1)
+            want = np.zeros(zs)
+            oracle_lib.orc_mul_raw(x.ctypes.data_as(C.c_void_p), sz(xs), y.ctypes.data_as(C.c_void_p), sz(ys),
+                                   want.ctypes.data_as(C.c_void_p), sz(zs), len(zs))
+            tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+            tz = torch.full(zs, 7.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            half = zs[0] // 2
+            genfer_amd.conv_raw(tx.data_ptr(), xs, ty.data_ptr(), ys, tz.data_ptr(), zs, 0, half)
+            genfer_amd.conv_raw(tx.data_ptr(), xs, ty.data_ptr(), ys, tz.data_ptr(), zs, half, zs[0])
+            genfer_amd.lib().gft_synchronize()
+            assert np.array_equal(tz.cpu().numpy(), want)
+    finally:
+        genfer_amd.lib().gft_set_conv_mode(0)
+
+
+def test_interval_ops(OTPI, GTPI):
+    """Interval<F64> planes: same op-for-op semantics as src/interval.rs (widen by one ulp, exact
+    zero/one short-circuits) => bit-exact against the oracle."""
+    for xs, ys, deg in SHAPES[:9]:
+        lo = rand(xs, 11, -1, 1)
+        x = np.stack([lo, lo + rand(xs, 12, 0, 1e-3)])
+        lo = rand(ys, 13, 0.5, 1.5)
+        y = np.stack([lo, lo + rand(ys, 14, 0, 1e-3)])
+        x[(slice(None),) + tuple(0 for _ in xs)] = [0.0, 0.0] if len(xs) % 2 else [1.0, 1.0]  # exercise short-circuits
+        ox, gx = OTPI.new(x, deg), GTPI.new(x, deg)
+        oy, gy = OTPI.new(y, deg), GTPI.new(y, deg)
+        check(ox + oy, gx + gy)
+        check(ox - oy, gx - gy)
+        check(ox * oy, gx * gy)
+        check(ox / oy, gx / gy)
+        check(-ox, -gx)
+        for v in range(len(xs)):
+            check(ox.derivative(v, 1), gx.derivative(v, 1))
+            check(ox.shift_down(v, 1), gx.shift_down(v, 1))
+            check(ox.subst_var(v, oy), gx.subst_var(v, gy))
+        check(oy.exp(), gy.exp(), exact=False, scale=np.abs(oy.exp().array()).max())
+        check(oy.log(), gy.log(), exact=False, scale=1.0)
+        # soundness: lo <= hi everywhere
+        r = (gx * gy).array()
+        assert np.all(r[0] <= r[1])
+    assert GTPI.from_scalar((2.0, 3.0)).constant_term() == (2.0, 3.0)
+    assert GTPI.var(1, (0.5, 0.5), 4).extract_linear() == OTPI.var(1, (0.5, 0.5), 4).extract_linear()
