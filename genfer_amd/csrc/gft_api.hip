@@ -538,6 +538,16 @@ struct Ops {
                 if (macs < 5.0e7) ok = false;
             }
             if (ok) {
+                // zero padding times inf/NaN would create NaNs the reference does not produce: such
+                // operands take the reference-order kernel
+                unsigned zero = 0, bad = 0;
+                HIP_OK(hipMemcpyAsync(R.d_flag + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+                any_nonfinite_f64(R.stream, x.p, x.numel(), R.d_flag + 2);
+                any_nonfinite_f64(R.stream, y.p, y.numel(), R.d_flag + 2);
+                read_back(&bad, R.d_flag + 2, sizeof(unsigned));
+                if (bad) ok = false;
+            }
+            if (ok) {
                 if (need > R.conv_ws_bytes) {
                     if (R.conv_ws) HIP_OK(hipFree(R.conv_ws));
                     R.conv_ws = nullptr;

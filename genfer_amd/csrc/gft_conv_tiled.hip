@@ -1,11 +1,633 @@
-// LDS-tiled f64 convolution for gfx950 — placeholder until the tiled kernel lands: reports
-// "unsupported" so that every product runs through the reference-order kernel.
+// LDS-tiled f64 truncated N-d convolution for gfx950 (the hot loop of TaylorPoly * TaylorPoly,
+// src/multivariate_taylor.rs:971-1012) — compute-bound on FP64 FMA, so the design goal is to keep
+// the 4 SIMDs of every CU issuing v_fma_f64 with both operands already on-chip:
+//
+//   canonical problem   z[u][k0][k1][k2] = sum_j x[ju][j0][j1][j2] * y[u-ju][k0-j0][k1-j1][k2-j2]
+//                       (rank 3: U = 1; rank 4: U = leading axis)
+//   lanes               the 64 lanes of a wave own an 8x8 tile of (k0,k1) output ROWS; each lane keeps
+//                       R = 8 consecutive k2 outputs of its row in registers (two such blocks per wave,
+//                       c and nb-1-c, so every wave of the workgroup has the same trip count although
+//                       the index space is triangular)
+//   x operand           wave-uniform: x[J][j2..j2+7] comes from scalar loads into SGPRs and is the
+//                       SGPR source of v_fma_f64 — zero VGPR/LDS traffic for one of the two operands
+//   y operand           an 8x8 window of y rows lives in LDS, row r = 8*slot0 + slot1 at offset r*P1 doubles
+//                       with P1 = ny8+1 (odd) => the rows read by any aligned group of 16 or 32 lanes
+//                       start in distinct 8-byte bank slots (conflict-free ds_read_b64 / ds_read2_b64);
+//                       each lane slides an 8-wide register window along its row: 8 new doubles from
+//                       LDS per 64 FMAs
+//   window motion       stepping j1 replaces one of the 8 ring slots (8 rows, prefetched global->VGPR
+//                       during the step, written to LDS after it); stepping j0/ju reloads the window
+//   triangular waste    none along k2 (the diagonal 8x8 chunk is a 36-FMA triangle); (n+8)/(n+1) per
+//                       lane axis from masked lanes in diagonal tiles
+//   load balance        stream-K: the linearised (tile, ju, j0, j1) step space is cut into equal
+//                       contiguous ranges, one per resident workgroup (2 per CU).  Tiles covered by a
+//                       single range are written straight to z; split tiles go through partial slabs
+//                       in a workspace and a fixed-order reduce kernel => deterministic results.
+//
+// Numerics: explicit fma (one rounding per MAC) and a different summation order than the
+// reference => 1e-10 relative parity, not bit-exact (the reference-order kernel in
+// gft_kernels.hip is the bit-exact path).  Operands must be finite (zero padding times inf would
+// create NaNs the reference does not produce); the caller checks and falls back otherwise.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
 #include "gft_kernels.hpp"
 
 namespace gft {
-bool conv_tiled_f64(hipStream_t, const double*, const double*, double*, const ConvArgs&, void*, size_t,
-                    size_t* ws_needed) {
-    if (ws_needed) *ws_needed = 0;
-    return false;
+
+namespace {
+
+struct TileSeg {
+    unsigned u, a, b;                // tile coordinates
+    unsigned step_begin, step_end;   // range in the tile's linearised (ju, j0, j1) space
+    int dest;                        // -1: write z directly; >= 0: workspace slot
+};
+
+struct RedTile {
+    unsigned u, a, b;
+    unsigned first, count;           // pieces: red_slots[first .. first+count)
+};
+
+struct TiledArgs {
+    unsigned xU, x0, x1, xI;
+    unsigned yU, y0, y1, yI;
+    unsigned zU, z0, z1, zI;
+    unsigned nx8, ny8;               // padded inner lengths of the packed operands
+    unsigned nxc, nyc, nb;           // chunk counts (nx8/8, ny8/8) and number of 8-wide output blocks
+    unsigned P0, P1;                 // LDS pitches in doubles
+    unsigned lead_is_u;              // 1: slab range applies to u, 0: to k0
+    unsigned slab_lo, slab_hi;
+    int accumulate;
+    const double* xp;
+    const double* yp;
+    double* z;
+    double* ws;
+    const TileSeg* segs;
+    const unsigned* wg_begin;        // segments of workgroup w: [wg_begin[w], wg_begin[w+1])
+    const RedTile* red;
+    const unsigned* red_slots;
+};
+
+__device__ inline void fma_full(double (&acc)[8], const double* __restrict__ xq, const double (&cur)[8],
+                                const double (&prev)[8]) {
+    // acc[r] += x[8q+s] * y[8(c-q) + r - s]; r-s >= 0 -> cur[r-s], else prev[8 + r - s]
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double xs = xq[s];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double yv = (r - s >= 0) ? cur[(r - s) & 7] : prev[(8 + r - s) & 7];
+            acc[r] = __builtin_fma(xs, yv, acc[r]);
+        }
+    }
 }
+
+__device__ inline void fma_tri(double (&acc)[8], const double* __restrict__ xq, const double (&cur)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double xs = xq[s];
+#pragma unroll
+        for (int r = s; r < 8; ++r) acc[r] = __builtin_fma(xs, cur[r - s], acc[r]);
+    }
+}
+
+__device__ inline void load8(double (&dst)[8], const double* p) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = p[i];
+}
+
+// One output block c (8 consecutive k2) of one lane-row for one (x row, y row) pair.
+__device__ inline void block_mac(double (&acc)[8], unsigned c, const double* __restrict__ xr,
+                                 const double* yrow, unsigned nxc, unsigned nyc) {
+    unsigned q_lo = c > nyc ? c - nyc : 0;
+    unsigned q_hi = c < nxc ? c : nxc;  // full chunks q in [q_lo, q_hi)
+    double A[8], B[8];
+    unsigned m0 = c - q_lo;
+    if (m0 < nyc) {
+        load8(A, yrow + 8 * m0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i] = 0.0;
+    }
+    unsigned q = q_lo;
+    // two chunks per iteration so the sliding window alternates between A and B without moves
+    for (; q + 2 <= q_hi; q += 2) {
+        load8(B, yrow + 8 * (c - q - 1));
+        fma_full(acc, xr + 8 * q, A, B);
+        load8(A, yrow + 8 * (c - q - 2));
+        fma_full(acc, xr + 8 * (q + 1), B, A);
+    }
+    if (q < q_hi) {
+        load8(B, yrow + 8 * (c - q - 1));
+        fma_full(acc, xr + 8 * q, A, B);
+        if (c < nxc) fma_tri(acc, xr + 8 * c, B);
+    } else {
+        if (c < nxc) fma_tri(acc, xr + 8 * c, A);
+    }
+}
+
+struct TileGeom {
+    unsigned julo, n_ju, j0lo, n_j0, j1lo, n_j1;
+};
+
+__host__ __device__ inline TileGeom tile_geom(const TiledArgs& A, unsigned u, unsigned a, unsigned b) {
+    TileGeom g;
+    // uniform axis: ju in [max(0,u+1-yU), min(u+1,xU))
+    g.julo = (u + 1 > A.yU) ? (u + 1 - A.yU) : 0;
+    unsigned juhi = (u + 1 < A.xU) ? (u + 1) : A.xU;
+    g.n_ju = juhi > g.julo ? juhi - g.julo : 0;
+    // lane axes: any lane of the tile valid.  k in [8a, min(8a+7, z-1)]
+    unsigned k0max = (8 * a + 7 < A.z0 - 1) ? 8 * a + 7 : A.z0 - 1;
+    g.j0lo = (8 * a + 1 > A.y0) ? (8 * a + 1 - A.y0) : 0;
+    unsigned j0hi = (k0max + 1 < A.x0) ? (k0max + 1) : A.x0;
+    g.n_j0 = j0hi > g.j0lo ? j0hi - g.j0lo : 0;
+    unsigned k1max = (8 * b + 7 < A.z1 - 1) ? 8 * b + 7 : A.z1 - 1;
+    g.j1lo = (8 * b + 1 > A.y1) ? (8 * b + 1 - A.y1) : 0;
+    unsigned j1hi = (k1max + 1 < A.x1) ? (k1max + 1) : A.x1;
+    g.n_j1 = j1hi > g.j1lo ? j1hi - g.j1lo : 0;
+    return g;
+}
+
+constexpr int MAX_PF = 1;  // prefetch pieces (16 B each) per thread for one ring slot refill: 8*ny8/2 <= 64*NW
+                           // because yI <= zI (operands never exceed the result shape) and NW >= nb/2
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4)  // 4 waves per SIMD = 16 waves per CU => <= 128 VGPRs
+k_conv_tiled(TiledArgs A) {
+    extern __shared__ double lds[];
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned l0 = lane >> 3, l1 = lane & 7u;
+    constexpr unsigned NT = NW * 64;
+
+    const unsigned c1 = wave;
+    const unsigned c2 = A.nb - 1 - wave;
+    const bool has1 = c1 < A.nb && c1 <= c2;
+    const bool has2 = c2 < A.nb && c2 > c1;
+
+    const unsigned half_row = A.ny8 >> 1;            // 16-byte pieces per row
+    const unsigned pf_pieces = 8 * half_row;         // one ring slot refill = 8 rows
+    const size_t y_row_stride = A.ny8;
+
+    const unsigned seg_begin = A.wg_begin[blockIdx.x], seg_end = A.wg_begin[blockIdx.x + 1];
+    for (unsigned si = seg_begin; si < seg_end; ++si) {
+        const TileSeg seg = A.segs[si];
+        const unsigned u = seg.u, a = seg.a, b = seg.b;
+        const TileGeom g = tile_geom(A, u, a, b);
+        const unsigned k0 = 8 * a + l0, k1 = 8 * b + l1;
+        bool lane_in = k0 < A.z0 && k1 < A.z1;
+        if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+
+        double acc1[8], acc2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc1[i] = acc2[i] = 0.0;
+
+        unsigned s = seg.step_begin;
+        unsigned tj1 = s % g.n_j1;
+        unsigned t = s / g.n_j1;
+        unsigned tj0 = t % g.n_j0;
+        unsigned tju = t / g.n_j0;
+        unsigned ju = g.julo + tju, j0 = g.j0lo + tj0, j1 = g.j1lo + tj1;
+
+        bool need_full = true;
+        while (s < seg.step_end) {
+            if (need_full) {
+                // (re)load the whole 8x8 window of y rows for (ju, j0, j1)
+                __syncthreads();
+                const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
+                for (unsigned p = tid; p < 64 * half_row; p += NT) {
+                    unsigned row = p / half_row, col = p - row * half_row;
+                    unsigned s0 = row >> 3, s1 = row & 7u;
+                    int R0 = (int)(8 * a + s0) - (int)j0;
+                    int R1 = (int)(8 * b + s1) - (int)j1;
+                    if (R0 >= 0 && R0 < (int)A.y0 && R1 >= 0 && R1 < (int)A.y1) {
+                        const double2 v = *reinterpret_cast<const double2*>(
+                            ybase + ((size_t)R0 * A.y1 + (size_t)R1) * y_row_stride + 2 * col);
+                        double* d = lds + s0 * A.P0 + ((unsigned)R1 & 7u) * A.P1 + 2 * col;
+                        d[0] = v.x;
+                        d[1] = v.y;
+                    }
+                }
+                __syncthreads();
+                need_full = false;
+            }
+            const bool more = s + 1 < seg.step_end;
+            const bool same_row = more && (j1 + 1 < g.j1lo + g.n_j1);
+            // prefetch the ring slot that the next j1 step needs: rows R1n = 8b - j1 - 1 (+ nothing else new)
+            double2 pf[MAX_PF];
+            const int R1n = (int)(8 * b) - (int)j1 - 1;
+            const bool do_pf = same_row && R1n >= 0 && R1n < (int)A.y1;
+            if (do_pf) {
+                const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
+#pragma unroll
+                for (int i = 0; i < MAX_PF; ++i) {
+                    unsigned p = tid + i * NT;
+                    if (p < pf_pieces) {
+                        unsigned s0 = p / half_row, col = p - s0 * half_row;
+                        int R0 = (int)(8 * a + s0) - (int)j0;
+                        if (R0 >= 0 && R0 < (int)A.y0)
+                            pf[i] = *reinterpret_cast<const double2*>(
+                                ybase + ((size_t)R0 * A.y1 + (size_t)R1n) * y_row_stride + 2 * col);
+                    }
+                }
+            }
+
+            // ---- compute this step -------------------------------------------------------------
+            {
+                const double* xr = A.xp + (((size_t)ju * A.x0 + j0) * A.x1 + j1) * A.nx8;  // wave-uniform
+                const bool valid = lane_in && j0 <= k0 && (k0 - j0) < A.y0 && j1 <= k1 && (k1 - j1) < A.y1;
+                if (valid) {
+                    const double* yrow = lds + l0 * A.P0 + ((k1 - j1) & 7u) * A.P1;
+                    if (has1) block_mac(acc1, c1, xr, yrow, A.nxc, A.nyc);
+                    if (has2) block_mac(acc2, c2, xr, yrow, A.nxc, A.nyc);
+                }
+            }
+
+            // ---- advance ---------------------------------------------------------------------------
+            if (same_row) {
+                __syncthreads();  // everyone is done reading the slot being replaced
+                if (do_pf) {
+#pragma unroll
+                    for (int i = 0; i < MAX_PF; ++i) {
+                        unsigned p = tid + i * NT;
+                        if (p < pf_pieces) {
+                            unsigned s0 = p / half_row, col = p - s0 * half_row;
+                            int R0 = (int)(8 * a + s0) - (int)j0;
+                            if (R0 >= 0 && R0 < (int)A.y0) {
+                                double* d = lds + s0 * A.P0 + ((unsigned)R1n & 7u) * A.P1 + 2 * col;
+                                d[0] = pf[i].x;
+                                d[1] = pf[i].y;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                j1++;
+            } else if (more) {
+                j1 = g.j1lo;
+                if (j0 + 1 < g.j0lo + g.n_j0) j0++;
+                else {
+                    j0 = g.j0lo;
+                    ju++;
+                }
+                need_full = true;
+            }
+            s++;
+        }
+
+        // ---- write out ---------------------------------------------------------------------------------
+        if (seg.dest < 0) {
+            if (lane_in) {
+                double* zrow = A.z + (((size_t)u * A.z0 + k0) * A.z1 + k1) * A.zI;
+                if (has1) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        unsigned k2 = 8 * c1 + r;
+                        if (k2 < A.zI) zrow[k2] = A.accumulate ? zrow[k2] + acc1[r] : acc1[r];
+                    }
+                }
+                if (has2) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        unsigned k2 = 8 * c2 + r;
+                        if (k2 < A.zI) zrow[k2] = A.accumulate ? zrow[k2] + acc2[r] : acc2[r];
+                    }
+                }
+            }
+        } else {
+            double* w = A.ws + (size_t)seg.dest * A.nb * 512;
+            if (has1) {
+                double* d = w + ((size_t)c1 * 64 + lane) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) d[r] = acc1[r];
+            }
+            if (has2) {
+                double* d = w + ((size_t)c2 * 64 + lane) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) d[r] = acc2[r];
+            }
+        }
+    }
+}
+
+// Fixed-order sum of the partial slabs of split tiles.
+__global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red) {
+    const unsigned ti = blockIdx.x;
+    if (ti >= n_red) return;
+    const RedTile rt = A.red[ti];
+    for (unsigned idx = threadIdx.x; idx < A.nb * 64; idx += blockDim.x) {
+        const unsigned c = idx >> 6, lane = idx & 63u;
+        const unsigned k0 = 8 * rt.a + (lane >> 3), k1 = 8 * rt.b + (lane & 7u);
+        bool lane_in = k0 < A.z0 && k1 < A.z1;
+        if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+        if (!lane_in) continue;
+        double v[8];
+        double* zrow = A.z + (((size_t)rt.u * A.z0 + k0) * A.z1 + k1) * A.zI;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            unsigned k2 = 8 * c + r;
+            v[r] = (A.accumulate && k2 < A.zI) ? zrow[k2] : 0.0;
+        }
+        for (unsigned p = 0; p < rt.count; ++p) {
+            const double* w = A.ws + (size_t)A.red_slots[rt.first + p] * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += w[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            unsigned k2 = 8 * c + r;
+            if (k2 < A.zI) zrow[k2] = v[r];
+        }
+    }
+}
+
+// out[row][i] = i < len ? in[row][i] : 0, rows x n8
+__global__ void __launch_bounds__(256) k_pack_rows(const double* __restrict__ in, double* __restrict__ out,
+                                                   size_t rows, unsigned len, unsigned n8) {
+    size_t total = rows * n8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t row = i / n8;
+        unsigned col = (unsigned)(i - row * n8);
+        out[i] = col < len ? in[row * len + col] : 0.0;
+    }
+}
+
+// *flag = 1 if any element is not finite
+__global__ void __launch_bounds__(256) k_any_nonfinite(const double* __restrict__ a, size_t n, unsigned* flag) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = a[i];
+        if (!((v - v) == 0.0)) bad = true;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// ---- host-side plan ------------------------------------------------------------------------------------
+
+struct PlanKey {
+    unsigned v[18];
+    bool operator<(const PlanKey& o) const { return std::memcmp(v, o.v, sizeof(v)) < 0; }
+};
+
+struct Plan {
+    TiledArgs base;  // shapes/pitches filled in; pointers to device tables filled in
+    unsigned n_wg = 0, n_red = 0, n_slots = 0, NW = 0;
+    size_t lds_bytes = 0;
+    void* d_tables = nullptr;
+};
+
+std::map<PlanKey, Plan>& plan_cache() {
+    static std::map<PlanKey, Plan> c;
+    return c;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+bool build_plan(const ConvArgs& a, Plan& P) {
+    TiledArgs& T = P.base;
+    std::memset(&T, 0, sizeof(T));
+    if (a.nd == 3) {
+        T.xU = T.yU = T.zU = 1;
+        T.x0 = a.xs[0]; T.x1 = a.xs[1]; T.xI = a.xs[2];
+        T.y0 = a.ys[0]; T.y1 = a.ys[1]; T.yI = a.ys[2];
+        T.z0 = a.zs[0]; T.z1 = a.zs[1]; T.zI = a.zs[2];
+        T.lead_is_u = 0;
+    } else if (a.nd == 4) {
+        T.xU = a.xs[0]; T.x0 = a.xs[1]; T.x1 = a.xs[2]; T.xI = a.xs[3];
+        T.yU = a.ys[0]; T.y0 = a.ys[1]; T.y1 = a.ys[2]; T.yI = a.ys[3];
+        T.zU = a.zs[0]; T.z0 = a.zs[1]; T.z1 = a.zs[2]; T.zI = a.zs[3];
+        T.lead_is_u = 1;
+    } else {
+        return false;
+    }
+    if (T.zI > 128 || T.xI > T.zI || T.yI > T.zI) return false;
+    if (a.j0_min != 0 || a.j0_excl != 0 || a.j0_desc != 0) return false;  // recurrence steps: reference-order kernel
+    T.nx8 = (T.xI + 7) / 8 * 8;
+    T.ny8 = (T.yI + 7) / 8 * 8;
+    T.nxc = T.nx8 / 8;
+    T.nyc = T.ny8 / 8;
+    T.nb = (T.zI + 7) / 8;
+    T.P1 = T.ny8 + 1;  // odd pitch: row index -> 8-byte bank slot is a bijection mod 16 and mod 32
+    T.P0 = 8 * T.P1;
+    T.slab_lo = a.slab_lo;
+    T.slab_hi = a.slab_hi;
+    T.accumulate = a.accumulate;
+    unsigned npairs = (T.nb + 1) / 2;
+    P.NW = npairs <= 1 ? 1 : (npairs <= 2 ? 2 : (npairs <= 4 ? 4 : 8));
+    P.lds_bytes = (size_t)8 * T.P0 * sizeof(double);
+
+    // tiles in (u, a, b) order
+    struct TileInfo { unsigned u, a, b; unsigned long long steps; };
+    std::vector<TileInfo> tiles;
+    unsigned u_lo = 0, u_hi = T.zU, a_lo = 0, a_hi = (T.z0 + 7) / 8;
+    if (T.lead_is_u) {
+        u_lo = a.slab_lo;
+        u_hi = a.slab_hi;
+    } else {
+        a_lo = a.slab_lo / 8;
+        a_hi = (a.slab_hi + 7) / 8;
+    }
+    unsigned b_hi = (T.z1 + 7) / 8;
+    unsigned long long S = 0;
+    for (unsigned u = u_lo; u < u_hi; ++u)
+        for (unsigned aa = a_lo; aa < a_hi; ++aa)
+            for (unsigned bb = 0; bb < b_hi; ++bb) {
+                TileGeom g = tile_geom(T, u, aa, bb);
+                unsigned long long st = (unsigned long long)g.n_ju * g.n_j0 * g.n_j1;
+                if (st == 0 || st > 0xffffffffull) return false;
+                tiles.push_back({u, aa, bb, st});
+                S += st;
+            }
+    if (tiles.empty()) return false;
+    unsigned wg_per_cu = std::min<unsigned>(16u / P.NW, (unsigned)(160 * 1024 / P.lds_bytes));
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    unsigned long long n_wg = (unsigned long long)num_cus() * wg_per_cu;
+    if (n_wg > S) n_wg = S;
+    P.n_wg = (unsigned)n_wg;
+
+    std::vector<TileSeg> segs;
+    std::vector<unsigned> wg_begin(P.n_wg + 1, 0);
+    std::vector<std::vector<unsigned>> tile_slots(tiles.size());
+    std::vector<int> tile_direct(tiles.size(), 0);
+    unsigned n_slots = 0;
+    size_t ti = 0;
+    unsigned long long tile_start = 0;  // global step index where tile ti starts
+    for (unsigned w = 0; w < P.n_wg; ++w) {
+        unsigned long long lo = S * w / n_wg, hi = S * (w + 1) / n_wg;
+        wg_begin[w] = (unsigned)segs.size();
+        unsigned long long pos = lo;
+        while (pos < hi) {
+            while (pos >= tile_start + tiles[ti].steps) {
+                tile_start += tiles[ti].steps;
+                ti++;
+            }
+            unsigned long long tend = tile_start + tiles[ti].steps;
+            unsigned long long e = hi < tend ? hi : tend;
+            TileSeg sg;
+            sg.u = tiles[ti].u;
+            sg.a = tiles[ti].a;
+            sg.b = tiles[ti].b;
+            sg.step_begin = (unsigned)(pos - tile_start);
+            sg.step_end = (unsigned)(e - tile_start);
+            if (sg.step_begin == 0 && sg.step_end == tiles[ti].steps) {
+                sg.dest = -1;
+                tile_direct[ti] = 1;
+            } else {
+                sg.dest = (int)n_slots;
+                tile_slots[ti].push_back(n_slots);
+                n_slots++;
+            }
+            segs.push_back(sg);
+            pos = e;
+        }
+    }
+    wg_begin[P.n_wg] = (unsigned)segs.size();
+    std::vector<RedTile> red;
+    std::vector<unsigned> red_slots;
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        if (tile_direct[i] || tile_slots[i].empty()) continue;
+        RedTile r;
+        r.u = tiles[i].u;
+        r.a = tiles[i].a;
+        r.b = tiles[i].b;
+        r.first = (unsigned)red_slots.size();
+        r.count = (unsigned)tile_slots[i].size();
+        for (unsigned sl : tile_slots[i]) red_slots.push_back(sl);
+        red.push_back(r);
+    }
+    P.n_red = (unsigned)red.size();
+    P.n_slots = n_slots;
+
+    // one device allocation for all tables
+    size_t b_segs = segs.size() * sizeof(TileSeg), b_wg = wg_begin.size() * sizeof(unsigned);
+    size_t b_red = red.size() * sizeof(RedTile), b_rs = red_slots.size() * sizeof(unsigned);
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t total = al(b_segs) + al(b_wg) + al(b_red) + al(b_rs) + 256;
+    if (hipMalloc(&P.d_tables, total) != hipSuccess) return false;
+    char* base = (char*)P.d_tables;
+    size_t off = 0;
+    auto put = [&](const void* src, size_t bytes) -> void* {
+        void* d = base + off;
+        if (bytes) (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+        off += al(bytes);
+        return d;
+    };
+    T.segs = (const TileSeg*)put(segs.data(), b_segs);
+    T.wg_begin = (const unsigned*)put(wg_begin.data(), b_wg);
+    T.red = (const RedTile*)put(red.data(), b_red);
+    T.red_slots = (const unsigned*)put(red_slots.data(), b_rs);
+    return true;
+}
+
+template <int NW>
+hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tiled<NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_tiled<NW>, dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
+                    size_t ws_bytes, size_t* ws_needed) {
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key));
+    if (a.nd != 3 && a.nd != 4) return false;
+    key.v[0] = (unsigned)a.nd;
+    for (int i = 0; i < a.nd; ++i) {
+        key.v[1 + i] = a.xs[i];
+        key.v[5 + i] = a.ys[i];
+        key.v[9 + i] = a.zs[i];
+    }
+    key.v[13] = a.slab_lo;
+    key.v[14] = a.slab_hi;
+    key.v[15] = (unsigned)a.accumulate;
+    key.v[16] = (unsigned)(a.j0_min | (a.j0_excl << 8) | (a.j0_desc << 16));
+    auto& cache = plan_cache();
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        Plan P;
+        if (!build_plan(a, P)) return false;
+        if (cache.size() > 64) {  // bounded: drop everything (plans are cheap to rebuild)
+            for (auto& kv : cache) (void)hipFree(kv.second.d_tables);
+            cache.clear();
+        }
+        it = cache.emplace(key, P).first;
+    }
+    const Plan& P = it->second;
+    const TiledArgs& B = P.base;
+    // workspace: [partial slabs][packed x][packed y][flag]
+    size_t b_slots = (size_t)P.n_slots * B.nb * 512 * sizeof(double);
+    size_t x_rows = (size_t)B.xU * B.x0 * B.x1, y_rows = (size_t)B.yU * B.y0 * B.y1;
+    bool pack_x = B.nx8 != B.xI || ((uintptr_t)x & 7);
+    bool pack_y = B.ny8 != B.yI || ((uintptr_t)y & 15);  // window loads are 16-byte
+    size_t b_xp = pack_x ? x_rows * B.nx8 * sizeof(double) : 0;
+    size_t b_yp = pack_y ? y_rows * B.ny8 * sizeof(double) : 0;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t need = al(b_slots) + al(b_xp) + al(b_yp) + 256;
+    if (ws_needed) *ws_needed = need;
+    if (!ws) return true;  // query
+    if (ws_bytes < need) return false;
+
+    char* wb = (char*)ws;
+    TiledArgs T = B;
+    T.ws = (double*)wb;
+    double* xp = (double*)(wb + al(b_slots));
+    double* yp = (double*)(wb + al(b_slots) + al(b_xp));
+    if (pack_x) {
+        size_t tot = x_rows * B.nx8;
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, x, xp,
+                           x_rows, B.xI, B.nx8);
+        T.xp = xp;
+    } else {
+        T.xp = x;
+    }
+    if (pack_y) {
+        size_t tot = y_rows * B.ny8;
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, y, yp,
+                           y_rows, B.yI, B.ny8);
+        T.yp = yp;
+    } else {
+        T.yp = y;
+    }
+    T.z = z;
+    hipError_t e;
+    switch (P.NW) {
+        case 1: e = launch_main<1>(st, P, T); break;
+        case 2: e = launch_main<2>(st, P, T); break;
+        case 4: e = launch_main<4>(st, P, T); break;
+        default: e = launch_main<8>(st, P, T); break;
+    }
+    if (e != hipSuccess) return false;
+    if (P.n_red) {
+        hipLaunchKernelGGL(k_conv_reduce, dim3(P.n_red), dim3(256), 0, st, T, P.n_red);
+        if (hipGetLastError() != hipSuccess) return false;
+    }
+    return true;
+}
+
+bool any_nonfinite_f64(hipStream_t st, const double* a, size_t n, unsigned* d_flag) {
+    hipLaunchKernelGGL(k_any_nonfinite, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, a, n,
+                       d_flag);
+    return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace gft

@@ -110,4 +110,7 @@ enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
                     size_t ws_bytes, size_t* ws_needed);
 
+// Launches a scan that ORs 1 into *d_flag if any of the n doubles is inf/NaN.
+bool any_nonfinite_f64(hipStream_t st, const double* a, size_t n, unsigned* d_flag);
+
 }  // namespace gft

@@ -240,3 +240,114 @@ def test_interval_ops(OTPI, GTPI):
         assert np.all(r[0] <= r[1])
     assert GTPI.from_scalar((2.0, 3.0)).constant_term() == (2.0, 3.0)
     assert GTPI.var(1, (0.5, 0.5), 4).extract_linear() == OTPI.var(1, (0.5, 0.5), 4).extract_linear()
+
+
+def _conv_raw_gpu(mode, x, y, zs, slab=None, accumulate=False, z0=None):
+    import torch
+
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    L.gft_set_conv_mode(mode)
+    try:
+        tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        tz = torch.from_numpy(z0.copy()).cuda() if z0 is not None else torch.full(tuple(zs), np.nan, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        lo, hi = (0, zs[0]) if slab is None else slab
+        genfer_amd.conv_raw(tx.data_ptr(), x.shape, ty.data_ptr(), y.shape, tz.data_ptr(), zs, lo, hi, accumulate)
+        L.gft_synchronize()
+        return tz.cpu().numpy()
+    finally:
+        L.gft_set_conv_mode(0)
+
+
+TILED_SHAPES = [
+    ((32, 32, 32), (32, 32, 32), (32, 32, 32)),
+    ((20, 17, 29), (13, 22, 30), (30, 30, 40)),       # ragged, compact operands, inner not a multiple of 8
+    ((9, 8, 7), (6, 8, 5), (12, 9, 10)),
+    ((40, 3, 128), (2, 40, 128), (41, 40, 128)),      # maximum inner size, thin lane axes
+    ((5, 6, 7, 20), (4, 3, 5, 17), (6, 6, 9, 24)),    # rank 4: uniform leading axis
+    ((16, 16, 16, 16), (16, 16, 16, 16), (16, 16, 16, 16)),
+    ((3, 70, 70, 8), (3, 70, 70, 8), (3, 70, 70, 8)),
+]
+
+
+@pytest.mark.parametrize("xs,ys,zs", TILED_SHAPES)
+def test_conv_tiled_matches_reference_order_kernel(xs, ys, zs):
+    """LDS-tiled FMA kernel vs the reference-order kernel (itself bit-exact vs the oracle, see
+    test_conv_raw_naive_bit_exact_vs_oracle): positive inputs => 1e-10 relative per coefficient;
+    mixed-sign inputs => normwise bound against |x| (*) |y|."""
+    x, y = rand(xs, 21), rand(ys, 22)
+    want = _conv_raw_gpu(1, x, y, zs)
+    got = _conv_raw_gpu(2, x, y, zs)
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / want).max()
+    # mixed sign
+    xm, ym = 2 * x - 1, 2 * y - 1
+    bound = _conv_raw_gpu(1, np.abs(xm), np.abs(ym), zs)
+    want = _conv_raw_gpu(1, xm, ym, zs)
+    got = _conv_raw_gpu(2, xm, ym, zs)
+    assert np.all(np.abs(got - want) <= 1e-10 * bound)
+    # slab range + accumulate: only the selected leading slabs change, by exactly the product
+    lo, hi = zs[0] // 3, max(zs[0] // 3 + 1, (2 * zs[0]) // 3)
+    z0 = rand(zs, 23)
+    got = _conv_raw_gpu(2, x, y, zs, slab=(lo, hi), accumulate=True, z0=z0)
+    full = _conv_raw_gpu(1, x, y, zs)
+    exp = z0.copy()
+    exp[lo:hi] += full[lo:hi]
+    assert np.array_equal(got[:lo], z0[:lo]) and np.array_equal(got[hi:], z0[hi:])
+    assert np.all(np.abs(got[lo:hi] - exp[lo:hi]) <= 1e-10 * np.abs(exp[lo:hi]))
+    # deterministic: two runs are bit-identical (fixed-order partial-slab reduction, no atomics)
+    assert np.array_equal(_conv_raw_gpu(2, x, y, zs), _conv_raw_gpu(2, x, y, zs))
+
+
+def test_conv_tiled_vs_oracle_and_pgf_like_dynamic_range(oracle_lib):
+    """Tiled kernel against the CPU oracle directly, including a pgf-like operand spanning > 100
+    orders of magnitude (relative accuracy per coefficient must survive: no FFT-style absolute error)."""
+    import ctypes as C
+    from math import lgamma, log
+
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_raw.restype = C.c_int
+    oracle_lib.orc_mul_raw.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t]
+    n = 40
+    shape = (n, n, n)
+    i = np.arange(n)
+    pois = lambda lam: np.exp(i * log(lam) - lam - np.array([lgamma(k + 1) for k in i]))
+    pgf = pois(20.0)[:, None, None] * pois(30.0)[None, :, None] * pois(40.0)[None, None, :]
+    x = pgf * (1 + 0.1 * rand(shape, 31))
+    y = pgf[::-1, ::-1, ::-1].copy() * (1 + 0.1 * rand(shape, 32))
+    assert x.max() / x[x > 0].min() > 1e30
+    want = np.zeros(shape)
+    sz = (C.c_size_t * 3)(*shape)
+    oracle_lib.orc_mul_raw(x.ctypes.data_as(C.c_void_p), sz, y.ctypes.data_as(C.c_void_p), sz,
+                           want.ctypes.data_as(C.c_void_p), sz, 3)
+    got = _conv_raw_gpu(2, x, y, shape)
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want))
+
+
+def test_conv_tiled_nonfinite_operands_fall_back():
+    """inf/NaN operands must not be polluted by zero padding: auto mode routes them to the
+    reference-order kernel and the result equals it bit for bit."""
+    x, y = rand((16, 16, 20), 41), rand((16, 16, 20), 42)
+    x[3, 4, 5] = np.inf
+    y[1, 2, 3] = np.nan
+    want = _conv_raw_gpu(1, x, y, (16, 16, 20))
+    got = _conv_raw_gpu(0, x, y, (16, 16, 20))
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] at full size (128^3): tiled result vs the reference-order kernel on the
+    whole tensor, plus size-independent properties: commutativity (bitwise on the tiled kernel is
+    not required; 1e-10), linearity in x, and the constant-term / corner known answers."""
+    shape = (128, 128, 128)
+    x, y = rand(shape, 1), rand(shape, 2)
+    got = _conv_raw_gpu(2, x, y, shape)
+    want = _conv_raw_gpu(1, x, y, shape)
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / want).max()
+    comm = _conv_raw_gpu(2, y, x, shape)
+    assert np.all(np.abs(got - comm) <= 1e-10 * np.abs(want))
+    got2 = _conv_raw_gpu(2, 2.0 * x, y, shape)  # scaling by a power of two is exact
+    assert np.array_equal(got2, 2.0 * got)
+    assert got[0, 0, 0] == x[0, 0, 0] * y[0, 0, 0]
+    assert abs(got[0, 0, 1] - (x[0, 0, 0] * y[0, 0, 1] + x[0, 0, 1] * y[0, 0, 0])) <= 1e-15
