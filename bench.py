@@ -145,6 +145,8 @@ def main():
 
     (lo0, hi0), (lo1, hi1), even = genfer_amd.plan_slabs(shape[0], world, rank)
     groups = [(lo0, hi0), (lo1, hi1)]
+    # adjacent groups (always the case on one GPU) are one launch: one stream-K partition over all tiles
+    launches = [(lo0, hi1)] if hi0 == lo1 else [g for g in groups if g[1] > g[0]]
     local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in groups if b > a)
     plans = [genfer_amd.plan_slabs(shape[0], world, r) for r in range(world)]
 
@@ -155,9 +157,8 @@ def main():
             z.zero_()
         if timed:
             L.gft_event_record(0)
-        for a, b in groups:
-            if b > a:
-                genfer_amd.conv_raw(x.data_ptr(), shape, y.data_ptr(), shape, z.data_ptr(), shape, a, b)
+        for a, b in launches:
+            genfer_amd.conv_raw(x.data_ptr(), shape, y.data_ptr(), shape, z.data_ptr(), shape, a, b)
         if timed:
             L.gft_event_record(1)
         if world > 1:

@@ -54,6 +54,7 @@ struct Runtime {
     double* h_pinned = nullptr;  // pinned staging for small D2H reads
     hipEvent_t events[16] = {};
     int conv_mode = 0;
+    int conv_variant = -1;
     void* conv_ws = nullptr;
     size_t conv_ws_bytes = 0;
 };
@@ -520,6 +521,7 @@ struct Ops {
         a.j0_min = j0_min;
         a.j0_excl = j0_excl;
         a.j0_desc = j0_desc;
+        a.variant = R.conv_variant;
         // number of non-unit axes that take part in the reference's "1-d like" inner product
         int first_inner_axis = slab_mode ? 1 : 0;
         int nonunit = 0;
@@ -1098,6 +1100,10 @@ float gft_event_elapsed_ms(int a, int b) {
         g_err = e.what();
         return -1.0f;
     }
+}
+int gft_set_conv_variant(int v) {
+    R.conv_variant = v;
+    return 0;
 }
 int gft_set_conv_mode(int mode) {
     if (mode < 0 || mode > 2) return -1;

@@ -8,8 +8,9 @@
 //                       R = 8 consecutive k2 outputs of its row in registers (two such blocks per wave,
 //                       c and nb-1-c, so every wave of the workgroup has the same trip count although
 //                       the index space is triangular)
-//   x operand           wave-uniform: x[J][j2..j2+7] comes from scalar loads into SGPRs and is the
-//                       SGPR source of v_fma_f64 — zero VGPR/LDS traffic for one of the two operands
+//   x operand           wave-uniform: x[J][j2..j2+7] comes from scalar loads (constant address space =>
+//                       s_load_dwordx16) into SGPRs and is the SGPR source of v_fma_f64 — zero VGPR/LDS
+//                       traffic for one of the two operands
 //   y operand           an 8x8 window of y rows lives in LDS, row r = 8*slot0 + slot1 at offset r*P1 doubles
 //                       with P1 = ny8+1 (odd) => the rows read by any aligned group of 16 or 32 lanes
 //                       start in distinct 8-byte bank slots (conflict-free ds_read_b64 / ds_read2_b64);
@@ -70,11 +71,34 @@ struct TiledArgs {
     const unsigned* red_slots;
 };
 
-__device__ inline void fma_full(double (&acc)[8], const double* __restrict__ xq, const double (&cur)[8],
-                                const double (&prev)[8]) {
+// x rows are read through the constant address space: the address is wave-uniform and x is never
+// written by this kernel, so hipcc emits s_load_dwordx16 into SGPRs (scalar cache path) instead of
+// 64-lane broadcast vector loads that would occupy the texture-address unit.
+typedef const double __attribute__((address_space(4))) * cptr_t;
+
+#ifndef GFT_TILED_DEFAULT_VARIANT
+#define GFT_TILED_DEFAULT_VARIANT 1
+#endif
+// VAR bits: 1 = software-pipelined fast path for full inner extents; diagnostics (wrong results, timing
+// only, built with -DGFT_TILED_DIAG): 16 = no LDS reads in the chunk loop, 32 = no scalar x loads,
+// 64 = no window maintenance / barriers.
+
+__device__ inline void loadx(double (&dst)[8], cptr_t p) {  // wave-uniform: 8 doubles -> 16 SGPRs
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = p[i];
+}
+
+__device__ inline void load8(double (&dst)[8], const double* p) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = p[i];
+}
+
+__device__ inline void fma_rows(double (&acc)[8], const double (&xq)[8], const double (&cur)[8],
+                                const double (&prev)[8], int s_lo, int s_hi) {
     // acc[r] += x[8q+s] * y[8(c-q) + r - s]; r-s >= 0 -> cur[r-s], else prev[8 + r - s]
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+        if (s < s_lo || s >= s_hi) continue;
         const double xs = xq[s];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -84,7 +108,12 @@ __device__ inline void fma_full(double (&acc)[8], const double* __restrict__ xq,
     }
 }
 
-__device__ inline void fma_tri(double (&acc)[8], const double* __restrict__ xq, const double (&cur)[8]) {
+__device__ inline void fma_full(double (&acc)[8], const double (&xq)[8], const double (&cur)[8],
+                                const double (&prev)[8]) {
+    fma_rows(acc, xq, cur, prev, 0, 8);
+}
+
+__device__ inline void fma_tri(double (&acc)[8], const double (&xq)[8], const double (&cur)[8]) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const double xs = xq[s];
@@ -93,17 +122,16 @@ __device__ inline void fma_tri(double (&acc)[8], const double* __restrict__ xq, 
     }
 }
 
-__device__ inline void load8(double (&dst)[8], const double* p) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = p[i];
-}
-
-// One output block c (8 consecutive k2) of one lane-row for one (x row, y row) pair.
-__device__ inline void block_mac(double (&acc)[8], unsigned c, const double* __restrict__ xr,
-                                 const double* yrow, unsigned nxc, unsigned nyc) {
+// General path: one output block c (8 consecutive k2) of one lane-row for one (x row, y row) pair; handles
+// compact operands (fewer x / y chunks than output blocks).
+template <int VAR>
+__device__ inline void block_mac(double (&acc)[8], unsigned c, cptr_t xr, const double* yrow, unsigned nxc,
+                                 unsigned nyc) {
+    constexpr bool NO_LDS = (VAR & 16) != 0;
+    constexpr bool NO_X = (VAR & 32) != 0;
     unsigned q_lo = c > nyc ? c - nyc : 0;
     unsigned q_hi = c < nxc ? c : nxc;  // full chunks q in [q_lo, q_hi)
-    double A[8], B[8];
+    double A[8], B[8], X[8];
     unsigned m0 = c - q_lo;
     if (m0 < nyc) {
         load8(A, yrow + 8 * m0);
@@ -111,20 +139,77 @@ __device__ inline void block_mac(double (&acc)[8], unsigned c, const double* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) A[i] = 0.0;
     }
+    if (NO_LDS) load8(B, yrow);
+    if (NO_X) loadx(X, xr);
     unsigned q = q_lo;
     // two chunks per iteration so the sliding window alternates between A and B without moves
     for (; q + 2 <= q_hi; q += 2) {
-        load8(B, yrow + 8 * (c - q - 1));
-        fma_full(acc, xr + 8 * q, A, B);
-        load8(A, yrow + 8 * (c - q - 2));
-        fma_full(acc, xr + 8 * (q + 1), B, A);
+        if (!NO_LDS) load8(B, yrow + 8 * (c - q - 1));
+        if (!NO_X) loadx(X, xr + 8 * q);
+        fma_full(acc, X, A, B);
+        if (!NO_LDS) load8(A, yrow + 8 * (c - q - 2));
+        if (!NO_X) loadx(X, xr + 8 * (q + 1));
+        fma_full(acc, X, B, A);
     }
     if (q < q_hi) {
-        load8(B, yrow + 8 * (c - q - 1));
-        fma_full(acc, xr + 8 * q, A, B);
-        if (c < nxc) fma_tri(acc, xr + 8 * c, B);
+        if (!NO_LDS) load8(B, yrow + 8 * (c - q - 1));
+        if (!NO_X) loadx(X, xr + 8 * q);
+        fma_full(acc, X, A, B);
+        if (c < nxc) {
+            if (!NO_X) loadx(X, xr + 8 * c);
+            fma_tri(acc, X, B);
+        }
+    } else if (c < nxc) {
+        if (!NO_X) loadx(X, xr + 8 * c);
+        fma_tri(acc, X, A);
+    }
+}
+
+// Fast path (x and y span every chunk the block touches: q_lo = 0, q_hi = c).  Three-way rotation of the
+// window buffers (A,B,C) and of the x buffers (X0,X1,X2): chunk i uses (X_i; cur, prev) and, right after
+// its first FMA row — i.e. after the s_waitcnt that the first use of its own operands triggers — requests
+// x[q+i+1] and W[q+i+2] for the following chunks.  Every LDS / scalar-load result is therefore >= 56 FMAs
+// (~250 cycles) old when first used, and the window slides without register moves.  The scheduling
+// barriers pin this order (hipcc otherwise sinks the loads next to their uses and stalls on them).
+// W[t] = yrow[8(c-t) ..+7]; t = c+1 reads the row's 8-double front padding, x[q] for q = nxc reads the
+// slack after the packed row — both are loaded but never used.
+#define GFT_STEP(XU, CUR, PREV, XN, TX, WN, TW)                 \
+    do {                                                        \
+        fma_rows(acc, XU, CUR, PREV, 0, 1);                     \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        if (!NO_X) loadx(XN, xr + 8 * (TX));                    \
+        if (!NO_LDS) load8(WN, w0 - 8 * (int)(TW));             \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        fma_rows(acc, XU, CUR, PREV, 1, 8);                     \
+    } while (0)
+
+template <int VAR>
+__device__ inline void block_fast(double (&acc)[8], unsigned c, cptr_t xr, const double* yrow) {
+    constexpr bool NO_LDS = (VAR & 16) != 0;
+    constexpr bool NO_X = (VAR & 32) != 0;
+    const double* w0 = yrow + 8 * c;  // W[t] = w0 - 8t
+    double A[8], B[8], C[8], X0[8], X1[8], X2[8];
+    load8(A, w0);
+    load8(B, w0 - 8);
+    loadx(X0, xr);
+    if (NO_LDS) load8(C, w0);
+    if (NO_X) loadx(X1, xr), loadx(X2, xr);
+    unsigned q = 0;
+    for (; q + 3 <= c; q += 3) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
+        GFT_STEP(X2, C, A, X0, q + 3, B, q + 4);
+    }
+    const unsigned rem = c - q;
+    if (rem == 2) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
+        fma_tri(acc, X2, C);
+    } else if (rem == 1) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        fma_tri(acc, X1, B);
     } else {
-        if (c < nxc) fma_tri(acc, xr + 8 * c, A);
+        fma_tri(acc, X0, A);
     }
 }
 
@@ -152,10 +237,13 @@ __host__ __device__ inline TileGeom tile_geom(const TiledArgs& A, unsigned u, un
 
 constexpr int MAX_PF = 1;  // prefetch pieces (16 B each) per thread for one ring slot refill: 8*ny8/2 <= 64*NW
                            // because yI <= zI (operands never exceed the result shape) and NW >= nb/2
+constexpr unsigned YPAD = 8;  // front padding of every LDS row (doubles)
 
-template <int NW>
+template <int NW, int VAR>
 __global__ void __launch_bounds__(NW * 64, 4)  // 4 waves per SIMD = 16 waves per CU => <= 128 VGPRs
 k_conv_tiled(TiledArgs A) {
+    constexpr bool FAST = (VAR & 1) != 0;
+    constexpr bool NO_WINDOW = (VAR & 64) != 0;
     extern __shared__ double lds[];
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -206,7 +294,7 @@ k_conv_tiled(TiledArgs A) {
                     if (R0 >= 0 && R0 < (int)A.y0 && R1 >= 0 && R1 < (int)A.y1) {
                         const double2 v = *reinterpret_cast<const double2*>(
                             ybase + ((size_t)R0 * A.y1 + (size_t)R1) * y_row_stride + 2 * col);
-                        double* d = lds + s0 * A.P0 + ((unsigned)R1 & 7u) * A.P1 + 2 * col;
+                        double* d = lds + s0 * A.P0 + ((unsigned)R1 & 7u) * A.P1 + YPAD + 2 * col;
                         d[0] = v.x;
                         d[1] = v.y;
                     }
@@ -219,7 +307,7 @@ k_conv_tiled(TiledArgs A) {
             // prefetch the ring slot that the next j1 step needs: rows R1n = 8b - j1 - 1 (+ nothing else new)
             double2 pf[MAX_PF];
             const int R1n = (int)(8 * b) - (int)j1 - 1;
-            const bool do_pf = same_row && R1n >= 0 && R1n < (int)A.y1;
+            const bool do_pf = !NO_WINDOW && same_row && R1n >= 0 && R1n < (int)A.y1;
             if (do_pf) {
                 const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
 #pragma unroll
@@ -237,18 +325,23 @@ k_conv_tiled(TiledArgs A) {
 
             // ---- compute this step -------------------------------------------------------------
             {
-                const double* xr = A.xp + (((size_t)ju * A.x0 + j0) * A.x1 + j1) * A.nx8;  // wave-uniform
+                cptr_t xr = (cptr_t)(A.xp + (((size_t)ju * A.x0 + j0) * A.x1 + j1) * A.nx8);  // wave-uniform
                 const bool valid = lane_in && j0 <= k0 && (k0 - j0) < A.y0 && j1 <= k1 && (k1 - j1) < A.y1;
                 if (valid) {
-                    const double* yrow = lds + l0 * A.P0 + ((k1 - j1) & 7u) * A.P1;
-                    if (has1) block_mac(acc1, c1, xr, yrow, A.nxc, A.nyc);
-                    if (has2) block_mac(acc2, c2, xr, yrow, A.nxc, A.nyc);
+                    const double* yrow = lds + l0 * A.P0 + ((k1 - j1) & 7u) * A.P1 + YPAD;
+                    if constexpr (FAST) {  // host guarantees nxc, nyc >= nb for this instantiation
+                        if (has1) block_fast<VAR>(acc1, c1, xr, yrow);
+                        if (has2) block_fast<VAR>(acc2, c2, xr, yrow);
+                    } else {
+                        if (has1) block_mac<VAR>(acc1, c1, xr, yrow, A.nxc, A.nyc);
+                        if (has2) block_mac<VAR>(acc2, c2, xr, yrow, A.nxc, A.nyc);
+                    }
                 }
             }
 
             // ---- advance ---------------------------------------------------------------------------
             if (same_row) {
-                __syncthreads();  // everyone is done reading the slot being replaced
+                if (!NO_WINDOW) __syncthreads();  // everyone is done reading the slot being replaced
                 if (do_pf) {
 #pragma unroll
                     for (int i = 0; i < MAX_PF; ++i) {
@@ -257,14 +350,14 @@ k_conv_tiled(TiledArgs A) {
                             unsigned s0 = p / half_row, col = p - s0 * half_row;
                             int R0 = (int)(8 * a + s0) - (int)j0;
                             if (R0 >= 0 && R0 < (int)A.y0) {
-                                double* d = lds + s0 * A.P0 + ((unsigned)R1n & 7u) * A.P1 + 2 * col;
+                                double* d = lds + s0 * A.P0 + ((unsigned)R1n & 7u) * A.P1 + YPAD + 2 * col;
                                 d[0] = pf[i].x;
                                 d[1] = pf[i].y;
                             }
                         }
                     }
                 }
-                __syncthreads();
+                if (!NO_WINDOW) __syncthreads();
                 j1++;
             } else if (more) {
                 j1 = g.j1lo;
@@ -273,7 +366,7 @@ k_conv_tiled(TiledArgs A) {
                     j0 = g.j0lo;
                     ju++;
                 }
-                need_full = true;
+                need_full = !NO_WINDOW;
             }
             s++;
         }
@@ -420,7 +513,7 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     T.nxc = T.nx8 / 8;
     T.nyc = T.ny8 / 8;
     T.nb = (T.zI + 7) / 8;
-    T.P1 = T.ny8 + 1;  // odd pitch: row index -> 8-byte bank slot is a bijection mod 16 and mod 32
+    T.P1 = T.ny8 + YPAD + 1;  // front padding + odd pitch: row index -> 8-byte bank slot is a bijection mod 16 and 32
     T.P0 = 8 * T.P1;
     T.slab_lo = a.slab_lo;
     T.slab_hi = a.slab_hi;
@@ -532,22 +625,24 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     return true;
 }
 
-template <int NW>
+template <int NW, int VAR>
 hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tiled<NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tiled<NW, VAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_tiled<NW>, dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
+    hipLaunchKernelGGL((k_conv_tiled<NW, VAR>), dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
     return hipGetLastError();
 }
 
 }  // namespace
 
-bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
+bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a_in, void* ws,
                     size_t ws_bytes, size_t* ws_needed) {
+    ConvArgs a = a_in;
+    if (a.variant < 0) a.variant = GFT_TILED_DEFAULT_VARIANT;
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     if (a.nd != 3 && a.nd != 4) return false;
@@ -561,6 +656,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     key.v[14] = a.slab_hi;
     key.v[15] = (unsigned)a.accumulate;
     key.v[16] = (unsigned)(a.j0_min | (a.j0_excl << 8) | (a.j0_desc << 16));
+    key.v[17] = (unsigned)a.variant;
     auto& cache = plan_cache();
     auto it = cache.find(key);
     if (it == cache.end()) {
@@ -577,9 +673,11 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     // workspace: [partial slabs][packed x][packed y][flag]
     size_t b_slots = (size_t)P.n_slots * B.nb * 512 * sizeof(double);
     size_t x_rows = (size_t)B.xU * B.x0 * B.x1, y_rows = (size_t)B.yU * B.y0 * B.y1;
-    bool pack_x = B.nx8 != B.xI || ((uintptr_t)x & 7);
+    // x is always packed: rows padded to whole chunks plus one chunk of slack after the last row (the
+    // pipelined path requests one chunk beyond the one it uses)
+    bool pack_x = true;
     bool pack_y = B.ny8 != B.yI || ((uintptr_t)y & 15);  // window loads are 16-byte
-    size_t b_xp = pack_x ? x_rows * B.nx8 * sizeof(double) : 0;
+    size_t b_xp = pack_x ? (x_rows * B.nx8 + 8) * sizeof(double) : 0;
     size_t b_yp = pack_y ? y_rows * B.ny8 * sizeof(double) : 0;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t need = al(b_slots) + al(b_xp) + al(b_yp) + 256;
@@ -609,12 +707,38 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
         T.yp = y;
     }
     T.z = z;
-    hipError_t e;
-    switch (P.NW) {
-        case 1: e = launch_main<1>(st, P, T); break;
-        case 2: e = launch_main<2>(st, P, T); break;
-        case 4: e = launch_main<4>(st, P, T); break;
-        default: e = launch_main<8>(st, P, T); break;
+    hipError_t e = hipSuccess;
+    constexpr int DEF = GFT_TILED_DEFAULT_VARIANT;
+    int variant = a.variant;
+    if (!(B.nxc >= B.nb && B.nyc >= B.nb)) variant &= ~1;  // pipelined fast path needs full inner extents
+    if (P.NW == 8) {
+        switch (variant) {
+            case 0: e = launch_main<8, 0>(st, P, T); break;
+            case 1: e = launch_main<8, 1>(st, P, T); break;
+#ifdef GFT_TILED_DIAG
+            case 17: e = launch_main<8, 17>(st, P, T); break;
+            case 33: e = launch_main<8, 33>(st, P, T); break;
+            case 49: e = launch_main<8, 49>(st, P, T); break;
+            case 65: e = launch_main<8, 65>(st, P, T); break;
+            case 113: e = launch_main<8, 113>(st, P, T); break;
+#endif
+            default: return false;
+        }
+    } else {
+        if ((variant | 1) != (DEF | 1)) return false;
+        if (variant & 1) {
+            switch (P.NW) {
+                case 1: e = launch_main<1, 1>(st, P, T); break;
+                case 2: e = launch_main<2, 1>(st, P, T); break;
+                default: e = launch_main<4, 1>(st, P, T); break;
+            }
+        } else {
+            switch (P.NW) {
+                case 1: e = launch_main<1, 0>(st, P, T); break;
+                case 2: e = launch_main<2, 0>(st, P, T); break;
+                default: e = launch_main<4, 0>(st, P, T); break;
+            }
+        }
     }
     if (e != hipSuccess) return false;
     if (P.n_red) {

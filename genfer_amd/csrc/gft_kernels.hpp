@@ -57,6 +57,7 @@ struct ConvArgs {
     int j0_excl;                // 1: exclude j0 == k0 (div/log: res[k] is not known yet)
     int j0_desc;                // iterate j0 downwards (log's summation order)
     int inner_from_zero;        // last axis' partial sum is formed from zero, then added (mul_1d, mt:971-982)
+    int variant;                // tiled-kernel variant (gft_set_conv_variant; -1 = library default)
 };
 
 template <class E>

@@ -56,6 +56,8 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
 /* Which convolution kernel `mul` may use: 0 = auto, 1 = force the simple one-thread-per-output
  * kernel, 2 = force the LDS-tiled kernel (errors if the shape is unsupported).  Test/bench knob. */
 int gft_set_conv_mode(int mode);
+/* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
+int gft_set_conv_variant(int variant);
 
 /* ---- raw device-pointer entry points (no handles) ---------------------------------------- */
 /* res[k] (+)= sum_j x[j]*y[k-j] for k0 in [slab_lo, slab_hi): the truncated N-d Cauchy product
