@@ -143,31 +143,17 @@ def main():
     total_macs = genfer_amd.conv_macs(shape, shape, shape)
     alg_bytes = 3 * n * 8  # read x, read y, write z once
 
-    (lo0, hi0), (lo1, hi1), even = genfer_amd.plan_slabs(shape[0], world, rank)
-    groups = [(lo0, hi0), (lo1, hi1)]
-    # adjacent groups (always the case on one GPU) are one launch: one stream-K partition over all tiles
-    launches = [(lo0, hi1)] if hi0 == lo1 else [g for g in groups if g[1] > g[0]]
-    local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in groups if b > a)
-    plans = [genfer_amd.plan_slabs(shape[0], world, r) for r in range(world)]
+    from genfer_amd.dist import gpu_conv_slabs, local_ranges, sharded_conv
+
+    g0, g1, even, launches = local_ranges(shape[0], world, rank)
+    local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in (g0, g1) if b > a)
 
     kern_ms = []
 
     def step(timed):
-        if world > 1 and not even:
-            z.zero_()
-        if timed:
-            L.gft_event_record(0)
-        for a, b in launches:
-            genfer_amd.conv_raw(x.data_ptr(), shape, y.data_ptr(), shape, z.data_ptr(), shape, a, b)
-        if timed:
-            L.gft_event_record(1)
-        if world > 1:
-            if even:
-                for g in (0, 1):
-                    outs = [z[plans[r][g][0]:plans[r][g][1]] for r in range(world)]
-                    dist.all_gather(outs, z[groups[g][0]:groups[g][1]])
-            else:
-                dist.all_reduce(z)  # every rank wrote only its own slabs into a zeroed tensor
+        sharded_conv(x, y, z, gpu_conv_slabs,
+                     before_local=(lambda: L.gft_event_record(0)) if timed else None,
+                     after_local=(lambda: L.gft_event_record(1)) if timed else None)
         if timed:
             kern_ms.append(L.gft_event_elapsed_ms(0, 1))
 

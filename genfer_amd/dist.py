@@ -1,0 +1,80 @@
+"""Output-sharded product across the GPUs of one node: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Every output slab ``z[k0, ...]`` of the truncated product depends only on ``x[0..=k0]`` and
+``y[0..=k0]`` and on no other output (src/multivariate_taylor.rs:1001-1011), so the path shards
+without any reduction: operands are replicated (``broadcast_operands`` when they originate on one
+rank), every rank computes its own leading-axis slabs — assigned by the folded plan of
+``gft_plan_slabs`` so that the triangular work is balanced — and the result slabs are exchanged with
+two all-gathers (low groups, mirrored high groups).  When the leading axis does not divide evenly
+the fallback is an all-reduce of zero-initialised tensors (adding zeros is exact, so the result is
+bit-identical to the single-GPU one).
+
+The local compute is injected (``conv_slabs(x, y, z, lo, hi)``): the product uses
+``genfer_amd.conv_raw`` (HIP kernels); the CPU tests inject the oracle to exercise the planner and
+the collectives under gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import plan_slabs
+
+
+def broadcast_operands(x: torch.Tensor, y: torch.Tensor, src: int = 0, group=None) -> None:
+    """Replicate the operands from ``src`` (RCCL broadcast over xGMI: the root pushes to its peers
+    on all links concurrently; 2 x 134 MB at 64^4 is ~2 ms, <= 3 % of the product)."""
+    dist.broadcast(x, src=src, group=group)
+    dist.broadcast(y, src=src, group=group)
+
+
+def local_ranges(n0: int, world: int, rank: int):
+    (a, b), (c, d), even = plan_slabs(n0, world, rank)
+    launches = [(a, d)] if b == c else [r for r in ((a, b), (c, d)) if r[1] > r[0]]
+    return (a, b), (c, d), even, launches
+
+
+def sharded_conv(
+    x: torch.Tensor,
+    y: torch.Tensor,
+    z: torch.Tensor,
+    conv_slabs: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int, int], None],
+    group=None,
+    before_local: Callable[[], None] | None = None,
+    after_local: Callable[[], None] | None = None,
+) -> torch.Tensor:
+    """z = x (*) y with the leading output axis sharded over the process group.  ``x`` and ``y``
+    must already hold identical data on every rank; ``z`` (full result shape, same on every rank) is
+    filled completely on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n0 = z.shape[0]
+    g0, g1, even, launches = local_ranges(n0, world, rank)
+    if world > 1 and not even:
+        z.zero_()
+    if before_local:
+        before_local()
+    for lo, hi in launches:
+        conv_slabs(x, y, z, lo, hi)
+    if after_local:  # e.g. record a HIP event: kernel time is reported separately from the exchange
+        after_local()
+    if world == 1:
+        return z
+    if even:
+        plans = [plan_slabs(n0, world, r) for r in range(world)]
+        for g, mine in ((0, g0), (1, g1)):
+            outs = [z[plans[r][g][0]:plans[r][g][1]] for r in range(world)]
+            dist.all_gather(outs, z[mine[0]:mine[1]], group=group)
+    else:
+        dist.all_reduce(z, group=group)
+    return z
+
+
+def gpu_conv_slabs(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, lo: int, hi: int) -> None:
+    """The product's local compute: HIP kernels on the caller's tensors (no CPU path)."""
+    from . import conv_raw
+
+    conv_raw(x.data_ptr(), tuple(x.shape), y.data_ptr(), tuple(y.shape), z.data_ptr(), tuple(z.shape), lo, hi)
