@@ -91,6 +91,51 @@ def __getattr__(name):  # lazy: `from genfer_amd import TaylorPoly` loads the li
     raise AttributeError(name)
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "csrc", "host", "libgfhost.so")
+_host = None
+
+
+def host_lib() -> ctypes.CDLL:
+    """The host interpreter (SGCL parser -> GF DAG -> eval -> report), backend-agnostic over the C ABI."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing — build it with `make -C genfer_amd/csrc/host`")
+        _host = ctypes.CDLL(HOST_LIB_PATH)
+        _host.gfh_run.restype = ctypes.c_int
+        _host.gfh_run.argtypes = [ctypes.c_char_p] * 4 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+        _host.gfh_free.argtypes = [ctypes.c_void_p]
+    return _host
+
+
+def run_sgcl_with_backend(source: str, flags: str, backend_lib: str, prefix: str):
+    """Run an SGCL program end to end against an explicit TaylorPoly backend library.
+    Returns (rc, report_text, timings_dict).  The product entry point is :func:`run_sgcl`."""
+    import json
+
+    H = host_lib()
+    out, tj = ctypes.c_void_p(), ctypes.c_void_p()
+    rc = H.gfh_run(source.encode(), flags.encode(), backend_lib.encode(), prefix.encode(), ctypes.byref(out), ctypes.byref(tj))
+    text = ctypes.string_at(out).decode() if out else ""
+    timings = json.loads(ctypes.string_at(tj).decode()) if tj else None
+    if out:
+        H.gfh_free(out)
+    if tj:
+        H.gfh_free(tj)
+    return rc, text, timings
+
+
+def run_sgcl(source: str, flags: str = ""):
+    """`genfer file.sgcl <flags>` on the GPU: the reference's report text (src/main.rs) with every
+    TaylorPoly operation executed by libgftaylor's HIP kernels.  `--bounds` selects interval tensors."""
+    lib()  # make sure the runtime (and torch's HIP runtime, see lib()) is loaded first
+    prefix = "gfti_" if any(t in ("-b", "--bounds") for t in flags.split()) else "gft_"
+    rc, text, timings = run_sgcl_with_backend(source, flags, LIB_PATH, prefix)
+    if rc != 0:
+        raise TaylorError(text)
+    return text, timings
+
+
 def _sz(seq):
     seq = [int(s) for s in seq]
     return (ctypes.c_size_t * max(len(seq), 1))(*seq)

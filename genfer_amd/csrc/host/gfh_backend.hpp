@@ -1,0 +1,187 @@
+// Host interpreter, part 1: the TaylorPoly value type used by the evaluator — a thin
+// RAII wrapper over the C ABI of include/gftaylor.h, bound at run time (dlopen + prefix) so the same
+// interpreter drives libgftaylor.so (HIP, the product) or any other library exporting the same
+// surface.  Mirrors the reference's `TaylorPoly<T>` method names (src/multivariate_taylor.rs).
+#pragma once
+#include <dlfcn.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace gfh {
+
+typedef std::vector<size_t> Dims;
+constexpr size_t UMAX = SIZE_MAX;
+
+struct Api {
+    void* lib = nullptr;
+    int width = 1;
+    const char* (*last_error)();
+    int (*width_fn)();
+    void* (*from_host)(const double*, const size_t*, const size_t*, size_t);
+    void* (*scalar)(const double*);
+    void* (*zero_with)(const size_t*, size_t);
+    void* (*var)(size_t, const double*, size_t);
+    void* (*var_at_zero)(size_t, size_t);
+    void* (*var_with_degrees_p1)(size_t, const double*, const size_t*, size_t);
+    void* (*clone)(const void*);
+    void (*free)(void*);
+    size_t (*num_vars)(const void*);
+    size_t (*numel)(const void*);
+    void (*shape)(const void*, size_t*);
+    void (*degrees_p1)(const void*, size_t*);
+    int (*to_host)(const void*, double*);
+    int (*is_zero)(const void*);
+    int (*is_one)(const void*);
+    int (*constant_term)(const void*, double*);
+    int (*extract_constant)(const void*, double*);
+    int (*coefficient)(const void*, const size_t*, size_t, double*);
+    void* (*add)(const void*, const void*);
+    void* (*sub)(const void*, const void*);
+    void* (*mul)(const void*, const void*);
+    void* (*div)(const void*, const void*);
+    void* (*neg)(const void*);
+    void* (*exp)(const void*);
+    void* (*log)(const void*);
+    void* (*pow)(const void*, uint32_t);
+    void* (*derivative)(const void*, size_t, size_t);
+    void* (*taylor_expansion_of_coeff)(const void*, size_t, size_t);
+    void* (*shift_down)(const void*, size_t, size_t);
+    void* (*subst_var)(const void*, size_t, const void*);
+    void* (*coefficients_of_term)(const void*, size_t, size_t);
+    void* (*taylor_polynomial_terms)(const void*, size_t, const size_t*, size_t);
+    void* (*truncate_to_degree_p1)(const void*, size_t);
+    void* (*remove_last_variable)(const void*);
+    void* (*extend_to_dim)(const void*, size_t, size_t);
+
+    static std::shared_ptr<Api> load(const std::string& path, const std::string& prefix) {
+        auto a = std::make_shared<Api>();
+        a->lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!a->lib) throw std::runtime_error(std::string("cannot load backend library: ") + dlerror());
+        auto sym = [&](const char* name) -> void* {
+            std::string full = prefix + name;
+            void* p = dlsym(a->lib, full.c_str());
+            if (!p) throw std::runtime_error("backend library does not export " + full);
+            return p;
+        };
+#define GFH_BIND(f) a->f = reinterpret_cast<decltype(a->f)>(sym(#f))
+        GFH_BIND(last_error);
+        a->width_fn = reinterpret_cast<int (*)()>(sym("width"));
+        GFH_BIND(from_host); GFH_BIND(scalar); GFH_BIND(zero_with); GFH_BIND(var); GFH_BIND(var_at_zero);
+        GFH_BIND(var_with_degrees_p1); GFH_BIND(clone); GFH_BIND(free); GFH_BIND(num_vars); GFH_BIND(numel);
+        GFH_BIND(shape); GFH_BIND(degrees_p1); GFH_BIND(to_host); GFH_BIND(is_zero); GFH_BIND(is_one);
+        GFH_BIND(constant_term); GFH_BIND(extract_constant); GFH_BIND(coefficient); GFH_BIND(add); GFH_BIND(sub);
+        GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
+        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var);
+        GFH_BIND(coefficients_of_term); GFH_BIND(taylor_polynomial_terms); GFH_BIND(truncate_to_degree_p1);
+        GFH_BIND(remove_last_variable); GFH_BIND(extend_to_dim);
+#undef GFH_BIND
+        a->width = a->width_fn();
+        return a;
+    }
+};
+
+// The value type: shared immutable handle (clone = refcount, like the ABI's O(1) clone).
+template <class T>
+class Poly {
+    struct H {
+        std::shared_ptr<Api> api;
+        void* h = nullptr;
+        H() {}
+        H(const H&) = delete;
+        H& operator=(const H&) = delete;
+        ~H() { if (h) api->free(h); }
+    };
+    std::shared_ptr<H> p_;
+    static std::shared_ptr<Api>& api_slot() { static std::shared_ptr<Api> a; return a; }
+    static Poly wrap(void* h) {
+        auto& a = api_slot();
+        if (!h) throw std::runtime_error(std::string("TaylorPoly backend error: ") + a->last_error());
+        Poly r;
+        r.p_ = std::make_shared<H>();
+        r.p_->api = a;
+        r.p_->h = h;
+        return r;
+    }
+    void* h() const { return p_->h; }
+
+  public:
+    static void bind(std::shared_ptr<Api> a) {
+        if (a->width != T::WIDTH) throw std::runtime_error("backend element width does not match the number type");
+        api_slot() = a;
+    }
+    static Api& api() { return *api_slot(); }
+
+    static Poly from_array(const std::vector<T>& data, const Dims& shape, const Dims& degs) {  // mt:33-41
+        size_t n = data.size();
+        std::vector<double> planes(n * T::WIDTH);
+        for (size_t i = 0; i < n; ++i) data[i].store_plane(planes.data(), n, i);
+        return wrap(api().from_host(planes.data(), shape.data(), degs.data(), shape.size()));
+    }
+    static Poly from(const T& x) { double b[2]; x.store(b); return wrap(api().scalar(b)); }          // mt:626-630
+    static Poly zero() { return from(T::zero()); }
+    static Poly one() { return from(T::one()); }
+    static Poly zero_with(const Dims& d) { return wrap(api().zero_with(d.data(), d.size())); }        // mt:208-216
+    static Poly var(size_t v, const T& x, size_t len) { double b[2]; x.store(b); return wrap(api().var(v, b, len)); }  // mt:239-248
+    static Poly var_at_zero(size_t v, size_t len) { return wrap(api().var_at_zero(v, len)); }          // mt:228-237
+    static Poly var_with_degrees_p1(size_t v, const T& x, const Dims& d) {                               // mt:250-259
+        double b[2]; x.store(b);
+        return wrap(api().var_with_degrees_p1(v, b, d.data(), d.size()));
+    }
+
+    size_t num_vars() const { return api().num_vars(h()); }
+    Dims shape() const { Dims d(num_vars()); api().degrees_p1(h(), d.data()); return d; }               // mt:53-56
+    Dims coeffs_shape() const { Dims d(num_vars()); api().shape(h(), d.data()); return d; }
+    bool is_constant() const { return api().numel(h()) == 1; }
+    bool is_zero() const { return api().is_zero(h()) == 1; }
+    bool is_one() const { return api().is_one(h()) == 1; }
+    T constant_term() const { double b[2] = {0, 0}; api().constant_term(h(), b); return T::load(b); }   // mt:296-299
+    bool extract_constant(T& out) const {                                                                // mt:262-269
+        double b[2] = {0, 0};
+        if (api().extract_constant(h(), b) != 1) return false;
+        out = T::load(b);
+        return true;
+    }
+    T coefficient(const Dims& idx) const {                                                               // mt:314-339
+        double b[2] = {0, 0};
+        if (api().coefficient(h(), idx.data(), idx.size(), b) != 0)
+            throw std::runtime_error(std::string("coefficient: ") + api().last_error());
+        return T::load(b);
+    }
+    // into_array(): host copy of the stored coefficients (plane-major -> T)
+    std::vector<T> to_vector(Dims* shape_out = nullptr) const {
+        size_t n = api().numel(h());
+        std::vector<double> planes(n * T::WIDTH);
+        api().to_host(h(), planes.data());
+        std::vector<T> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = T::load_plane(planes.data(), n, i);
+        if (shape_out) *shape_out = coeffs_shape();
+        return out;
+    }
+
+    Poly operator+(const Poly& o) const { return wrap(api().add(h(), o.h())); }
+    Poly operator-(const Poly& o) const { return wrap(api().sub(h(), o.h())); }
+    Poly operator*(const Poly& o) const { return wrap(api().mul(h(), o.h())); }
+    Poly operator/(const Poly& o) const { return wrap(api().div(h(), o.h())); }
+    Poly operator-() const { return wrap(api().neg(h())); }
+    Poly exp() const { return wrap(api().exp(h())); }
+    Poly log() const { return wrap(api().log(h())); }
+    Poly pow(uint32_t e) const { return wrap(api().pow(h(), e)); }
+    Poly derivative(size_t v, size_t n) const { return wrap(api().derivative(h(), v, n)); }
+    Poly taylor_expansion_of_coeff(size_t v, size_t n) const { return wrap(api().taylor_expansion_of_coeff(h(), v, n)); }
+    Poly shift_down(size_t v, size_t n) const { return wrap(api().shift_down(h(), v, n)); }
+    Poly subst_var(size_t v, const Poly& s) const { return wrap(api().subst_var(h(), v, s.h())); }
+    Poly coefficients_of_term(size_t v, size_t o) const { return wrap(api().coefficients_of_term(h(), v, o)); }
+    Poly taylor_polynomial_terms(size_t v, const Dims& orders) const {
+        return wrap(api().taylor_polynomial_terms(h(), v, orders.data(), orders.size()));
+    }
+    Poly truncate_to_degree_p1(size_t d) const { return wrap(api().truncate_to_degree_p1(h(), d)); }
+    Poly remove_last_variable() const { return wrap(api().remove_last_variable(h())); }
+    Poly extend_to_dim(size_t nd, size_t d) const { return wrap(api().extend_to_dim(h(), nd, d)); }
+};
+
+}  // namespace gfh

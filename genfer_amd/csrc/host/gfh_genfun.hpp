@@ -1,0 +1,454 @@
+// Host interpreter, part 5: the generating-function DAG and its evaluator (src/generating_function.rs).
+// `GenFun<T>` = shared immutable nodes (Rc in the reference); `simplify` folds polynomial sub-DAGs into a
+// single Polynomial node; `eval` interprets the DAG, turning every arithmetic node into one TaylorPoly
+// operation on the backend (gf.rs:548-668) — this is the sole caller of the hot path.
+#pragma once
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "gfh_backend.hpp"
+#include "gfh_support.hpp"
+
+namespace gfh {
+
+template <class T>
+struct GenFun {
+    enum Kind { Var, Const, Add, Neg, Mul, Div, Polynomial, Exp, Log, Pow, UniformMgf, Subst, Derivative,
+                TaylorPolynomial, TaylorCoeffAtZero, TaylorCoeff, ShiftTaylorAtZero, Max };
+    struct Node {
+        Kind kind;
+        size_t var = 0;
+        T c;
+        uint32_t n = 0;          // Pow exponent
+        size_t order = 0;        // Derivative / TaylorCoeff(AtZero) / Shift order
+        Dims orders;             // TaylorPolynomial
+        GenFun a, b;             // children (b: second operand / substitution)
+        std::vector<T> coeffs;   // Polynomial
+        Dims shape;
+    };
+    std::shared_ptr<const Node> p;
+
+    static GenFun mk(Node n) { GenFun g; g.p = std::make_shared<const Node>(std::move(n)); return g; }
+    static GenFun var(size_t v) { Node n; n.kind = Var; n.var = v; return mk(n); }
+    static GenFun constant(const T& x) { Node n; n.kind = Const; n.c = x; return mk(n); }
+    static GenFun zero() { return constant(T::zero()); }
+    static GenFun one() { return constant(T::one()); }
+    static GenFun from_u32(uint32_t u) { return constant(T::from_u32(u)); }
+    static GenFun from_ratio(const PosRatio& r) { return constant(T::from_ratio(r.numer, r.denom)); }
+    static GenFun polynomial(std::vector<T> coeffs, Dims shape) { Node n; n.kind = Polynomial; n.coeffs = std::move(coeffs); n.shape = std::move(shape); return mk(n); }
+    static GenFun un(Kind k, const GenFun& a) { Node n; n.kind = k; n.a = a; return mk(n); }
+    static GenFun bin(Kind k, const GenFun& a, const GenFun& b) { Node n; n.kind = k; n.a = a; n.b = b; return mk(n); }
+    GenFun exp() const { return un(Exp, *this); }
+    GenFun log() const { return un(Log, *this); }
+    GenFun pow(uint32_t e) const { Node n; n.kind = Pow; n.a = *this; n.n = e; return mk(n); }
+    GenFun max(const GenFun& g) const { return bin(Max, *this, g); }
+    static GenFun uniform_mgf(const GenFun& g) { return un(UniformMgf, g); }
+    GenFun derive(size_t v, size_t order) const { Node n; n.kind = Derivative; n.a = *this; n.var = v; n.order = order; return mk(n); }
+    GenFun taylor_polynomial_at_zero(size_t v, Dims orders) const { Node n; n.kind = TaylorPolynomial; n.a = *this; n.var = v; n.orders = std::move(orders); return mk(n); }
+    GenFun taylor_coeff_at_zero(size_t v, size_t order) const { Node n; n.kind = TaylorCoeffAtZero; n.a = *this; n.var = v; n.order = order; return mk(n); }
+    GenFun taylor_coeff(size_t v, size_t order) const { Node n; n.kind = TaylorCoeff; n.a = *this; n.var = v; n.order = order; return mk(n); }
+    GenFun shift_down_taylor_at_zero(size_t v, size_t order) const { Node n; n.kind = ShiftTaylorAtZero; n.a = *this; n.var = v; n.order = order; return mk(n); }
+    GenFun substitute_var(size_t v, const GenFun& val) const { Node n; n.kind = Subst; n.a = *this; n.var = v; n.b = val; return mk(n); }
+    friend GenFun operator+(const GenFun& a, const GenFun& b) { return bin(Add, a, b); }
+    friend GenFun operator-(const GenFun& a) { return un(Neg, a); }
+    friend GenFun operator-(const GenFun& a, const GenFun& b) { return a + (-b); }
+    friend GenFun operator*(const GenFun& a, const GenFun& b) { return bin(Mul, a, b); }
+    friend GenFun operator/(const GenFun& a, const GenFun& b) { return bin(Div, a, b); }
+
+    // derived PartialEq (structural)
+    bool operator==(const GenFun& o) const {
+        if (p == o.p) return true;
+        if (!p || !o.p) return false;
+        const Node &x = *p, &y = *o.p;
+        if (x.kind != y.kind) return false;
+        switch (x.kind) {
+            case Var: return x.var == y.var;
+            case Const: return x.c == y.c;
+            case Add: case Mul: case Div: case Max: return x.a == y.a && x.b == y.b;
+            case Neg: case Exp: case Log: case UniformMgf: return x.a == y.a;
+            case Pow: return x.a == y.a && x.n == y.n;
+            case Polynomial: return x.shape == y.shape && x.coeffs == y.coeffs;
+            case Subst: return x.a == y.a && x.var == y.var && x.b == y.b;
+            case Derivative: case TaylorCoeffAtZero: case TaylorCoeff: case ShiftTaylorAtZero: return x.a == y.a && x.var == y.var && x.order == y.order;
+            case TaylorPolynomial: return x.a == y.a && x.var == y.var && x.orders == y.orders;
+        }
+        return false;
+    }
+    bool operator!=(const GenFun& o) const { return !(*this == o); }
+
+    // gf.rs:422-443
+    VarRange used_vars() const {
+        std::unordered_map<const Node*, VarRange> cache;
+        return used_vars_with(cache);
+    }
+    VarRange used_vars_with(std::unordered_map<const Node*, VarRange>& cache) const {
+        auto it = cache.find(p.get());
+        if (it != cache.end()) return it->second;
+        const Node& x = *p;
+        VarRange r;
+        switch (x.kind) {
+            case Var: r = VarRange::of(x.var); break;
+            case Const: break;
+            case Add: case Mul: case Div: case Max: r = x.a.used_vars_with(cache).unite(x.b.used_vars_with(cache)); break;
+            case Neg: case Exp: case Log: case Pow: case UniformMgf: r = x.a.used_vars_with(cache); break;
+            case Polynomial: r = VarRange{x.shape.size()}; break;
+            case Subst: r = x.a.used_vars_with(cache).remove(x.var).unite(x.b.used_vars_with(cache)); break;
+            case TaylorCoeffAtZero: r = x.a.used_vars_with(cache).remove(x.var); break;
+            case Derivative: case TaylorPolynomial: case TaylorCoeff: case ShiftTaylorAtZero: r = x.a.used_vars_with(cache); break;
+        }
+        cache[p.get()] = r;
+        return r;
+    }
+
+    // ---- simplify (gf.rs:152-158, 474-545) ----------------------------------------------------------
+    typedef Poly<T> TP;
+    struct MaybeTP { bool some = false; TP v; };
+    GenFun simplify() const {
+        std::unordered_map<const Node*, MaybeTP> cache;
+        MaybeTP r = simplify_with(cache);
+        if (!r.some) return *this;
+        Dims shape;
+        std::vector<T> data = r.v.to_vector(&shape);
+        return polynomial(std::move(data), shape);
+    }
+    MaybeTP simplify_with(std::unordered_map<const Node*, MaybeTP>& cache) const {
+        auto it = cache.find(p.get());
+        if (it != cache.end()) return it->second;
+        MaybeTP r = simplify_node(cache);
+        cache[p.get()] = r;
+        return r;
+    }
+    MaybeTP simplify_node(std::unordered_map<const Node*, MaybeTP>& cache) const {
+        const Node& x = *p;
+        auto some = [](TP v) { MaybeTP m; m.some = true; m.v = v; return m; };
+        MaybeTP none;
+        switch (x.kind) {
+            case Var: return some(TP::var_with_degrees_p1(x.var, T::zero(), Dims(x.var + 1, UMAX)));
+            case Const: return some(TP::from(x.c));
+            case Add: { auto g = x.a.simplify_with(cache), h = x.b.simplify_with(cache); return (g.some && h.some) ? some(g.v + h.v) : none; }
+            case Neg: { auto g = x.a.simplify_with(cache); return g.some ? some(-g.v) : none; }
+            case Mul: { auto g = x.a.simplify_with(cache), h = x.b.simplify_with(cache); return (g.some && h.some) ? some(g.v * h.v) : none; }
+            case Div: {
+                auto g = x.a.simplify_with(cache), h = x.b.simplify_with(cache);
+                T c;
+                if (g.some && h.some && h.v.extract_constant(c)) return some(g.v / h.v);
+                return none;
+            }
+            case Polynomial: case Exp: case Log: case Max: case UniformMgf: return none;
+            case Pow: { auto g = x.a.simplify_with(cache); return g.some ? some(g.v.pow(x.n)) : none; }
+            case Subst: { auto g = x.a.simplify_with(cache), s = x.b.simplify_with(cache); return (g.some && s.some) ? some(g.v.subst_var(x.var, s.v)) : none; }
+            case Derivative: { auto g = x.a.simplify_with(cache); return g.some ? some(g.v.derivative(x.var, x.order)) : none; }
+            case TaylorPolynomial: { auto g = x.a.simplify_with(cache); return g.some ? some(g.v.taylor_polynomial_terms(x.var, x.orders)) : none; }
+            case TaylorCoeffAtZero: {
+                auto g = x.a.simplify_with(cache);
+                if (!g.some) return none;
+                TP res = g.v.coefficients_of_term(x.var, x.order);
+                if (x.var + 1 == res.num_vars()) res = res.remove_last_variable();
+                return some(res);
+            }
+            case TaylorCoeff: { auto g = x.a.simplify_with(cache); return g.some ? some(g.v.taylor_expansion_of_coeff(x.var, x.order)) : none; }
+            case ShiftTaylorAtZero: { auto g = x.a.simplify_with(cache); return g.some ? some(g.v.shift_down(x.var, x.order)) : none; }
+        }
+        return none;
+    }
+
+    // ---- eval (gf.rs:180-222, 548-765) ------------------------------------------------------------------
+    // `gf` keeps the node alive so its address cannot be recycled for another node while it is a cache key
+    // (the reference stores `gf: self.clone()` for the same reason, gf.rs:212-219)
+    struct EvalResult { GenFun gf; std::vector<T> inputs; size_t degree_p1; TP output; };
+    typedef std::unordered_map<const Node*, EvalResult> EvalCache;
+
+    TP eval(const std::vector<T>& inputs, size_t degree_p1) const {
+        EvalCache cache;
+        return eval_with(inputs, degree_p1, cache);
+    }
+    TP eval_with(const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) const {
+        const bool shared = p.use_count() > 1;
+        if (shared) {
+            auto it = cache.find(p.get());
+            if (it != cache.end() && it->second.inputs == inputs && it->second.degree_p1 == degree_p1) return it->second.output;
+        }
+        TP result = eval_node(inputs, degree_p1, cache);
+        if (shared) cache[p.get()] = EvalResult{*this, inputs, degree_p1, result};
+        return result;
+    }
+    TP eval_node(const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) const {
+        const Node& x = *p;
+        switch (x.kind) {
+            case Var: return TP::var(x.var, inputs.at(x.var), degree_p1);
+            case Const: return TP::from(x.c);
+            case Add: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g + h; }
+            case Neg: return -x.a.eval_with(inputs, degree_p1, cache);
+            case Mul: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g * h; }
+            case Div: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g / h; }
+            case Polynomial: {
+                TP taylor = TP::from_array(x.coeffs, x.shape, Dims(x.shape.size(), UMAX));
+                for (size_t v = 0; v < inputs.size(); ++v) taylor = taylor.subst_var(v, TP::var(v, inputs[v], degree_p1));
+                size_t ndim = taylor.num_vars();
+                if (ndim > inputs.size()) {
+                    if (ndim != inputs.size() + 1) throw std::runtime_error("assertion failed: ndim == inputs.len() + 1");
+                    taylor = taylor.remove_last_variable();
+                }
+                return taylor.extend_to_dim(inputs.size(), degree_p1).truncate_to_degree_p1(degree_p1);
+            }
+            case Exp: return x.a.eval_with(inputs, degree_p1, cache).exp();
+            case Log: return x.a.eval_with(inputs, degree_p1, cache).log();
+            case Max: {
+                TP s = x.a.eval_with(inputs, degree_p1, cache), t = x.b.eval_with(inputs, degree_p1, cache);
+                return TP::from(s.constant_term().max(t.constant_term()));
+            }
+            case Pow: return x.a.eval_with(inputs, degree_p1, cache).pow(x.n);
+            case UniformMgf: {
+                TP xx = x.a.eval_with(inputs, degree_p1, cache);
+                if (xx.constant_term().is_zero()) {
+                    TP y = TP::var_at_zero(0, degree_p1 + 1);
+                    TP numerator = y.exp() - TP::one();
+                    Dims shape;
+                    std::vector<T> arr = numerator.to_vector(&shape);  // 1-d; divide by y: drop entry 0
+                    std::vector<T> sliced(arr.begin() + 1, arr.end());
+                    TP fraction = TP::from_array(sliced, Dims{sliced.size()}, Dims{degree_p1});
+                    return fraction.subst_var(0, xx);
+                }
+                TP numerator = xx.exp() - TP::one();
+                return (numerator / xx).truncate_to_degree_p1(degree_p1);
+            }
+            case Subst: {
+                std::vector<T> new_inputs = inputs;
+                TP subst = x.b.eval_with(inputs, degree_p1, cache);
+                T c = subst.constant_term();
+                subst = subst - TP::from(c);
+                if (x.var < inputs.size()) new_inputs[x.var] = c;
+                else {
+                    if (x.var != inputs.size()) throw std::runtime_error("assertion failed: v.id() == inputs.len()");
+                    new_inputs.push_back(c);
+                }
+                TP taylor = x.a.eval_with(new_inputs, degree_p1, cache);
+                TP result = taylor.subst_var(x.var, subst);
+                if (taylor.shape().size() > inputs.size()) {
+                    if (taylor.shape().size() != inputs.size() + 1) throw std::runtime_error("assertion failed: taylor.shape().len() == inputs.len() + 1");
+                    result = result.remove_last_variable();
+                }
+                return result;
+            }
+            case Derivative: return x.a.eval_with(inputs, degree_p1 + x.order, cache).derivative(x.var, x.order).truncate_to_degree_p1(degree_p1);
+            case TaylorPolynomial: {
+                std::vector<T> ni = inputs;
+                ni.at(x.var) = T::zero();
+                size_t max_order = 0;
+                for (size_t o : x.orders) max_order = std::max(max_order, o);
+                TP taylor = x.a.eval_with(ni, degree_p1 + max_order, cache);
+                TP result = taylor.taylor_polynomial_terms(x.var, x.orders);
+                result = result.subst_var(x.var, TP::var(x.var, inputs[x.var], degree_p1));
+                return result.truncate_to_degree_p1(degree_p1);
+            }
+            case TaylorCoeffAtZero: return eval_taylor_coeff_at_zero(x.a, x.var, x.order, inputs, degree_p1, cache);
+            case TaylorCoeff: return x.a.eval_with(inputs, degree_p1 + x.order, cache).taylor_expansion_of_coeff(x.var, x.order).truncate_to_degree_p1(degree_p1);
+            case ShiftTaylorAtZero: {
+                if (inputs.at(x.var).is_zero())
+                    return x.a.eval_with(inputs, degree_p1 + x.order, cache).shift_down(x.var, x.order).truncate_to_degree_p1(degree_p1);
+                Dims orders;
+                for (size_t i = 0; i < x.order; ++i) orders.push_back(i);
+                GenFun first = x.a.taylor_polynomial_at_zero(x.var, orders);
+                GenFun add_mass = first.substitute_var(x.var, one());
+                GenFun h = (x.a - first) / var(x.var).pow((uint32_t)x.order) + add_mass;
+                return h.eval_with(inputs, degree_p1, cache);
+            }
+        }
+        throw std::runtime_error("unreachable");
+    }
+
+    // recognisers (gf.rs:840-914)
+    static bool recognize_discrete_poisson(const GenFun& g, size_t aux, size_t& pv, T& lambda, GenFun& inner) {
+        const Node& s = *g.p;
+        if (s.kind != Subst) return false;
+        const Node& m = *s.b.p;
+        if (m.kind != Mul) return false;
+        if (m.a != var(s.var)) return false;
+        const Node& e = *m.b.p;
+        if (e.kind != Exp) return false;
+        const Node& mm = *e.a.p;
+        if (mm.kind != Mul) return false;
+        if (mm.a.p->kind != Const) return false;
+        if (mm.b == var(aux) - constant(T::one())) { pv = s.var; lambda = mm.a.p->c; inner = s.a; return true; }
+        return false;
+    }
+    static bool recognize_continuous_poisson(const GenFun& g, size_t aux, size_t& pv, T& lambda, GenFun& inner) {
+        const Node& s = *g.p;
+        if (s.kind != Subst) return false;
+        const Node& ad = *s.b.p;
+        if (ad.kind != Add) return false;
+        if (ad.a != var(s.var)) return false;
+        const Node& mm = *ad.b.p;
+        if (mm.kind != Mul) return false;
+        if (mm.a.p->kind != Const) return false;
+        if (mm.b == var(aux) - constant(T::one())) { pv = s.var; lambda = mm.a.p->c; inner = s.a; return true; }
+        return false;
+    }
+    static bool recognize_negative_binomial(const GenFun& g, size_t aux, size_t& pv, T& pp, GenFun& inner) {
+        const Node& s = *g.p;
+        if (s.kind != Subst) return false;
+        const Node& m = *s.b.p;
+        if (m.kind != Mul) return false;
+        if (m.a != var(s.var)) return false;
+        const Node& d = *m.b.p;
+        if (d.kind != Div) return false;
+        if (d.a.p->kind != Const) return false;
+        T pr = d.a.p->c;
+        GenFun expected = one() - constant(T::one() - pr) * var(aux);
+        if (d.b == expected) { pv = s.var; pp = pr; inner = s.a; return true; }
+        return false;
+    }
+
+    static TP eval_taylor_coeff_at_zero(const GenFun& g, size_t v, size_t order, const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) {
+        size_t pv;
+        T lambda;
+        GenFun inner;
+        if (recognize_discrete_poisson(g, v, pv, lambda, inner)) {
+            GenFun gf = inner;
+            for (size_t k = 1; k <= order; ++k) gf = gf.derive(pv, 1) * var(pv) * constant(lambda / T::from_u32((uint32_t)k));
+            GenFun replacement = constant((-lambda).exp()) * var(pv);
+            gf = gf.substitute_var(pv, replacement);
+            return gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+        }
+        if (recognize_continuous_poisson(g, v, pv, lambda, inner)) {
+            GenFun gf = inner;
+            for (size_t k = 1; k <= order; ++k) gf = gf.derive(pv, 1) * constant(lambda / T::from_u32((uint32_t)k));
+            GenFun replacement = var(pv) - constant(lambda);
+            gf = gf.substitute_var(pv, replacement);
+            return gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+        }
+        T pr;
+        if (recognize_negative_binomial(g, v, pv, pr, inner)) {
+            std::vector<T> lahs_cur(1, T::one());
+            T one_mp = T::one() - pr;
+            for (size_t d = 1; d <= order; ++d) {
+                std::vector<T> next;
+                for (size_t i = 0; i <= d; ++i) {
+                    T lah_dm1_i = i < lahs_cur.size() ? lahs_cur[i] : T::zero();
+                    T lah_dm1_im1 = (1 <= i && i <= lahs_cur.size()) ? lahs_cur[i - 1] : T::zero();
+                    T lah_d_i = one_mp / T::from_u32((uint32_t)d) * (lah_dm1_i * T::from_u32((uint32_t)(d + i - 1)) + lah_dm1_im1);
+                    next.push_back(lah_d_i);
+                }
+                lahs_cur = next;
+            }
+            TP sum = TP::zero_with(Dims(inputs.size(), degree_p1));
+            std::vector<T> ni = inputs;
+            ni.at(pv) = pr * inputs[pv];
+            TP inner_result = inner.eval_with(ni, degree_p1 + order, cache);
+            TP p_pow = TP::one();
+            TP pv_tp = TP::var(pv, inputs[pv], degree_p1);
+            TP p_pv = TP::from(pr) * pv_tp;
+            for (const T& lah : lahs_cur) {
+                TP subst = TP::from(pr) * TP::var_at_zero(pv, degree_p1);
+                sum = sum + inner_result.subst_var(pv, subst) * p_pow * TP::from(lah);
+                p_pow = p_pow * p_pv;
+                inner_result = inner_result.derivative(pv, 1);
+            }
+            return sum.truncate_to_degree_p1(degree_p1);
+        }
+        std::vector<T> ni = inputs;
+        TP result;
+        if (v == ni.size()) {
+            ni.push_back(T::zero());
+            result = g.eval_with(ni, degree_p1 + order, cache).coefficients_of_term(v, order).remove_last_variable();
+        } else {
+            ni.at(v) = T::zero();
+            result = g.eval_with(ni, degree_p1 + order, cache).coefficients_of_term(v, order);
+        }
+        return result.truncate_to_degree_p1(degree_p1);
+    }
+};
+
+// ---- probabilities and moments (gf.rs:937-1086) ------------------------------------------------------------
+template <class T>
+std::vector<T> probs_taylor(const GenFun<T>& pgf, size_t v, const VarSupport& vi, size_t max_n) {
+    if (!vi[v].is_discrete()) throw std::runtime_error("Can only compute probabilities for discrete variables");
+    size_t nv = vi.num_vars();
+    std::vector<T> substs;
+    for (size_t i = 0; i < nv; ++i) substs.push_back(vi[i].is_discrete() ? T::one() : T::zero());
+    substs[v] = T::zero();
+    Poly<T> expansion = pgf.eval(substs, max_n + 1);
+    Dims index(nv, 0);
+    std::vector<T> probs;
+    for (size_t i = 0; i < max_n; ++i) { index[v] = i; probs.push_back(expansion.coefficient(index)); }
+    return probs;
+}
+
+template <class T>
+std::pair<T, std::vector<T>> factorial_moments_to_moments(const std::vector<T>& fm) {
+    size_t len = fm.size();
+    std::vector<std::vector<T>> st(len, std::vector<T>(len, T::zero()));
+    for (size_t n = 0; n < len; ++n) {
+        st[n][0] = T::zero();
+        st[n][n] = T::one();
+        for (size_t k = 1; k < n; ++k) st[n][k] = st[n - 1][k - 1] + T::from_u32((uint32_t)k) * st[n - 1][k];
+    }
+    T total = fm[0];
+    std::vector<T> moments(len - 1, T::zero());
+    for (size_t n = 1; n < len; ++n)
+        for (size_t k = 0; k <= n; ++k) moments[n - 1] = moments[n - 1] + st[n][k] * fm[k];
+    for (auto& m : moments) m = m / total;
+    return {total, moments};
+}
+
+template <class T>
+std::pair<T, std::vector<T>> moments_taylor(const GenFun<T>& pgf, size_t v, const VarSupport& vi, size_t limit) {
+    size_t nv = vi.num_vars();
+    std::vector<T> substs;
+    for (size_t i = 0; i < nv; ++i) substs.push_back(vi[i].is_discrete() ? T::one() : T::zero());
+    Poly<T> expansion = pgf.eval(substs, limit);
+    std::vector<T> result;
+    Dims index(nv, 0);
+    T factor = T::one();
+    for (size_t i = 0; i < limit; ++i) {
+        index[v] = i;
+        result.push_back(expansion.coefficient(index) * factor);
+        factor = factor * T::from_u32((uint32_t)(i + 1));
+    }
+    if (vi[v].is_discrete()) return factorial_moments_to_moments(result);
+    T total = result[0];
+    std::vector<T> moments;
+    for (size_t i = 1; i < result.size(); ++i) moments.push_back(result[i] / total);
+    return {total, moments};
+}
+
+template <class T>
+std::pair<T, std::vector<T>> moments_to_central_moments(const std::vector<T>& moments) {
+    size_t len = moments.size() + 1;
+    T mean = moments[0];
+    std::vector<std::vector<T>> bc(len, std::vector<T>(len, T::zero()));
+    for (size_t n = 0; n < len; ++n) {
+        bc[n][0] = T::one();
+        bc[n][n] = T::one();
+        for (size_t k = 1; k < n; ++k) bc[n][k] = bc[n - 1][k - 1] + bc[n - 1][k];
+    }
+    T neg_mean = -mean;
+    std::vector<T> cm(len - 2, T::zero());
+    for (size_t n = 2; n < len; ++n) {
+        for (size_t k = 1; k <= n; ++k) cm[n - 2] = cm[n - 2] + bc[n][k] * neg_mean.pow((uint32_t)(n - k)) * moments[k - 1];
+        cm[n - 2] = cm[n - 2] + neg_mean.pow((uint32_t)n);
+    }
+    return {mean, cm};
+}
+
+template <class T>
+std::pair<T, std::vector<T>> central_to_standardized_moments(const std::vector<T>& cm) {
+    T variance = cm[0];
+    T sigma = variance.sqrt();
+    std::vector<T> out;
+    for (size_t i = 0; i + 1 < cm.size(); ++i) {
+        const T& x = cm[i + 1];
+        if (x.is_zero() && !variance.is_nan() && !variance.is_zero()) out.push_back(x);
+        else {
+            T sp = (i % 2 == 0) ? sigma.pow((uint32_t)(i + 3)) : variance.pow((uint32_t)((i + 3) / 2));
+            out.push_back(x / sp);
+        }
+    }
+    return {variance, out};
+}
+
+}  // namespace gfh

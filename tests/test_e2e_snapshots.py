@@ -1,0 +1,121 @@
+"""End-to-end snapshot tests: the reference's own `.sgcl` -> `.expect` pairs
+(tests/integration.rs protocol: `--no-timing` + the file's `# flags:` line), copied as data fixtures into
+tests/golden/sgcl/.  The host interpreter (genfer_amd/csrc/host) is backend-agnostic over the C ABI:
+
+  * oracle backend (CPU, always run): the report must match the `.expect` file BYTE FOR BYTE — this pins
+    the oracle on 109 whole programs (moments, probability masses, supports to 16-17 digits);
+  * hip backend (-m gpu): the same programs through libgftaylor; primary quantities (Z, E, raw moments,
+    probability masses) within 1e-10 relative, derived central/standardised moments within an absolute
+    tolerance scaled by the raw moments they are differences of.
+"""
+import glob
+import os
+import re
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+SGCL = os.path.join(GOLDEN, "sgcl")
+FILES = sorted(glob.glob(os.path.join(SGCL, "**", "*.sgcl"), recursive=True))
+FILES = [f for f in FILES if os.path.exists(f[:-5] + ".expect")]
+SLOW = [f for f in FILES if os.sep + "slow" + os.sep in f]
+FAST = [f for f in FILES if f not in SLOW]
+
+
+def flags_of(path):
+    first = open(path).readline()
+    return first[len("# flags:"):].strip() if first.startswith("# flags:") else ""
+
+
+def run(path, backend, prefix):
+    import genfer_amd
+
+    rc, text, _ = genfer_amd.run_sgcl_with_backend(open(path).read(), "--no-timing " + flags_of(path), backend, prefix)
+    return rc, text
+
+
+@pytest.fixture(scope="module")
+def oracle_path(oracle_lib):
+    return os.path.join(ROOT, "oracle", "liborc.so")
+
+
+def rel(path):
+    return os.path.relpath(path, SGCL)
+
+
+@pytest.mark.parametrize("path", FAST, ids=rel)
+def test_snapshot_oracle_byte_exact(path, oracle_path):
+    rc, text = run(path, oracle_path, "orc_")
+    assert rc == 0, text
+    assert text == open(path[:-5] + ".expect").read()
+
+
+@pytest.mark.parametrize("path", SLOW[:2], ids=rel)
+def test_snapshot_oracle_byte_exact_slow(path, oracle_path):
+    rc, text = run(path, oracle_path, "orc_")
+    assert rc == 0, text
+    assert text == open(path[:-5] + ".expect").read()
+
+
+def test_example_sgcl_matches_readme_and_closed_form(oracle_path):
+    """BASELINE configs[0]: example.sgcl --limit 26 has no .expect; it is pinned by README.md:92-109 and by
+    the closed form p(n) = Pois(n;10) * n * 0.2 * 0.8^(n-1) (posterior calls-1 ~ Poisson(8))."""
+    from math import exp, factorial
+
+    rc, text = run(os.path.join(SGCL, "example.sgcl"), oracle_path, "orc_")
+    assert rc == 0, text
+    assert "Total measure:             Z = 0.27067056647322557" in text  # README.md:94
+    assert "Unnormalized: p(1)     = 0.00009079985952496972" in text     # README.md:100 (older print layout: "p(1) = ...")
+    assert "p(n)     <= 3.1727834072246485e-7 for all n >= 26" in text     # README.md:109
+    seen = 0
+    for line in text.splitlines():
+        m = re.match(r"Unnormalized: p\((\d+)\)\s+= (\S+)", line)
+        if m:
+            n, p = int(m.group(1)), float(m.group(2))
+            want = exp(-10) * 10**n / factorial(n) * n * 0.2 * 0.8 ** (n - 1) if n >= 1 else 0.0
+            assert abs(p - want) <= 1e-12 * max(want, 1e-300) or p == want
+            seen += 1
+    assert seen == 26
+
+
+NUM = re.compile(r"[-+]?(?:\d+\.\d+(?:e-?\d+)?|\d+e-?\d+|inf|NaN)")
+
+
+def numbers(line):
+    return [float(x) for x in NUM.findall(line)]
+
+
+def compare_reports(got, want):
+    gl, wl = got.splitlines(), want.splitlines()
+    assert len(gl) == len(wl), "different number of report lines"
+    raw = {}
+    for g, w in zip(gl, wl):
+        gs, ws = NUM.sub("#", g), NUM.sub("#", w)
+        assert gs == ws, f"report text differs:\n{g}\n{w}"
+        gn, wn = numbers(g), numbers(w)
+        if not wn:
+            continue
+        primary = any(k in w for k in ("Total measure", "Expected value", "raw moment", "p(")) and "<=" not in w
+        if "Expected value" in w:
+            raw["E"] = abs(wn[-1])
+        if "4th raw moment" in w:
+            raw["m4"] = abs(wn[-1])
+        for a, b in zip(gn, wn):
+            if primary:
+                assert abs(a - b) <= 1e-10 * abs(b) or a == b or abs(b) < 1e-300, f"{g} vs {w}"
+            else:
+                # central / standardised moments and tail bounds: differences of raw moments
+                scale = max(abs(b), raw.get("m4", 1.0), 1.0)
+                assert abs(a - b) <= 1e-9 * scale or a == b, f"{g} vs {w}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FAST, ids=rel)
+def test_snapshot_hip_within_tolerance(path):
+    import genfer_amd
+
+    genfer_amd.lib()
+    rc, text = run(path, genfer_amd.LIB_PATH, "gft_")
+    assert rc == 0, text
+    compare_reports(text, open(path[:-5] + ".expect").read())
