@@ -102,6 +102,8 @@ def compare_reports(got, want):
         if "4th raw moment" in w:
             raw["m4"] = abs(wn[-1])
         for a, b in zip(gn, wn):
+            if a != a and b != b:  # NaN in both reports (e.g. skewness of a point mass)
+                continue
             if primary:
                 assert abs(a - b) <= 1e-10 * abs(b) or a == b or abs(b) < 1e-300, f"{g} vs {w}"
             else:
