@@ -100,6 +100,21 @@ def cpu_baseline(shape, x, y, budget_hint_s=20.0):
     }, res, slabs
 
 
+def pmc_traffic(world):
+    """HBM-side bytes per product launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01/pmc_k_conv_tiled.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md §HBM — gfx950 reports half of wide coalesced reads).  PMC counters
+    cannot be read from inside this process; null when no matching profile is committed (N > 1)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_k_conv_tiled.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    try:
+        return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+    except KeyError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +221,7 @@ def main():
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / FP64_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic(world),
             "note": "FP64 FMA roof (vector == matrix FP64 peak on gfx950, 78.6 TFLOP/s); flops = 2*MACs of the "
                     "slabs this rank computes / mean HIP-event duration of the product launch(es) on its stream",
             "kernel_ms": k_ms,

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""End-to-end seconds on the NeurIPS'23 benchmark programs (BASELINE configs[2]): the host interpreter
+with the HIP backend (libgftaylor) vs the same interpreter over the CPU oracle, on this box, best of N
+("Total inference time" protocol of the reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105).
+Usage: bench_e2e.py [--limit 100] [--runs 3] [--only substr]"""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import genfer_amd  # noqa: E402
+
+args = sys.argv[1:]
+
+
+def opt(name, default):
+    for i, a in enumerate(args):
+        if a == name:
+            return args[i + 1]
+    return default
+
+
+limit = opt("--limit", "100")
+runs = int(opt("--runs", "3"))
+only = opt("--only", "")
+files = sorted(glob.glob(os.path.join(ROOT, "tests/golden/sgcl/neurips2023/**/*.sgcl"), recursive=True))
+files = [f for f in files if only in f]
+oracle = os.path.join(ROOT, "oracle", "liborc.so")
+if not os.path.exists(oracle):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+genfer_amd.init(0)
+rows = []
+for f in files:
+    src = open(f).read()
+    first = src.splitlines()[0] if src else ""
+    file_flags = first[len("# flags:"):].strip() if first.startswith("# flags:") else ""
+    flags = file_flags if "--limit" in file_flags or "--no-probs" in file_flags else (file_flags + f" --limit {limit}").strip()
+    row = {"program": os.path.relpath(f, os.path.join(ROOT, "tests/golden/sgcl/neurips2023")), "flags": flags}
+    for name, lib, prefix in (("gpu", genfer_amd.LIB_PATH, "gft_"), ("cpu_oracle", oracle, "orc_")):
+        best = None
+        for _ in range(runs):
+            rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, prefix)
+            if rc != 0:
+                best = None
+                row[name + "_error"] = text[-200:]
+                break
+            best = t["time_infer"] if best is None else min(best, t["time_infer"])
+        row[name + "_s"] = best
+    rows.append(row)
+    print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row['cpu_oracle_s']!s:>10}", flush=True)
+print(json.dumps({"limit": limit, "runs": runs, "host_cores": os.cpu_count(), "rows": rows}))
