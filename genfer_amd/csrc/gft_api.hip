@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -51,6 +52,7 @@ struct Runtime {
     std::multimap<size_t, void*> free_blocks;
     size_t in_use = 0, cached = 0, peak = 0;
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
+    double* d_scratch = nullptr; // small device scratch for packed read-backs
     double* h_pinned = nullptr;  // pinned staging for small D2H reads
     hipEvent_t events[16] = {};
     int conv_mode = 0;
@@ -242,8 +244,8 @@ struct Ops {
     }
     static P from_host_scalar(const double* x, const Dims& shape, const Dims& deg) {
         P r = make(shape, deg);
-        HIP_OK(hipMemcpyAsync(r.buf->p, x, sizeof(double) * W, hipMemcpyHostToDevice, R.stream));
-        HIP_OK(hipStreamSynchronize(R.stream));  // x may be a caller stack temporary
+        Scalar2 v{x[0], W == 2 ? x[1] : 0.0};
+        K<E>::set_small(R.stream, r.buf->p, r.numel, 1, v, v);  // value travels as a kernel argument: no copy, no sync
         r.cached = true;
         r.cv[0] = x[0];
         r.cv[1] = W == 2 ? x[1] : 0.0;
@@ -263,8 +265,11 @@ struct Ops {
             return;
         }
         double tmp[2] = {0, 0};
-        read_back(&tmp[0], p.buf->p, sizeof(double));
-        if (W == 2) read_back(&tmp[1], p.buf->p + p.numel, sizeof(double));
+        HIP_OK(hipMemcpyAsync(R.h_pinned, p.buf->p, sizeof(double), hipMemcpyDeviceToHost, R.stream));
+        if (W == 2) HIP_OK(hipMemcpyAsync(R.h_pinned + 1, p.buf->p + p.numel, sizeof(double), hipMemcpyDeviceToHost, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        tmp[0] = R.h_pinned[0];
+        tmp[1] = W == 2 ? R.h_pinned[1] : 0.0;
         out[0] = tmp[0];
         out[1] = tmp[1];
         if (p.numel == 1) {
@@ -405,22 +410,15 @@ struct Ops {
         Dims shape(deg.size(), 1);
         shape[v] = len_v_shape;
         P r = make(shape, deg);
-        double host[4] = {0, 0, 0, 0};  // [lo plane: e0, e1][hi plane: e0, e1]
-        size_t n = r.numel;             // 1 or 2
-        if (have_x) {
-            host[0] = x[0];
-            if (W == 2) host[n] = x[1];
-        }
-        if (n == 2 && second_is_one) {
-            host[1] = 1.0;
-            if (W == 2) host[n + 1] = 1.0;
-        }
-        HIP_OK(hipMemcpyAsync(r.buf->p, host, sizeof(double) * n * W, hipMemcpyHostToDevice, R.stream));
-        HIP_OK(hipStreamSynchronize(R.stream));
+        size_t n = r.numel;  // 1 or 2
+        Scalar2 v0{0.0, 0.0}, v1{0.0, 0.0};
+        if (have_x) v0 = Scalar2{x[0], W == 2 ? x[1] : 0.0};
+        if (n == 2 && second_is_one) v1 = Scalar2{1.0, 1.0};
+        K<E>::set_small(R.stream, r.buf->p, r.numel, (unsigned)n, v0, v1);
         if (n == 1) {
             r.cached = true;
-            r.cv[0] = host[0];
-            r.cv[1] = W == 2 ? host[1] : 0.0;
+            r.cv[0] = v0.a;
+            r.cv[1] = W == 2 ? v0.b : 0.0;
         }
         return r;
     }
@@ -432,16 +430,15 @@ struct Ops {
         self = truncate_degrees(self, rd);
         other = truncate_degrees(other, rd);
         if (other.numel == 1) {
-            P out = copy_of(self);
-            K<E>::first_elem(R.stream, out.buf->p, out.numel, subtract ? FIRST_SUB : FIRST_ADD, other.buf->p, other.numel);
-            out.deg = rd;
+            P out = make(self.shape, rd);
+            K<E>::copy_first(R.stream, self.buf->p, self.numel, out.buf->p, out.numel, self.numel,
+                             subtract ? FIRST_SUB : FIRST_ADD, other.buf->p, other.numel);
             return out;
         }
         if (self.numel == 1) {
-            P out = copy_of(other);
-            K<E>::first_elem(R.stream, out.buf->p, out.numel, subtract ? FIRST_SUB : FIRST_ADD, self.buf->p, self.numel);
-            if (subtract) K<E>::map_inplace(R.stream, out.buf->p, out.numel, out.numel, MAP_NEG, 0, Scalar2{0, 0});
-            out.deg = rd;
+            P out = make(other.shape, rd);
+            K<E>::copy_first(R.stream, other.buf->p, other.numel, out.buf->p, out.numel, other.numel,
+                             subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, self.buf->p, self.numel);
             return out;
         }
         Dims shape = max_shape(self, other);
@@ -464,24 +461,22 @@ struct Ops {
         unsigned cmask = 0;
         for (size_t i = 0; i < keep.size(); ++i)
             if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
-        HIP_OK(hipMemcpyAsync(R.d_flag, &cmask, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipMemsetD32Async((hipDeviceptr_t)R.d_flag, (int)cmask, 1, R.stream));
         HV v = view(p);
-        K<E>::linear_mask(R.stream, dview(v, &keep), R.d_flag);
-        unsigned got = 0;
-        read_back(&got, R.d_flag, sizeof(unsigned));
+        DView dv = dview(v, &keep);
+        K<E>::linear_mask(R.stream, dv, R.d_flag);
+        K<E>::linear_finish(R.stream, dv, R.d_flag, R.d_scratch);
+        double res[5];
+        read_back(res, R.d_scratch, sizeof(res));
+        unsigned got = (unsigned)res[0];
         if (!got) return false;
         size_t ci = 0;
         while (!((got >> ci) & 1u)) ci++;
-        size_t ax = keep[ci];
-        Dims st = c_strides(p.shape);
-        read_back(&c[0], p.buf->p, sizeof(double));
-        read_back(&m[0], p.buf->p + st[ax], sizeof(double));
-        c[1] = m[1] = 0.0;
-        if (W == 2) {
-            read_back(&c[1], p.buf->p + p.numel, sizeof(double));
-            read_back(&m[1], p.buf->p + p.numel + st[ax], sizeof(double));
-        }
-        *var = ax;
+        c[0] = res[1];
+        c[1] = res[2];
+        m[0] = res[3];
+        m[1] = res[4];
+        *var = keep[ci];
         return true;
     }
 
@@ -542,8 +537,8 @@ struct Ops {
             if (ok) {
                 // zero padding times inf/NaN would create NaNs the reference does not produce: such
                 // operands take the reference-order kernel
-                unsigned zero = 0, bad = 0;
-                HIP_OK(hipMemcpyAsync(R.d_flag + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+                unsigned bad = 0;
+                HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 2), 0, 1, R.stream));
                 any_nonfinite_f64(R.stream, x.p, x.numel(), R.d_flag + 2);
                 any_nonfinite_f64(R.stream, y.p, y.numel(), R.d_flag + 2);
                 read_back(&bad, R.d_flag + 2, sizeof(unsigned));
@@ -676,8 +671,7 @@ struct Ops {
     // xs scaled slab-wise by T::from(j) along axis 0 (mt:1308-1310): xs[j] * j
     static std::shared_ptr<Buf> scaled_by_index(const HV& xs, HV* out) {
         std::shared_ptr<Buf> buf = alloc_doubles(xs.numel() * W);
-        std::shared_ptr<Buf> tab = alloc_doubles(xs.shape[0] * W);
-        K<E>::factor_table(R.stream, TAB_INDEX, 0, (unsigned)xs.shape[0], nullptr, 0, tab->p, xs.shape[0]);
+        std::shared_ptr<Buf> tab = cached_table(TAB_INDEX, 0, xs.shape[0]);
         GatherArgs a;
         std::memset(&a, 0, sizeof(a));
         size_t inner = xs.numel() / std::max<size_t>(xs.shape[0], 1);
@@ -796,6 +790,20 @@ struct Ops {
         return res;
     }
 
+    // Device-resident factor tables for derivative / coefficient expansion / index scaling depend only on
+    // (kind, n, len): computed once by k_factor_table (reference operation order) and reused.
+    static std::shared_ptr<Buf> cached_table(int table_op, size_t n, size_t len) {
+        static std::map<std::tuple<int, size_t, size_t>, std::shared_ptr<Buf>> cache;
+        auto key = std::make_tuple(table_op, n, len);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+        if (cache.size() > 4096) cache.clear();
+        std::shared_ptr<Buf> tab = alloc_doubles(len * W);
+        K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        cache[key] = tab;
+        return tab;
+    }
+
     // ---- derivative-like slab scalings (mt:457-509) ---------------------------------------------------------------
     static P deriv_like(const P& a, size_t v, size_t n, int table_op, const char* what) {
         size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
@@ -805,8 +813,7 @@ struct Ops {
         d[v] = d[v] > n ? d[v] - n : 0;
         if (n >= a.shape[v]) return zero_with(d);
         size_t len = a.shape[v] - n;
-        std::shared_ptr<Buf> tab = alloc_doubles(len * W);
-        K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        std::shared_ptr<Buf> tab = cached_table(table_op, n, len);
         return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len);
     }
 
@@ -977,8 +984,8 @@ struct Ops {
 
     static bool equal(const P& a, const P& b) {
         if (a.deg != b.deg || a.shape != b.shape) return false;
-        unsigned zero = 0;
-        HIP_OK(hipMemcpyAsync(R.d_flag + 1, &zero, sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+
+        HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 1), 0, 1, R.stream));
         K<E>::count_neq(R.stream, a.buf->p, a.numel, b.buf->p, b.numel, a.numel, R.d_flag + 1);
         unsigned cnt = 0;
         read_back(&cnt, R.d_flag + 1, sizeof(unsigned));
@@ -1034,6 +1041,7 @@ int gft_init(int device) {
         HIP_OK(hipStreamCreateWithFlags(&R.own_stream, hipStreamNonBlocking));
         R.stream = R.own_stream;
         HIP_OK(hipMalloc((void**)&R.d_flag, 256));
+        HIP_OK(hipMalloc((void**)&R.d_scratch, 256));
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
         R.device = device;
@@ -1055,6 +1063,7 @@ void gft_shutdown(void) {
     R.conv_ws = nullptr;
     R.conv_ws_bytes = 0;
     (void)hipFree(R.d_flag);
+    (void)hipFree(R.d_scratch);
     (void)hipHostFree(R.h_pinned);
     for (auto& ev : R.events) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(R.own_stream);

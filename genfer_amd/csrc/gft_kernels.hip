@@ -118,6 +118,59 @@ void K<E>::first_elem(hipStream_t st, double* p, size_t plane, int op, const dou
 }
 
 template <class E>
+__global__ void __launch_bounds__(256) k_copy_first(const double* __restrict__ src, size_t sp, double* __restrict__ dst,
+                                                    size_t dp, size_t n, int op, const double* s, size_t s_plane) {
+    typedef typename E::V V;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        V x = E::ld(src, sp, i);
+        if (i == 0) {
+            V y = E::ld(s, s_plane, 0);
+            x = (op == FIRST_ADD) ? E::add(x, y) : E::sub(x, y);
+        }
+        if (op == FIRST_SUB_NEG_ALL) x = E::neg(x);
+        E::st(dst, dp, i, x);
+    }
+}
+template <class E>
+void K<E>::copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n, int op,
+                      const double* s, size_t s_plane) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_copy_first<E>, dim3(grid_for(n)), dim3(256), 0, st, src, src_plane, dst, dst_plane, n, op, s,
+                       s_plane);
+}
+
+template <class E>
+__global__ void k_set_small(double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1) {
+    E::st(p, plane, 0, E::from(v0));
+    if (n > 1) E::st(p, plane, 1, E::from(v1));
+}
+template <class E>
+void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1) {
+    hipLaunchKernelGGL(k_set_small<E>, dim3(1), dim3(1), 0, st, p, plane, n, v0, v1);
+}
+
+template <class E>
+__global__ void k_linear_finish(DView t, const unsigned* mask, double* out) {
+    unsigned m = *mask;
+    out[0] = (double)m;
+    out[1] = out[2] = out[3] = out[4] = 0.0;
+    if (!m) return;
+    int ax = __ffs((int)m) - 1;
+    size_t stride = 1;
+    for (int i = t.sh.nd - 1; i > ax; --i) stride *= t.sh.d[i];
+    out[1] = t.p[0];
+    out[3] = t.p[stride];
+    if (E::W == 2) {
+        out[2] = t.p[t.plane];
+        out[4] = t.p[t.plane + stride];
+    }
+}
+template <class E>
+void K<E>::linear_finish(hipStream_t st, const DView& t, const unsigned* mask, double* out) {
+    hipLaunchKernelGGL(k_linear_finish<E>, dim3(1), dim3(1), 0, st, t, mask, out);
+}
+
+template <class E>
 __global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b, size_t bp, double* out,
                             size_t op_plane) {
     typename E::V x = E::ld(a, ap, 0);

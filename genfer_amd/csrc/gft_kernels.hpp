@@ -29,7 +29,7 @@ struct DView {
 
 enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB = 4, OP_LMUL_S = 5 };
 enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_DIV_S = 4, MAP_LMUL_S = 5 };
-enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1 };
+enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1, FIRST_SUB_NEG_ALL = 2 };
 enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
 enum ScalarOp { SC_EXP = 0, SC_LOG = 1, SC_DIV = 2 };
 enum TableOp { TAB_DERIV = 0, TAB_COEFF = 1, TAB_POW = 2, TAB_INDEX = 3 };
@@ -69,6 +69,15 @@ struct K {
     static void addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract);
     // p[0] = p[0] (+|-) s
     static void first_elem(hipStream_t st, double* p, size_t plane, int op, const double* s, size_t s_plane);
+    // dst = copy of src (n contiguous elements) with element 0 replaced by src[0] (+|-) s; FIRST_SUB_NEG_ALL:
+    // dst[0] = -(src[0] - s), dst[i>0] = -src[i]  (mt:862-868, 919-925 in one launch)
+    static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,
+                           int op, const double* s, size_t s_plane);
+    // p[0] = v0, p[1] = v1 (if n == 2): constants and `var` constructors without a host->device copy
+    static void set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1);
+    // after linear_mask: out[0] = mask (as a double), out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the
+    // first axis v whose bit is set (zeros if none) — one 40-byte read-back instead of up to five
+    static void linear_finish(hipStream_t st, const DView& t, const unsigned* mask, double* out);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
     // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])
