@@ -138,7 +138,7 @@ struct gft_poly {
     int width = 1;              // 1: F64, 2: Interval (lo plane, hi plane)
     Dims shape;                 // stored (compact) coefficient shape
     Dims deg;                   // degrees_p1
-    std::shared_ptr<Buf> buf;   // width * numel doubles, plane stride == numel
+    mutable std::shared_ptr<Buf> buf;   // width * numel doubles, plane stride == numel (null: lazy host-cached scalar)
     size_t numel = 1;
     // host cache of the value when numel == 1 (filled on construction from host scalars or lazily)
     mutable bool cached = false;
@@ -146,6 +146,19 @@ struct gft_poly {
 };
 
 namespace {
+
+// Device pointer of a polynomial's coefficients.  1-element polynomials built from host scalars are lazy:
+// their value travels as a kernel argument wherever possible (constant scaling, scalar add, division by a
+// constant) and a device buffer is only created when some kernel really needs to read it from memory.
+template <class E>
+static double* dp(const gft_poly& p) {
+    if (!p.buf) {
+        p.buf = alloc_doubles(p.numel * E::W);
+        Scalar2 v{p.cv[0], p.cv[1]};
+        K<E>::set_small(R.stream, p.buf.get()->p, p.numel, 1, v, v);
+    }
+    return p.buf.get()->p;
+}
 
 static size_t prod(const Dims& s) {
     size_t n = 1;
@@ -215,7 +228,7 @@ struct Ops {
             return r;
         }
     };
-    static HV view(const P& p) { return HV{p.buf->p, p.numel, p.shape}; }
+    static HV view(const P& p) { return HV{dp<E>(p), p.numel, p.shape}; }
     static DView dview(const HV& v, const Dims* keep = nullptr) {
         DView d;
         d.p = v.p;
@@ -243,17 +256,20 @@ struct Ops {
         return r;
     }
     static P from_host_scalar(const double* x, const Dims& shape, const Dims& deg) {
-        P r = make(shape, deg);
-        Scalar2 v{x[0], W == 2 ? x[1] : 0.0};
-        K<E>::set_small(R.stream, r.buf->p, r.numel, 1, v, v);  // value travels as a kernel argument: no copy, no sync
-        r.cached = true;
+        check_invariants(shape, deg);
+        P r;
+        r.width = W;
+        r.shape = shape;
+        r.deg = deg;
+        r.numel = 1;
+        r.cached = true;   // lazy: no device buffer until a kernel has to read it (see dp())
         r.cv[0] = x[0];
         r.cv[1] = W == 2 ? x[1] : 0.0;
         return r;
     }
     static P copy_of(const P& a) {
         P r = make(a.shape, a.deg);
-        HIP_OK(hipMemcpyAsync(r.buf->p, a.buf->p, sizeof(double) * a.numel * W, hipMemcpyDeviceToDevice, R.stream));
+        HIP_OK(hipMemcpyAsync(dp<E>(r), dp<E>(a), sizeof(double) * a.numel * W, hipMemcpyDeviceToDevice, R.stream));
         return r;
     }
 
@@ -265,8 +281,8 @@ struct Ops {
             return;
         }
         double tmp[2] = {0, 0};
-        HIP_OK(hipMemcpyAsync(R.h_pinned, p.buf->p, sizeof(double), hipMemcpyDeviceToHost, R.stream));
-        if (W == 2) HIP_OK(hipMemcpyAsync(R.h_pinned + 1, p.buf->p + p.numel, sizeof(double), hipMemcpyDeviceToHost, R.stream));
+        HIP_OK(hipMemcpyAsync(R.h_pinned, dp<E>(p), sizeof(double), hipMemcpyDeviceToHost, R.stream));
+        if (W == 2) HIP_OK(hipMemcpyAsync(R.h_pinned + 1, dp<E>(p) + p.numel, sizeof(double), hipMemcpyDeviceToHost, R.stream));
         HIP_OK(hipStreamSynchronize(R.stream));
         tmp[0] = R.h_pinned[0];
         tmp[1] = W == 2 ? R.h_pinned[1] : 0.0;
@@ -348,7 +364,7 @@ struct Ops {
             if (out_shape[ax] == 1 && (int)ax != tab_axis) {
                 long long si = shift[ax];
                 if (si < 0 || (size_t)si >= src_len[ax]) {  // whole output is outside the source box
-                    HIP_OK(hipMemsetAsync(out.buf->p, 0, sizeof(double) * out.numel * W, R.stream));
+                    HIP_OK(hipMemsetAsync(dp<E>(out), 0, sizeof(double) * out.numel * W, R.stream));
                     return out;
                 }
                 base += (size_t)si * sst[ax];
@@ -371,7 +387,7 @@ struct Ops {
         a.tab = tab;
         a.tab_plane = tab_plane;
         a.keep = keep;
-        K<E>::gather(R.stream, src.buf->p + base, src.numel, out.buf->p, out.numel, a);
+        K<E>::gather(R.stream, dp<E>(src) + base, src.numel, dp<E>(out), out.numel, a);
         return out;
     }
     static P lead_block(const P& p, const Dims& lens, const Dims& deg) {  // slice 0..lens per axis
@@ -414,7 +430,7 @@ struct Ops {
         Scalar2 v0{0.0, 0.0}, v1{0.0, 0.0};
         if (have_x) v0 = Scalar2{x[0], W == 2 ? x[1] : 0.0};
         if (n == 2 && second_is_one) v1 = Scalar2{1.0, 1.0};
-        K<E>::set_small(R.stream, r.buf->p, r.numel, (unsigned)n, v0, v1);
+        K<E>::set_small(R.stream, dp<E>(r), r.numel, (unsigned)n, v0, v1);
         if (n == 1) {
             r.cached = true;
             r.cv[0] = v0.a;
@@ -429,16 +445,18 @@ struct Ops {
         broadcast(self, other);
         self = truncate_degrees(self, rd);
         other = truncate_degrees(other, rd);
+        // a host-cached scalar operand travels as a kernel argument (no device read, no materialisation)
+        auto sptr = [](const P& s) -> const double* { return (s.cached && !s.buf) ? nullptr : dp<E>(s); };
         if (other.numel == 1) {
             P out = make(self.shape, rd);
-            K<E>::copy_first(R.stream, self.buf->p, self.numel, out.buf->p, out.numel, self.numel,
-                             subtract ? FIRST_SUB : FIRST_ADD, other.buf->p, other.numel);
+            K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
+                             subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
             return out;
         }
         if (self.numel == 1) {
             P out = make(other.shape, rd);
-            K<E>::copy_first(R.stream, other.buf->p, other.numel, out.buf->p, out.numel, other.numel,
-                             subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, self.buf->p, self.numel);
+            K<E>::copy_first(R.stream, dp<E>(other), other.numel, dp<E>(out), out.numel, other.numel,
+                             subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, sptr(self), self.numel, Scalar2{self.cv[0], self.cv[1]});
             return out;
         }
         Dims shape = max_shape(self, other);
@@ -755,11 +773,11 @@ struct Ops {
             }
             // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
             P num = make(sub, sub), den = make(x0.shape, sub);
-            copy_planes(num.buf->p, num.numel, cur.p, cur.plane, cur.numel());
-            copy_planes(den.buf->p, den.numel, x0.p, x0.plane, x0.numel());
+            copy_planes(dp<E>(num), num.numel, cur.p, cur.plane, cur.numel());
+            copy_planes(dp<E>(den), den.numel, x0.p, x0.plane, x0.numel());
             P q = div(num, den);
             if (q.shape != sub) throw Error("log: internal shape mismatch after division");
-            copy_planes(cur.p, cur.plane, q.buf->p, q.numel, cur.numel());
+            copy_planes(cur.p, cur.plane, dp<E>(q), q.numel, cur.numel());
             K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_DIV_U32, (unsigned)k, Scalar2{0, 0});
             HV rk = rs.index0(k);
             copy_planes(rk.p, rk.plane, cur.p, cur.plane, cur.numel());
@@ -826,7 +844,7 @@ struct Ops {
         // ndarray 0.15.6 sum_axis: 2-d array whose summed axis has unit stride => per-lane 8-way fold
         if (a.shape.size() == 2 && inner == 1) mode = SUM_UNROLL8;
         if (W == 1 && inner == 1 && upto >= 128) mode = SUM_WAVE;  // long rows: wavefront-shuffle reduction
-        K<E>::sum_axis(R.stream, a.buf->p, a.numel, (unsigned)outer, (unsigned)upto, (unsigned)inner,
+        K<E>::sum_axis(R.stream, dp<E>(a), a.numel, (unsigned)outer, (unsigned)upto, (unsigned)inner,
                        a.shape[v] * inner, out, out_plane, mode);
     }
     static P shift_down(const P& a, size_t v, size_t n) {
@@ -839,7 +857,7 @@ struct Ops {
             Dims rs = a.shape;
             rs[v] = 1;
             P out = make(rs, d);
-            sum_axis_into(a, v, a.shape[v], out.buf->p, out.numel);
+            sum_axis_into(a, v, a.shape[v], dp<E>(out), out.numel);
             return out;
         }
         P out = slab_range(a, v, n, a.shape[v], d);
@@ -866,7 +884,7 @@ struct Ops {
                 for (size_t i = 0; i < lens.size(); ++i) lens[i] = std::min(lens[i], deg[i]);
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 Dims sst = c_strides(subst.shape);
-                K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], subst.buf->p + sst[w], subst.numel, tab->p, lens[v]);
+                K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
                 std::vector<long long> shift(lens.size(), 0);
                 return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v]);
             }
@@ -978,15 +996,15 @@ struct Ops {
         }
         if (consumed != a.shape.size()) throw Error("index is too short");
         out[1] = 0.0;
-        read_back(&out[0], a.buf->p + off, sizeof(double));
-        if (W == 2) read_back(&out[1], a.buf->p + a.numel + off, sizeof(double));
+        read_back(&out[0], dp<E>(a) + off, sizeof(double));
+        if (W == 2) read_back(&out[1], dp<E>(a) + a.numel + off, sizeof(double));
     }
 
     static bool equal(const P& a, const P& b) {
         if (a.deg != b.deg || a.shape != b.shape) return false;
 
         HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 1), 0, 1, R.stream));
-        K<E>::count_neq(R.stream, a.buf->p, a.numel, b.buf->p, b.numel, a.numel, R.d_flag + 1);
+        K<E>::count_neq(R.stream, dp<E>(a), a.numel, dp<E>(b), b.numel, a.numel, R.d_flag + 1);
         unsigned cnt = 0;
         read_back(&cnt, R.d_flag + 1, sizeof(unsigned));
         return cnt == 0;
@@ -1186,7 +1204,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     gft_poly* PFX##from_host(const double* c, const size_t* sh, const size_t* dg, size_t nd) {                \
         return guard([&] {                                                                                    \
             gft_poly r = Ops<E>::make(dims(sh, nd), dims(dg, nd));                                            \
-            HIP_OK(hipMemcpyAsync(r.buf->p, c, sizeof(double) * r.numel * E::W, hipMemcpyHostToDevice, R.stream)); \
+            HIP_OK(hipMemcpyAsync(dp<E>(r), c, sizeof(double) * r.numel * E::W, hipMemcpyHostToDevice, R.stream)); \
             HIP_OK(hipStreamSynchronize(R.stream));                                                           \
             return r;                                                                                         \
         });                                                                                                   \
@@ -1220,7 +1238,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     void PFX##degrees_p1(const gft_poly* p, size_t* out) { std::copy(p->deg.begin(), p->deg.end(), out); }    \
     int PFX##to_host(const gft_poly* p, double* out) {                                                        \
         return guard_int([&] {                                                                                \
-            HIP_OK(hipMemcpyAsync(out, p->buf->p, sizeof(double) * p->numel * E::W, hipMemcpyDeviceToHost, R.stream)); \
+            HIP_OK(hipMemcpyAsync(out, dp<E>(*p), sizeof(double) * p->numel * E::W, hipMemcpyDeviceToHost, R.stream)); \
             HIP_OK(hipStreamSynchronize(R.stream));                                                           \
             return 0;                                                                                         \
         });                                                                                                   \

@@ -119,12 +119,13 @@ void K<E>::first_elem(hipStream_t st, double* p, size_t plane, int op, const dou
 
 template <class E>
 __global__ void __launch_bounds__(256) k_copy_first(const double* __restrict__ src, size_t sp, double* __restrict__ dst,
-                                                    size_t dp, size_t n, int op, const double* s, size_t s_plane) {
+                                                    size_t dp, size_t n, int op, const double* s, size_t s_plane,
+                                                    Scalar2 sv) {
     typedef typename E::V V;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         V x = E::ld(src, sp, i);
         if (i == 0) {
-            V y = E::ld(s, s_plane, 0);
+            V y = s ? E::ld(s, s_plane, 0) : E::from(sv);
             x = (op == FIRST_ADD) ? E::add(x, y) : E::sub(x, y);
         }
         if (op == FIRST_SUB_NEG_ALL) x = E::neg(x);
@@ -133,10 +134,10 @@ __global__ void __launch_bounds__(256) k_copy_first(const double* __restrict__ s
 }
 template <class E>
 void K<E>::copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n, int op,
-                      const double* s, size_t s_plane) {
+                      const double* s, size_t s_plane, Scalar2 sv) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_copy_first<E>, dim3(grid_for(n)), dim3(256), 0, st, src, src_plane, dst, dst_plane, n, op, s,
-                       s_plane);
+                       s_plane, sv);
 }
 
 template <class E>

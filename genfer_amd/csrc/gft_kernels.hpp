@@ -72,7 +72,7 @@ struct K {
     // dst = copy of src (n contiguous elements) with element 0 replaced by src[0] (+|-) s; FIRST_SUB_NEG_ALL:
     // dst[0] = -(src[0] - s), dst[i>0] = -src[i]  (mt:862-868, 919-925 in one launch)
     static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,
-                           int op, const double* s, size_t s_plane);
+                           int op, const double* s, size_t s_plane, Scalar2 s_value);  // s == nullptr: use s_value
     // p[0] = v0, p[1] = v1 (if n == 2): constants and `var` constructors without a host->device copy
     static void set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1);
     // after linear_mask: out[0] = mask (as a double), out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the
