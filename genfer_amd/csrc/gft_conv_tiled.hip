@@ -77,7 +77,7 @@ struct TiledArgs {
 typedef const double __attribute__((address_space(4))) * cptr_t;
 
 #ifndef GFT_TILED_DEFAULT_VARIANT
-#define GFT_TILED_DEFAULT_VARIANT 1
+#define GFT_TILED_DEFAULT_VARIANT 3
 #endif
 // VAR bits: 1 = software-pipelined fast path for full inner extents; diagnostics (wrong results, timing
 // only, built with -DGFT_TILED_DIAG): 16 = no LDS reads in the chunk loop, 32 = no scalar x loads,
@@ -91,6 +91,17 @@ __device__ inline void loadx(double (&dst)[8], cptr_t p) {  // wave-uniform: 8 d
 __device__ inline void load8(double (&dst)[8], const double* p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = p[i];
+}
+
+// 16-byte aligned window chunk: four ds_read_b128 (4 LDS cycles each) instead of four ds_read2_b64 (8 each)
+__device__ inline void load8_b128(double (&dst)[8], const double* p) {
+    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double2 v = q[i];
+        dst[2 * i] = v.x;
+        dst[2 * i + 1] = v.y;
+    }
 }
 
 __device__ inline void fma_rows(double (&acc)[8], const double (&xq)[8], const double (&cur)[8],
@@ -178,7 +189,7 @@ __device__ inline void block_mac(double (&acc)[8], unsigned c, cptr_t xr, const 
         fma_rows(acc, XU, CUR, PREV, 0, 1);                     \
         __builtin_amdgcn_sched_barrier(0);                      \
         if (!NO_X) loadx(XN, xr + 8 * (TX));                    \
-        if (!NO_LDS) load8(WN, w0 - 8 * (int)(TW));             \
+        if (!NO_LDS) { if (B128) load8_b128(WN, w0 - 8 * (int)(TW)); else load8(WN, w0 - 8 * (int)(TW)); } \
         __builtin_amdgcn_sched_barrier(0);                      \
         fma_rows(acc, XU, CUR, PREV, 1, 8);                     \
     } while (0)
@@ -187,10 +198,10 @@ template <int VAR>
 __device__ inline void block_fast(double (&acc)[8], unsigned c, cptr_t xr, const double* yrow) {
     constexpr bool NO_LDS = (VAR & 16) != 0;
     constexpr bool NO_X = (VAR & 32) != 0;
+    constexpr bool B128 = (VAR & 2) != 0;
     const double* w0 = yrow + 8 * c;  // W[t] = w0 - 8t
     double A[8], B[8], C[8], X0[8], X1[8], X2[8];
-    load8(A, w0);
-    load8(B, w0 - 8);
+    if (B128) { load8_b128(A, w0); load8_b128(B, w0 - 8); } else { load8(A, w0); load8(B, w0 - 8); }
     loadx(X0, xr);
     if (NO_LDS) load8(C, w0);
     if (NO_X) loadx(X1, xr), loadx(X2, xr);
@@ -513,7 +524,9 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     T.nxc = T.nx8 / 8;
     T.nyc = T.ny8 / 8;
     T.nb = (T.zI + 7) / 8;
-    T.P1 = T.ny8 + YPAD + 1;  // front padding + odd pitch: row index -> 8-byte bank slot is a bijection mod 16 and 32
+    // front padding + pitch: odd (8-byte slots, bijective mod 16/32 for ds_read_b64/read2_b64) or, for the
+    // ds_read_b128 variant, even with P1/2 odd (16-byte slots bijective mod 16 for the b128 lane groups)
+    T.P1 = (a.variant & 2) ? T.ny8 + YPAD + 2 : T.ny8 + YPAD + 1;
     T.P0 = 8 * T.P1;
     T.slab_lo = a.slab_lo;
     T.slab_hi = a.slab_hi;
@@ -643,6 +656,10 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
                     size_t ws_bytes, size_t* ws_needed) {
     ConvArgs a = a_in;
     if (a.variant < 0) a.variant = GFT_TILED_DEFAULT_VARIANT;
+    if (a.nd == 3 || a.nd == 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
+        unsigned nb = (a.zs[a.nd - 1] + 7) / 8;
+        if ((a.xs[a.nd - 1] + 7) / 8 < nb || (a.ys[a.nd - 1] + 7) / 8 < nb) a.variant &= ~3;
+    }
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
     if (a.nd != 3 && a.nd != 4) return false;
@@ -710,11 +727,11 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     hipError_t e = hipSuccess;
     constexpr int DEF = GFT_TILED_DEFAULT_VARIANT;
     int variant = a.variant;
-    if (!(B.nxc >= B.nb && B.nyc >= B.nb)) variant &= ~1;  // pipelined fast path needs full inner extents
     if (P.NW == 8) {
         switch (variant) {
             case 0: e = launch_main<8, 0>(st, P, T); break;
             case 1: e = launch_main<8, 1>(st, P, T); break;
+            case 3: e = launch_main<8, 3>(st, P, T); break;
 #ifdef GFT_TILED_DIAG
             case 17: e = launch_main<8, 17>(st, P, T); break;
             case 33: e = launch_main<8, 33>(st, P, T); break;
@@ -725,12 +742,12 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
             default: return false;
         }
     } else {
-        if ((variant | 1) != (DEF | 1)) return false;
+        if (variant != 0 && variant != DEF) return false;
         if (variant & 1) {
             switch (P.NW) {
-                case 1: e = launch_main<1, 1>(st, P, T); break;
-                case 2: e = launch_main<2, 1>(st, P, T); break;
-                default: e = launch_main<4, 1>(st, P, T); break;
+                case 1: e = launch_main<1, DEF>(st, P, T); break;
+                case 2: e = launch_main<2, DEF>(st, P, T); break;
+                default: e = launch_main<4, DEF>(st, P, T); break;
             }
         } else {
             switch (P.NW) {
