@@ -106,6 +106,12 @@ struct Buf {
     double* p = nullptr;
     size_t cls = 0;
     bool borrowed = false;
+    // memoised extract_linear() verdict: buffers are immutable once their polynomial is returned, and the
+    // metadata-only reshapes that share a buffer (extend_to_dim, dropping a trailing unit axis) keep the
+    // indices of all non-unit axes, so the verdict is a property of the buffer
+    int lin_state = 0;  // 0 unknown, 1 not linear, 2 linear
+    double lin_c[2] = {0, 0}, lin_m[2] = {0, 0};
+    size_t lin_var = 0;
     ~Buf() {
         if (p && !borrowed && R.ready) pool_free(p, cls);
     }
@@ -431,6 +437,12 @@ struct Ops {
         if (have_x) v0 = Scalar2{x[0], W == 2 ? x[1] : 0.0};
         if (n == 2 && second_is_one) v1 = Scalar2{1.0, 1.0};
         K<E>::set_small(R.stream, dp<E>(r), r.numel, (unsigned)n, v0, v1);
+        if (n == 2) {  // x + 1*eps_v (or 0*eps_v): its extract_linear verdict is known from the host-provided values
+            r.buf->lin_state = 2;
+            r.buf->lin_c[0] = v0.a; r.buf->lin_c[1] = W == 2 ? v0.b : 0.0;
+            r.buf->lin_m[0] = v1.a; r.buf->lin_m[1] = W == 2 ? v1.b : 0.0;
+            r.buf->lin_var = v;
+        }
         if (n == 1) {
             r.cached = true;
             r.cv[0] = v0.a;
@@ -474,20 +486,28 @@ struct Ops {
         for (size_t v = 0; v < p.shape.size(); ++v)
             if (p.shape[v] >= 2) mask |= 1u << v;
         if (!mask) return false;
+        if (p.buf && p.buf->lin_state) {
+            if (p.buf->lin_state == 1) return false;
+            c[0] = p.buf->lin_c[0]; c[1] = p.buf->lin_c[1];
+            m[0] = p.buf->lin_m[0]; m[1] = p.buf->lin_m[1];
+            *var = p.buf->lin_var;
+            return true;
+        }
         // kernel works on the collapsed view; map collapsed axis bits back to real axes
         Dims keep = collapse_mask({&p.shape}, false);
         unsigned cmask = 0;
         for (size_t i = 0; i < keep.size(); ++i)
             if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
-        HIP_OK(hipMemsetD32Async((hipDeviceptr_t)R.d_flag, (int)cmask, 1, R.stream));
         HV v = view(p);
         DView dv = dview(v, &keep);
-        K<E>::linear_mask(R.stream, dv, R.d_flag);
-        K<E>::linear_finish(R.stream, dv, R.d_flag, R.d_scratch);
+        K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, R.d_scratch);  // one launch (state words 8, 9)
         double res[5];
         read_back(res, R.d_scratch, sizeof(res));
         unsigned got = (unsigned)res[0];
-        if (!got) return false;
+        if (!got) {
+            p.buf->lin_state = 1;
+            return false;
+        }
         size_t ci = 0;
         while (!((got >> ci) & 1u)) ci++;
         c[0] = res[1];
@@ -495,6 +515,10 @@ struct Ops {
         m[0] = res[3];
         m[1] = res[4];
         *var = keep[ci];
+        p.buf->lin_state = 2;
+        p.buf->lin_c[0] = c[0]; p.buf->lin_c[1] = c[1];
+        p.buf->lin_m[0] = m[0]; p.buf->lin_m[1] = m[1];
+        p.buf->lin_var = *var;
         return true;
     }
 
@@ -1059,6 +1083,11 @@ int gft_init(int device) {
         HIP_OK(hipStreamCreateWithFlags(&R.own_stream, hipStreamNonBlocking));
         R.stream = R.own_stream;
         HIP_OK(hipMalloc((void**)&R.d_flag, 256));
+        {
+            unsigned init[64] = {0};
+            init[8] = 0xffffffffu;  // linear_scan state: mask word, arrival counter
+            HIP_OK(hipMemcpy(R.d_flag, init, sizeof(init), hipMemcpyHostToDevice));
+        }
         HIP_OK(hipMalloc((void**)&R.d_scratch, 256));
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));

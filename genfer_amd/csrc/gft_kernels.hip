@@ -151,6 +151,67 @@ void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar
 }
 
 template <class E>
+__global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask, unsigned* state, double* out, size_t total) {
+    unsigned local = axes_mask;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
+        size_t r = lin;
+        int nonzero_axes = 0, which = -1;
+        bool unit = true;
+#pragma unroll 1
+        for (int ax = t.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = t.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k != 0) {
+                nonzero_axes++;
+                which = ax;
+                if (k != 1) unit = false;
+            }
+        }
+        if (nonzero_axes == 0) continue;
+        if (nonzero_axes == 1 && unit) local &= (1u << which);
+        else local = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
+    __shared__ unsigned s_last;
+    if ((threadIdx.x & 63) == 0) atomicAnd(&state[0], local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned ticket = atomicAdd(&state[1], 1u);
+        s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    unsigned m = atomicAnd(&state[0], 0xffffffffu);  // device-scope read of the combined mask
+    out[0] = (double)m;
+    out[1] = out[2] = out[3] = out[4] = 0.0;
+    if (m) {
+        int ax = __ffs((int)m) - 1;
+        size_t stride = 1;
+        for (int i = t.sh.nd - 1; i > ax; --i) stride *= t.sh.d[i];
+        out[1] = t.p[0];
+        out[3] = t.p[stride];
+        if (E::W == 2) {
+            out[2] = t.p[t.plane];
+            out[4] = t.p[t.plane + stride];
+        }
+    }
+    atomicExch(&state[0], 0xffffffffu);  // restore for the next call on this stream
+    atomicExch(&state[1], 0u);
+}
+template <class E>
+void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out) {
+    size_t total = 1;
+    for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_linear_scan<E>, dim3(grid_for(total)), dim3(256), 0, st, t, axes_mask, state, out, total);
+}
+
+template <class E>
 __global__ void k_linear_finish(DView t, const unsigned* mask, double* out) {
     unsigned m = *mask;
     out[0] = (double)m;

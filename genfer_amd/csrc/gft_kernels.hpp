@@ -78,6 +78,10 @@ struct K {
     // after linear_mask: out[0] = mask (as a double), out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the
     // first axis v whose bit is set (zeros if none) — one 40-byte read-back instead of up to five
     static void linear_finish(hipStream_t st, const DView& t, const unsigned* mask, double* out);
+    // extract_linear in ONE launch: linear_mask + linear_finish fused with the "last block finishes" pattern.
+    // `state` = {mask word (must be 0xffffffff on entry), arrival counter (0 on entry)}; both are restored by
+    // the last block, so back-to-back calls on one stream need no memset.  out[0..4] as linear_finish.
+    static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
     // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])
