@@ -121,3 +121,77 @@ def test_snapshot_hip_within_tolerance(path):
     rc, text = run(path, genfer_amd.LIB_PATH, "gft_")
     assert rc == 0, text
     compare_reports(text, open(path[:-5] + ".expect").read())
+
+
+# ---- `--bounds` (BASELINE configs[4]): Interval<F64> tensors through the same interpreter -------------
+BOUNDS_PROGRAMS = [
+    "example.sgcl",
+    "test_expect/sample/poisson.sgcl",
+    "test_expect/sample/geometric.sgcl",
+    "test_expect/sample/binomial-var.sgcl",
+    "test_expect/observe/poisson-var.sgcl",
+    "test_expect/observe/negbinomial.sgcl",
+    "test_expect/sample/exponential.sgcl",
+    "test_expect/real_world/50_2vars.sgcl",
+]
+BOUNDS_PROGRAMS = [p for p in BOUNDS_PROGRAMS if os.path.exists(os.path.join(SGCL, p))]
+
+
+def run_flags(path, backend, prefix, flags):
+    import genfer_amd
+
+    return genfer_amd.run_sgcl_with_backend(open(path).read(), flags, backend, prefix)[:2]
+
+
+def intervals_and_points(text):
+    out = []
+    for line in text.splitlines():
+        m = re.search(r"∈ \[(\S+), (\S+)\]", line)
+        if m:
+            out.append((line.split("∈")[0].strip(), float(m.group(1)), float(m.group(2))))
+        else:
+            m = re.search(r"= (\S+)$", line)
+            if m and ("p(" in line or ":" in line):
+                try:
+                    v = float(m.group(1))
+                    out.append((line.split("=")[0].strip(), v, v))
+                except ValueError:
+                    pass
+    return out
+
+
+@pytest.mark.parametrize("prog", BOUNDS_PROGRAMS)
+def test_bounds_oracle_encloses_point_results(prog, oracle_path):
+    """The reference's tests never use --bounds (interval parity is unpinned by it), so the
+    interval path is checked for SOUNDNESS: every reported interval must contain the plain-f64 value."""
+    path = os.path.join(SGCL, prog)
+    flags = "--no-timing --limit 12 " + " ".join(t for t in flags_of(path).split() if t.startswith("--no-probs"))
+    rc, pt = run_flags(path, oracle_path, "orc_", flags)
+    assert rc == 0, pt
+    rc, iv = run_flags(path, oracle_path, "orci_", flags + " --bounds")
+    assert rc == 0, iv
+    p, i = intervals_and_points(pt), intervals_and_points(iv)
+    assert len(p) == len(i) and len(p) > 10
+    for (kp, lo_p, hi_p), (ki, lo, hi) in zip(p, i):
+        assert kp == ki
+        if lo_p != lo_p:  # NaN
+            continue
+        slack = 1e-9 * max(abs(lo_p), 1.0) if "Normalized" in kp or "p(n)" in kp else 0.0
+        assert lo - slack <= lo_p <= hi + slack, (kp, lo, lo_p, hi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", BOUNDS_PROGRAMS)
+def test_bounds_hip_matches_oracle(prog, oracle_path):
+    """Interval tensors on the GPU (two planes, same kernels over the interval element functor) vs the
+    oracle's Interval<f64>: same op order and widening => bounds agree to 1e-10 (device libm seeds aside)."""
+    import genfer_amd
+
+    genfer_amd.lib()
+    path = os.path.join(SGCL, prog)
+    flags = "--no-timing --bounds --limit 12 " + " ".join(t for t in flags_of(path).split() if t.startswith("--no-probs"))
+    rc, want = run_flags(path, oracle_path, "orci_", flags)
+    assert rc == 0, want
+    rc, got = run_flags(path, genfer_amd.LIB_PATH, "gfti_", flags)
+    assert rc == 0, got
+    compare_reports(got, want)
