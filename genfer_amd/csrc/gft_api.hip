@@ -859,6 +859,59 @@ struct Ops {
         return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len);
     }
 
+    // ---- fused observation step ------------------------------------------------------------------------
+    // (a.derivative(v, 1).truncate_to_degree_p1(d) * var(v, x, d)) * from(c) — the body of the reference's
+    // compound-Poisson observation loop (gf.rs:684-689) — in one launch, no dispatch read-backs.
+    static P observe_step(const P& a, size_t v, const double* x, const double* c, size_t d) {
+        auto generic = [&]() {
+            P D = truncate_to_degree_p1(deriv_like(a, v, 1, TAB_DERIV, "derivative"), d);
+            P V = var_like(v, x, true, std::min<size_t>(d, 2), d > 1, Dims(v + 1, d));
+            return mul(mul(D, V), scalar(c));
+        };
+        size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+        if (!(v < a.deg.size() && 1 < len_of)) return generic();          // reference assertion path
+        if (v >= a.shape.size() || a.shape[v] < 2 || d < 2) return generic();  // zero_with / constant var
+        if (val_is_zero(c)) return generic();                             // -> zero_with(deg)
+        for (int i = 0; i < W; ++i)
+            if (!(x[i] - x[i] == 0.0) || !(c[i] - c[i] == 0.0)) return generic();  // inf/NaN scalars: keep the exact dispatch
+        Dims dshape = a.shape, ddeg = a.deg;
+        dshape[v] -= 1;
+        ddeg[v] -= 1;
+        for (size_t ax = 0; ax < ddeg.size(); ++ax) {
+            ddeg[ax] = std::min(ddeg[ax], d);
+            dshape[ax] = std::min(dshape[ax], d);
+        }
+        if (prod(dshape) < 2) return generic();                            // scalar shortcuts of Mul
+        Dims sh = dshape;
+        sh[v] = std::min(ddeg[v], dshape[v] + 1);
+        P out = make(sh, ddeg);
+        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, 1, a.shape[v] - 1);
+        ObserveArgs g;
+        std::memset(&g, 0, sizeof(g));
+        Dims ast = c_strides(a.shape);
+        int nd = 0;
+        g.axis = -1;
+        for (size_t ax = 0; ax < sh.size(); ++ax) {
+            if (sh[ax] == 1 && ax != v) continue;  // collapsed: index 0 on this axis
+            if (nd >= MAXD) return generic();
+            g.out.d[nd] = (unsigned)sh[ax];
+            g.d_len[nd] = (unsigned)dshape[ax];
+            g.a_stride[nd] = ast[ax];
+            if (ax == v) g.axis = nd;
+            nd++;
+        }
+        g.out.nd = nd;
+        g.x = Scalar2{x[0], W == 2 ? x[1] : 0.0};
+        g.c = Scalar2{c[0], W == 2 ? c[1] : 0.0};
+        g.x_is_zero = val_is_zero(x);
+        g.x_is_one = val_is_one(x);
+        g.c_is_one = val_is_one(c);
+        g.tab = tab->p;
+        g.tab_plane = a.shape[v] - 1;
+        K<E>::observe_step(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g);
+        return out;
+    }
+
     // ---- shift_down (mt:514-536) -------------------------------------------------------------------------------------
     static void sum_axis_into(const P& a, size_t v, size_t upto, double* out, size_t out_plane) {
         size_t outer = 1, inner = 1;
@@ -1328,6 +1381,9 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::deriv_like(*a, v, n, TAB_COEFF, "taylor_expansion_of_coeff"); });   \
     }                                                                                                         \
     gft_poly* PFX##shift_down(const gft_poly* a, size_t v, size_t n) { return guard([&] { return Ops<E>::shift_down(*a, v, n); }); } \
+    gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
+        return guard([&] { return Ops<E>::observe_step(*a, v, x, c, d); });                                   \
+    }                                                                                                         \
     gft_poly* PFX##subst_var(const gft_poly* a, size_t v, const gft_poly* s) {                                \
         return guard([&] { return Ops<E>::subst_var(*a, v, *s); });                                           \
     }                                                                                                         \

@@ -233,6 +233,65 @@ void K<E>::linear_finish(hipStream_t st, const DView& t, const unsigned* mask, d
 }
 
 template <class E>
+__global__ void __launch_bounds__(256) k_observe_step(const double* __restrict__ a, size_t ap, double* __restrict__ out,
+                                                      size_t op, ObserveArgs g, size_t total) {
+    typedef typename E::V V;
+    const V xv = E::from(g.x), cv = E::from(g.c);
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, off = 0;
+        unsigned kv = 0;
+        bool in_d = true;  // inside D' on every axis other than v
+#pragma unroll 1
+        for (int ax = g.out.nd - 1; ax >= 0; --ax) {
+            unsigned d = g.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (ax == g.axis) kv = k;
+            else {
+                if (k >= g.d_len[ax]) in_d = false;
+                off += (size_t)k * g.a_stride[ax];
+            }
+        }
+        const size_t sv = g.a_stride[g.axis];
+        const unsigned dl = g.d_len[g.axis];
+        // D'_j = a[.., j+1, ..] * ff_j   (derivative, mt:471-479)
+        V res;
+        if (g.x_is_zero) {  // mul_var only (mt:619-621): zeros, then slab assignment
+            res = E::zero();
+            if (in_d && kv >= 1 && kv - 1 < dl) {
+                V dj = E::mul(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1));
+                res = E::mul(dj, E::one());
+            }
+        } else {  // mul_var(...) + self * from(x): zeros += A; += B  (mt:622, 873-880)
+            res = E::zero();
+            V A = E::zero();
+            if (in_d && kv >= 1 && kv - 1 < dl) {
+                V dj = E::mul(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1));
+                A = E::mul(dj, E::one());
+            }
+            res = E::add(res, A);
+            if (in_d && kv < dl) {
+                V di = E::mul(E::ld(a, ap, off + (size_t)(kv + 1) * sv), E::ld(g.tab, g.tab_plane, kv));
+                V B = g.x_is_one ? di : E::mul(xv, di);
+                res = E::add(res, B);
+            }
+        }
+        if (!g.c_is_one) res = E::mul(cv, res);
+        E::st(out, op, lin, res);
+    }
+}
+template <class E>
+void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                        const ObserveArgs& args) {
+    size_t total = 1;
+    for (int i = 0; i < args.out.nd; ++i) total *= args.out.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_observe_step<E>, dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args,
+                       total);
+}
+
+template <class E>
 __global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b, size_t bp, double* out,
                             size_t op_plane) {
     typename E::V x = E::ld(a, ap, 0);

@@ -47,6 +47,20 @@ struct GatherArgs {
     const unsigned char* keep;  // optional: keep[k_axis] == 0 -> write zero
 };
 
+// Fused observation step (generating_function.rs:678-700): out = c * ((D * 1)>>v + x * D) with
+// D = derivative(a, v, 1) truncated, i.e. the reference sequence derivative -> truncate -> * (x + eps_v)
+// (mul_linear: mul_var + constant scale + add) -> * c, element for element in the same operation order.
+struct ObserveArgs {
+    Shape out;                 // result shape (collapsed)
+    unsigned d_len[MAXD];      // shape of D' (the truncated derivative) per axis
+    size_t a_stride[MAXD];     // strides of the input tensor a
+    int axis;                  // collapsed index of v
+    Scalar2 x, c;
+    int x_is_zero, x_is_one, c_is_one;
+    const double* tab;         // derivative factors ff_j (mt:472-478), tab_plane apart for intervals
+    size_t tab_plane;
+};
+
 struct ConvArgs {
     int nd;
     unsigned xs[MAXD], ys[MAXD], zs[MAXD];
@@ -82,6 +96,8 @@ struct K {
     // `state` = {mask word (must be 0xffffffff on entry), arrival counter (0 on entry)}; both are restored by
     // the last block, so back-to-back calls on one stream need no memset.  out[0..4] as linear_finish.
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out);
+    static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                             const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
     // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])

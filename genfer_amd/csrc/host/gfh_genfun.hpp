@@ -183,7 +183,22 @@ struct GenFun {
             case Const: return TP::from(x.c);
             case Add: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g + h; }
             case Neg: return -x.a.eval_with(inputs, degree_p1, cache);
-            case Mul: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g * h; }
+            case Mul: {
+                // (d/dv G) * v * const — one level of the compound-Poisson observation chain built by
+                // eval_taylor_coeff_at_zero (gf.rs:684-689): evaluated by the backend's fused observe_step, which
+                // performs exactly the three reference operations derivative/truncate, * var, * const.
+                if (x.b.p->kind == Const && x.a.p->kind == Mul) {
+                    const Node& m = *x.a.p;
+                    if (m.a.p->kind == Derivative && m.a.p->order == 1 && m.b.p->kind == Var && m.b.p->var == m.a.p->var) {
+                        size_t v = m.b.p->var;
+                        TP t = m.a.p->a.eval_with(inputs, degree_p1 + 1, cache);
+                        return t.observe_step(v, inputs.at(v), x.b.p->c, degree_p1);
+                    }
+                }
+                TP g = x.a.eval_with(inputs, degree_p1, cache);
+                TP h = x.b.eval_with(inputs, degree_p1, cache);
+                return g * h;
+            }
             case Div: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g / h; }
             case Polynomial: {
                 TP taylor = TP::from_array(x.coeffs, x.shape, Dims(x.shape.size(), UMAX));

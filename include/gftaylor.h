@@ -120,6 +120,10 @@ gft_poly* gft_pow(const gft_poly* a, uint32_t e);                       /* pow  
 gft_poly* gft_derivative(const gft_poly* a, size_t v, size_t n);        /* derivative             mt:457-481 */
 gft_poly* gft_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n); /*                mt:484-509 */
 gft_poly* gft_shift_down(const gft_poly* a, size_t v, size_t n);        /* shift_down (axis sum)  mt:514-536 */
+/* Fused form of three reference calls: (derivative(a, v, 1).truncate_to_degree_p1(d) * var(v, x, d))
+ * * from(c) — one step of the compound-Poisson observation loop, generating_function.rs:684-689 — same
+ * per-element operation order, one kernel launch, no dispatch read-backs. */
+gft_poly* gft_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
 gft_poly* gft_subst_var(const gft_poly* a, size_t v, const gft_poly* subst); /* subst_var (Taylor shift / marginalize / Horner) mt:540-580 */
 gft_poly* gft_coefficients_of_term(const gft_poly* a, size_t v, size_t order); /*                 mt:341-358 */
 gft_poly* gft_taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders,
@@ -172,6 +176,7 @@ gft_poly* gfti_pow(const gft_poly* a, uint32_t e);
 gft_poly* gfti_derivative(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_shift_down(const gft_poly* a, size_t v, size_t n);
+gft_poly* gfti_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
 gft_poly* gfti_subst_var(const gft_poly* a, size_t v, const gft_poly* subst);
 gft_poly* gfti_coefficients_of_term(const gft_poly* a, size_t v, size_t order);
 gft_poly* gfti_taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders, size_t n);

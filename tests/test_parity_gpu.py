@@ -351,3 +351,35 @@ def test_full_size_c2_properties():
     assert np.array_equal(got2, 2.0 * got)
     assert got[0, 0, 0] == x[0, 0, 0] * y[0, 0, 0]
     assert abs(got[0, 0, 1] - (x[0, 0, 0] * y[0, 0, 1] + x[0, 0, 1] * y[0, 0, 0])) <= 1e-15
+
+
+@pytest.mark.parametrize("xs,ys,deg", SHAPES)
+def test_observe_step_fused_equals_reference_sequence(OTP, GTP, xs, ys, deg):
+    """gft_observe_step (one kernel) == derivative -> truncate -> * var -> * const (three reference calls),
+    bit for bit, on both backends; includes the exact-zero / exact-one scalar shortcuts."""
+    x = rand(xs, 51, -1, 1)
+    ox, gx = both(OTP, GTP, x, deg)
+    for v in range(len(xs)):
+        for d in (1, 2, 3, max(deg)):
+            for xv in (0.0, 1.0, 0.37):
+                for c in (1.0, 0.25, 0.0):
+                    if not (1 < deg[v]):
+                        continue
+                    want = (ox.derivative(v, 1).truncate_to_degree_p1(d) * OTP.var(v, xv, d)) * OTP.from_scalar(c)
+                    check(want, ox.observe_step(v, xv, c, d))
+                    check(want, gx.observe_step(v, xv, c, d))
+                    unfused = (gx.derivative(v, 1).truncate_to_degree_p1(d) * GTP.var(v, xv, d)) * GTP.from_scalar(c)
+                    check(want, unfused)
+
+
+def test_observe_step_interval(OTPI, GTPI):
+    for xs, ys, deg in SHAPES[:8]:
+        lo = rand(xs, 52, -1, 1)
+        x = np.stack([lo, lo + rand(xs, 53, 0, 1e-3)])
+        ox, gx = OTPI.new(x, deg), GTPI.new(x, deg)
+        for v in range(len(xs)):
+            if not (1 < deg[v]):
+                continue
+            for xv, c in (((0.0, 0.0), (0.5, 0.5)), ((1.0, 1.0), (1.0, 1.0)), ((0.3, 0.31), (0.2, 0.21))):
+                want = (ox.derivative(v, 1).truncate_to_degree_p1(3) * OTPI.var(v, xv, 3)) * OTPI.from_scalar(c)
+                check(want, gx.observe_step(v, xv, c, 3))
