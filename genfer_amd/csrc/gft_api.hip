@@ -384,6 +384,28 @@ struct Ops {
             if ((int)ax == tab_axis) a.tab_axis = nd;
             nd++;
         }
+        // merge adjacent axes that are unmasked and contiguous in the source (elementwise maps become 1-D,
+        // slab ops 3-D): less index arithmetic per element, longer unit-stride runs for 16-byte accesses
+        for (int i = nd - 1; i >= 1;) {
+            int o = i - 1;
+            bool ok = a.shift[o] == 0 && a.shift[i] == 0 && a.out.d[o] <= a.src_len[o] && a.out.d[i] <= a.src_len[i] &&
+                      a.src_stride[o] == (size_t)a.out.d[i] * a.src_stride[i] && o != a.tab_axis && i != a.tab_axis &&
+                      (unsigned long long)a.out.d[o] * a.out.d[i] <= 0xffffffffull;
+            if (ok) {
+                a.out.d[o] = a.out.d[o] * a.out.d[i];
+                a.src_len[o] = a.out.d[o];
+                a.src_stride[o] = a.src_stride[i];
+                for (int j = i; j + 1 < nd; ++j) {
+                    a.out.d[j] = a.out.d[j + 1];
+                    a.shift[j] = a.shift[j + 1];
+                    a.src_len[j] = a.src_len[j + 1];
+                    a.src_stride[j] = a.src_stride[j + 1];
+                }
+                if (a.tab_axis > i) a.tab_axis--;
+                nd--;
+            }
+            i--;
+        }
         a.out.nd = nd;
         a.op = op;
         if (s) {

@@ -54,12 +54,64 @@ __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, 
     }
 }
 
+// f64 fast path: the innermost (collapsed) axis is unit-stride, unshifted, fully valid and even, all outer
+// strides are even and both bases 16-byte aligned => every thread moves one double2 (global_load_dwordx4).
+__global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__ src, double* __restrict__ out,
+                                                      GatherArgs a, size_t total_pairs) {
+    const int last = a.out.nd - 1;
+    const unsigned half = a.out.d[last] >> 1;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total_pairs;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin / half;
+        unsigned kp = (unsigned)(lin - r * half);
+        size_t soff = 2 * (size_t)kp;
+        bool valid = true;
+        unsigned kaxis = 0;
+#pragma unroll 1
+        for (int ax = last - 1; ax >= 0; --ax) {
+            unsigned d = a.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            long long si = (long long)k + a.shift[ax];
+            if (si < 0 || si >= (long long)a.src_len[ax]) valid = false;
+            soff += (size_t)(si < 0 ? 0 : si) * a.src_stride[ax];
+            if (ax == a.tab_axis) kaxis = k;
+        }
+        if (valid && a.keep && !a.keep[kaxis]) valid = false;
+        double2 v = make_double2(0.0, 0.0);
+        if (valid) {
+            v = *reinterpret_cast<const double2*>(src + soff);
+            switch (a.op) {
+                case OP_MUL_S: v.x = v.x * a.s.a; v.y = v.y * a.s.a; break;
+                case OP_DIV_S: v.x = v.x / a.s.a; v.y = v.y / a.s.a; break;
+                case OP_LMUL_S: v.x = a.s.a * v.x; v.y = a.s.a * v.y; break;
+                case OP_NEG: v.x = -v.x; v.y = -v.y; break;
+                case OP_MUL_TAB: { double f = a.tab[kaxis]; v.x = v.x * f; v.y = v.y * f; break; }
+                default: break;
+            }
+        }
+        *reinterpret_cast<double2*>(out + 2 * lin) = v;
+    }
+}
+
 template <class E>
 void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* out, size_t out_plane,
                   const GatherArgs& a) {
     size_t total = 1;
     for (int i = 0; i < a.out.nd; ++i) total *= a.out.d[i];
     if (total == 0) return;
+    if (E::W == 1 && a.out.nd >= 1) {
+        const int last = a.out.nd - 1;
+        bool ok = a.src_stride[last] == 1 && a.shift[last] == 0 && a.out.d[last] <= a.src_len[last] &&
+                  (a.out.d[last] & 1u) == 0 && a.tab_axis != last && (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+        for (int i = 0; i < last && ok; ++i)
+            if (a.src_stride[i] & 1) ok = false;
+        if (ok) {
+            size_t pairs = total / 2;
+            hipLaunchKernelGGL(k_gather_f64x2, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, pairs);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_gather<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, a,
                        total);
 }
@@ -96,11 +148,31 @@ __global__ void __launch_bounds__(256) k_addsub_padded(DView out, DView a, DView
     }
 }
 
+// Equal shapes (the common case): 1-D, two f64 per thread.  Same per-element order: (0 + a) (+|-) b.
+__global__ void __launch_bounds__(256) k_addsub_f64x2(const double* __restrict__ a, const double* __restrict__ b,
+                                                      double* __restrict__ out, size_t pairs, int subtract) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+        double2 x = reinterpret_cast<const double2*>(a)[i], y = reinterpret_cast<const double2*>(b)[i], r;
+        r.x = 0.0 + x.x;
+        r.y = 0.0 + x.y;
+        r.x = subtract ? r.x - y.x : r.x + y.x;
+        r.y = subtract ? r.y - y.y : r.y + y.y;
+        reinterpret_cast<double2*>(out)[i] = r;
+    }
+}
+
 template <class E>
 void K<E>::addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract) {
     size_t total = 1;
     for (int i = 0; i < out.sh.nd; ++i) total *= out.sh.d[i];
     if (total == 0) return;
+    bool same = E::W == 1 && (total & 1) == 0 && (((uintptr_t)out.p | (uintptr_t)a.p | (uintptr_t)b.p) & 15) == 0;
+    for (int i = 0; i < out.sh.nd && same; ++i)
+        if (a.sh.d[i] != out.sh.d[i] || b.sh.d[i] != out.sh.d[i]) same = false;
+    if (same) {
+        hipLaunchKernelGGL(k_addsub_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, a.p, b.p, out.p, total / 2, subtract);
+        return;
+    }
     hipLaunchKernelGGL(k_addsub_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, subtract, total);
 }
 
@@ -550,6 +622,7 @@ __global__ void __launch_bounds__(256) k_sum_axis_seq(const double* __restrict__
             acc = E::add(acc, E::add(p[3], p[7]));
             for (; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
         } else {
+#pragma unroll 8
             for (unsigned k = 0; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
         }
         E::st(out, op, lin, acc);
@@ -574,6 +647,28 @@ __global__ void __launch_bounds__(256) k_sum_last_axis_wave(const double* __rest
     }
 }
 
+// f64, even inner extent: two adjacent outputs per thread (16-byte loads), 8 loads in flight per thread;
+// per-output summation order unchanged (sequential ascending k).
+__global__ void __launch_bounds__(256) k_sum_axis_seq_f64x2(const double* __restrict__ in, unsigned outer, unsigned len,
+                                                            unsigned inner, size_t outer_stride, double* __restrict__ out) {
+    const unsigned half = inner >> 1;
+    size_t total = (size_t)outer * half;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        unsigned ip = (unsigned)(lin % half);
+        size_t o = lin / half;
+        const double* p = in + o * outer_stride + 2 * (size_t)ip;
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll 8
+        for (unsigned k = 0; k < len; ++k) {
+            double2 v = *reinterpret_cast<const double2*>(p + (size_t)k * inner);
+            acc.x = acc.x + v.x;
+            acc.y = acc.y + v.y;
+        }
+        *reinterpret_cast<double2*>(out + o * inner + 2 * (size_t)ip) = acc;
+    }
+}
+
 template <class E>
 void K<E>::sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
                     unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode) {
@@ -583,6 +678,12 @@ void K<E>::sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned 
         size_t blocks = (outer + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(k_sum_last_axis_wave, dim3((unsigned)blocks), dim3(256), 0, st, in, outer, len,
+                           axis_stride_outer, out);
+        return;
+    }
+    if (E::W == 1 && mode != SUM_UNROLL8 && (inner & 1u) == 0 && (axis_stride_outer & 1) == 0 &&
+        (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_sum_axis_seq_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, in, outer, len, inner,
                            axis_stride_outer, out);
         return;
     }
