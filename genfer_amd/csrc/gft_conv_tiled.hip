@@ -61,6 +61,7 @@ struct TiledArgs {
     unsigned lead_is_u;              // 1: slab range applies to u, 0: to k0
     unsigned slab_lo, slab_hi;
     int accumulate;
+    unsigned xcd_remap;              // 1: remap blockIdx so that each XCD owns a contiguous chunk of ranges
     const double* xp;
     const double* yp;
     double* z;
@@ -77,7 +78,7 @@ struct TiledArgs {
 typedef const double __attribute__((address_space(4))) * cptr_t;
 
 #ifndef GFT_TILED_DEFAULT_VARIANT
-#define GFT_TILED_DEFAULT_VARIANT 3
+#define GFT_TILED_DEFAULT_VARIANT 7
 #endif
 // VAR bits: 1 = software-pipelined fast path for full inner extents; diagnostics (wrong results, timing
 // only, built with -DGFT_TILED_DIAG): 16 = no LDS reads in the chunk loop, 32 = no scalar x loads,
@@ -271,7 +272,11 @@ k_conv_tiled(TiledArgs A) {
     const unsigned pf_pieces = 8 * half_row;         // one ring slot refill = 8 rows
     const size_t y_row_stride = A.ny8;
 
-    const unsigned seg_begin = A.wg_begin[blockIdx.x], seg_end = A.wg_begin[blockIdx.x + 1];
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a CONTIGUOUS eighth of
+    // the stream-K ranges — neighbouring ranges sweep overlapping y-row windows and then share one L2.
+    unsigned wg = blockIdx.x;
+    if (A.xcd_remap) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned seg_begin = A.wg_begin[wg], seg_end = A.wg_begin[wg + 1];
     for (unsigned si = seg_begin; si < seg_end; ++si) {
         const TileSeg seg = A.segs[si];
         const unsigned u = seg.u, a = seg.a, b = seg.b;
@@ -724,14 +729,16 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
         T.yp = y;
     }
     T.z = z;
+    T.xcd_remap = ((a.variant & 4) && (P.n_wg % 8 == 0)) ? 1u : 0u;
     hipError_t e = hipSuccess;
     constexpr int DEF = GFT_TILED_DEFAULT_VARIANT;
     int variant = a.variant;
     if (P.NW == 8) {
         switch (variant) {
-            case 0: e = launch_main<8, 0>(st, P, T); break;
+            case 0: case 4: e = launch_main<8, 0>(st, P, T); break;
             case 1: e = launch_main<8, 1>(st, P, T); break;
             case 3: e = launch_main<8, 3>(st, P, T); break;
+            case 7: e = launch_main<8, 3>(st, P, T); break;  // 3 + XCD-contiguous ranges (runtime flag)
 #ifdef GFT_TILED_DIAG
             case 17: e = launch_main<8, 17>(st, P, T); break;
             case 33: e = launch_main<8, 33>(st, P, T); break;
@@ -742,12 +749,12 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
             default: return false;
         }
     } else {
-        if (variant != 0 && variant != DEF) return false;
+        if (variant != 0 && variant != 4 && variant != DEF && variant != (DEF & 3)) return false;
         if (variant & 1) {
             switch (P.NW) {
-                case 1: e = launch_main<1, DEF>(st, P, T); break;
-                case 2: e = launch_main<2, DEF>(st, P, T); break;
-                default: e = launch_main<4, DEF>(st, P, T); break;
+                case 1: e = launch_main<1, (DEF & 3)>(st, P, T); break;
+                case 2: e = launch_main<2, (DEF & 3)>(st, P, T); break;
+                default: e = launch_main<4, (DEF & 3)>(st, P, T); break;
             }
         } else {
             switch (P.NW) {
