@@ -588,7 +588,7 @@ struct Ops {
             if (a.zs[i] != 1) nonunit++;
         a.inner_from_zero = nonunit >= 1 ? 1 : 0;
 
-        bool want_tiled = (W == 1) && R.conv_mode != 1;
+        bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
         if (want_tiled) {
             size_t need = 0;
             bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, a, nullptr, 0, &need);
@@ -620,6 +620,9 @@ struct Ops {
                 return;
             }
             if (R.conv_mode == 2) throw Error("conv_mode=2 (tiled) requested but the shape is not supported by the tiled kernel");
+        }
+        if (R.conv_mode == 0 || R.conv_mode == 3) {
+            if (conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, R.conv_mode == 3)) return;
         }
         K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
     }
@@ -1167,6 +1170,10 @@ int gft_init(int device) {
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
         R.device = device;
+        if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
+            int m = atoi(cm);
+            if (m >= 0 && m <= 3) R.conv_mode = m;
+        }
         R.ready = true;
         return 0;
     } catch (const std::exception& e) {
@@ -1237,7 +1244,7 @@ int gft_set_conv_variant(int v) {
     return 0;
 }
 int gft_set_conv_mode(int mode) {
-    if (mode < 0 || mode > 2) return -1;
+    if (mode < 0 || mode > 3) return -1;
     R.conv_mode = mode;
     return 0;
 }

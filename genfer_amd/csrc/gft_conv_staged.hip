@@ -1,0 +1,299 @@
+// LDS-staged reference-order convolution (f64 and interval).
+//
+// Same arithmetic as k_conv_naive (gft_kernels.hip): every output element is accumulated by ONE
+// thread in exactly the reference's loop order (mt:971-1012: outer axes lexicographic ascending,
+// last axis' partial sum from zero, separate multiply and add), so the result is bit-identical to
+// the CPU algorithm — only the data movement differs.  The naive kernel streams both operands from
+// L1/L2 for every MAC (4 global loads per interval MAC); here a workgroup owns up to CH outputs that
+// share their "outer" multi-index K_o (all axes but the last S in {1,2}), walks the outer j_o in
+// reference order, and for every j_o stages the x sub-tensor x[j_o, ...] and the y sub-tensor
+// y[K_o - j_o, ...] (the last S axes, contiguous in HBM) into LDS once for all its threads.
+//
+// LDS layout: x sub-tensor dense; y sub-tensor with row pitch nb (= the output's last-axis length), so
+// that a thread's y address is (its linear output index) - (j_a * nb + j_b): consecutive lanes read
+// consecutive LDS words for every (j_a, j_b) => conflict-free ds_read_b64, while the x address is
+// wave-uniform (LDS broadcast).  Only the rows/columns the chunk can reach are staged.
+//
+// Work decomposition: blocks = (outer K_o within the slab) x (chunks of the staged subspace), issued
+// heaviest-first (largest K first), 256..1024 threads by LDS footprint so that a CU always holds
+// >= 4 waves per SIMD.  HBM traffic per block step is (|x sub| + |y sub|) * 8 * W bytes for
+// CH * (MACs per output) work: the kernel is VALU/LDS-bound (2 ds_read + mul + add per f64 MAC).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+namespace {
+
+constexpr int MAXO = MAXD - 1;  // max number of outer axes
+
+struct StagedArgs {
+    int S;                   // staged axes (1 or 2)
+    int no;                  // outer axes = nd - S
+    unsigned chunks;         // chunks of the staged subspace per outer K
+    unsigned long long sub_lo, sub_hi;  // linear output range inside the staged subspace
+    unsigned sxa, sxb, sya, syb, na, nb;  // staged extents (S == 1: sxa = sya = na = 1)
+    unsigned xcap, ycap;     // LDS plane sizes (doubles) of the x / y regions
+};
+
+template <class E, bool INNER0, int S>
+__global__ void __launch_bounds__(1024)
+k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+              double* __restrict__ z, size_t zp, ConvArgs a, StagedArgs g) {
+    typedef typename E::V V;
+    extern __shared__ double smem[];
+    double* xl = smem;                         // [W][xcap]
+    double* yl = smem + (size_t)E::W * g.xcap;  // [W][ycap]
+    const unsigned CH = blockDim.x, tid = threadIdx.x;
+
+    // ---- which outputs --------------------------------------------------------------------------
+    const unsigned long long b = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest first
+    const unsigned chunk = (unsigned)(b % g.chunks);
+    unsigned long long ko_lin = b / g.chunks;
+    unsigned K[MAXO], lo[MAXO], cnt[MAXO], pos[MAXO];
+    unsigned long long steps = 1;
+    size_t zoff = 0;
+#pragma unroll
+    for (int ax = MAXO - 1; ax >= 0; --ax) {
+        K[ax] = lo[ax] = pos[ax] = 0;
+        cnt[ax] = 1;
+        if (ax < g.no) {
+            unsigned d = a.zs[ax], base = 0;
+            if (ax == 0) {
+                d = a.slab_hi - a.slab_lo;
+                base = a.slab_lo;
+            }
+            K[ax] = base + (unsigned)(ko_lin % d);
+            ko_lin /= d;
+            zoff += (size_t)K[ax] * a.zstr[ax];
+            unsigned l = (K[ax] + 1 > a.ys[ax]) ? (K[ax] + 1 - a.ys[ax]) : 0;
+            unsigned h = (K[ax] + 1 < a.xs[ax]) ? (K[ax] + 1) : a.xs[ax];
+            if (ax == 0) {
+                if (l < (unsigned)a.j0_min) l = (unsigned)a.j0_min;
+                if (a.j0_excl && h > K[ax]) h = K[ax];
+            }
+            lo[ax] = l;
+            cnt[ax] = h > l ? h - l : 0;
+            steps *= cnt[ax];
+        }
+    }
+    const unsigned long long first = g.sub_lo + (unsigned long long)chunk * CH;
+    const unsigned long long lin = first + tid;
+    const bool active = lin < g.sub_hi;
+    unsigned long long last = first + CH - 1;
+    if (last > g.sub_hi - 1) last = g.sub_hi - 1;
+    const unsigned ka = S == 2 ? (unsigned)(lin / g.nb) : 0;
+    const unsigned kb = (unsigned)(lin % g.nb);
+    // staged extents this chunk can reach
+    unsigned xrows = 1, yrows = 1, xcols, ycols;
+    if (S == 2) {
+        unsigned ka_hi = (unsigned)(last / g.nb);
+        xrows = ka_hi + 1 < g.sxa ? ka_hi + 1 : g.sxa;
+        yrows = ka_hi + 1 < g.sya ? ka_hi + 1 : g.sya;
+        xcols = g.sxb;
+        ycols = g.syb;
+    } else {
+        unsigned kb_hi = (unsigned)last;
+        xcols = kb_hi + 1 < g.sxb ? kb_hi + 1 : g.sxb;
+        ycols = kb_hi + 1 < g.syb ? kb_hi + 1 : g.syb;
+    }
+    const unsigned nx = xrows * xcols, ny = yrows * ycols;
+
+    // ---- per-thread loop bounds on the staged axes (constant over the outer steps) ----------------
+    const bool a_is_axis0 = (S == 2) && g.no == 0;
+    const bool b_is_axis0 = (S == 1) && g.no == 0;
+    unsigned lo_a = 0, hi_a = 1;
+    if (S == 2) {
+        lo_a = (ka + 1 > g.sya) ? (ka + 1 - g.sya) : 0;
+        hi_a = (ka + 1 < g.sxa) ? (ka + 1) : g.sxa;
+        if (a_is_axis0) {
+            if (lo_a < (unsigned)a.j0_min) lo_a = (unsigned)a.j0_min;
+            if (a.j0_excl && hi_a > ka) hi_a = ka;
+        }
+    }
+    unsigned lo_b = (kb + 1 > g.syb) ? (kb + 1 - g.syb) : 0;
+    unsigned hi_b = (kb + 1 < g.sxb) ? (kb + 1) : g.sxb;
+    if (b_is_axis0) {
+        if (lo_b < (unsigned)a.j0_min) lo_b = (unsigned)a.j0_min;
+        if (a.j0_excl && hi_b > kb) hi_b = kb;
+    }
+    const bool desc_a = a_is_axis0 && a.j0_desc;
+    const bool desc_b = b_is_axis0 && a.j0_desc;
+    const bool desc_0 = g.no > 0 && a.j0_desc;
+
+    const size_t zlin = zoff + (size_t)lin;
+    V acc = E::zero();
+    if (active && a.accumulate) acc = E::ld(z, zp, zlin);
+
+    for (unsigned long long step = 0; step < steps; ++step) {
+        // offsets of the staged sub-tensors for the current outer j
+        size_t xoff = 0, yoff = 0;
+#pragma unroll
+        for (int ax = 0; ax < MAXO; ++ax) {
+            if (ax < g.no) {
+                unsigned j = (ax == 0 && desc_0) ? (lo[ax] + cnt[ax] - 1 - pos[ax]) : (lo[ax] + pos[ax]);
+                xoff += (size_t)j * a.xstr[ax];
+                yoff += (size_t)(K[ax] - j) * a.ystr[ax];
+            }
+        }
+        __syncthreads();  // everyone is done with the previous sub-tensors
+        for (unsigned i = tid; i < nx; i += CH) {
+            V v = E::ld(x, xp, xoff + i);
+            E::st(xl, g.xcap, i, v);
+        }
+        if (S == 2 && g.syb != g.nb) {
+            for (unsigned i = tid; i < ny; i += CH) {
+                unsigned r = i / g.syb, c = i - r * g.syb;
+                V v = E::ld(y, yp, yoff + i);
+                E::st(yl, g.ycap, (size_t)r * g.nb + c, v);
+            }
+        } else {
+            for (unsigned i = tid; i < ny; i += CH) {
+                V v = E::ld(y, yp, yoff + i);
+                E::st(yl, g.ycap, i, v);
+            }
+        }
+        __syncthreads();
+
+        if (active) {
+            const unsigned cnt_a = hi_a > lo_a ? hi_a - lo_a : 0;
+            for (unsigned t = 0; t < cnt_a; ++t) {
+                const unsigned ja = desc_a ? (hi_a - 1 - t) : (lo_a + t);
+                const unsigned xb = ja * g.sxb;                       // wave-uniform when the wave shares ja
+                const unsigned yb = (S == 2 ? (ka - ja) * g.nb : 0) + kb;
+                if (hi_b > lo_b) {
+                    if (INNER0) {
+                        V inner = E::zero();
+#pragma unroll 4
+                        for (unsigned j = lo_b; j < hi_b; ++j)
+                            inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                        acc = E::add(acc, inner);
+                    } else {
+                        const unsigned cnt_b = hi_b - lo_b;
+                        for (unsigned u = 0; u < cnt_b; ++u) {
+                            const unsigned j = desc_b ? (hi_b - 1 - u) : (lo_b + u);
+                            acc = E::add(acc, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                        }
+                    }
+                }
+            }
+        }
+
+        // advance the outer odometer (last outer axis fastest)
+        bool carry = true;
+#pragma unroll
+        for (int ax = MAXO - 1; ax >= 0; --ax) {
+            if (ax < g.no && carry) {
+                if (++pos[ax] == cnt[ax]) pos[ax] = 0;
+                else carry = false;
+            }
+        }
+    }
+    if (active) E::st(z, zp, zlin, acc);
+}
+
+template <class E, bool INNER0, int S>
+bool launch(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp,
+            const ConvArgs& a, const StagedArgs& g, unsigned blocks, unsigned threads, size_t lds) {
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_staged<E, INNER0, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_staged<E, INNER0, S>), dim3(blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
+    return true;
+}
+
+}  // namespace
+
+// Returns false (nothing launched) when the shape does not suit the staged kernel; the caller then
+// uses conv_naive.  `force`: ignore the "worth it" thresholds (tests).
+template <class E>
+bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp,
+                 const ConvArgs& a, bool force) {
+    const int nd = a.nd;
+    if (nd < 1) return false;
+    if (a.slab_hi <= a.slab_lo) return true;  // nothing to do
+    constexpr size_t LDS_MAX = 160 * 1024;
+    const size_t W = E::W;
+    StagedArgs g;
+    // S = 2 (planes of the last two axes) while the planes are small enough for >= 4 workgroups per CU;
+    // larger planes would leave one fat workgroup per CU with a triangular load => rows (S = 1) instead,
+    // unless the rows are too short to fill a wave.
+    static const int force_s = [] {
+        const char* e = getenv("GFT_STAGED_S");  // experiment knob
+        return e ? atoi(e) : 0;
+    }();
+    auto fits = [&](int s, size_t budget) {
+        unsigned sxa = s == 2 ? a.xs[nd - 2] : 1, sya = s == 2 ? a.ys[nd - 2] : 1;
+        size_t xcap = (size_t)sxa * a.xs[nd - 1], ycap = (size_t)sya * (s == 2 ? a.zs[nd - 1] : a.ys[nd - 1]);
+        return (xcap + ycap) * 8 * W <= budget;
+    };
+    for (int i = 0; i < nd; ++i)
+        if (a.xs[i] > a.zs[i] || a.ys[i] > a.zs[i]) return false;  // operands are pre-truncated; be safe
+    int S = 0;
+    if (force_s == 1 || force_s == 2) {
+        if (force_s <= nd && fits(force_s, LDS_MAX)) S = force_s;
+    } else if (nd >= 2 && fits(2, 40 * 1024)) S = 2;
+    else if (a.zs[nd - 1] >= 32 && fits(1, LDS_MAX)) S = 1;
+    else if (nd >= 2 && fits(2, LDS_MAX)) S = 2;
+    else if (fits(1, LDS_MAX)) S = 1;
+    if (S) {
+        g.S = S;
+        g.sxa = S == 2 ? a.xs[nd - 2] : 1; g.sya = S == 2 ? a.ys[nd - 2] : 1; g.na = S == 2 ? a.zs[nd - 2] : 1;
+        g.sxb = a.xs[nd - 1]; g.syb = a.ys[nd - 1]; g.nb = a.zs[nd - 1];
+        g.xcap = g.sxa * g.sxb;
+        g.ycap = g.sya * (S == 2 ? g.nb : g.syb);
+    }
+    if (S == 0) return false;
+    g.no = nd - S;
+    unsigned long long sub = (unsigned long long)g.na * g.nb, n_outer = 1;
+    if (g.no == 0) {  // axis 0 is a staged axis: the slab restricts the subspace range
+        unsigned long long rest = sub / a.zs[0];
+        g.sub_lo = a.slab_lo * rest;
+        g.sub_hi = a.slab_hi * rest;
+    } else {
+        g.sub_lo = 0;
+        g.sub_hi = sub;
+        n_outer = a.slab_hi - a.slab_lo;
+        for (int ax = 1; ax < g.no; ++ax) n_outer *= a.zs[ax];
+    }
+    const unsigned long long span = g.sub_hi - g.sub_lo;
+    if (span == 0 || n_outer == 0) return true;
+    if (!force) {
+        // interval MACs are ~130 VALU instructions: staging only pays once the rows fill a good part of a wave
+        if (W == 2 && g.nb < 24) return false;
+    }
+    const size_t lds = (size_t)(g.xcap + g.ycap) * 8 * W;
+    unsigned threads = lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
+    // do not use more threads than one balanced chunk needs
+    unsigned long long chunks = (span + threads - 1) / threads;
+    unsigned per = (unsigned)((span + chunks - 1) / chunks);
+    unsigned need = (per + 63) / 64 * 64;
+    if (need < threads && lds <= 40 * 1024) threads = need;
+    chunks = (span + threads - 1) / threads;
+    g.chunks = (unsigned)chunks;
+    unsigned long long blocks = n_outer * chunks;
+    if (blocks == 0) return true;
+    if (blocks > 0x7fffffffULL) return false;
+#define GFT_ST(I0, SS) launch<E, I0, SS>(st, x, xp, y, yp, z, zp, a, g, (unsigned)blocks, threads, lds)
+    if (a.inner_from_zero) return S == 2 ? GFT_ST(true, 2) : GFT_ST(true, 1);
+    return S == 2 ? GFT_ST(false, 2) : GFT_ST(false, 1);
+#undef GFT_ST
+}
+
+template bool conv_staged<EF64>(hipStream_t, const double*, size_t, const double*, size_t, double*, size_t,
+                                const ConvArgs&, bool);
+template bool conv_staged<EIv>(hipStream_t, const double*, size_t, const double*, size_t, double*, size_t,
+                               const ConvArgs&, bool);
+
+}  // namespace gft

@@ -38,19 +38,23 @@ struct EF64 {
 };
 
 // f64.rs:127-171 — integer arithmetic on the bits.
+// Branch-free: bits + (+1 | -1 by sign) is right for every input except -0.0 (-> smallest subnormal of the
+// target sign) and NaN / the infinity in the direction of travel (-> unchanged); two selects fix those.
 __device__ inline double next_up(double x) {
-    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-    if (x != x || bits == 0x7ff0000000000000ULL) return x;
-    unsigned long long a = bits & 0x7fffffffffffffffULL;
-    unsigned long long nx = (a == 0) ? 0x1ULL : (bits == a ? bits + 1 : bits - 1);
-    return __longlong_as_double((long long)nx);
+    const long long bits = __double_as_longlong(x);
+    const long long step = (bits >> 63) | 1LL;  // +1 for the positive half, -1 for the negative half
+    long long r = bits + step;
+    r = (x == 0.0) ? 0x1LL : r;
+    r = (x != x || bits == 0x7ff0000000000000LL) ? bits : r;
+    return __longlong_as_double(r);
 }
 __device__ inline double next_down(double x) {
-    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-    if (x != x || bits == 0xfff0000000000000ULL) return x;
-    unsigned long long a = bits & 0x7fffffffffffffffULL;
-    unsigned long long nx = (a == 0) ? 0x8000000000000001ULL : (bits == a ? bits - 1 : bits + 1);
-    return __longlong_as_double((long long)nx);
+    const long long bits = __double_as_longlong(x);
+    const long long step = (bits >> 63) | 1LL;
+    long long r = bits - step;
+    r = (x == 0.0) ? (long long)0x8000000000000001ULL : r;
+    r = (x != x || bits == (long long)0xfff0000000000000ULL) ? bits : r;
+    return __longlong_as_double(r);
 }
 __device__ inline double fmin_ref(double a, double b) { return a < b ? a : b; }  // f64.rs:68-74
 __device__ inline double fmax_ref(double a, double b) { return a > b ? a : b; }  // f64.rs:77-83
@@ -79,20 +83,36 @@ struct EIv {
     __device__ static bool is_nan(V x) { return x.lo != x.lo || x.hi != x.hi; }
     __device__ static bool eq(V a, V b) { return a.lo == b.lo && a.hi == b.hi; }
     __device__ static V neg(V a) { return Iv{-a.hi, -a.lo}; }                     // :117-124
+    // add / mul are written as "compute the general result, then select" (no control flow): the hot
+    // convolution loops run them once per MAC and divergent early returns cost more than the selects.
     __device__ static V add(V a, V b) {                                           // :126-139
-        if (is_zero(a)) return b;
-        if (is_zero(b)) return a;
-        return widen(a.lo + b.lo, a.hi + b.hi);
+        V g = widen(a.lo + b.lo, a.hi + b.hi);
+        const bool za = is_zero(a), zb = is_zero(b);
+        g.lo = zb ? a.lo : g.lo;
+        g.hi = zb ? a.hi : g.hi;
+        g.lo = za ? b.lo : g.lo;
+        g.hi = za ? b.hi : g.hi;
+        return g;
     }
     __device__ static V sub(V a, V b) { return add(a, neg(b)); }                  // :148-155
     __device__ static V mul(V a, V b) {                                           // :164-190
-        if ((is_zero(a) && is_finite(b)) || (is_finite(a) && is_zero(b))) return zero();
-        if (is_one(a)) return b;
-        if (is_one(b)) return a;
-        if (is_one(neg(a))) return neg(b);
-        if (is_one(neg(b))) return neg(a);
-        double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
-        return widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
+        const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
+        V g = widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
+        // the reference's short-circuits, lowest priority first so that the first match of its if-chain wins
+        const bool b_m1 = b.lo == -1.0 && b.hi == -1.0, a_m1 = a.lo == -1.0 && a.hi == -1.0;
+        const bool b_1 = is_one(b), a_1 = is_one(a);
+        const bool z = (is_zero(a) && is_finite(b)) || (is_finite(a) && is_zero(b));
+        g.lo = b_m1 ? -a.hi : g.lo;
+        g.hi = b_m1 ? -a.lo : g.hi;
+        g.lo = a_m1 ? -b.hi : g.lo;
+        g.hi = a_m1 ? -b.lo : g.hi;
+        g.lo = b_1 ? a.lo : g.lo;
+        g.hi = b_1 ? a.hi : g.hi;
+        g.lo = a_1 ? b.lo : g.lo;
+        g.hi = a_1 ? b.hi : g.hi;
+        g.lo = z ? 0.0 : g.lo;
+        g.hi = z ? 0.0 : g.hi;
+        return g;
     }
     __device__ static V div(V a, V b) {                                           // :199-234
         if (is_nan(a) || is_nan(b)) {

@@ -180,16 +180,6 @@ void K<E>::addsub_padded(hipStream_t st, const DView& out, const DView& a, const
 // tiny scalar kernels
 // ------------------------------------------------------------------------------------------
 template <class E>
-__global__ void k_first_elem(double* p, size_t plane, int op, const double* s, size_t s_plane) {
-    typename E::V x = E::ld(p, plane, 0), y = E::ld(s, s_plane, 0);
-    E::st(p, plane, 0, op == FIRST_ADD ? E::add(x, y) : E::sub(x, y));
-}
-template <class E>
-void K<E>::first_elem(hipStream_t st, double* p, size_t plane, int op, const double* s, size_t s_plane) {
-    hipLaunchKernelGGL(k_first_elem<E>, dim3(1), dim3(1), 0, st, p, plane, op, s, s_plane);
-}
-
-template <class E>
 __global__ void __launch_bounds__(256) k_copy_first(const double* __restrict__ src, size_t sp, double* __restrict__ dst,
                                                     size_t dp, size_t n, int op, const double* s, size_t s_plane,
                                                     Scalar2 sv) {
@@ -281,27 +271,6 @@ void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsig
     for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
     if (total == 0) return;
     hipLaunchKernelGGL(k_linear_scan<E>, dim3(grid_for(total)), dim3(256), 0, st, t, axes_mask, state, out, total);
-}
-
-template <class E>
-__global__ void k_linear_finish(DView t, const unsigned* mask, double* out) {
-    unsigned m = *mask;
-    out[0] = (double)m;
-    out[1] = out[2] = out[3] = out[4] = 0.0;
-    if (!m) return;
-    int ax = __ffs((int)m) - 1;
-    size_t stride = 1;
-    for (int i = t.sh.nd - 1; i > ax; --i) stride *= t.sh.d[i];
-    out[1] = t.p[0];
-    out[3] = t.p[stride];
-    if (E::W == 2) {
-        out[2] = t.p[t.plane];
-        out[4] = t.p[t.plane + stride];
-    }
-}
-template <class E>
-void K<E>::linear_finish(hipStream_t st, const DView& t, const unsigned* mask, double* out) {
-    hipLaunchKernelGGL(k_linear_finish<E>, dim3(1), dim3(1), 0, st, t, mask, out);
 }
 
 template <class E>
@@ -548,46 +517,6 @@ template <class E>
 void K<E>::factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                         double* tab, size_t tab_plane) {
     hipLaunchKernelGGL(k_factor_table<E>, dim3(1), dim3(64), 0, st, op, n, len, m, m_plane, tab, tab_plane);
-}
-
-// ------------------------------------------------------------------------------------------
-// extract_linear predicate (mt:275-294) for all axes at once
-// ------------------------------------------------------------------------------------------
-template <class E>
-__global__ void __launch_bounds__(256) k_linear_mask(DView t, unsigned* mask, size_t total) {
-    unsigned local = 0xffffffffu;
-    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
-         lin += (size_t)gridDim.x * blockDim.x) {
-        if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
-        // a non-zero entry at multi-index I is compatible with "linear in axis a" iff I == 0 or I == e_a
-        size_t r = lin;
-        int nonzero_axes = 0, which = -1;
-        bool unit = true;
-#pragma unroll 1
-        for (int ax = t.sh.nd - 1; ax >= 0; --ax) {
-            unsigned d = t.sh.d[ax];
-            unsigned k = (unsigned)(r % d);
-            r /= d;
-            if (k != 0) {
-                nonzero_axes++;
-                which = ax;
-                if (k != 1) unit = false;
-            }
-        }
-        if (nonzero_axes == 0) continue;
-        if (nonzero_axes == 1 && unit) local &= (1u << which);
-        else local = 0;
-    }
-    // wave-level AND, then one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local != 0xffffffffu) atomicAnd(mask, local);
-}
-template <class E>
-void K<E>::linear_mask(hipStream_t st, const DView& t, unsigned* mask) {
-    size_t total = 1;
-    for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
-    if (total == 0) return;
-    hipLaunchKernelGGL(k_linear_mask<E>, dim3(grid_for(total)), dim3(256), 0, st, t, mask, total);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -81,20 +81,18 @@ struct K {
                        const GatherArgs& a);
     // out[k] = ((0 + a[k]?) +/- b[k]?) with a, b leading blocks of out's shape  (mt:873-880, 927-934)
     static void addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract);
-    // p[0] = p[0] (+|-) s
-    static void first_elem(hipStream_t st, double* p, size_t plane, int op, const double* s, size_t s_plane);
     // dst = copy of src (n contiguous elements) with element 0 replaced by src[0] (+|-) s; FIRST_SUB_NEG_ALL:
     // dst[0] = -(src[0] - s), dst[i>0] = -src[i]  (mt:862-868, 919-925 in one launch)
     static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,
                            int op, const double* s, size_t s_plane, Scalar2 s_value);  // s == nullptr: use s_value
     // p[0] = v0, p[1] = v1 (if n == 2): constants and `var` constructors without a host->device copy
     static void set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1);
-    // after linear_mask: out[0] = mask (as a double), out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the
-    // first axis v whose bit is set (zeros if none) — one 40-byte read-back instead of up to five
-    static void linear_finish(hipStream_t st, const DView& t, const unsigned* mask, double* out);
-    // extract_linear in ONE launch: linear_mask + linear_finish fused with the "last block finishes" pattern.
-    // `state` = {mask word (must be 0xffffffff on entry), arrival counter (0 on entry)}; both are restored by
-    // the last block, so back-to-back calls on one stream need no memset.  out[0..4] as linear_finish.
+    // extract_linear (mt:275-294) for all axes in ONE launch.  Bit a of the mask survives iff the tensor is
+    // "linear in axis a" (every non-zero entry sits at index 0 or at e_a); blocks AND their verdicts into
+    // state[0] and the last block to arrive (ticket in state[1]) writes out[0] = mask (as a double),
+    // out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the first surviving axis v — one 40-byte read-back.
+    // `state` must be {0xffffffff, 0} on entry; the last block restores it, so back-to-back calls on one
+    // stream need no memset.
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
@@ -119,8 +117,6 @@ struct K {
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);
-    // bit a of *mask stays set iff the tensor is "linear in axis a" (mt:275-294); *mask pre-set by the host
-    static void linear_mask(hipStream_t st, const DView& t, unsigned* mask);
     // out[o, i] = sum_k in[o, k, i] (sequential ascending k; unrolled8 = ndarray's 8-way fold for the lane)
     static void sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
                          unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode);
@@ -139,6 +135,13 @@ enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
 // split-J partial tiles (may be null to query the needed size via *ws_needed).
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
                     size_t ws_bytes, size_t* ws_needed);
+
+// LDS-staged reference-order convolution (gft_conv_staged.hip): bit-identical to K<E>::conv_naive, operands
+// staged through LDS once per workgroup step.  Returns false (nothing launched) if the shape does not suit
+// it; `force` ignores the "worth it" thresholds.
+template <class E>
+bool conv_staged(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z,
+                 size_t z_plane, const ConvArgs& a, bool force);
 
 // Launches a scan that ORs 1 into *d_flag if any of the n doubles is inf/NaN.
 bool any_nonfinite_f64(hipStream_t st, const double* a, size_t n, unsigned* d_flag);

@@ -54,7 +54,9 @@ void gft_pool_stats(size_t out[3]);
 int gft_event_record(int slot);
 float gft_event_elapsed_ms(int slot_a, int slot_b);
 /* Which convolution kernel `mul` may use: 0 = auto, 1 = force the simple one-thread-per-output
- * kernel, 2 = force the LDS-tiled kernel (errors if the shape is unsupported).  Test/bench knob. */
+ * kernel, 2 = force the LDS-tiled FMA kernel (errors if the shape is unsupported), 3 = force the
+ * LDS-staged reference-order kernel wherever its shape limits allow.  Modes 1 and 3 are bit-identical
+ * to each other and to the CPU algorithm.  Test/bench knob. */
 int gft_set_conv_mode(int mode);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);

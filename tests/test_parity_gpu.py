@@ -261,6 +261,70 @@ def _conv_raw_gpu(mode, x, y, zs, slab=None, accumulate=False, z0=None):
         L.gft_set_conv_mode(0)
 
 
+STAGED_SHAPES = [
+    ((17,), (9,), (20,)),                                  # rank 1: rows only, axis 0 is the staged axis
+    ((300,), (300,), (300,)),                              # more than one chunk per row
+    ((9, 8), (6, 8), (12, 9)),                             # rank 2: plane staging, axis 0 staged
+    ((120, 130), (90, 130), (150, 130)),                   # rank 2, plane too large for 4 WGs/CU => rows
+    ((9, 8, 7), (6, 8, 5), (12, 9, 10)),
+    ((20, 17, 29), (13, 22, 30), (30, 30, 40)),            # y rows shorter than the output row (pitch != syb)
+    ((3, 70, 70), (3, 70, 70), (3, 70, 70)),               # 76 KB of planes => rows
+    ((5, 6, 3, 4), (4, 3, 3, 2), (6, 6, 4, 4)),
+    ((3, 2, 4, 3, 5, 4), (2, 3, 2, 4, 3, 5), (4, 4, 5, 5, 6, 6)),   # rank 6: odometer over four outer axes
+    ((1, 5, 1, 6), (3, 1, 4, 6), (3, 5, 4, 6)),            # unit axes (collapsed by the host)
+]
+
+
+@pytest.mark.parametrize("xs,ys,zs", STAGED_SHAPES)
+def test_conv_staged_bit_identical_to_reference_order_kernel(xs, ys, zs, oracle_lib):
+    """LDS-staged kernel (conv mode 3) == one-thread-per-output kernel (mode 1) == oracle, bit for bit:
+    same per-output operation order, only the data movement differs.  Also slab ranges + accumulation."""
+    import ctypes as C
+
+    x, y = rand(xs, 31, -1, 1), rand(ys, 32, -1, 1)
+    want = _conv_raw_gpu(1, x, y, zs)
+    got = _conv_raw_gpu(3, x, y, zs)
+    assert np.array_equal(got, want)
+    sz = lambda s: (C.c_size_t * len(s))(*s)
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_raw.restype = C.c_int
+    oracle_lib.orc_mul_raw.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t]
+    ref = np.zeros(zs)
+    oracle_lib.orc_mul_raw(x.ctypes.data_as(C.c_void_p), sz(xs), y.ctypes.data_as(C.c_void_p), sz(ys),
+                           ref.ctypes.data_as(C.c_void_p), sz(zs), len(zs))
+    assert np.array_equal(got, ref)
+    lo, hi = zs[0] // 3, max(zs[0] // 3 + 1, (2 * zs[0]) // 3)
+    z0 = rand(zs, 33)
+    a = _conv_raw_gpu(1, x, y, zs, slab=(lo, hi), accumulate=True, z0=z0)
+    b = _conv_raw_gpu(3, x, y, zs, slab=(lo, hi), accumulate=True, z0=z0)
+    assert np.array_equal(a, b)
+    assert np.array_equal(b[:lo], z0[:lo]) and np.array_equal(b[hi:], z0[hi:])
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_recurrences_same_bits_in_both_reference_order_kernels(mode, OTP, GTP, OTPI, GTPI):
+    """div / exp / log / pow / subst_var drive the convolution kernels in slab mode (j0 bounds, exclusive and
+    descending j0): forced one-thread-per-output (1) and forced LDS-staged (3) both reproduce the oracle."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    L.gft_set_conv_mode(mode)
+    try:
+        for shape in [(40,), (12, 70), (9, 8, 7), (4, 5, 3, 6)]:
+            deg = list(shape)
+            x, y = rand(shape, 41, 0.5, 1.5), rand(shape, 42, 0.5, 1.5)
+            for O, G, mk in ((OTP, GTP, lambda a: a), (OTPI, GTPI, lambda a: np.stack([a, a + 1e-6]))):
+                ox, gx, oy, gy = O.new(mk(x), deg), G.new(mk(x), deg), O.new(mk(y), deg), G.new(mk(y), deg)
+                check(ox * oy, gx * gy)
+                check(ox / oy, gx / gy)
+                check(ox.pow(3), gx.pow(3))
+                check(ox.subst_var(len(shape) - 1, oy), gx.subst_var(len(shape) - 1, gy))
+                check(oy.exp(), gy.exp(), exact=False, scale=np.abs(np.asarray(oy.exp().array())).max())
+                check(oy.log(), gy.log(), exact=False, scale=1.0)
+    finally:
+        L.gft_set_conv_mode(0)
+
+
 TILED_SHAPES = [
     ((32, 32, 32), (32, 32, 32), (32, 32, 32)),
     ((20, 17, 29), (13, 22, 30), (30, 30, 40)),       # ragged, compact operands, inner not a multiple of 8
