@@ -56,6 +56,8 @@ struct Runtime {
     double* h_pinned = nullptr;  // pinned staging for small D2H reads
     hipEvent_t events[16] = {};
     int conv_mode = 0;
+    double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
+    unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
     size_t conv_ws_bytes = 0;
@@ -591,22 +593,12 @@ struct Ops {
         bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
         if (want_tiled) {
             size_t need = 0;
-            bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, a, nullptr, 0, &need);
+            bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, a, nullptr, 0, &need, nullptr, 0);
             if (ok && R.conv_mode == 0) {
-                // auto: only worth it when the product is large (the naive kernel is exact-order)
+                // auto: below this the bit-exact reference-order kernels are as fast (fixed costs dominate)
                 double macs = 1.0;
                 for (int i = 0; i < a.nd; ++i) macs *= 0.5 * (double)a.zs[i] * (double)std::min(a.xs[i], a.ys[i]);
-                if (macs < 5.0e7) ok = false;
-            }
-            if (ok) {
-                // zero padding times inf/NaN would create NaNs the reference does not produce: such
-                // operands take the reference-order kernel
-                unsigned bad = 0;
-                HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 2), 0, 1, R.stream));
-                any_nonfinite_f64(R.stream, x.p, x.numel(), R.d_flag + 2);
-                any_nonfinite_f64(R.stream, y.p, y.numel(), R.d_flag + 2);
-                read_back(&bad, R.d_flag + 2, sizeof(unsigned));
-                if (bad) ok = false;
+                if (macs < R.tiled_min_macs) ok = false;
             }
             if (ok) {
                 if (need > R.conv_ws_bytes) {
@@ -615,8 +607,20 @@ struct Ops {
                     HIP_OK(hipMalloc(&R.conv_ws, need));
                     R.conv_ws_bytes = need;
                 }
-                if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need))
+                // Zero padding times inf/NaN would create NaNs the reference does not produce.  The verdict stays
+                // on the device: the packing/scan kernels stamp R.d_flag[2] with this product's epoch if an
+                // operand is not finite; the tiled kernels then leave z alone and the guarded reference-order
+                // launch below computes it (and is a no-op otherwise).  No host round trip.
+                if (++R.nf_epoch == 0) {
+                    HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 2), 0, 1, R.stream));
+                    R.nf_epoch = 1;
+                }
+                if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need, R.d_flag + 2, R.nf_epoch))
                     throw Error("tiled convolution launch failed");
+                a.guard = R.d_flag + 2;
+                a.guard_epoch = R.nf_epoch;
+                if (!conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, false))
+                    K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
                 return;
             }
             if (R.conv_mode == 2) throw Error("conv_mode=2 (tiled) requested but the shape is not supported by the tiled kernel");
@@ -1170,6 +1174,10 @@ int gft_init(int device) {
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
         R.device = device;
+        if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
+            double v = atof(tm);
+            if (v >= 0) R.tiled_min_macs = v;
+        }
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;

@@ -47,6 +47,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
               double* __restrict__ z, size_t zp, ConvArgs a, StagedArgs g) {
     typedef typename E::V V;
     extern __shared__ double smem[];
+    if (a.guard && *a.guard != a.guard_epoch) return;
     double* xl = smem;                         // [W][xcap]
     double* yl = smem + (size_t)E::W * g.xcap;  // [W][ycap]
     const unsigned CH = blockDim.x, tid = threadIdx.x;

@@ -30,6 +30,7 @@
 // gft_kernels.hip is the bit-exact path).  Operands must be finite (zero padding times inf would
 // create NaNs the reference does not produce); the caller checks and falls back otherwise.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -70,6 +71,8 @@ struct TiledArgs {
     const unsigned* wg_begin;        // segments of workgroup w: [wg_begin[w], wg_begin[w+1])
     const RedTile* red;
     const unsigned* red_slots;
+    const unsigned* guard;           // non-finite verdict word: main/reduce kernels do nothing if *guard == guard_epoch
+    unsigned guard_epoch;
 };
 
 // x rows are read through the constant address space: the address is wave-uniform and x is never
@@ -257,6 +260,8 @@ k_conv_tiled(TiledArgs A) {
     constexpr bool FAST = (VAR & 1) != 0;
     constexpr bool NO_WINDOW = (VAR & 64) != 0;
     extern __shared__ double lds[];
+    // an operand holds inf/NaN: the reference-order kernel (launched next, guarded the other way) owns z
+    if (A.guard && *A.guard == A.guard_epoch) return;
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,6 +431,7 @@ k_conv_tiled(TiledArgs A) {
 __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red) {
     const unsigned ti = blockIdx.x;
     if (ti >= n_red) return;
+    if (A.guard && *A.guard == A.guard_epoch) return;
     const RedTile rt = A.red[ti];
     for (unsigned idx = threadIdx.x; idx < A.nb * 64; idx += blockDim.x) {
         const unsigned c = idx >> 6, lane = idx & 63u;
@@ -454,24 +460,33 @@ __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red
 }
 
 // out[row][i] = i < len ? in[row][i] : 0, rows x n8
-__global__ void __launch_bounds__(256) k_pack_rows(const double* __restrict__ in, double* __restrict__ out,
-                                                   size_t rows, unsigned len, unsigned n8) {
-    size_t total = rows * n8;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t row = i / n8;
-        unsigned col = (unsigned)(i - row * n8);
-        out[i] = col < len ? in[row * len + col] : 0.0;
-    }
-}
-
-// *flag = 1 if any element is not finite
-__global__ void __launch_bounds__(256) k_any_nonfinite(const double* __restrict__ a, size_t n, unsigned* flag) {
+// Operand preparation: rows are copied into the zero-padded packed layout and, on the way, *flag is raised to
+// `epoch` if any element is inf/NaN (the verdict is an epoch stamp, so the word never needs resetting).
+// Both operands in one launch: x is always packed; y is packed if yp != nullptr, otherwise only scanned.
+__global__ void __launch_bounds__(256) k_prep_operands(const double* __restrict__ x, double* __restrict__ xp, size_t x_rows,
+                                                       unsigned xlen, unsigned nx8, const double* __restrict__ y,
+                                                       double* __restrict__ yp, size_t y_rows, unsigned ylen, unsigned ny8,
+                                                       unsigned* flag, unsigned epoch) {
+    const size_t tx = x_rows * nx8, ty = yp ? y_rows * ny8 : y_rows * ylen;
     bool bad = false;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double v = a[i];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tx + ty; i += (size_t)gridDim.x * blockDim.x) {
+        double v;
+        if (i < tx) {
+            size_t row = i / nx8;
+            unsigned col = (unsigned)(i - row * nx8);
+            v = col < xlen ? x[row * xlen + col] : 0.0;
+            xp[i] = v;
+        } else if (yp) {
+            size_t k = i - tx, row = k / ny8;
+            unsigned col = (unsigned)(k - row * ny8);
+            v = col < ylen ? y[row * ylen + col] : 0.0;
+            yp[k] = v;
+        } else {
+            v = y[i - tx];
+        }
         if (!((v - v) == 0.0)) bad = true;
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(flag, epoch);
 }
 
 // ---- host-side plan ------------------------------------------------------------------------------------
@@ -566,7 +581,19 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     unsigned wg_per_cu = std::min<unsigned>(16u / P.NW, (unsigned)(160 * 1024 / P.lds_bytes));
     if (wg_per_cu < 1) wg_per_cu = 1;
     unsigned long long n_wg = (unsigned long long)num_cus() * wg_per_cu;
-    if (n_wg > S) n_wg = S;
+    // Every range pays a window fill and, if it splits a tile, a 4 KB-per-block partial slab plus its share of the
+    // reduction, so small products must not be cut into confetti.  A step costs ~ (chunk pairs + 3) units
+    // (pairs = nb(nb+1)/2 8x8x8 chunk products per lane tile, 3 ~ barriers + refill) and the fixed part grows
+    // with the row length; ranges get >= ~(64 + 20 nb) units (sweep on MI355X: 24^3 171 -> 50 us,
+    // 30^3 91 -> 71 us, 10x10x100 154 -> 92 us per product).
+    static const unsigned long long MIN_UNITS = [] {
+        const char* e = getenv("GFT_TILED_MIN_UNITS");  // tuning knob (base of the model)
+        return (unsigned long long)(e ? std::max(1, atoi(e)) : 64);
+    }();
+    const unsigned long long step_units = (unsigned long long)T.nb * (T.nb + 1) / 2 + 3;
+    const unsigned long long min_steps =
+        std::max<unsigned long long>(1, (MIN_UNITS + 20ull * T.nb + step_units / 2) / step_units);
+    if (n_wg > S / min_steps) n_wg = std::max<unsigned long long>(1, S / min_steps);
     P.n_wg = (unsigned)n_wg;
 
     std::vector<TileSeg> segs;
@@ -658,7 +685,7 @@ hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
 }  // namespace
 
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a_in, void* ws,
-                    size_t ws_bytes, size_t* ws_needed) {
+                    size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch) {
     ConvArgs a = a_in;
     if (a.variant < 0) a.variant = GFT_TILED_DEFAULT_VARIANT;
     if (a.nd == 3 || a.nd == 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
@@ -712,22 +739,15 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     T.ws = (double*)wb;
     double* xp = (double*)(wb + al(b_slots));
     double* yp = (double*)(wb + al(b_slots) + al(b_xp));
-    if (pack_x) {
-        size_t tot = x_rows * B.nx8;
-        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, x, xp,
-                           x_rows, B.xI, B.nx8);
+    {
+        size_t tot = x_rows * B.nx8 + (pack_y ? y_rows * B.ny8 : y_rows * B.yI);
+        hipLaunchKernelGGL(k_prep_operands, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, x,
+                           xp, x_rows, B.xI, B.nx8, y, pack_y ? yp : nullptr, y_rows, B.yI, B.ny8, nf_flag, nf_epoch);
         T.xp = xp;
-    } else {
-        T.xp = x;
+        T.yp = pack_y ? yp : y;
     }
-    if (pack_y) {
-        size_t tot = y_rows * B.ny8;
-        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, y, yp,
-                           y_rows, B.yI, B.ny8);
-        T.yp = yp;
-    } else {
-        T.yp = y;
-    }
+    T.guard = nf_flag;
+    T.guard_epoch = nf_epoch;
     T.z = z;
     T.xcd_remap = ((a.variant & 4) && (P.n_wg % 8 == 0)) ? 1u : 0u;
     hipError_t e = hipSuccess;
@@ -770,12 +790,6 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
         if (hipGetLastError() != hipSuccess) return false;
     }
     return true;
-}
-
-bool any_nonfinite_f64(hipStream_t st, const double* a, size_t n, unsigned* d_flag) {
-    hipLaunchKernelGGL(k_any_nonfinite, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, a, n,
-                       d_flag);
-    return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace gft

@@ -693,6 +693,7 @@ __global__ void __launch_bounds__(256) k_conv_naive(const double* __restrict__ x
                                                     double* __restrict__ z, size_t zp, ConvArgs a, size_t total,
                                                     size_t slab_elems) {
     typedef typename E::V V;
+    if (a.guard && *a.guard != a.guard_epoch) return;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
          lin += (size_t)gridDim.x * blockDim.x) {
         size_t zlin = lin + (size_t)a.slab_lo * slab_elems;

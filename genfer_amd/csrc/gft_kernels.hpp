@@ -72,6 +72,8 @@ struct ConvArgs {
     int j0_desc;                // iterate j0 downwards (log's summation order)
     int inner_from_zero;        // last axis' partial sum is formed from zero, then added (mul_1d, mt:971-982)
     int variant;                // tiled-kernel variant (gft_set_conv_variant; -1 = library default)
+    const unsigned* guard;      // optional device word: the reference-order kernels run only if *guard == guard_epoch
+    unsigned guard_epoch;       // (fallback for non-finite operands of the tiled kernel, decided on the device)
 };
 
 template <class E>
@@ -133,8 +135,11 @@ enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
 // LDS-tiled f64 convolution (gft_conv_tiled.hip).  Returns false if the shape is not supported
 // by the tiled kernel (caller falls back to conv_naive).  `ws`/`ws_bytes`: workspace for
 // split-J partial tiles (may be null to query the needed size via *ws_needed).
+// `nf_flag`/`nf_epoch`: the packing/scan kernels raise *nf_flag to nf_epoch if an operand holds inf/NaN, in which
+// case the main and reduce kernels leave z untouched (zero padding times inf would create NaNs the reference
+// does not produce) and the caller's guarded reference-order launch computes z instead — no host round trip.
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
-                    size_t ws_bytes, size_t* ws_needed);
+                    size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch);
 
 // LDS-staged reference-order convolution (gft_conv_staged.hip): bit-identical to K<E>::conv_naive, operands
 // staged through LDS once per workgroup step.  Returns false (nothing launched) if the shape does not suit
@@ -142,8 +147,5 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 template <class E>
 bool conv_staged(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z,
                  size_t z_plane, const ConvArgs& a, bool force);
-
-// Launches a scan that ORs 1 into *d_flag if any of the n doubles is inf/NaN.
-bool any_nonfinite_f64(hipStream_t st, const double* a, size_t n, unsigned* d_flag);
 
 }  // namespace gft

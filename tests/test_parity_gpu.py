@@ -389,15 +389,25 @@ def test_conv_tiled_vs_oracle_and_pgf_like_dynamic_range(oracle_lib):
     assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want))
 
 
-def test_conv_tiled_nonfinite_operands_fall_back():
-    """inf/NaN operands must not be polluted by zero padding: auto mode routes them to the
-    reference-order kernel and the result equals it bit for bit."""
-    x, y = rand((16, 16, 20), 41), rand((16, 16, 20), 42)
-    x[3, 4, 5] = np.inf
-    y[1, 2, 3] = np.nan
-    want = _conv_raw_gpu(1, x, y, (16, 16, 20))
-    got = _conv_raw_gpu(0, x, y, (16, 16, 20))
-    assert np.array_equal(got, want, equal_nan=True)
+@pytest.mark.parametrize("shape", [(16, 16, 20), (40, 40, 40), (6, 20, 20, 24)])
+def test_conv_tiled_nonfinite_operands_fall_back(shape):
+    """inf/NaN operands must not be polluted by zero padding.  The verdict is taken on the device (epoch stamp
+    written by the packing/scan kernels): the tiled kernels leave z alone and the guarded reference-order launch
+    computes it, so auto mode AND forced-tiled mode equal the reference-order kernel bit for bit; a following
+    finite product on the same stream is unaffected (the stamp is per product)."""
+    x, y = rand(shape, 41), rand(shape, 42)
+    xf, yf = x.copy(), y.copy()
+    x[(3, 4, 5, 1)[: len(shape)]] = np.inf
+    y[(1, 2, 3, 0)[: len(shape)]] = np.nan
+    want = _conv_raw_gpu(1, x, y, shape)
+    for mode in (0, 2):
+        got = _conv_raw_gpu(mode, x, y, shape)
+        assert np.array_equal(got, want, equal_nan=True)
+        only_x = _conv_raw_gpu(mode, x, yf, shape)
+        assert np.array_equal(only_x, _conv_raw_gpu(1, x, yf, shape), equal_nan=True)
+        fin = _conv_raw_gpu(mode, xf, yf, shape)
+        ref = _conv_raw_gpu(1, xf, yf, shape)
+        assert np.all(np.isfinite(fin)) and np.all(np.abs(fin - ref) <= 1e-10 * np.abs(ref))
 
 
 def test_full_size_c2_properties():

@@ -13,7 +13,7 @@ for sh in [(8,8,8),(12,12,12),(16,16,16),(20,20,20),(24,24,24),(30,30,30),(40,40
     x, y = rng.random(sh), rng.random(sh)
     a, b = F.new(x, list(sh)), F.new(y, list(sh))
     out = {"shape": sh, "macs": genfer_amd.conv_macs(sh, sh, sh)}
-    for mode, name in ((1,"naive"),(3,"staged"),(2,"tiled")):
+    for mode, name in ((3,"staged"),(2,"tiled")):
         L.gft_set_conv_mode(mode)
         try:
             out[name] = round(timed(lambda: a*b)*1000, 1)
