@@ -151,6 +151,12 @@ struct gft_poly {
     // host cache of the value when numel == 1 (filled on construction from host scalars or lazily)
     mutable bool cached = false;
     mutable double cv[2] = {0, 0};
+    // lazy `x + m*eps_v` built from host scalars (numel == 2, buf == null until a kernel has to read it):
+    // element 0 = cv, element 1 = cv1, v = lazy_var.  Products with it take the mul_linear path from these
+    // host values, so most such tensors never reach the device.
+    bool lazy_lin = false;
+    double cv1[2] = {0, 0};
+    size_t lazy_var = 0;
 };
 
 namespace {
@@ -163,7 +169,16 @@ static double* dp(const gft_poly& p) {
     if (!p.buf) {
         p.buf = alloc_doubles(p.numel * E::W);
         Scalar2 v{p.cv[0], p.cv[1]};
-        K<E>::set_small(R.stream, p.buf.get()->p, p.numel, 1, v, v);
+        if (p.lazy_lin) {
+            K<E>::set_small(R.stream, p.buf.get()->p, p.numel, 2, v, Scalar2{p.cv1[0], p.cv1[1]});
+            Buf* b = p.buf.get();
+            b->lin_state = 2;
+            b->lin_c[0] = p.cv[0]; b->lin_c[1] = p.cv[1];
+            b->lin_m[0] = p.cv1[0]; b->lin_m[1] = p.cv1[1];
+            b->lin_var = p.lazy_var;
+        } else {
+            K<E>::set_small(R.stream, p.buf.get()->p, p.numel, 1, v, v);
+        }
     }
     return p.buf.get()->p;
 }
@@ -455,22 +470,24 @@ struct Ops {
     static P var_like(size_t v, const double* x, bool have_x, size_t len_v_shape, bool second_is_one, const Dims& deg) {
         Dims shape(deg.size(), 1);
         shape[v] = len_v_shape;
-        P r = make(shape, deg);
-        size_t n = r.numel;  // 1 or 2
+        check_invariants(shape, deg);
+        P r;  // lazy (see gft_poly / dp()): nothing is launched here
+        r.width = W;
+        r.shape = shape;
+        r.deg = deg;
+        r.numel = prod(shape);  // 1 or 2
         Scalar2 v0{0.0, 0.0}, v1{0.0, 0.0};
         if (have_x) v0 = Scalar2{x[0], W == 2 ? x[1] : 0.0};
-        if (n == 2 && second_is_one) v1 = Scalar2{1.0, 1.0};
-        K<E>::set_small(R.stream, dp<E>(r), r.numel, (unsigned)n, v0, v1);
-        if (n == 2) {  // x + 1*eps_v (or 0*eps_v): its extract_linear verdict is known from the host-provided values
-            r.buf->lin_state = 2;
-            r.buf->lin_c[0] = v0.a; r.buf->lin_c[1] = W == 2 ? v0.b : 0.0;
-            r.buf->lin_m[0] = v1.a; r.buf->lin_m[1] = W == 2 ? v1.b : 0.0;
-            r.buf->lin_var = v;
-        }
-        if (n == 1) {
+        if (r.numel == 2 && second_is_one) v1 = Scalar2{1.0, 1.0};
+        r.cv[0] = v0.a;
+        r.cv[1] = W == 2 ? v0.b : 0.0;
+        if (r.numel == 2) {  // x + 1*eps_v (or 0*eps_v): its extract_linear verdict is known from the host values
+            r.lazy_lin = true;
+            r.cv1[0] = v1.a;
+            r.cv1[1] = W == 2 ? v1.b : 0.0;
+            r.lazy_var = v;
+        } else {
             r.cached = true;
-            r.cv[0] = v0.a;
-            r.cv[1] = W == 2 ? v0.b : 0.0;
         }
         return r;
     }
@@ -510,6 +527,12 @@ struct Ops {
         for (size_t v = 0; v < p.shape.size(); ++v)
             if (p.shape[v] >= 2) mask |= 1u << v;
         if (!mask) return false;
+        if (!p.buf && p.lazy_lin) {
+            c[0] = p.cv[0]; c[1] = p.cv[1];
+            m[0] = p.cv1[0]; m[1] = p.cv1[1];
+            *var = p.lazy_var;
+            return true;
+        }
         if (p.buf && p.buf->lin_state) {
             if (p.buf->lin_state == 1) return false;
             c[0] = p.buf->lin_c[0]; c[1] = p.buf->lin_c[1];
