@@ -59,6 +59,7 @@ def _declare_runtime(L):
     L.gft_synchronize.restype, L.gft_synchronize.argtypes = c.c_int, []
     L.gft_last_error.restype, L.gft_last_error.argtypes = c.c_char_p, []
     L.gft_pool_stats.restype, L.gft_pool_stats.argtypes = None, [sz]
+    L.gft_op_stats.restype, L.gft_op_stats.argtypes = None, [sz]
     L.gft_event_record.restype, L.gft_event_record.argtypes = c.c_int, [c.c_int]
     L.gft_event_elapsed_ms.restype, L.gft_event_elapsed_ms.argtypes = c.c_float, [c.c_int, c.c_int]
     L.gft_set_conv_mode.restype, L.gft_set_conv_mode.argtypes = c.c_int, [c.c_int]

@@ -57,6 +57,7 @@ struct Runtime {
     hipEvent_t events[16] = {};
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
+    size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
@@ -304,6 +305,7 @@ struct Ops {
             return;
         }
         double tmp[2] = {0, 0};
+        R.stats[1]++;
         HIP_OK(hipMemcpyAsync(R.h_pinned, dp<E>(p), sizeof(double), hipMemcpyDeviceToHost, R.stream));
         if (W == 2) HIP_OK(hipMemcpyAsync(R.h_pinned + 1, dp<E>(p) + p.numel, sizeof(double), hipMemcpyDeviceToHost, R.stream));
         HIP_OK(hipStreamSynchronize(R.stream));
@@ -548,6 +550,7 @@ struct Ops {
         HV v = view(p);
         DView dv = dview(v, &keep);
         K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, R.d_scratch);  // one launch (state words 8, 9)
+        R.stats[0]++;
         double res[5];
         read_back(res, R.d_scratch, sizeof(res));
         unsigned got = (unsigned)res[0];
@@ -640,6 +643,7 @@ struct Ops {
                 }
                 if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need, R.d_flag + 2, R.nf_epoch))
                     throw Error("tiled convolution launch failed");
+                R.stats[3]++;
                 a.guard = R.d_flag + 2;
                 a.guard_epoch = R.nf_epoch;
                 if (!conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, false))
@@ -649,8 +653,12 @@ struct Ops {
             if (R.conv_mode == 2) throw Error("conv_mode=2 (tiled) requested but the shape is not supported by the tiled kernel");
         }
         if (R.conv_mode == 0 || R.conv_mode == 3) {
-            if (conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, R.conv_mode == 3)) return;
+            if (conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, R.conv_mode == 3)) {
+                R.stats[4]++;
+                return;
+            }
         }
+        R.stats[5]++;
         K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
     }
 
@@ -1125,6 +1133,7 @@ struct Ops {
         }
         if (consumed != a.shape.size()) throw Error("index is too short");
         out[1] = 0.0;
+        R.stats[2]++;
         read_back(&out[0], dp<E>(a) + off, sizeof(double));
         if (W == 2) read_back(&out[1], dp<E>(a) + a.numel + off, sizeof(double));
     }
@@ -1246,6 +1255,9 @@ int gft_synchronize(void) {
 }
 const char* gft_last_error(void) { return g_err.c_str(); }
 const char* gfti_last_error(void) { return g_err.c_str(); }
+void gft_op_stats(size_t out[8]) {
+    for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
+}
 void gft_pool_stats(size_t out[3]) {
     out[0] = R.in_use;
     out[1] = R.cached;

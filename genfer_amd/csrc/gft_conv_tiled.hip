@@ -73,6 +73,7 @@ struct TiledArgs {
     const unsigned* red_slots;
     const unsigned* guard;           // non-finite verdict word: main/reduce kernels do nothing if *guard == guard_epoch
     unsigned guard_epoch;
+    unsigned char blk1[8], blk2[8];  // output blocks (8 consecutive k2) owned by wave w; 0xff = none
 };
 
 // x rows are read through the constant address space: the address is wave-uniform and x is never
@@ -268,10 +269,10 @@ k_conv_tiled(TiledArgs A) {
     const unsigned l0 = lane >> 3, l1 = lane & 7u;
     constexpr unsigned NT = NW * 64;
 
-    const unsigned c1 = wave;
-    const unsigned c2 = A.nb - 1 - wave;
-    const bool has1 = c1 < A.nb && c1 <= c2;
-    const bool has2 = c2 < A.nb && c2 > c1;
+    const unsigned c1 = A.blk1[wave];
+    const unsigned c2 = A.blk2[wave];
+    const bool has1 = c1 != 0xffu;
+    const bool has2 = c2 != 0xffu;
 
     const unsigned half_row = A.ny8 >> 1;            // 16-byte pieces per row
     const unsigned pf_pieces = 8 * half_row;         // one ring slot refill = 8 rows
@@ -520,6 +521,8 @@ int num_cus() {
     return n;
 }
 
+static void assign_blocks(TiledArgs& T, unsigned NW);
+
 bool build_plan(const ConvArgs& a, Plan& P) {
     TiledArgs& T = P.base;
     std::memset(&T, 0, sizeof(T));
@@ -554,6 +557,7 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     unsigned npairs = (T.nb + 1) / 2;
     P.NW = npairs <= 1 ? 1 : (npairs <= 2 ? 2 : (npairs <= 4 ? 4 : 8));
     P.lds_bytes = (size_t)8 * T.P0 * sizeof(double);
+    assign_blocks(T, P.NW);
 
     // tiles in (u, a, b) order
     struct TileInfo { unsigned u, a, b; unsigned long long steps; };
@@ -668,6 +672,51 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     T.red = (const RedTile*)put(red.data(), b_red);
     T.red_slots = (const unsigned*)put(red_slots.data(), b_rs);
     return true;
+}
+
+// Which output blocks each wave of a workgroup accumulates (at most two: 16 accumulator VGPR pairs each).
+// Block c costs one 8x8x8 chunk product per (x chunk, y chunk) pair that lands in it, i.e. c + 1 for full
+// operands.  The classic pairing (c, nb-1-c) gives every ACTIVE wave the same load, but when nb < 2*NW the
+// active waves sit unevenly on the CU's four SIMDs (wave w runs on SIMD w % 4): nb = 10 keeps two busy waves on
+// SIMD 0 and one on the others, and the whole CU waits for SIMD 0 — measured 62% of the nb = 16 rate.
+// Longest-processing-time assignment over SIMDs instead, then over the waves of the SIMD.
+static void assign_blocks(TiledArgs& T, unsigned NW) {
+    static const int mode = [] {
+        const char* e = getenv("GFT_TILED_BLOCK_MAP");  // 0 = classic pairs, 1 = LPT with SIMD = w % 4, 2 = SIMD = w / 2
+        return e ? atoi(e) : 1;
+    }();
+    for (int w = 0; w < 8; ++w) T.blk1[w] = T.blk2[w] = 0xff;
+    if (mode == 0 || 2 * NW == T.nb || NW < 4) {
+        for (unsigned w = 0; w < NW; ++w) {
+            unsigned c1 = w, c2 = T.nb - 1 - w;
+            if (c1 < T.nb && c1 <= c2) T.blk1[w] = (unsigned char)c1;
+            if (c2 < T.nb && c2 > c1) T.blk2[w] = (unsigned char)c2;
+        }
+        return;
+    }
+    auto cost = [&](unsigned c) {
+        unsigned n = 0;
+        for (unsigned xc = 0; xc <= c && xc < T.nxc; ++xc)
+            if (c - xc < T.nyc) n++;
+        return n;
+    };
+    unsigned simd_load[4] = {0, 0, 0, 0}, wave_load[8] = {0}, wave_cnt[8] = {0};
+    auto simd_of = [&](unsigned w) { return mode == 2 ? (w / 2) % 4 : w % 4; };
+    for (unsigned i = 0; i < T.nb; ++i) {
+        unsigned c = T.nb - 1 - i;  // heaviest first
+        int best = -1;
+        for (unsigned w = 0; w < NW; ++w) {
+            if (wave_cnt[w] >= 2) continue;
+            if (best < 0) { best = (int)w; continue; }
+            unsigned sb = simd_load[simd_of((unsigned)best)], sw = simd_load[simd_of(w)];
+            if (sw < sb || (sw == sb && wave_load[w] < wave_load[best])) best = (int)w;
+        }
+        if (wave_cnt[best] == 0) T.blk1[best] = (unsigned char)c;
+        else T.blk2[best] = (unsigned char)c;
+        wave_cnt[best]++;
+        wave_load[best] += cost(c);
+        simd_load[simd_of((unsigned)best)] += cost(c);
+    }
 }
 
 template <int NW, int VAR>

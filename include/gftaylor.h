@@ -50,6 +50,10 @@ int gft_synchronize(void);
 const char* gft_last_error(void);
 /* Device-memory pool statistics in bytes: {in_use, cached, peak_in_use}. */
 void gft_pool_stats(size_t out[3]);
+/* Cumulative operation counters since gft_init: {extract_linear device scans (each a host round trip),
+ * 1-element value read-backs, coefficient() read-backs, products on the tiled kernel, on the LDS-staged
+ * reference-order kernel, on the one-thread-per-output kernel, reserved, reserved}.  Diagnostics. */
+void gft_op_stats(size_t out[8]);
 /* hipEvent timing on the library's stream: record into slot 0..15, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
 float gft_event_elapsed_ms(int slot_a, int slot_b);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of tiled-kernel variants in ONE process on ONE device (the only valid
-way to rank builds: cdna_hip_programming.md §5.4 rule 24).  Usage: ab_conv.py v0 v1 ... [--rounds N]"""
+way to rank builds: cdna_hip_programming.md §5.4 rule 24).  Usage: ab_conv.py v0 v1 ... [--rounds=N] [--shape=AxBxC]"""
 import ctypes
 import sys
 
@@ -19,7 +19,10 @@ for a in sys.argv[1:]:
         rounds = int(a.split("=")[1])
 variants = [int(v) for v in args] or [0, 1]
 shape = [128, 128, 128]
-n = 128**3
+for a in sys.argv[1:]:
+    if a.startswith("--shape="):
+        shape = [int(t) for t in a.split("=")[1].split("x")]
+n = int(np.prod(shape))
 genfer_amd.init(0)
 L = genfer_amd.lib()
 L.gft_set_conv_variant.argtypes = [ctypes.c_int]

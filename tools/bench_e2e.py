@@ -3,6 +3,7 @@
 with the HIP backend (libgftaylor) vs the same interpreter over the CPU oracle, on this box, best of N
 ("Total inference time" protocol of the reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105).
 Usage: bench_e2e.py [--limit 100] [--runs 3] [--only substr] [--gpu-only]"""
+import ctypes
 import glob
 import json
 import os
@@ -50,6 +51,9 @@ for f in files:
                 break
             best = t["time_infer"] if best is None else min(best, t["time_infer"])
         row[name + "_s"] = best
+    st = (ctypes.c_size_t * 8)()
+    genfer_amd.lib().gft_op_stats(st)
+    row["gpu_op_stats_cumulative"] = dict(zip(("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output"), list(st)[:6]))
     rows.append(row)
     print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}", flush=True)
 print(json.dumps({"limit": limit, "runs": runs, "host_cores": os.cpu_count(), "rows": rows}))
