@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -54,6 +55,9 @@ struct Runtime {
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
     double* d_scratch = nullptr; // small device scratch for packed read-backs
     double* h_pinned = nullptr;  // pinned staging for small D2H reads
+    double* h_mail = nullptr;    // mailbox (mapped coherent pinned memory): 8 doubles payload + sequence word
+    double* d_mail = nullptr;    // the same slot as the device sees it
+    unsigned long long mail_seq = 0;
     hipEvent_t events[16] = {};
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
@@ -136,6 +140,40 @@ static void read_back(void* dst, const void* dev_src, size_t bytes) {
     HIP_OK(hipMemcpyAsync(R.h_pinned, dev_src, bytes, hipMemcpyDeviceToHost, R.stream));
     HIP_OK(hipStreamSynchronize(R.stream));
     std::memcpy(dst, R.h_pinned, bytes);
+}
+
+// Host round trips through the mailbox (gft_kernels.hpp): next_mail() hands the kernel its slot + sequence number,
+// wait_mail() polls the sequence word.  The poll is bounded: every ~20 us it asks the stream for errors, and a
+// stream that went idle without publishing is an error (a kernel died).
+static Mailbox next_mail() {
+    Mailbox mb;
+    mb.payload = R.d_mail;
+    mb.seq = (unsigned long long*)(R.d_mail + 8);
+    mb.value = ++R.mail_seq;
+    return mb;
+}
+static void wait_mail(const Mailbox& mb, double* out, unsigned n) {
+    volatile unsigned long long* seq = (volatile unsigned long long*)(R.h_mail + 8);
+    for (unsigned long long spins = 0;; ++spins) {
+        if (*seq == mb.value) break;
+        if ((spins & 0x3fff) == 0x3fff) {
+            hipError_t q = hipStreamQuery(R.stream);
+            if (q == hipSuccess) {
+                if (*seq == mb.value) break;
+                throw Error("device read-back kernel finished without publishing its result");
+            }
+            if (q != hipErrorNotReady) HIP_OK(q);
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (unsigned i = 0; i < n; ++i) out[i] = ((volatile double*)R.h_mail)[i];
+}
+// n <= 7 doubles at src[i * stride] -> host
+static void peek(double* out, const double* dev_src, size_t stride, unsigned n) {
+    Mailbox mb = next_mail();
+    peek_to_mailbox(R.stream, dev_src, stride, n, mb);
+    wait_mail(mb, out, n);
 }
 
 }  // namespace
@@ -306,11 +344,7 @@ struct Ops {
         }
         double tmp[2] = {0, 0};
         R.stats[1]++;
-        HIP_OK(hipMemcpyAsync(R.h_pinned, dp<E>(p), sizeof(double), hipMemcpyDeviceToHost, R.stream));
-        if (W == 2) HIP_OK(hipMemcpyAsync(R.h_pinned + 1, dp<E>(p) + p.numel, sizeof(double), hipMemcpyDeviceToHost, R.stream));
-        HIP_OK(hipStreamSynchronize(R.stream));
-        tmp[0] = R.h_pinned[0];
-        tmp[1] = W == 2 ? R.h_pinned[1] : 0.0;
+        peek(tmp, dp<E>(p), p.numel, W);
         out[0] = tmp[0];
         out[1] = tmp[1];
         if (p.numel == 1) {
@@ -549,10 +583,11 @@ struct Ops {
             if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
         HV v = view(p);
         DView dv = dview(v, &keep);
-        K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, R.d_scratch);  // one launch (state words 8, 9)
+        Mailbox mb = next_mail();
+        K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, mb);  // one launch (state words 8, 9), result by mailbox
         R.stats[0]++;
         double res[5];
-        read_back(res, R.d_scratch, sizeof(res));
+        wait_mail(mb, res, 5);
         unsigned got = (unsigned)res[0];
         if (!got) {
             p.buf->lin_state = 1;
@@ -569,6 +604,46 @@ struct Ops {
         p.buf->lin_c[0] = c[0]; p.buf->lin_c[1] = c[1];
         p.buf->lin_m[0] = m[0]; p.buf->lin_m[1] = m[1];
         p.buf->lin_var = *var;
+        return true;
+    }
+
+    // Inner-axis split for the tiled kernel (gft_conv_tiled.hip, k_pad_rows / k_fold_rows): rank 2 with a long last
+    // axis, or rank 2/3 whose last axis exceeds 128.  Fills the rank-(d+1) problem into `t` and the piece length.
+    static bool plan_inner_split(const ConvArgs& a, ConvArgs& t, unsigned* B_out) {
+        const int nd = a.nd;
+        if (nd != 2 && nd != 3) return false;
+        if (a.j0_min || a.j0_excl || a.j0_desc) return false;
+        const unsigned zI = a.zs[nd - 1];
+        if (!(zI > 128 || (nd == 2 && zI >= 96))) return false;
+        // piece length: multiple of 8, <= 64 (2B - 1 <= 127); prefer full 8-lane groups along the piece axis and
+        // long pieces (the kernel's efficiency grows with the number of 8-wide output blocks)
+        unsigned best = 0;
+        double best_score = -1.0;
+        for (unsigned B = 64; B >= 32; B -= 8) {
+            unsigned P = (zI + B - 1) / B;
+            double util = (double)P / (8.0 * ((P + 7) / 8));
+            double score = util * (0.45 + 0.55 * B / 64.0) * ((double)zI / (P * B));
+            if (score > best_score) {
+                best_score = score;
+                best = B;
+            }
+        }
+        const unsigned B = best;
+        t = a;
+        t.nd = nd + 1;
+        for (int i = 0; i + 1 < nd; ++i) {
+            t.xs[i] = a.xs[i];
+            t.ys[i] = a.ys[i];
+            t.zs[i] = a.zs[i];
+        }
+        t.xs[nd - 1] = (a.xs[nd - 1] + B - 1) / B;
+        t.ys[nd - 1] = (a.ys[nd - 1] + B - 1) / B;
+        t.zs[nd - 1] = (zI + B - 1) / B;
+        t.xs[nd] = B;
+        t.ys[nd] = B;
+        t.zs[nd] = 2 * B - 1;
+        t.accumulate = 0;  // the fold applies it
+        *B_out = B;
         return true;
     }
 
@@ -618,20 +693,31 @@ struct Ops {
 
         bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
         if (want_tiled) {
+            // rank 2, or a last axis longer than the tiled kernel's 128: split the last axis into (P, B) pieces
+            ConvArgs at = a;
+            unsigned B = 0;
+            const bool split = plan_inner_split(a, at, &B);
             size_t need = 0;
-            bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, a, nullptr, 0, &need, nullptr, 0);
+            bool ok = conv_tiled_f64(R.stream, x.p, y.p, z.p, at, nullptr, 0, &need, nullptr, 0);
             if (ok && R.conv_mode == 0) {
                 // auto: below this the bit-exact reference-order kernels are as fast (fixed costs dominate)
                 double macs = 1.0;
                 for (int i = 0; i < a.nd; ++i) macs *= 0.5 * (double)a.zs[i] * (double)std::min(a.xs[i], a.ys[i]);
-                if (macs < R.tiled_min_macs) ok = false;
+                if (macs < R.tiled_min_macs * (split ? 10.0 : 1.0)) ok = false;
             }
             if (ok) {
-                if (need > R.conv_ws_bytes) {
+                if (need > R.conv_ws_bytes) {  // grow geometrically: supports (and workspaces) grow statement by statement
+                    size_t want = std::max(need, std::min<size_t>(2 * R.conv_ws_bytes, (size_t)1 << 32));
+                    want = std::max<size_t>(want, (size_t)8 << 20);
                     if (R.conv_ws) HIP_OK(hipFree(R.conv_ws));
                     R.conv_ws = nullptr;
-                    HIP_OK(hipMalloc(&R.conv_ws, need));
-                    R.conv_ws_bytes = need;
+                    R.conv_ws_bytes = 0;
+                    if (hipMalloc(&R.conv_ws, want) != hipSuccess) {
+                        (void)hipGetLastError();
+                        want = need;
+                        HIP_OK(hipMalloc(&R.conv_ws, want));
+                    }
+                    R.conv_ws_bytes = want;
                 }
                 // Zero padding times inf/NaN would create NaNs the reference does not produce.  The verdict stays
                 // on the device: the packing/scan kernels stamp R.d_flag[2] with this product's epoch if an
@@ -641,10 +727,33 @@ struct Ops {
                     HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 2), 0, 1, R.stream));
                     R.nf_epoch = 1;
                 }
-                if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need, R.d_flag + 2, R.nf_epoch))
-                    throw Error("tiled convolution launch failed");
+                unsigned* flag = R.d_flag + 2;
+                if (!split) {
+                    if (!conv_tiled_f64(R.stream, x.p, y.p, z.p, a, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch))
+                        throw Error("tiled convolution launch failed");
+                } else {
+                    const int nd = a.nd;
+                    size_t xrows = 1, yrows = 1, zrows = 1, zrows_per0 = 1;
+                    for (int i = 0; i + 1 < nd; ++i) {
+                        xrows *= a.xs[i];
+                        yrows *= a.ys[i];
+                        zrows *= a.zs[i];
+                        if (i > 0) zrows_per0 *= a.zs[i];
+                    }
+                    const unsigned Px = at.xs[nd - 1], Py = at.ys[nd - 1], Pz = at.zs[nd - 1], RI = 2 * B - 1;
+                    std::shared_ptr<Buf> xt = alloc_doubles(xrows * Px * B), yt = alloc_doubles(yrows * Py * B);
+                    std::shared_ptr<Buf> zt = alloc_doubles(zrows * Pz * RI);
+                    tiled_pad_rows_f64(R.stream, x.p, xt->p, xrows, a.xs[nd - 1], Px * B);
+                    tiled_pad_rows_f64(R.stream, y.p, yt->p, yrows, a.ys[nd - 1], Py * B);
+                    if (!conv_tiled_f64(R.stream, xt->p, yt->p, zt->p, at, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch))
+                        throw Error("tiled convolution launch failed");
+                    // rank 2: the slab range is a row range; rank 3: slabs of z.shape[1] rows
+                    size_t per0 = nd == 2 ? 1 : zrows_per0;
+                    tiled_fold_rows_f64(R.stream, zt->p, z.p, a.slab_lo * per0, a.slab_hi * per0, Pz, B, a.zs[nd - 1],
+                                        a.accumulate, flag, R.nf_epoch);
+                }
                 R.stats[3]++;
-                a.guard = R.d_flag + 2;
+                a.guard = flag;
                 a.guard_epoch = R.nf_epoch;
                 if (!conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, false))
                     K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
@@ -1134,8 +1243,7 @@ struct Ops {
         if (consumed != a.shape.size()) throw Error("index is too short");
         out[1] = 0.0;
         R.stats[2]++;
-        read_back(&out[0], dp<E>(a) + off, sizeof(double));
-        if (W == 2) read_back(&out[1], dp<E>(a) + a.numel + off, sizeof(double));
+        peek(out, dp<E>(a) + off, a.numel, W);
     }
 
     static bool equal(const P& a, const P& b) {
@@ -1204,6 +1312,9 @@ int gft_init(int device) {
         }
         HIP_OK(hipMalloc((void**)&R.d_scratch, 256));
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void**)&R.h_mail, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(R.h_mail, 0, 4096);
+        HIP_OK(hipHostGetDevicePointer((void**)&R.d_mail, R.h_mail, 0));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
         R.device = device;
         if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
@@ -1234,6 +1345,8 @@ void gft_shutdown(void) {
     (void)hipFree(R.d_flag);
     (void)hipFree(R.d_scratch);
     (void)hipHostFree(R.h_pinned);
+    (void)hipHostFree(R.h_mail);
+    R.h_mail = R.d_mail = nullptr;
     for (auto& ev : R.events) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(R.own_stream);
     R.ready = false;

@@ -490,6 +490,37 @@ __global__ void __launch_bounds__(256) k_prep_operands(const double* __restrict_
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(flag, epoch);
 }
 
+// ---- inner-axis splitting (rank 2, or an inner axis longer than 128) ---------------------------------------------
+// A row of length n is viewed as P = ceil(n / B) pieces of B: x~[p][r] = x[pB + r] (zero padded).  The product of
+// the (.., Px, B) and (.., Py, B) tensors with an UNtruncated last axis (2B - 1 <= 127 coefficients) contains
+// exactly the products of the original one: z[pB + r] = z~[p][r] + z~[p - 1][B + r] (overlap-add of the carries).
+// That turns a rank-d product with a long last axis into a rank-(d+1) product the tiled kernel supports.
+__global__ void __launch_bounds__(256) k_pad_rows(const double* __restrict__ in, double* __restrict__ out, size_t rows,
+                                                  unsigned len, unsigned plen) {
+    size_t total = rows * plen;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t row = i / plen;
+        unsigned col = (unsigned)(i - row * plen);
+        out[i] = col < len ? in[row * len + col] : 0.0;
+    }
+}
+__global__ void __launch_bounds__(256) k_fold_rows(const double* __restrict__ zt, double* __restrict__ z, size_t row_lo,
+                                                   size_t row_hi, unsigned Pz, unsigned B, unsigned zI, int accumulate,
+                                                   const unsigned* guard, unsigned epoch) {
+    if (guard && *guard == epoch) return;
+    const unsigned RI = 2 * B - 1;
+    size_t total = (row_hi - row_lo) * zI;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t row = row_lo + i / zI;
+        unsigned k = (unsigned)(i % zI), p = k / B, r = k - p * B;
+        const double* zr = zt + row * Pz * RI;
+        double v = zr[(size_t)p * RI + r];
+        if (p > 0 && r + 1 < B) v += zr[(size_t)(p - 1) * RI + B + r];
+        double* dst = z + row * zI + k;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
 // ---- host-side plan ------------------------------------------------------------------------------------
 
 struct PlanKey {
@@ -503,6 +534,32 @@ struct Plan {
     size_t lds_bytes = 0;
     void* d_tables = nullptr;
 };
+
+struct TableArena {
+    char* dev = nullptr;
+    char* host = nullptr;  // pinned mirror
+    size_t bytes = 0, head = 0;
+    bool tried = false;
+    bool ensure() {
+        if (dev) return true;
+        if (tried) return false;
+        tried = true;
+        const size_t n = 32u << 20;
+        if (hipMalloc((void**)&dev, n) != hipSuccess) { dev = nullptr; (void)hipGetLastError(); return false; }
+        if (hipHostMalloc((void**)&host, n, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(dev);
+            dev = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        bytes = n;
+        return true;
+    }
+};
+TableArena& arena() {
+    static TableArena a;
+    return a;
+}
 
 std::map<PlanKey, Plan>& plan_cache() {
     static std::map<PlanKey, Plan> c;
@@ -523,7 +580,7 @@ int num_cus() {
 
 static void assign_blocks(TiledArgs& T, unsigned NW);
 
-bool build_plan(const ConvArgs& a, Plan& P) {
+bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     TiledArgs& T = P.base;
     std::memset(&T, 0, sizeof(T));
     if (a.nd == 3) {
@@ -653,17 +710,37 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     P.n_red = (unsigned)red.size();
     P.n_slots = n_slots;
 
-    // one device allocation for all tables
+    // All tables of a plan live in one slice of a persistent device arena and are uploaded with ONE stream-ordered
+    // copy from the pinned host mirror of that slice: building a plan for a new shape costs no hipMalloc and no
+    // host synchronisation (Genfer's supports grow statement by statement, so new shapes are the common case).
     size_t b_segs = segs.size() * sizeof(TileSeg), b_wg = wg_begin.size() * sizeof(unsigned);
     size_t b_red = red.size() * sizeof(RedTile), b_rs = red_slots.size() * sizeof(unsigned);
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t total = al(b_segs) + al(b_wg) + al(b_red) + al(b_rs) + 256;
-    if (hipMalloc(&P.d_tables, total) != hipSuccess) return false;
-    char* base = (char*)P.d_tables;
+    TableArena& A = arena();
+    char *base = nullptr, *hbase = nullptr;
+    if (A.ensure() && total <= A.bytes / 4) {
+        if (A.head + total > A.bytes) {  // wrap: every cached plan's slice may be overwritten from now on
+            (void)hipStreamSynchronize(st);   // pending uploads still read the host mirror
+            for (auto& kv : plan_cache())
+                if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
+            plan_cache().clear();
+            A.head = 0;
+        }
+        base = A.dev + A.head;
+        hbase = A.host + A.head;
+        A.head += total;
+    } else {
+        if (hipMalloc(&P.d_tables, total) != hipSuccess) return false;
+        base = (char*)P.d_tables;
+    }
     size_t off = 0;
     auto put = [&](const void* src, size_t bytes) -> void* {
         void* d = base + off;
-        if (bytes) (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+        if (bytes) {
+            if (hbase) std::memcpy(hbase + off, src, bytes);
+            else (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+        }
         off += al(bytes);
         return d;
     };
@@ -671,6 +748,7 @@ bool build_plan(const ConvArgs& a, Plan& P) {
     T.wg_begin = (const unsigned*)put(wg_begin.data(), b_wg);
     T.red = (const RedTile*)put(red.data(), b_red);
     T.red_slots = (const unsigned*)put(red_slots.data(), b_rs);
+    if (hbase && hipMemcpyAsync(base, hbase, off, hipMemcpyHostToDevice, st) != hipSuccess) return false;
     return true;
 }
 
@@ -733,6 +811,21 @@ hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
 
 }  // namespace
 
+void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned plen) {
+    size_t tot = rows * plen;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, in, out, rows,
+                       len, plen);
+}
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t row_lo, size_t row_hi, unsigned Pz, unsigned B,
+                         unsigned zI, int accumulate, const unsigned* guard, unsigned epoch) {
+    size_t tot = (row_hi - row_lo) * zI;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, row_lo,
+                       row_hi, Pz, B, zI, accumulate, guard, epoch);
+}
+
+
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a_in, void* ws,
                     size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch) {
     ConvArgs a = a_in;
@@ -759,11 +852,14 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     auto it = cache.find(key);
     if (it == cache.end()) {
         Plan P;
-        if (!build_plan(a, P)) return false;
-        if (cache.size() > 64) {  // bounded: drop everything (plans are cheap to rebuild)
-            for (auto& kv : cache) (void)hipFree(kv.second.d_tables);
+        if (cache.size() >= 1024) {  // bounded: drop everything (plans are cheap to rebuild) and reuse the arena
+            (void)hipStreamSynchronize(st);
+            for (auto& kv : cache)
+                if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
             cache.clear();
+            arena().head = 0;
         }
+        if (!build_plan(a, P, st)) return false;  // may itself reset the cache when the table arena wraps
         it = cache.emplace(key, P).first;
     }
     const Plan& P = it->second;

@@ -213,9 +213,10 @@ void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar
 }
 
 template <class E>
-__global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask, unsigned* state, double* out, size_t total) {
+__global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask, unsigned* state, Mailbox mb, size_t total) {
+    double* out = mb.payload;
     unsigned local = axes_mask;
-    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total && local != 0;
          lin += (size_t)gridDim.x * blockDim.x) {
         if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
         size_t r = lin;
@@ -234,13 +235,19 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
         }
         if (nonzero_axes == 0) continue;
         if (nonzero_axes == 1 && unit) local &= (1u << which);
-        else local = 0;
+        else local = 0;  // nothing more to learn: the loop ends
     }
+    // block-level AND, then at most one device atomic per block — and none if the global verdict already
+    // implies ours (a dense tensor is settled by the first block; ~1400 same-address atomics cost 20 us)
     for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
+    __shared__ unsigned s_and[4];
     __shared__ unsigned s_last;
-    if ((threadIdx.x & 63) == 0) atomicAnd(&state[0], local);
+    if ((threadIdx.x & 63) == 0) s_and[threadIdx.x >> 6] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
+        unsigned blk = s_and[0] & s_and[1] & s_and[2] & s_and[3];
+        unsigned cur = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur & ~blk) atomicAnd(&state[0], blk);
         __threadfence();
         unsigned ticket = atomicAdd(&state[1], 1u);
         s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
@@ -264,13 +271,15 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
     }
     atomicExch(&state[0], 0xffffffffu);  // restore for the next call on this stream
     atomicExch(&state[1], 0u);
+    mailbox_publish(mb);
 }
 template <class E>
-void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out) {
+void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb) {
     size_t total = 1;
     for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
     if (total == 0) return;
-    hipLaunchKernelGGL(k_linear_scan<E>, dim3(grid_for(total)), dim3(256), 0, st, t, axes_mask, state, out, total);
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 128);  // few tickets; dense tensors exit at once
+    hipLaunchKernelGGL(k_linear_scan<E>, dim3(blocks), dim3(256), 0, st, t, axes_mask, state, mb, total);
 }
 
 template <class E>
@@ -740,6 +749,15 @@ void K<E>::conv_naive(hipStream_t st, const double* x, size_t x_plane, const dou
                       size_t z_plane, const ConvArgs& a) {
     if (a.inner_from_zero) launch_conv_naive<E, true>(st, x, x_plane, y, y_plane, z, z_plane, a);
     else launch_conv_naive<E, false>(st, x, x_plane, y, y_plane, z, z_plane, a);
+}
+
+__global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {
+    if (threadIdx.x < n) mb.payload[threadIdx.x] = src[threadIdx.x * stride];
+    __syncthreads();
+    if (threadIdx.x == 0) mailbox_publish(mb);
+}
+void peek_to_mailbox(hipStream_t st, const double* src, size_t stride, unsigned n, const Mailbox& mb) {
+    hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, st, src, stride, n, mb);
 }
 
 template struct K<EF64>;

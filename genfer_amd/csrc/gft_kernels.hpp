@@ -61,6 +61,21 @@ struct ObserveArgs {
     size_t tab_plane;
 };
 
+// Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
+// sequence number (system-scope release); the host polls the sequence word instead of paying a D2H copy launch
+// plus hipStreamSynchronize (22 -> ~7 us per host round trip, see tools/bench_sync.py).
+struct Mailbox {
+    double* payload;              // device-visible address of the pinned slot (8 doubles)
+    unsigned long long* seq;      // payload + 8
+    unsigned long long value;     // sequence number this kernel must publish
+};
+__device__ inline void mailbox_publish(const Mailbox& mb) {
+    __threadfence_system();
+    __hip_atomic_store(mb.seq, mb.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// copies n <= 7 doubles (src[i * stride]) into the mailbox
+void peek_to_mailbox(hipStream_t st, const double* src, size_t stride, unsigned n, const Mailbox& mb);
+
 struct ConvArgs {
     int nd;
     unsigned xs[MAXD], ys[MAXD], zs[MAXD];
@@ -95,7 +110,7 @@ struct K {
     // out[1..2] = coeffs[0], out[3..4] = coeffs[e_v] for the first surviving axis v — one 40-byte read-back.
     // `state` must be {0xffffffff, 0} on entry; the last block restores it, so back-to-back calls on one
     // stream need no memset.
-    static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, double* out);
+    static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements
@@ -140,6 +155,12 @@ enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
 // does not produce) and the caller's guarded reference-order launch computes z instead — no host round trip.
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
                     size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch);
+
+// Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
+// overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
+void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned plen);
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t row_lo, size_t row_hi, unsigned Pz, unsigned B,
+                         unsigned zI, int accumulate, const unsigned* guard, unsigned epoch);
 
 // LDS-staged reference-order convolution (gft_conv_staged.hip): bit-identical to K<E>::conv_naive, operands
 // staged through LDS once per workgroup step.  Returns false (nothing launched) if the shape does not suit

@@ -389,6 +389,41 @@ def test_conv_tiled_vs_oracle_and_pgf_like_dynamic_range(oracle_lib):
     assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want))
 
 
+SPLIT_SHAPES = [
+    ((378, 378), (378, 378), (378, 378)),             # rank 2 (two_populations-like): last axis split into 6 x 64
+    ((100, 130), (70, 97), (150, 200)),               # ragged rank 2, compact operands
+    ((40, 96), (40, 96), (40, 96)),                   # rank 2, shortest last axis that is split
+    ((12, 20, 300), (12, 20, 300), (12, 20, 300)),    # rank 3 with a last axis > 128 -> rank 4
+    ((9, 7, 129), (5, 7, 140), (12, 9, 200)),
+    ((3, 1000), (2, 1000), (4, 1000)),                # long rows, few of them
+]
+
+
+@pytest.mark.parametrize("xs,ys,zs", SPLIT_SHAPES)
+def test_conv_tiled_inner_split_matches_reference_order_kernel(xs, ys, zs):
+    """Rank-2 products and last axes longer than 128 reach the tiled kernel through the (P, B) inner split with
+    overlap-add of the carries: same products as the reference => 1e-10 (positive inputs), normwise bound for
+    mixed signs; slab range + accumulate only touch the selected rows."""
+    x, y = rand(xs, 51), rand(ys, 52)
+    want = _conv_raw_gpu(1, x, y, zs)
+    got = _conv_raw_gpu(2, x, y, zs)
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / want).max()
+    xm, ym = 2 * x - 1, 2 * y - 1
+    bound = _conv_raw_gpu(1, np.abs(xm), np.abs(ym), zs)
+    assert np.all(np.abs(_conv_raw_gpu(2, xm, ym, zs) - _conv_raw_gpu(1, xm, ym, zs)) <= 1e-10 * bound)
+    lo, hi = zs[0] // 3, max(zs[0] // 3 + 1, (2 * zs[0]) // 3)
+    z0 = rand(zs, 53)
+    got = _conv_raw_gpu(2, x, y, zs, slab=(lo, hi), accumulate=True, z0=z0)
+    exp = z0.copy()
+    exp[lo:hi] += want[lo:hi]
+    assert np.array_equal(got[:lo], z0[:lo]) and np.array_equal(got[hi:], z0[hi:])
+    assert np.all(np.abs(got[lo:hi] - exp[lo:hi]) <= 1e-10 * np.abs(exp[lo:hi]))
+    # non-finite operands: the device-side guard routes the whole product to the reference-order kernel
+    xi = x.copy()
+    xi[(1,) * len(xs)] = np.inf
+    assert np.array_equal(_conv_raw_gpu(2, xi, y, zs), _conv_raw_gpu(1, xi, y, zs), equal_nan=True)
+
+
 @pytest.mark.parametrize("shape", [(16, 16, 20), (40, 40, 40), (6, 20, 20, 24)])
 def test_conv_tiled_nonfinite_operands_fall_back(shape):
     """inf/NaN operands must not be polluted by zero padding.  The verdict is taken on the device (epoch stamp

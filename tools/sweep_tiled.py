@@ -13,7 +13,8 @@ F = genfer_amd.TaylorPoly
 L.gft_set_conv_mode(2)
 rng = np.random.default_rng(0)
 shapes = [(32,) * 3, (40,) * 3, (48,) * 3, (56,) * 3, (64,) * 3, (80,) * 3, (96,) * 3, (112,) * 3, (128,) * 3, (16,) * 4, (24,) * 4,
-          (32,) * 4, (48,) * 4, (64, 64, 128), (128, 128, 32), (256, 256, 16), (200, 200, 64)]
+          (32,) * 4, (48,) * 4, (64, 64, 128), (128, 128, 32), (256, 256, 16), (200, 200, 64),
+          (378, 378), (1000, 1000), (2000, 2000), (100, 100, 300), (64, 64, 512)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(t) for t in a.split("x")) for a in sys.argv[1:]]
 for sh in shapes:
