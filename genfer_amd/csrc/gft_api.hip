@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -337,7 +338,7 @@ struct Ops {
 
     // ---- value inspection (the only host syncs) ---------------------------------------------
     static void first_value(const P& p, double out[2]) {
-        if (p.numel == 1 && p.cached) {
+        if ((p.numel == 1 && p.cached) || (!p.buf && p.lazy_lin)) {  // host-known element 0
             out[0] = p.cv[0];
             out[1] = p.cv[1];
             return;
@@ -528,6 +529,36 @@ struct Ops {
         return r;
     }
 
+    // lazy (0 + m*eps_v) (+|-) cached scalar d -> lazy (d or -d) + m*eps_v; false if the constant is not an exact zero
+    static bool lazy_zero_plus(const P& lazy, const P& scalar, bool subtract, P* out) {
+        const double d0 = scalar.cv[0], d1 = scalar.cv[1];
+        if (W == 1) {
+            if (lazy.cv[0] != 0.0) return false;
+            double r;
+            if (d0 != 0.0 || d0 != d0) r = subtract ? -d0 : d0;  // 0 +/- d (NaN stays NaN)
+            else {
+                // signed zeros: (+0)+(+0)=+0, (+0)+(-0)=+0, (-0)+(-0)=-0, (-0)+(+0)=+0; x - y = x + (-y)
+                bool ns = std::signbit(lazy.cv[0]), nd = std::signbit(d0) != subtract;
+                r = (ns && nd) ? -0.0 : 0.0;
+            }
+            P res = lazy;
+            res.cv[0] = r;
+            *out = res;
+            return true;
+        }
+        if (!(lazy.cv[0] == 0.0 && lazy.cv[1] == 0.0)) return false;
+        P res = lazy;
+        if (subtract) {  // add(a, neg(b)) with a == 0 -> neg(b) = (-hi, -lo)
+            res.cv[0] = -d1;
+            res.cv[1] = -d0;
+        } else {
+            res.cv[0] = d0;
+            res.cv[1] = d1;
+        }
+        *out = res;
+        return true;
+    }
+
     // ---- Add / Sub / Neg (mt:854-937) -----------------------------------------------------------------
     static P addsub(P self, P other, bool subtract) {
         Dims rd = min_degrees(self, other);
@@ -537,12 +568,29 @@ struct Ops {
         // a host-cached scalar operand travels as a kernel argument (no device read, no materialisation)
         auto sptr = [](const P& s) -> const double* { return (s.cached && !s.buf) ? nullptr : dp<E>(s); };
         if (other.numel == 1) {
+            // (c + m*eps_v) - c for a still-lazy variable and the host-cached scalar c it was built from (the
+            // reference's Subst evaluation: subst - constant_term(subst)): x - x = +0 exactly for finite x, so the
+            // result stays lazy as 0 + m*eps_v.  F64 only (an interval difference widens).
+            if (W == 1 && subtract && !self.buf && self.lazy_lin && other.cached && !other.buf && std::isfinite(self.cv[0]) &&
+                std::memcmp(&self.cv[0], &other.cv[0], sizeof(double)) == 0 && self.deg == rd) {
+                P r = self;
+                r.cv[0] = 0.0;
+                return r;
+            }
+            // (0 + m*eps_v) +/- d for a still-lazy variable with an exactly zero constant and a host-cached scalar d:
+            // 0 + d = d, 0 - d = -d (IEEE identities; interval.rs:126-155 returns the other operand for an exact
+            // zero), so `Var(x) + Const(d)` substitutions never touch the device before they are consumed.
+            if (!self.buf && self.lazy_lin && other.cached && !other.buf && self.deg == rd && lazy_zero_plus(self, other, subtract, &self))
+                return self;
             P out = make(self.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
                              subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
             return out;
         }
         if (self.numel == 1) {
+            if (!subtract && !other.buf && other.lazy_lin && self.cached && !self.buf && other.deg == rd &&
+                lazy_zero_plus(other, self, false, &other))
+                return other;
             P out = make(other.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(other), other.numel, dp<E>(out), out.numel, other.numel,
                              subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, sptr(self), self.numel, Scalar2{self.cv[0], self.cv[1]});
@@ -785,6 +833,29 @@ struct Ops {
         return addsub(mul_var(self, m, v, shape, deg), mul(self, scalar(c)), false);
     }
 
+    // c * eps_v for a still-lazy plain variable (0 + 1*eps_v) and a finite host-known scalar c: the result is
+    // (c*0, c*1) = (0 with c's sign, c) by IEEE identities (interval: the exact zero / one short-circuits of
+    // interval.rs:164-190), so it can stay lazy — and a later subst_var(.., c*eps_v) knows from the host that the
+    // substitution is a pure scaling instead of scanning a 2-element device tensor (one host round trip less).
+    static bool scaled_lazy_var(const P& var, const double c[2], P* out) {
+        if (var.buf || !var.lazy_lin || var.numel != 2) return false;
+        auto is_pz = [](double x) { return x == 0.0 && !std::signbit(x); };
+        if (!is_pz(var.cv[0]) || var.cv1[0] != 1.0) return false;
+        if (W == 2 && (!is_pz(var.cv[1]) || var.cv1[1] != 1.0)) return false;
+        if (!std::isfinite(c[0]) || (W == 2 && !std::isfinite(c[1]))) return false;
+        P r = var;
+        if (W == 1) {
+            r.cv[0] = std::copysign(0.0, c[0]);
+            r.cv[1] = 0.0;
+        } else {
+            r.cv[0] = r.cv[1] = 0.0;
+        }
+        r.cv1[0] = c[0];
+        r.cv1[1] = W == 2 ? c[1] : 0.0;
+        *out = r;
+        return true;
+    }
+
     static P mul(P self, P other) {  // mt:1014-1072
         Dims deg = min_degrees(self, other);
         if (is_zero(self) || is_zero(other)) return zero_with(deg);
@@ -797,10 +868,14 @@ struct Ops {
         double c[2], m[2];
         if (self.numel == 1) {
             first_value(self, c);
+            P lazy;
+            if (scaled_lazy_var(other, c, &lazy)) return lazy;
             return map_copy(other, OP_LMUL_S, c);
         }
         if (other.numel == 1) {
             first_value(other, c);
+            P lazy;
+            if (scaled_lazy_var(self, c, &lazy)) return lazy;
             return map_copy(self, OP_LMUL_S, c);
         }
         size_t v;
@@ -1128,6 +1203,7 @@ struct Ops {
             if (v == w && val_is_zero(c)) {
                 Dims lens = a.shape;
                 for (size_t i = 0; i < lens.size(); ++i) lens[i] = std::min(lens[i], deg[i]);
+                if (val_is_one(m)) return lead_block(a, lens, deg);  // powers of one: x * 1 == x, nothing to compute
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 Dims sst = c_strides(subst.shape);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);

@@ -261,6 +261,46 @@ def _conv_raw_gpu(mode, x, y, zs, slab=None, accumulate=False, z0=None):
         L.gft_set_conv_mode(0)
 
 
+@pytest.mark.parametrize("interval", [False, True])
+def test_lazy_variables_and_scaled_variables(interval, OTP, GTP, OTPI, GTPI):
+    """Variables built from host scalars stay on the host until a kernel must read them, and c * eps_v of a plain
+    variable stays lazy too (IEEE identities c*0, c*1): every way of consuming them must match the oracle bit for
+    bit — export, arithmetic, use as a substitution (the pure-scaling shortcut of mt:547-556) and as a product
+    operand (mul_linear path)."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda v: (v, v)) if interval else (lambda v: v)
+    base = rand((5, 4, 6), 61, 0.1, 1.0)
+    arr = np.stack([base, base + 1e-9]) if interval else base
+    deg = [7, 6, 8]
+    for v in range(3):
+        for c in (2.5, -3.0, 0.5, 1.0, -0.0, 0.0):
+            for x0 in (0.0, 0.75):
+                ov = O.var_with_degrees_p1(v, mk(x0), deg)
+                gv = G.var_with_degrees_p1(v, mk(x0), deg)
+                check(ov, gv)
+                os_, gs_ = ov * O.from_scalar(mk(c)), gv * G.from_scalar(mk(c))
+                check(os_, gs_)
+                assert os_.extract_linear() == gs_.extract_linear()
+                check(O.from_scalar(mk(c)) * ov, G.from_scalar(mk(c)) * gv)
+                op, gp = O.new(arr, deg), G.new(arr, deg)
+                check(op.subst_var(v, os_), gp.subst_var(v, gs_))
+                check(op * os_, gp * gs_)
+                check(os_ + op, gs_ + gp)
+                check(os_ - os_ * os_, gs_ - gs_ * gs_)
+                check(os_.derivative(v, 1), gs_.derivative(v, 1))
+                # affine substitutions built the way the interpreter builds them (Var +/- Const, Const + Var),
+                # then "subst - constant_term(subst)" (generating_function.rs Subst evaluation)
+                for d in (-1.0, 0.25, 0.0, -0.0):
+                    for mkaff in (lambda t, k: t + k, lambda t, k: t - k, lambda t, k: k + t):
+                        oa, ga = mkaff(os_, O.from_scalar(mk(d))), mkaff(gs_, G.from_scalar(mk(d)))
+                        check(oa, ga)
+                        assert oa.constant_term() == ga.constant_term()
+                        oc, gc = oa - O.from_scalar(oa.constant_term()), ga - G.from_scalar(ga.constant_term())
+                        check(oc, gc)
+                        check(op.subst_var(v, oc), gp.subst_var(v, gc))
+                        check(op.subst_var(v, oa), gp.subst_var(v, ga))
+
+
 STAGED_SHAPES = [
     ((17,), (9,), (20,)),                                  # rank 1: rows only, axis 0 is the staged axis
     ((300,), (300,), (300,)),                              # more than one chunk per row
