@@ -63,6 +63,7 @@ struct Runtime {
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
+    bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
@@ -1215,7 +1216,13 @@ struct Ops {
         Dims cshape = a.shape;
         while (cshape.size() < deg.size()) cshape.push_back(1);
         P ca = with_meta_unchecked(a, cshape);
+        // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
+        const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2 && R.fuse_horner;
         for (size_t i = cshape[v]; i-- > 0;) {
+            if (lin_known && res.numel > 1 && res.shape.size() == deg.size()) {
+                res = horner_linear_step(res, ca, v, i, c, m, w, deg);
+                continue;
+            }
             Dims out = cshape;
             out[v] = 1;
             for (size_t ax = 0; ax < out.size(); ++ax) out[ax] = std::min(out[ax], deg[ax]);
@@ -1225,6 +1232,50 @@ struct Ops {
             res = addsub(mul(res, subst), coeff, false);
         }
         return res;
+    }
+    // res * (c + m*eps_w) + a[.., i, ..] in one launch (k_horner_linear), element for element the sequence
+    // mul -> mul_linear -> mul_var / scale / add -> add that the generic loop above performs.  The generic mul
+    // would first ask whether `res` itself is linear (a device scan + host round trip per step) and, if so,
+    // multiply the other way round — the same products and sums (commutativity), so only the stored shape of an
+    // accumulator that happens to be exactly linear can differ (explicit zeros instead of a compact shape).
+    static P horner_linear_step(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
+                                const Dims& deg) {
+        const size_t nd = deg.size();
+        Dims rs = res.shape, sh = res.shape, oc = ca.shape;
+        sh[w] = std::min(deg[w], sh[w] + 1);
+        oc[v] = 1;
+        for (size_t ax = 0; ax < nd; ++ax) oc[ax] = std::min(oc[ax], deg[ax]);
+        const bool coeff_scalar = prod(oc) == 1;
+        Dims os = sh;
+        if (!coeff_scalar)
+            for (size_t ax = 0; ax < nd; ++ax) os[ax] = std::min(std::max(sh[ax], oc[ax]), deg[ax]);
+        P out = make(os, deg);
+        Dims keep = collapse_mask({&os}, false);
+        if (keep.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
+        HornerArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.out = to_shape(pick(os, keep));
+        Dims rst = c_strides(rs), ast = c_strides(ca.shape);
+        g.w = -1;
+        for (size_t j = 0; j < keep.size(); ++j) {
+            size_t ax = keep[j];
+            g.rs[j] = (unsigned)rs[ax];
+            g.sh[j] = (unsigned)sh[ax];
+            g.oc[j] = (unsigned)oc[ax];
+            g.rstr[j] = rst[ax];
+            g.astr[j] = ax == v ? 0 : ast[ax];
+            if (ax == w) g.w = (int)j;
+        }
+        if (g.w < 0) throw Error("horner_linear_step: substitution axis collapsed");  // sh[w] >= 2 => kept
+        g.a_base = i * ast[v];
+        g.upper = (unsigned)std::min(sh[w] - 1, rs[w]);
+        g.c = Scalar2{c[0], W == 2 ? c[1] : 0.0};
+        g.m = Scalar2{m[0], W == 2 ? m[1] : 0.0};
+        g.c_zero = val_is_zero(c) ? 1 : 0;
+        g.c_one = val_is_one(c) ? 1 : 0;
+        g.coeff_scalar = coeff_scalar ? 1 : 0;
+        K<E>::horner_linear(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), out.numel, g);
+        return out;
     }
     static P with_meta_unchecked(const P& src, const Dims& shape) {
         P r = src;
@@ -1397,6 +1448,7 @@ int gft_init(int device) {
             double v = atof(tm);
             if (v >= 0) R.tiled_min_macs = v;
         }
+        if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;

@@ -751,6 +751,68 @@ void K<E>::conv_naive(hipStream_t st, const double* x, size_t x_plane, const dou
     else launch_conv_naive<E, false>(st, x, x_plane, y, y_plane, z, z_plane, a);
 }
 
+template <class E>
+__global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict__ res, size_t rp, const double* __restrict__ a,
+                                                       size_t ap, double* __restrict__ out, size_t op, HornerArgs g,
+                                                       size_t total) {
+    typedef typename E::V V;
+    const V cv = E::from(g.c), mv = E::from(g.m);
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, roff = 0, aoff = g.a_base;
+        unsigned kw = 0;
+        bool in_p = true, in_r = true, in_c = true;
+#pragma unroll 1
+        for (int ax = g.out.nd - 1; ax >= 0; --ax) {
+            unsigned d = g.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k >= g.sh[ax]) in_p = false;
+            if (k >= g.rs[ax]) in_r = false;
+            if (k >= g.oc[ax]) in_c = false;
+            if (ax == g.w) kw = k;
+            roff += (size_t)k * g.rstr[ax];
+            aoff += (size_t)k * g.astr[ax];
+        }
+        V p = E::zero();
+        if (in_p) {
+            // A = mul_var(res, m, w): res[k - e_w] * m inside the shifted source box, zero elsewhere
+            bool in_src = kw >= 1 && kw - 1 < g.upper;
+            if (in_src) {  // the other axes of the source box are res's own extents == sh's
+                V A = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);
+                p = A;
+            }
+            if (!g.c_zero) {
+                p = E::add(E::zero(), p);
+                if (in_r) {
+                    V x = E::ld(res, rp, roff);
+                    V B = g.c_one ? x : E::mul(cv, x);
+                    p = E::add(p, B);
+                }
+            }
+        }
+        V v;
+        if (g.coeff_scalar) {
+            v = p;
+            if (lin == 0) v = E::add(p, E::ld(a, ap, g.a_base));
+        } else {
+            v = E::zero();
+            if (in_p) v = E::add(v, p);
+            if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+        }
+        E::st(out, op, lin, v);
+    }
+}
+template <class E>
+void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
+                         size_t out_plane, const HornerArgs& args) {
+    size_t total = 1;
+    for (int i = 0; i < args.out.nd; ++i) total *= args.out.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_horner_linear<E>, dim3(grid_for(total)), dim3(256), 0, st, res, res_plane, a, a_plane, out, out_plane,
+                       args, total);
+}
+
 __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {
     if (threadIdx.x < n) mb.payload[threadIdx.x] = src[threadIdx.x * stride];
     __syncthreads();

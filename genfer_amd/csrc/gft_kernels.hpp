@@ -61,6 +61,27 @@ struct ObserveArgs {
     size_t tab_plane;
 };
 
+// One Horner step of subst_var with a LINEAR substitution s = c + m*eps_w (mt:566-579, 589-623, 873-880):
+//   out = res * s + coeff_i,   coeff_i = a[.., i, ..] along the substituted axis,
+// computed per element in exactly the order of the reference's op sequence
+//   A = mul_var(res, m, w);  B = res * c (skipped if c == 1);  P = (0 + A) + B (or P = A if c == 0);
+//   out = (0 + P) + coeff_i   (or P with element 0 += coeff_i when the slab is a single coefficient)
+// in ONE launch instead of gather + gather + gather + addsub + addsub, and without the per-step
+// extract_linear(res) round trip.
+struct HornerArgs {
+    Shape out;                 // result shape (collapsed)
+    unsigned rs[MAXD];         // shape of res
+    unsigned sh[MAXD];         // shape of P = res * s  (rs with axis w grown by one, capped by degrees_p1)
+    unsigned oc[MAXD];         // box of coeff_i (1 along the substituted axis)
+    size_t rstr[MAXD];         // strides of res
+    size_t astr[MAXD];         // strides of a
+    size_t a_base;             // i * stride of the substituted axis in a
+    int w;                     // collapsed index of the substitution's variable
+    unsigned upper;            // mul_var: source indices 0 .. upper-1 along w
+    Scalar2 c, m;
+    int c_zero, c_one, coeff_scalar;
+};
+
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
 // sequence number (system-scope release); the host polls the sequence word instead of paying a D2H copy launch
 // plus hipStreamSynchronize (22 -> ~7 us per host round trip, see tools/bench_sync.py).
@@ -111,6 +132,8 @@ struct K {
     // `state` must be {0xffffffff, 0} on entry; the last block restores it, so back-to-back calls on one
     // stream need no memset.
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb);
+    static void horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
+                              size_t out_plane, const HornerArgs& args);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements

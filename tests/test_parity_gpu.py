@@ -301,6 +301,30 @@ def test_lazy_variables_and_scaled_variables(interval, OTP, GTP, OTPI, GTPI):
                         check(op.subst_var(v, oa), gp.subst_var(v, ga))
 
 
+@pytest.mark.parametrize("interval", [False, True])
+def test_subst_var_linear_substitution_fused_horner(interval, OTP, GTP, OTPI, GTPI):
+    """subst_var with a linear substitution c + m*eps_w (c != 0 or w != v) runs the fused Horner step
+    (k_horner_linear): bit-exact against the oracle's generic mul/add loop for every combination of substituted
+    axis, substitution variable, c in {generic, 1, 0 with w != v}, ragged degrees and 1-d inputs."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + 1e-7])) if interval else (lambda a: a)
+    cases = [((5, 4, 6), [7, 6, 8]), ((3, 7), [9, 7]), ((6,), [8]), ((2, 3, 2, 4), [4, 3, 3, 5]), ((4, 1, 5), [6, 4, 5])]
+    for shape, deg in cases:
+        base = rand(shape, 71, -1.0, 1.0)
+        op, gp = O.new(mk(base), deg), G.new(mk(base), deg)
+        nd = len(shape)
+        for v in range(nd):
+            for w in range(nd):
+                for c, m in ((0.3, 0.7), (1.0, -0.5), (-2.0, 1.0), (0.0, 0.25)):
+                    if c == 0.0 and v == w:
+                        continue  # pure scaling: different (table) path, covered elsewhere
+                    lin = np.zeros([2 if ax == w else 1 for ax in range(nd)])
+                    lin.flat[0], lin.flat[1] = c, m
+                    sdeg = list(deg)
+                    os_, gs_ = O.new(mk(lin), sdeg), G.new(mk(lin), sdeg)
+                    check(op.subst_var(v, os_), gp.subst_var(v, gs_))
+
+
 STAGED_SHAPES = [
     ((17,), (9,), (20,)),                                  # rank 1: rows only, axis 0 is the staged axis
     ((300,), (300,), (300,)),                              # more than one chunk per row

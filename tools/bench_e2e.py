@@ -2,7 +2,7 @@
 """End-to-end seconds on the NeurIPS'23 benchmark programs (BASELINE configs[2]): the host interpreter
 with the HIP backend (libgftaylor) vs the same interpreter over the CPU oracle, on this box, best of N
 ("Total inference time" protocol of the reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105).
-Usage: bench_e2e.py [--limit 100] [--runs 3] [--only substr] [--gpu-only]"""
+Usage: bench_e2e.py [--limit 100] [--runs 3] [--only substr] [--gpu-only] [--bounds]"""
 import ctypes
 import glob
 import json
@@ -28,6 +28,7 @@ limit = opt("--limit", "100")
 runs = int(opt("--runs", "3"))
 only = opt("--only", "")
 gpu_only = "--gpu-only" in args
+bounds = "--bounds" in args  # interval tensors (gfti_/orci_ entry points)
 files = sorted(glob.glob(os.path.join(ROOT, "tests/golden/sgcl/neurips2023/**/*.sgcl"), recursive=True))
 files = [f for f in files if only in f]
 oracle = os.path.join(ROOT, "oracle", "liborc.so")
@@ -41,7 +42,10 @@ for f in files:
     file_flags = first[len("# flags:"):].strip() if first.startswith("# flags:") else ""
     flags = file_flags if "--limit" in file_flags or "--no-probs" in file_flags else (file_flags + f" --limit {limit}").strip()
     row = {"program": os.path.relpath(f, os.path.join(ROOT, "tests/golden/sgcl/neurips2023")), "flags": flags}
-    for name, lib, prefix in (("gpu", genfer_amd.LIB_PATH, "gft_"), ("cpu_oracle", oracle, "orc_"))[: 1 if gpu_only else 2]:
+    if bounds:
+        flags += " --bounds"
+    backends = (("gpu", genfer_amd.LIB_PATH, "gfti_" if bounds else "gft_"), ("cpu_oracle", oracle, "orci_" if bounds else "orc_"))
+    for name, lib, prefix in backends[: 1 if gpu_only else 2]:
         best = None
         for _ in range(runs):
             rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, prefix)
