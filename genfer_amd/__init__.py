@@ -63,6 +63,7 @@ def _declare_runtime(L):
     L.gft_event_record.restype, L.gft_event_record.argtypes = c.c_int, [c.c_int]
     L.gft_event_elapsed_ms.restype, L.gft_event_elapsed_ms.argtypes = c.c_float, [c.c_int, c.c_int]
     L.gft_set_conv_mode.restype, L.gft_set_conv_mode.argtypes = c.c_int, [c.c_int]
+    L.gft_set_option.restype, L.gft_set_option.argtypes = c.c_int, [c.c_char_p, c.c_double]
     L.gft_conv_raw.restype = c.c_int
     L.gft_conv_raw.argtypes = [c.c_void_p, sz, c.c_void_p, sz, c.c_void_p, sz, c.c_size_t, c.c_size_t, c.c_size_t, c.c_int]
     L.gft_conv_macs.restype = c.c_double

@@ -63,6 +63,7 @@ struct Runtime {
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
+    size_t horner_loop_max = 2048;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
@@ -1220,6 +1221,8 @@ struct Ops {
         const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2 && R.fuse_horner;
         for (size_t i = cshape[v]; i-- > 0;) {
             if (lin_known && res.numel > 1 && res.shape.size() == deg.size()) {
+                // small tensors: every remaining step in one single-workgroup launch
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res)) break;
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
                 continue;
             }
@@ -1238,6 +1241,55 @@ struct Ops {
     // would first ask whether `res` itself is linear (a device scan + host round trip per step) and, if so,
     // multiply the other way round — the same products and sums (commutativity), so only the stored shape of an
     // accumulator that happens to be exactly linear can differ (explicit zeros instead of a compact shape).
+    // Steps i, i-1, .., 0 in one launch (k_horner_linear_loop) when the final tensor is small enough for a single
+    // workgroup to be the faster machine (a launch per step costs ~4 us of host time + ~4 us on the device).
+    static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
+                                   const Dims& deg, P* result) {
+        const size_t nd = deg.size();
+        Dims oc = ca.shape;
+        oc[v] = 1;
+        for (size_t ax = 0; ax < nd; ++ax) oc[ax] = std::min(oc[ax], deg[ax]);
+        const bool coeff_scalar = prod(oc) == 1;
+        Dims fs = res.shape;  // shape after all remaining steps
+        for (size_t t = 0; t <= i; ++t) {
+            fs[w] = std::min(deg[w], fs[w] + 1);
+            if (!coeff_scalar)
+                for (size_t ax = 0; ax < nd; ++ax) fs[ax] = std::max(fs[ax], oc[ax]);
+        }
+        const size_t fn = prod(fs);
+        if (fn > R.horner_loop_max) return false;
+        Dims keep = collapse_mask({&fs}, false);
+        if (keep.size() > (size_t)MAXD) return false;
+        P out = make(fs, deg);
+        std::shared_ptr<Buf> tmp = alloc_doubles(fn * W);
+        HornerLoopArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.nd = (int)keep.size();
+        Dims rst = c_strides(res.shape), fst = c_strides(fs), ast = c_strides(ca.shape);
+        g.w = -1;
+        for (size_t j = 0; j < keep.size(); ++j) {
+            size_t ax = keep[j];
+            g.deg[j] = (unsigned)std::min<size_t>(deg[ax], 0x7fffffffu);
+            g.rs0[j] = (unsigned)res.shape[ax];
+            g.oc[j] = (unsigned)oc[ax];
+            g.rstr0[j] = rst[ax];
+            g.fstr[j] = fst[ax];
+            g.astr[j] = ax == v ? 0 : ast[ax];
+            if (ax == w) g.w = (int)j;
+        }
+        if (g.w < 0) return false;
+        g.a_vstride = ast[v];
+        g.first_i = (unsigned)i;
+        g.nsteps = (unsigned)(i + 1);
+        g.c = Scalar2{c[0], W == 2 ? c[1] : 0.0};
+        g.m = Scalar2{m[0], W == 2 ? m[1] : 0.0};
+        g.c_zero = val_is_zero(c) ? 1 : 0;
+        g.c_one = val_is_one(c) ? 1 : 0;
+        g.coeff_scalar = coeff_scalar ? 1 : 0;
+        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), tmp->p, fn, g);
+        *result = out;
+        return true;
+    }
     static P horner_linear_step(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
                                 const Dims& deg) {
         const size_t nd = deg.size();
@@ -1449,6 +1501,7 @@ int gft_init(int device) {
             if (v >= 0) R.tiled_min_macs = v;
         }
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
+        if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;
@@ -1522,6 +1575,14 @@ float gft_event_elapsed_ms(int a, int b) {
         g_err = e.what();
         return -1.0f;
     }
+}
+int gft_set_option(const char* name, double value) {
+    std::string n = name ? name : "";
+    if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
+    else if (n == "fuse_horner") R.fuse_horner = value != 0;
+    else if (n == "tiled_min_macs") R.tiled_min_macs = value;
+    else return -1;
+    return 0;
 }
 int gft_set_conv_variant(int v) {
     R.conv_variant = v;

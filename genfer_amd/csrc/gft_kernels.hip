@@ -813,6 +813,95 @@ void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, co
                        args, total);
 }
 
+template <class E>
+__global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __restrict__ res0, size_t rp0,
+                                                             const double* __restrict__ a, size_t ap, double* out, double* tmp,
+                                                             size_t plane, HornerLoopArgs g) {
+    typedef typename E::V V;
+    const V cv = E::from(g.c), mv = E::from(g.m);
+    unsigned rs[MAXD], sh[MAXD], os[MAXD];
+#pragma unroll
+    for (int ax = 0; ax < MAXD; ++ax) rs[ax] = ax < g.nd ? g.rs0[ax] : 1;
+    for (unsigned t = 0; t < g.nsteps; ++t) {
+        const double* src = t == 0 ? res0 : (((g.nsteps - t) & 1u) ? tmp : out);   // what step t-1 wrote
+        const size_t sp = t == 0 ? rp0 : plane;
+        double* dst = ((g.nsteps - 1 - t) & 1u) ? tmp : out;                        // the last step writes `out`
+        size_t total = 1;
+        unsigned upper = 0;
+#pragma unroll
+        for (int ax = 0; ax < MAXD; ++ax) {
+            if (ax < g.nd) {
+                sh[ax] = rs[ax];
+                if (ax == g.w) {
+                    sh[ax] = rs[ax] + 1 < g.deg[ax] ? rs[ax] + 1 : g.deg[ax];
+                    upper = sh[ax] - 1 < rs[ax] ? sh[ax] - 1 : rs[ax];
+                }
+                unsigned o = sh[ax];
+                if (!g.coeff_scalar && g.oc[ax] > o) o = g.oc[ax];
+                os[ax] = o;
+                total *= o;
+            } else {
+                sh[ax] = os[ax] = 1;
+            }
+        }
+        const size_t a_base = (size_t)(g.first_i - t) * g.a_vstride;
+        for (size_t lin = threadIdx.x; lin < total; lin += blockDim.x) {
+            size_t r = lin, soff = 0, doff = 0, aoff = a_base, wstr = 0;
+            unsigned kw = 0;
+            bool in_p = true, in_r = true, in_c = true;
+#pragma unroll
+            for (int ax = MAXD - 1; ax >= 0; --ax) {
+                if (ax < g.nd) {
+                    unsigned d = os[ax];
+                    unsigned k = (unsigned)(r % d);
+                    r /= d;
+                    if (k >= sh[ax]) in_p = false;
+                    if (k >= rs[ax]) in_r = false;
+                    if (k >= g.oc[ax]) in_c = false;
+                    const size_t ss = t == 0 ? g.rstr0[ax] : g.fstr[ax];
+                    if (ax == g.w) {
+                        kw = k;
+                        wstr = ss;
+                    }
+                    soff += (size_t)k * ss;
+                    doff += (size_t)k * g.fstr[ax];
+                    aoff += (size_t)k * g.astr[ax];
+                }
+            }
+            V p = E::zero();
+            if (in_p) {
+                if (kw >= 1 && kw - 1 < upper) p = E::mul(E::ld(src, sp, soff - wstr), mv);
+                if (!g.c_zero) {
+                    p = E::add(E::zero(), p);
+                    if (in_r) {
+                        V x = E::ld(src, sp, soff);
+                        p = E::add(p, g.c_one ? x : E::mul(cv, x));
+                    }
+                }
+            }
+            V v;
+            if (g.coeff_scalar) {
+                v = p;
+                if (lin == 0) v = E::add(p, E::ld(a, ap, a_base));
+            } else {
+                v = E::zero();
+                if (in_p) v = E::add(v, p);
+                if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+            }
+            E::st(dst, plane, doff, v);
+        }
+#pragma unroll
+        for (int ax = 0; ax < MAXD; ++ax) rs[ax] = os[ax];
+        __syncthreads();  // step t's writes (global, this block only) are visible to step t+1
+    }
+}
+template <class E>
+void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
+                              double* tmp, size_t plane, const HornerLoopArgs& args) {
+    if (args.nsteps == 0) return;
+    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(1), dim3(1024), 0, st, res0, res0_plane, a, a_plane, out, tmp, plane, args);
+}
+
 __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {
     if (threadIdx.x < n) mb.payload[threadIdx.x] = src[threadIdx.x * stride];
     __syncthreads();

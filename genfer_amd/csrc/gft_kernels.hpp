@@ -82,6 +82,24 @@ struct HornerArgs {
     int c_zero, c_one, coeff_scalar;
 };
 
+// ALL remaining Horner steps of a small subst_var in one single-workgroup launch: the per-step shapes are
+// re-derived on the device (they depend on shapes only), intermediates ping-pong between `out` and `tmp` in the
+// strides of the FINAL shape, __syncthreads() separates the steps.  Same per-element operations as HornerArgs.
+struct HornerLoopArgs {
+    int nd;                    // collapsed rank (axes where the final shape is > 1)
+    unsigned deg[MAXD];        // degrees_p1, clamped to 2^31
+    unsigned rs0[MAXD];        // shape of the incoming accumulator
+    unsigned oc[MAXD];         // box of a coefficient slab
+    size_t rstr0[MAXD];        // strides of the incoming accumulator (compact)
+    size_t fstr[MAXD];         // strides of the final shape (all in-kernel intermediates use these)
+    size_t astr[MAXD];         // strides of a (0 on the substituted axis)
+    size_t a_vstride;          // stride of the substituted axis in a
+    int w;
+    unsigned first_i, nsteps;  // coefficient index of the first in-kernel step; steps i = first_i, first_i-1, ...
+    Scalar2 c, m;
+    int c_zero, c_one, coeff_scalar;
+};
+
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
 // sequence number (system-scope release); the host polls the sequence word instead of paying a D2H copy launch
 // plus hipStreamSynchronize (22 -> ~7 us per host round trip, see tools/bench_sync.py).
@@ -134,6 +152,8 @@ struct K {
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb);
     static void horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
                               size_t out_plane, const HornerArgs& args);
+    static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
+                                   double* out, double* tmp, size_t plane, const HornerLoopArgs& args);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements

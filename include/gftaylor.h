@@ -62,6 +62,10 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
  * LDS-staged reference-order kernel wherever its shape limits allow.  Modes 1 and 3 are bit-identical
  * to each other and to the CPU algorithm.  Test/bench knob. */
 int gft_set_conv_mode(int mode);
+/* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
+ * tiled product), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
+ * in elements, for which all Horner steps of a linear substitution run in one launch). */
+int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);
 

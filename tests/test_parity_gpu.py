@@ -301,14 +301,19 @@ def test_lazy_variables_and_scaled_variables(interval, OTP, GTP, OTPI, GTPI):
                         check(op.subst_var(v, oa), gp.subst_var(v, ga))
 
 
+@pytest.mark.parametrize("loop_max", [1 << 20, 0])
 @pytest.mark.parametrize("interval", [False, True])
-def test_subst_var_linear_substitution_fused_horner(interval, OTP, GTP, OTPI, GTPI):
+def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP, OTPI, GTPI):
     """subst_var with a linear substitution c + m*eps_w (c != 0 or w != v) runs the fused Horner step
     (k_horner_linear): bit-exact against the oracle's generic mul/add loop for every combination of substituted
     axis, substitution variable, c in {generic, 1, 0 with w != v}, ragged degrees and 1-d inputs."""
+    import genfer_amd
+
     O, G = (OTPI, GTPI) if interval else (OTP, GTP)
     mk = (lambda a: np.stack([a, a + 1e-7])) if interval else (lambda a: a)
     cases = [((5, 4, 6), [7, 6, 8]), ((3, 7), [9, 7]), ((6,), [8]), ((2, 3, 2, 4), [4, 3, 3, 5]), ((4, 1, 5), [6, 4, 5])]
+    # loop_max 2^20: all remaining steps in one single-workgroup launch; 0: one launch per step
+    assert genfer_amd.lib().gft_set_option(b"horner_loop_max", float(loop_max)) == 0
     for shape, deg in cases:
         base = rand(shape, 71, -1.0, 1.0)
         op, gp = O.new(mk(base), deg), G.new(mk(base), deg)
@@ -323,6 +328,7 @@ def test_subst_var_linear_substitution_fused_horner(interval, OTP, GTP, OTPI, GT
                     sdeg = list(deg)
                     os_, gs_ = O.new(mk(lin), sdeg), G.new(mk(lin), sdeg)
                     check(op.subst_var(v, os_), gp.subst_var(v, gs_))
+    genfer_amd.lib().gft_set_option(b"horner_loop_max", 2048.0)
 
 
 STAGED_SHAPES = [
