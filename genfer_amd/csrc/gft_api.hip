@@ -1257,11 +1257,10 @@ struct Ops {
                 for (size_t ax = 0; ax < nd; ++ax) fs[ax] = std::max(fs[ax], oc[ax]);
         }
         const size_t fn = prod(fs);
-        if (fn > R.horner_loop_max) return false;
+        if (fn > R.horner_loop_max || fn > K<E>::HORNER_LOOP_MAX) return false;
         Dims keep = collapse_mask({&fs}, false);
         if (keep.size() > (size_t)MAXD) return false;
         P out = make(fs, deg);
-        std::shared_ptr<Buf> tmp = alloc_doubles(fn * W);
         HornerLoopArgs g;
         std::memset(&g, 0, sizeof(g));
         g.nd = (int)keep.size();
@@ -1286,7 +1285,7 @@ struct Ops {
         g.c_zero = val_is_zero(c) ? 1 : 0;
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
-        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), tmp->p, fn, g);
+        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)fn);
         *result = out;
         return true;
     }

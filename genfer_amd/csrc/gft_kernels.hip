@@ -813,20 +813,59 @@ void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, co
                        args, total);
 }
 
+// Thread -> element mapping is fixed over the steps (positions of the FINAL shape, <= HL_EPT per thread); a step only
+// changes which positions are inside the current boxes.  Intermediates ping-pong in LDS, the coefficient of the
+// next step is prefetched while the current one is computed, the last step writes to global memory.
+constexpr int HL_EPT = 2;          // elements per thread: final tensors up to 2048 elements
+constexpr int HL_MAX = 1024 * HL_EPT;
 template <class E>
 __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __restrict__ res0, size_t rp0,
-                                                             const double* __restrict__ a, size_t ap, double* out, double* tmp,
-                                                             size_t plane, HornerLoopArgs g) {
+                                                             const double* __restrict__ a, size_t ap,
+                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                             unsigned fn) {
     typedef typename E::V V;
+    __shared__ double lds[2 * E::W * HL_MAX];  // [buffer][plane][fn]
     const V cv = E::from(g.c), mv = E::from(g.m);
+    // fixed positions of this thread
+    unsigned kk[HL_EPT][MAXD];
+    size_t foff[HL_EPT], aoff[HL_EPT], roff0[HL_EPT];
+    bool have[HL_EPT], in_c[HL_EPT];
+#pragma unroll
+    for (int e = 0; e < HL_EPT; ++e) {
+        unsigned lin = threadIdx.x + e * blockDim.x;
+        have[e] = lin < fn;
+        foff[e] = lin;
+        aoff[e] = 0;
+        roff0[e] = 0;
+        in_c[e] = true;
+        // decode lin in the final shape: fstr are its strides (row-major), so k = (lin / fstr) % extent
+        size_t r = lin;
+#pragma unroll
+        for (int ax = 0; ax < MAXD; ++ax) {
+            unsigned k = 0;
+            if (ax < g.nd) {
+                k = (unsigned)(r / g.fstr[ax]);
+                r -= (size_t)k * g.fstr[ax];
+                if (k >= g.oc[ax]) in_c[e] = false;
+                aoff[e] += (size_t)k * g.astr[ax];
+                roff0[e] += (size_t)k * g.rstr0[ax];
+            }
+            kk[e][ax] = k;
+        }
+    }
     unsigned rs[MAXD], sh[MAXD], os[MAXD];
 #pragma unroll
     for (int ax = 0; ax < MAXD; ++ax) rs[ax] = ax < g.nd ? g.rs0[ax] : 1;
+    const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w];
+    V coef[HL_EPT];
+    {
+        const size_t a_base = (size_t)g.first_i * g.a_vstride;
+#pragma unroll
+        for (int e = 0; e < HL_EPT; ++e)
+            coef[e] = (have[e] && (g.coeff_scalar ? (threadIdx.x + e * blockDim.x == 0) : in_c[e])) ? E::ld(a, ap, a_base + aoff[e])
+                                                                                                  : E::zero();
+    }
     for (unsigned t = 0; t < g.nsteps; ++t) {
-        const double* src = t == 0 ? res0 : (((g.nsteps - t) & 1u) ? tmp : out);   // what step t-1 wrote
-        const size_t sp = t == 0 ? rp0 : plane;
-        double* dst = ((g.nsteps - 1 - t) & 1u) ? tmp : out;                        // the last step writes `out`
-        size_t total = 1;
         unsigned upper = 0;
 #pragma unroll
         for (int ax = 0; ax < MAXD; ++ax) {
@@ -839,42 +878,46 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                 unsigned o = sh[ax];
                 if (!g.coeff_scalar && g.oc[ax] > o) o = g.oc[ax];
                 os[ax] = o;
-                total *= o;
             } else {
                 sh[ax] = os[ax] = 1;
             }
         }
-        const size_t a_base = (size_t)(g.first_i - t) * g.a_vstride;
-        for (size_t lin = threadIdx.x; lin < total; lin += blockDim.x) {
-            size_t r = lin, soff = 0, doff = 0, aoff = a_base, wstr = 0;
-            unsigned kw = 0;
-            bool in_p = true, in_r = true, in_c = true;
+        // prefetch the next step's coefficients (independent of this step's result)
+        V next[HL_EPT];
+        const bool more = t + 1 < g.nsteps;
+        {
+            const size_t a_base = (size_t)(g.first_i - (more ? t + 1 : t)) * g.a_vstride;
 #pragma unroll
-            for (int ax = MAXD - 1; ax >= 0; --ax) {
+            for (int e = 0; e < HL_EPT; ++e)
+                next[e] = (more && have[e] && (g.coeff_scalar ? (threadIdx.x + e * blockDim.x == 0) : in_c[e]))
+                              ? E::ld(a, ap, a_base + aoff[e])
+                              : E::zero();
+        }
+        const double* src_l = lds + (size_t)((t + 1) & 1u) * E::W * HL_MAX;  // written by step t-1
+        double* dst_l = lds + (size_t)(t & 1u) * E::W * HL_MAX;
+        const bool last = t + 1 == g.nsteps;
+#pragma unroll
+        for (int e = 0; e < HL_EPT; ++e) {
+            if (!have[e]) continue;
+            bool in_o = true, in_p = true, in_r = true;
+#pragma unroll
+            for (int ax = 0; ax < MAXD; ++ax) {
                 if (ax < g.nd) {
-                    unsigned d = os[ax];
-                    unsigned k = (unsigned)(r % d);
-                    r /= d;
-                    if (k >= sh[ax]) in_p = false;
-                    if (k >= rs[ax]) in_r = false;
-                    if (k >= g.oc[ax]) in_c = false;
-                    const size_t ss = t == 0 ? g.rstr0[ax] : g.fstr[ax];
-                    if (ax == g.w) {
-                        kw = k;
-                        wstr = ss;
-                    }
-                    soff += (size_t)k * ss;
-                    doff += (size_t)k * g.fstr[ax];
-                    aoff += (size_t)k * g.astr[ax];
+                    if (kk[e][ax] >= os[ax]) in_o = false;
+                    if (kk[e][ax] >= sh[ax]) in_p = false;
+                    if (kk[e][ax] >= rs[ax]) in_r = false;
                 }
             }
+            if (!in_o) continue;
+            const unsigned kw = kk[e][g.w];
             V p = E::zero();
             if (in_p) {
-                if (kw >= 1 && kw - 1 < upper) p = E::mul(E::ld(src, sp, soff - wstr), mv);
+                if (kw >= 1 && kw - 1 < upper)
+                    p = E::mul(t == 0 ? E::ld(res0, rp0, roff0[e] - wstr_0) : E::ld(src_l, HL_MAX, foff[e] - wstr_f), mv);
                 if (!g.c_zero) {
                     p = E::add(E::zero(), p);
                     if (in_r) {
-                        V x = E::ld(src, sp, soff);
+                        V x = t == 0 ? E::ld(res0, rp0, roff0[e]) : E::ld(src_l, HL_MAX, foff[e]);
                         p = E::add(p, g.c_one ? x : E::mul(cv, x));
                     }
                 }
@@ -882,24 +925,28 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             V v;
             if (g.coeff_scalar) {
                 v = p;
-                if (lin == 0) v = E::add(p, E::ld(a, ap, a_base));
+                if (threadIdx.x + e * blockDim.x == 0) v = E::add(p, coef[e]);
             } else {
                 v = E::zero();
                 if (in_p) v = E::add(v, p);
-                if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+                if (in_c[e]) v = E::add(v, coef[e]);
             }
-            E::st(dst, plane, doff, v);
+            if (last) E::st(out, plane, foff[e], v);
+            else E::st(dst_l, HL_MAX, foff[e], v);
         }
 #pragma unroll
+        for (int e = 0; e < HL_EPT; ++e) coef[e] = next[e];
+#pragma unroll
         for (int ax = 0; ax < MAXD; ++ax) rs[ax] = os[ax];
-        __syncthreads();  // step t's writes (global, this block only) are visible to step t+1
+        __syncthreads();
     }
 }
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
-                              double* tmp, size_t plane, const HornerLoopArgs& args) {
-    if (args.nsteps == 0) return;
-    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(1), dim3(1024), 0, st, res0, res0_plane, a, a_plane, out, tmp, plane, args);
+                              size_t plane, const HornerLoopArgs& args, unsigned fn) {
+    if (args.nsteps == 0 || fn == 0) return;
+    unsigned threads = std::min<unsigned>(1024, (fn + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(1), dim3(threads), 0, st, res0, res0_plane, a, a_plane, out, plane, args, fn);
 }
 
 __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {

@@ -83,8 +83,8 @@ struct HornerArgs {
 };
 
 // ALL remaining Horner steps of a small subst_var in one single-workgroup launch: the per-step shapes are
-// re-derived on the device (they depend on shapes only), intermediates ping-pong between `out` and `tmp` in the
-// strides of the FINAL shape, __syncthreads() separates the steps.  Same per-element operations as HornerArgs.
+// re-derived on the device (they depend on shapes only), intermediates ping-pong in LDS in the strides of the
+// FINAL shape, __syncthreads() separates the steps.  Same per-element operations as HornerArgs.
 struct HornerLoopArgs {
     int nd;                    // collapsed rank (axes where the final shape is > 1)
     unsigned deg[MAXD];        // degrees_p1, clamped to 2^31
@@ -152,8 +152,9 @@ struct K {
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb);
     static void horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
                               size_t out_plane, const HornerArgs& args);
+    static constexpr unsigned HORNER_LOOP_MAX = 2048;  // largest final tensor (elements) of horner_linear_loop
     static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
-                                   double* out, double* tmp, size_t plane, const HornerLoopArgs& args);
+                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned fn);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements
