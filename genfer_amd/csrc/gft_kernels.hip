@@ -853,10 +853,8 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             kk[e][ax] = k;
         }
     }
-    unsigned rs[MAXD], sh[MAXD], os[MAXD];
-#pragma unroll
-    for (int ax = 0; ax < MAXD; ++ax) rs[ax] = ax < g.nd ? g.rs0[ax] : 1;
     const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w];
+    const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
     V coef[HL_EPT];
     {
         const size_t a_base = (size_t)g.first_i * g.a_vstride;
@@ -865,23 +863,32 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             coef[e] = (have[e] && (g.coeff_scalar ? (threadIdx.x + e * blockDim.x == 0) : in_c[e])) ? E::ld(a, ap, a_base + aoff[e])
                                                                                                   : E::zero();
     }
-    for (unsigned t = 0; t < g.nsteps; ++t) {
-        unsigned upper = 0;
+    // Off the substitution axis the boxes are rs0 at step 0 and max(rs0, oc) — the final extents — from step 1 on,
+    // so after step 0 only the position along w decides membership: three scalar compares per element and step.
+    bool off_p0[HL_EPT], off_r0[HL_EPT], off_o0[HL_EPT];  // step 0, axes other than w
+    unsigned kw[HL_EPT];
+#pragma unroll
+    for (int e = 0; e < HL_EPT; ++e) {
+        off_p0[e] = off_r0[e] = off_o0[e] = true;
+        kw[e] = 0;
 #pragma unroll
         for (int ax = 0; ax < MAXD; ++ax) {
             if (ax < g.nd) {
-                sh[ax] = rs[ax];
                 if (ax == g.w) {
-                    sh[ax] = rs[ax] + 1 < g.deg[ax] ? rs[ax] + 1 : g.deg[ax];
-                    upper = sh[ax] - 1 < rs[ax] ? sh[ax] - 1 : rs[ax];
+                    kw[e] = kk[e][ax];
+                } else {
+                    unsigned r0 = g.rs0[ax], o0 = (!g.coeff_scalar && g.oc[ax] > r0) ? g.oc[ax] : r0;
+                    if (kk[e][ax] >= r0) off_p0[e] = off_r0[e] = false;
+                    if (kk[e][ax] >= o0) off_o0[e] = false;
                 }
-                unsigned o = sh[ax];
-                if (!g.coeff_scalar && g.oc[ax] > o) o = g.oc[ax];
-                os[ax] = o;
-            } else {
-                sh[ax] = os[ax] = 1;
             }
         }
+    }
+    unsigned rsw = g.rs0[g.w];
+    for (unsigned t = 0; t < g.nsteps; ++t) {
+        const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
+        const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
+        const unsigned osw = ocw > shw ? ocw : shw;
         // prefetch the next step's coefficients (independent of this step's result)
         V next[HL_EPT];
         const bool more = t + 1 < g.nsteps;
@@ -899,25 +906,19 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) {
             if (!have[e]) continue;
-            bool in_o = true, in_p = true, in_r = true;
-#pragma unroll
-            for (int ax = 0; ax < MAXD; ++ax) {
-                if (ax < g.nd) {
-                    if (kk[e][ax] >= os[ax]) in_o = false;
-                    if (kk[e][ax] >= sh[ax]) in_p = false;
-                    if (kk[e][ax] >= rs[ax]) in_r = false;
-                }
-            }
+            const bool first = t == 0;
+            const bool in_o = (first ? off_o0[e] : true) && kw[e] < osw;
             if (!in_o) continue;
-            const unsigned kw = kk[e][g.w];
+            const bool in_p = (first ? off_p0[e] : true) && kw[e] < shw;
+            const bool in_r = (first ? off_r0[e] : true) && kw[e] < rsw;
             V p = E::zero();
             if (in_p) {
-                if (kw >= 1 && kw - 1 < upper)
-                    p = E::mul(t == 0 ? E::ld(res0, rp0, roff0[e] - wstr_0) : E::ld(src_l, HL_MAX, foff[e] - wstr_f), mv);
+                if (kw[e] >= 1 && kw[e] - 1 < upper)
+                    p = E::mul(first ? E::ld(res0, rp0, roff0[e] - wstr_0) : E::ld(src_l, HL_MAX, foff[e] - wstr_f), mv);
                 if (!g.c_zero) {
                     p = E::add(E::zero(), p);
                     if (in_r) {
-                        V x = t == 0 ? E::ld(res0, rp0, roff0[e]) : E::ld(src_l, HL_MAX, foff[e]);
+                        V x = first ? E::ld(res0, rp0, roff0[e]) : E::ld(src_l, HL_MAX, foff[e]);
                         p = E::add(p, g.c_one ? x : E::mul(cv, x));
                     }
                 }
@@ -936,8 +937,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
         }
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) coef[e] = next[e];
-#pragma unroll
-        for (int ax = 0; ax < MAXD; ++ax) rs[ax] = os[ax];
+        rsw = osw;
         __syncthreads();
     }
 }
