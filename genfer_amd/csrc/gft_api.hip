@@ -148,6 +148,29 @@ static void read_back(void* dst, const void* dev_src, size_t bytes) {
 // Host round trips through the mailbox (gft_kernels.hpp): next_mail() hands the kernel its slot + sequence number,
 // wait_mail() polls the sequence word.  The poll is bounded: every ~20 us it asks the stream for errors, and a
 // stream that went idle without publishing is an error (a kernel died).
+// GFT_TRACE_SCANS=1: histogram of extract_linear device scans by call site and tensor size, printed at exit
+struct ScanTrace {
+    bool on = getenv("GFT_TRACE_SCANS") != nullptr;
+    const char* ctx = "api";
+    std::map<std::string, size_t> counts;
+    void hit(size_t numel, size_t nd) {
+        if (!on) return;
+        char key[128];
+        snprintf(key, sizeof key, "%s numel<=%zu nd=%zu", ctx, (size_t)1 << (numel <= 1 ? 0 : (64 - __builtin_clzll(numel - 1))), nd);
+        counts[key]++;
+    }
+    ~ScanTrace() {
+        if (!on) return;
+        for (auto& kv : counts) fprintf(stderr, "[gft scans] %-40s %zu\n", kv.first.c_str(), kv.second);
+    }
+};
+static ScanTrace g_scan_trace;
+struct ScanCtx {
+    const char* prev;
+    explicit ScanCtx(const char* c) : prev(g_scan_trace.ctx) { g_scan_trace.ctx = c; }
+    ~ScanCtx() { g_scan_trace.ctx = prev; }
+};
+
 static Mailbox next_mail() {
     Mailbox mb;
     mb.payload = R.d_mail;
@@ -199,6 +222,11 @@ struct gft_poly {
     bool lazy_lin = false;
     double cv1[2] = {0, 0};
     size_t lazy_var = 0;
+    // element 0 of a device tensor (numel > 1) when the host happens to know it: after a constant_term() read-back,
+    // and after `p - constant_term(p)` (x - x = +0 exactly, F64) — the interpreter does exactly this pair on every
+    // Subst node, and subst_var then needs no device scan to learn that a 2-element substitution has no constant
+    mutable bool c0_known = false;
+    mutable double c0[2] = {0, 0};
 };
 
 namespace {
@@ -345,6 +373,11 @@ struct Ops {
             out[1] = p.cv[1];
             return;
         }
+        if (p.c0_known) {
+            out[0] = p.c0[0];
+            out[1] = p.c0[1];
+            return;
+        }
         double tmp[2] = {0, 0};
         R.stats[1]++;
         peek(tmp, dp<E>(p), p.numel, W);
@@ -354,6 +387,10 @@ struct Ops {
             p.cached = true;
             p.cv[0] = tmp[0];
             p.cv[1] = tmp[1];
+        } else {
+            p.c0_known = true;
+            p.c0[0] = tmp[0];
+            p.c0[1] = tmp[1];
         }
     }
     static bool val_is_zero(const double v[2]) { return W == 1 ? v[0] == 0.0 : (v[0] == 0.0 && v[1] == 0.0); }
@@ -587,6 +624,11 @@ struct Ops {
             P out = make(self.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
                              subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
+            if (W == 1 && subtract && self.c0_known && other.cached && std::isfinite(self.c0[0]) &&
+                std::memcmp(&self.c0[0], &other.cv[0], sizeof(double)) == 0) {
+                out.c0_known = true;  // x - x = +0 exactly: the device computes it, the host merely knows the outcome
+                out.c0[0] = out.c0[1] = 0.0;
+            }
             return out;
         }
         if (self.numel == 1) {
@@ -636,6 +678,7 @@ struct Ops {
         Mailbox mb = next_mail();
         K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, mb);  // one launch (state words 8, 9), result by mailbox
         R.stats[0]++;
+        g_scan_trace.hit(p.numel, keep.size());
         double res[5];
         wait_mail(mb, res, 5);
         unsigned got = (unsigned)res[0];
@@ -881,11 +924,13 @@ struct Ops {
             return map_copy(self, OP_LMUL_S, c);
         }
         size_t v;
+        ScanCtx sc_self("mul.self");
         if (extract_linear(self, c, m, &v)) {
             Dims sh = other.shape;
             sh[v] = std::min(deg[v], sh[v] + 1);
             return mul_linear(other, c, m, v, sh, deg);
         }
+        ScanCtx sc_other("mul.other");
         if (extract_linear(other, c, m, &v)) {
             Dims sh = self.shape;
             sh[v] = std::min(deg[v], sh[v] + 1);
@@ -1200,12 +1245,27 @@ struct Ops {
         Dims deg = min_degrees(a, subst);
         if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
         double c[2], m[2];
-        size_t w;
-        if (extract_linear(subst, c, m, &w)) {
+        size_t w = 0;
+        ScanCtx sc_subst("subst_var.subst");
+        // A 2-element tensor is linear by structure; if the host also knows its constant term (see gft_poly::c0_known)
+        // the verdict needs no device scan.  m stays on the device (the power table reads it from there).
+        bool have_lin = false, m_known = true;
+        if (subst.buf && !subst.buf->lin_state && subst.numel == 2 && subst.c0_known && val_is_zero(subst.c0)) {
+            for (size_t ax = 0; ax < subst.shape.size(); ++ax)
+                if (subst.shape[ax] == 2) w = ax;
+            if (v == w) {
+                c[0] = subst.c0[0];
+                c[1] = subst.c0[1];
+                have_lin = true;
+                m_known = false;
+            }
+        }
+        if (!have_lin) have_lin = extract_linear(subst, c, m, &w);
+        if (have_lin) {
             if (v == w && val_is_zero(c)) {
                 Dims lens = a.shape;
                 for (size_t i = 0; i < lens.size(); ++i) lens[i] = std::min(lens[i], deg[i]);
-                if (val_is_one(m)) return lead_block(a, lens, deg);  // powers of one: x * 1 == x, nothing to compute
+                if (m_known && val_is_one(m)) return lead_block(a, lens, deg);  // powers of one: x * 1 == x, nothing to compute
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 Dims sst = c_strides(subst.shape);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
@@ -1232,9 +1292,33 @@ struct Ops {
             std::vector<long long> shift(out.size(), 0);
             shift[v] = (long long)i;
             P coeff = gather(ca, out, deg, shift, cshape);
-            res = addsub(mul(res, subst), coeff, false);
+            res = addsub(R.fuse_horner ? mul_horner(res, subst) : mul(res, subst), coeff, false);
         }
         return res;
+    }
+    // res * subst inside the Horner loop.  The generic mul first asks whether `res` is linear (device scan + host
+    // round trip on every step, because res is new each time) before it looks at `subst`, whose verdict is
+    // memoised.  Multiplying the other way round gives the same products and sums (see horner_linear_step), so
+    // here only subst's verdict is consulted; shapes with a 1-element operand keep the generic value dispatch.
+    static P mul_horner(const P& res, const P& subst) {
+        if (res.numel == 1 || subst.numel == 1) return mul(res, subst);
+        P self = res, other = subst;
+        Dims deg = min_degrees(self, other);
+        broadcast(self, other);
+        Dims shape = sum_shape(self, other);
+        self = truncate_degrees(self, deg);
+        other = truncate_degrees(other, deg);
+        if (self.numel == 1 || other.numel == 1) return mul(res, subst);
+        double c[2], m[2];
+        size_t v;
+        if (extract_linear(other, c, m, &v)) {
+            Dims sh = self.shape;
+            sh[v] = std::min(deg[v], sh[v] + 1);
+            return mul_linear(self, c, m, v, sh, deg);
+        }
+        P out = make(shape, deg);
+        conv(view(self), view(other), view(out), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
+        return out;
     }
     // res * (c + m*eps_w) + a[.., i, ..] in one launch (k_horner_linear), element for element the sequence
     // mul -> mul_linear -> mul_var / scale / add -> add that the generic loop above performs.  The generic mul

@@ -328,6 +328,14 @@ def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP
                     sdeg = list(deg)
                     os_, gs_ = O.new(mk(lin), sdeg), G.new(mk(lin), sdeg)
                     check(op.subst_var(v, os_), gp.subst_var(v, gs_))
+                    # the interpreter's Subst evaluation: read the constant term, subtract it, substitute — the
+                    # host then knows element 0 of the device tensor (x - x = +0) and skips the device scan
+                    oc0, gc0 = os_.constant_term(), gs_.constant_term()
+                    assert oc0 == gc0
+                    oz, gz = os_ - O.from_scalar(oc0), gs_ - G.from_scalar(gc0)
+                    check(oz, gz)
+                    check(op.subst_var(v, oz), gp.subst_var(v, gz))
+                    check(op.subst_var(w, oz), gp.subst_var(w, gz))
     genfer_amd.lib().gft_set_option(b"horner_loop_max", 2048.0)
 
 
