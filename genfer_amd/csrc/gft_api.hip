@@ -533,6 +533,14 @@ struct Ops {
         return lead_block(p, lens, nd);
     }
     static P map_copy(const P& p, int op, const double* s) {  // fresh tensor = f(p) elementwise
+        if (p.numel == 1 && p.cached && !p.buf && (op == OP_LMUL_S || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG)) {
+            // both operands are host-cached scalars: they travel as kernel arguments, nothing is materialised first
+            P out = make(p.shape, p.deg);
+            int kind = op == OP_LMUL_S ? IMM_LMUL : (op == OP_MUL_S ? IMM_MUL : (op == OP_DIV_S ? IMM_DIV : IMM_NEG));
+            Scalar2 b{s ? s[0] : 0.0, (s && W == 2) ? s[1] : 0.0};
+            K<E>::scalar_imm(R.stream, kind, Scalar2{p.cv[0], p.cv[1]}, b, dp<E>(out), out.numel);
+            return out;
+        }
         std::vector<long long> shift(p.shape.size(), 0);
         return gather(p, p.shape, p.deg, shift, p.shape, op, s);
     }
@@ -622,6 +630,11 @@ struct Ops {
             if (!self.buf && self.lazy_lin && other.cached && !other.buf && self.deg == rd && lazy_zero_plus(self, other, subtract, &self))
                 return self;
             P out = make(self.shape, rd);
+            if (self.numel == 1 && self.cached && !self.buf && other.cached && !other.buf) {
+                K<E>::scalar_imm(R.stream, subtract ? IMM_SUB : IMM_ADD, Scalar2{self.cv[0], self.cv[1]},
+                                 Scalar2{other.cv[0], other.cv[1]}, dp<E>(out), out.numel);
+                return out;
+            }
             K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
                              subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
             if (W == 1 && subtract && self.c0_known && other.cached && std::isfinite(self.c0[0]) &&

@@ -208,6 +208,26 @@ __global__ void k_set_small(double* p, size_t plane, unsigned n, Scalar2 v0, Sca
     if (n > 1) E::st(p, plane, 1, E::from(v1));
 }
 template <class E>
+__global__ void k_scalar_imm(int kind, Scalar2 a, Scalar2 b, double* out, size_t plane) {
+    typedef typename E::V V;
+    const V x = E::from(a), y = E::from(b);
+    V v;
+    switch (kind) {
+        case IMM_LMUL: v = E::mul(y, x); break;
+        case IMM_MUL: v = E::mul(x, y); break;
+        case IMM_DIV: v = E::div(x, y); break;
+        case IMM_NEG: v = E::neg(x); break;
+        case IMM_ADD: v = E::add(x, y); break;
+        case IMM_SUB: v = E::sub(x, y); break;
+        default: v = E::neg(E::sub(x, y)); break;
+    }
+    E::st(out, plane, 0, v);
+}
+template <class E>
+void K<E>::scalar_imm(hipStream_t st, int kind, Scalar2 a, Scalar2 b, double* out, size_t out_plane) {
+    hipLaunchKernelGGL(k_scalar_imm<E>, dim3(1), dim3(1), 0, st, kind, a, b, out, out_plane);
+}
+template <class E>
 void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1) {
     hipLaunchKernelGGL(k_set_small<E>, dim3(1), dim3(1), 0, st, p, plane, n, v0, v1);
 }

@@ -31,6 +31,7 @@ enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB 
 enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_DIV_S = 4, MAP_LMUL_S = 5 };
 enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1, FIRST_SUB_NEG_ALL = 2 };
 enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
+enum ImmOp { IMM_LMUL = 0 /* b*a */, IMM_MUL = 1 /* a*b */, IMM_DIV = 2, IMM_NEG = 3, IMM_ADD = 4, IMM_SUB = 5, IMM_SUB_NEG = 6 /* -(a-b) */ };
 enum ScalarOp { SC_EXP = 0, SC_LOG = 1, SC_DIV = 2 };
 enum TableOp { TAB_DERIV = 0, TAB_COEFF = 1, TAB_POW = 2, TAB_INDEX = 3 };
 
@@ -142,6 +143,8 @@ struct K {
     static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,
                            int op, const double* s, size_t s_plane, Scalar2 s_value);  // s == nullptr: use s_value
     // p[0] = v0, p[1] = v1 (if n == 2): constants and `var` constructors without a host->device copy
+    // out[0] = a (op) b for two immediates (both operands are lazy host-cached scalars): kind = ImmOp
+    static void scalar_imm(hipStream_t st, int kind, Scalar2 a, Scalar2 b, double* out, size_t out_plane);
     static void set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1);
     // extract_linear (mt:275-294) for all axes in ONE launch.  Bit a of the mask survives iff the tensor is
     // "linear in axis a" (every non-zero entry sits at index 0 or at e_a); blocks AND their verdicts into
