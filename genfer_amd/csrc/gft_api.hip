@@ -63,7 +63,7 @@ struct Runtime {
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
-    size_t horner_loop_max = 2048;  // elements of the final tensor up to which the whole Horner loop is one launch
+    size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
@@ -1354,7 +1354,7 @@ struct Ops {
                 for (size_t ax = 0; ax < nd; ++ax) fs[ax] = std::max(fs[ax], oc[ax]);
         }
         const size_t fn = prod(fs);
-        if (fn > R.horner_loop_max || fn > K<E>::HORNER_LOOP_MAX) return false;
+        if (fn > R.horner_loop_max || fs[w] > K<E>::HORNER_LINE_MAX || fn / fs[w] > 0x7fffffffu) return false;
         Dims keep = collapse_mask({&fs}, false);
         if (keep.size() > (size_t)MAXD) return false;
         P out = make(fs, deg);
@@ -1367,6 +1367,7 @@ struct Ops {
             size_t ax = keep[j];
             g.deg[j] = (unsigned)std::min<size_t>(deg[ax], 0x7fffffffu);
             g.rs0[j] = (unsigned)res.shape[ax];
+            g.fs[j] = (unsigned)fs[ax];
             g.oc[j] = (unsigned)oc[ax];
             g.rstr0[j] = rst[ax];
             g.fstr[j] = fst[ax];
@@ -1382,7 +1383,8 @@ struct Ops {
         g.c_zero = val_is_zero(c) ? 1 : 0;
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
-        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)fn);
+        g.lw_pad = (unsigned)((fs[w] + 7) / 8 * 8);
+        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]));
         *result = out;
         return true;
     }

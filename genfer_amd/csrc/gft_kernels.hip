@@ -833,112 +833,84 @@ void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, co
                        args, total);
 }
 
-// Thread -> element mapping is fixed over the steps (positions of the FINAL shape, <= HL_EPT per thread); a step only
-// changes which positions are inside the current boxes.  Intermediates ping-pong in LDS, the coefficient of the
-// next step is prefetched while the current one is computed, the last step writes to global memory.
-constexpr int HL_EPT = 2;          // elements per thread: final tensors up to 2048 elements
-constexpr int HL_MAX = 1024 * HL_EPT;
+// The Horner recursion out[k] = f(res[k], res[k - e_w], coeff[k]) couples positions along the substitution axis w
+// only, so every LINE along w (one position on all other axes) runs ALL steps on its own: one workgroup per line,
+// no synchronisation between workgroups, intermediates ping-pong in LDS, the next step's coefficient is prefetched
+// while the current one is computed, the last step writes to global memory.  A step only changes which positions
+// along w are inside the current boxes (off the axis the boxes are rs0 at step 0 and the final extents afterwards).
+constexpr int HL_EPT = 2;  // positions along w per thread: lines up to 2048 long
 template <class E>
 __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __restrict__ res0, size_t rp0,
                                                              const double* __restrict__ a, size_t ap,
-                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g,
-                                                             unsigned fn) {
+                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g) {
     typedef typename E::V V;
-    __shared__ double lds[2 * E::W * HL_MAX];  // [buffer][plane][fn]
+    extern __shared__ double hl_lds[];  // [buffer][plane][lw_pad]
+    const unsigned lw = g.fs[g.w], lw_pad = g.lw_pad;
     const V cv = E::from(g.c), mv = E::from(g.m);
-    // fixed positions of this thread
-    unsigned kk[HL_EPT][MAXD];
-    size_t foff[HL_EPT], aoff[HL_EPT], roff0[HL_EPT];
-    bool have[HL_EPT], in_c[HL_EPT];
-#pragma unroll
-    for (int e = 0; e < HL_EPT; ++e) {
-        unsigned lin = threadIdx.x + e * blockDim.x;
-        have[e] = lin < fn;
-        foff[e] = lin;
-        aoff[e] = 0;
-        roff0[e] = 0;
-        in_c[e] = true;
-        // decode lin in the final shape: fstr are its strides (row-major), so k = (lin / fstr) % extent
-        size_t r = lin;
-#pragma unroll
-        for (int ax = 0; ax < MAXD; ++ax) {
-            unsigned k = 0;
-            if (ax < g.nd) {
-                k = (unsigned)(r / g.fstr[ax]);
-                r -= (size_t)k * g.fstr[ax];
-                if (k >= g.oc[ax]) in_c[e] = false;
-                aoff[e] += (size_t)k * g.astr[ax];
-                roff0[e] += (size_t)k * g.rstr0[ax];
-            }
-            kk[e][ax] = k;
-        }
-    }
-    const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w];
-    const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
-    V coef[HL_EPT];
+    // this block's line: position on the axes other than w
+    size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
+    bool off_p0 = true, off_o0 = true, in_c_b = true;  // step 0 / coefficient box, axes other than w
     {
-        const size_t a_base = (size_t)g.first_i * g.a_vstride;
+        size_t r = blockIdx.x;
 #pragma unroll
-        for (int e = 0; e < HL_EPT; ++e)
-            coef[e] = (have[e] && (g.coeff_scalar ? (threadIdx.x + e * blockDim.x == 0) : in_c[e])) ? E::ld(a, ap, a_base + aoff[e])
-                                                                                                  : E::zero();
-    }
-    // Off the substitution axis the boxes are rs0 at step 0 and max(rs0, oc) — the final extents — from step 1 on,
-    // so after step 0 only the position along w decides membership: three scalar compares per element and step.
-    bool off_p0[HL_EPT], off_r0[HL_EPT], off_o0[HL_EPT];  // step 0, axes other than w
-    unsigned kw[HL_EPT];
-#pragma unroll
-    for (int e = 0; e < HL_EPT; ++e) {
-        off_p0[e] = off_r0[e] = off_o0[e] = true;
-        kw[e] = 0;
-#pragma unroll
-        for (int ax = 0; ax < MAXD; ++ax) {
-            if (ax < g.nd) {
-                if (ax == g.w) {
-                    kw[e] = kk[e][ax];
-                } else {
-                    unsigned r0 = g.rs0[ax], o0 = (!g.coeff_scalar && g.oc[ax] > r0) ? g.oc[ax] : r0;
-                    if (kk[e][ax] >= r0) off_p0[e] = off_r0[e] = false;
-                    if (kk[e][ax] >= o0) off_o0[e] = false;
-                }
+        for (int ax = MAXD - 1; ax >= 0; --ax) {
+            if (ax < g.nd && ax != g.w) {
+                unsigned d = g.fs[ax];
+                unsigned k = (unsigned)(r % d);
+                r /= d;
+                foff_b += (size_t)k * g.fstr[ax];
+                aoff_b += (size_t)k * g.astr[ax];
+                roff0_b += (size_t)k * g.rstr0[ax];
+                unsigned r0 = g.rs0[ax], o0 = (!g.coeff_scalar && g.oc[ax] > r0) ? g.oc[ax] : r0;
+                if (k >= r0) off_p0 = false;
+                if (k >= o0) off_o0 = false;
+                if (k >= g.oc[ax]) in_c_b = false;
             }
         }
+    }
+    const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w], wstr_a = g.astr[g.w];
+    const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
+    unsigned kw[HL_EPT];
+    bool have[HL_EPT], takes_c[HL_EPT];
+    V coef[HL_EPT];
+#pragma unroll
+    for (int e = 0; e < HL_EPT; ++e) {
+        kw[e] = threadIdx.x + e * blockDim.x;
+        have[e] = kw[e] < lw;
+        takes_c[e] = have[e] && (g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : (in_c_b && kw[e] < g.oc[g.w]));
+        coef[e] = takes_c[e] ? E::ld(a, ap, (size_t)g.first_i * g.a_vstride + aoff_b + (size_t)kw[e] * wstr_a) : E::zero();
     }
     unsigned rsw = g.rs0[g.w];
     for (unsigned t = 0; t < g.nsteps; ++t) {
         const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
         const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
         const unsigned osw = ocw > shw ? ocw : shw;
-        // prefetch the next step's coefficients (independent of this step's result)
         V next[HL_EPT];
         const bool more = t + 1 < g.nsteps;
         {
-            const size_t a_base = (size_t)(g.first_i - (more ? t + 1 : t)) * g.a_vstride;
+            const size_t a_base = (size_t)(g.first_i - (more ? t + 1 : t)) * g.a_vstride + aoff_b;
 #pragma unroll
             for (int e = 0; e < HL_EPT; ++e)
-                next[e] = (more && have[e] && (g.coeff_scalar ? (threadIdx.x + e * blockDim.x == 0) : in_c[e]))
-                              ? E::ld(a, ap, a_base + aoff[e])
-                              : E::zero();
+                next[e] = (more && takes_c[e]) ? E::ld(a, ap, a_base + (size_t)kw[e] * wstr_a) : E::zero();
         }
-        const double* src_l = lds + (size_t)((t + 1) & 1u) * E::W * HL_MAX;  // written by step t-1
-        double* dst_l = lds + (size_t)(t & 1u) * E::W * HL_MAX;
-        const bool last = t + 1 == g.nsteps;
+        const double* src_l = hl_lds + (size_t)((t + 1) & 1u) * E::W * lw_pad;  // written by step t-1
+        double* dst_l = hl_lds + (size_t)(t & 1u) * E::W * lw_pad;
+        const bool last = t + 1 == g.nsteps, first = t == 0;
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) {
             if (!have[e]) continue;
-            const bool first = t == 0;
-            const bool in_o = (first ? off_o0[e] : true) && kw[e] < osw;
+            const bool in_o = (first ? off_o0 : true) && kw[e] < osw;
             if (!in_o) continue;
-            const bool in_p = (first ? off_p0[e] : true) && kw[e] < shw;
-            const bool in_r = (first ? off_r0[e] : true) && kw[e] < rsw;
+            const bool in_p = (first ? off_p0 : true) && kw[e] < shw;
+            const bool in_r = (first ? off_p0 : true) && kw[e] < rsw;
             V p = E::zero();
             if (in_p) {
                 if (kw[e] >= 1 && kw[e] - 1 < upper)
-                    p = E::mul(first ? E::ld(res0, rp0, roff0[e] - wstr_0) : E::ld(src_l, HL_MAX, foff[e] - wstr_f), mv);
+                    p = E::mul(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
                 if (!g.c_zero) {
                     p = E::add(E::zero(), p);
                     if (in_r) {
-                        V x = first ? E::ld(res0, rp0, roff0[e]) : E::ld(src_l, HL_MAX, foff[e]);
+                        V x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
                         p = E::add(p, g.c_one ? x : E::mul(cv, x));
                     }
                 }
@@ -946,14 +918,14 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             V v;
             if (g.coeff_scalar) {
                 v = p;
-                if (threadIdx.x + e * blockDim.x == 0) v = E::add(p, coef[e]);
+                if (blockIdx.x == 0 && kw[e] == 0) v = E::add(p, coef[e]);
             } else {
                 v = E::zero();
                 if (in_p) v = E::add(v, p);
-                if (in_c[e]) v = E::add(v, coef[e]);
+                if (takes_c[e]) v = E::add(v, coef[e]);
             }
-            if (last) E::st(out, plane, foff[e], v);
-            else E::st(dst_l, HL_MAX, foff[e], v);
+            if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
+            else E::st(dst_l, lw_pad, kw[e], v);
         }
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) coef[e] = next[e];
@@ -963,10 +935,12 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
 }
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
-                              size_t plane, const HornerLoopArgs& args, unsigned fn) {
-    if (args.nsteps == 0 || fn == 0) return;
-    unsigned threads = std::min<unsigned>(1024, (fn + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(1), dim3(threads), 0, st, res0, res0_plane, a, a_plane, out, plane, args, fn);
+                              size_t plane, const HornerLoopArgs& args, unsigned lines) {
+    if (args.nsteps == 0 || lines == 0) return;
+    const unsigned lw = args.fs[args.w];
+    unsigned threads = std::min<unsigned>(1024, (lw + 63) / 64 * 64);
+    size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
+    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args);
 }
 
 __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {

@@ -83,13 +83,16 @@ struct HornerArgs {
     int c_zero, c_one, coeff_scalar;
 };
 
-// ALL remaining Horner steps of a small subst_var in one single-workgroup launch: the per-step shapes are
-// re-derived on the device (they depend on shapes only), intermediates ping-pong in LDS in the strides of the
-// FINAL shape, __syncthreads() separates the steps.  Same per-element operations as HornerArgs.
+// ALL remaining Horner steps of a subst_var with a linear substitution in ONE launch: the recursion couples
+// positions along the substitution axis w only, so each line along w is one workgroup that runs every step on
+// its own (per-step shapes re-derived on the device, intermediates in LDS).  Same per-element operations as
+// HornerArgs.
 struct HornerLoopArgs {
     int nd;                    // collapsed rank (axes where the final shape is > 1)
     unsigned deg[MAXD];        // degrees_p1, clamped to 2^31
     unsigned rs0[MAXD];        // shape of the incoming accumulator
+    unsigned fs[MAXD];         // final shape
+    unsigned lw_pad;           // LDS line pitch (>= fs[w])
     unsigned oc[MAXD];         // box of a coefficient slab
     size_t rstr0[MAXD];        // strides of the incoming accumulator (compact)
     size_t fstr[MAXD];         // strides of the final shape (all in-kernel intermediates use these)
@@ -155,9 +158,9 @@ struct K {
     static void linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsigned* state, const Mailbox& mb);
     static void horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
                               size_t out_plane, const HornerArgs& args);
-    static constexpr unsigned HORNER_LOOP_MAX = 2048;  // largest final tensor (elements) of horner_linear_loop
+    static constexpr unsigned HORNER_LINE_MAX = 2048;  // longest line along the substitution axis of horner_linear_loop
     static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
-                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned fn);
+                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements

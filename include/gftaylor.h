@@ -64,7 +64,7 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
 int gft_set_conv_mode(int mode);
 /* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
  * tiled product), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
- * in elements, for which all Horner steps of a linear substitution run in one launch). */
+ * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);

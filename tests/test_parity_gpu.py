@@ -301,7 +301,7 @@ def test_lazy_variables_and_scaled_variables(interval, OTP, GTP, OTPI, GTPI):
                         check(op.subst_var(v, oa), gp.subst_var(v, ga))
 
 
-@pytest.mark.parametrize("loop_max", [1 << 20, 0])
+@pytest.mark.parametrize("loop_max", [1 << 40, 0])
 @pytest.mark.parametrize("interval", [False, True])
 def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP, OTPI, GTPI):
     """subst_var with a linear substitution c + m*eps_w (c != 0 or w != v) runs the fused Horner step
@@ -312,7 +312,7 @@ def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP
     O, G = (OTPI, GTPI) if interval else (OTP, GTP)
     mk = (lambda a: np.stack([a, a + 1e-7])) if interval else (lambda a: a)
     cases = [((5, 4, 6), [7, 6, 8]), ((3, 7), [9, 7]), ((6,), [8]), ((2, 3, 2, 4), [4, 3, 3, 5]), ((4, 1, 5), [6, 4, 5])]
-    # loop_max 2^20: all remaining steps in one single-workgroup launch; 0: one launch per step
+    # loop_max 2^40: all remaining steps in one launch (one workgroup per line); 0: one launch per step
     assert genfer_amd.lib().gft_set_option(b"horner_loop_max", float(loop_max)) == 0
     for shape, deg in cases:
         base = rand(shape, 71, -1.0, 1.0)
@@ -336,7 +336,7 @@ def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP
                     check(oz, gz)
                     check(op.subst_var(v, oz), gp.subst_var(v, gz))
                     check(op.subst_var(w, oz), gp.subst_var(w, gz))
-    genfer_amd.lib().gft_set_option(b"horner_loop_max", 2048.0)
+    genfer_amd.lib().gft_set_option(b"horner_loop_max", float(1 << 40))
 
 
 STAGED_SHAPES = [
