@@ -339,6 +339,22 @@ def test_subst_var_linear_substitution_fused_horner(interval, loop_max, OTP, GTP
     genfer_amd.lib().gft_set_option(b"horner_loop_max", float(1 << 40))
 
 
+def test_subst_var_linear_long_axis_and_wide_tensor(OTP, GTP):
+    """Lines longer than the loop kernel's 2048 fall back to one fused launch per Horner step; a wide tensor
+    (many lines, substitution axis not last => strided lines) stays on the one-launch loop kernel."""
+    base = rand((2100,), 81, -1.0, 1.0) * 0.999 ** np.arange(2100)
+    op, gp = OTP.new(base, [2200]), GTP.new(base, [2200])
+    lin = np.array([0.25, 0.5])
+    check(op.subst_var(0, OTP.new(lin, [2200])), gp.subst_var(0, GTP.new(lin, [2200])))
+    wide = rand((40, 30, 20), 82, -1.0, 1.0)
+    deg = [45, 30, 20]
+    ow, gw = OTP.new(wide, deg), GTP.new(wide, deg)
+    for v, w in ((0, 0), (0, 1), (2, 0), (1, 2)):
+        lin = np.zeros([2 if ax == w else 1 for ax in range(3)])
+        lin.flat[0], lin.flat[1] = -0.5, 1.25
+        check(ow.subst_var(v, OTP.new(lin, deg)), gw.subst_var(v, GTP.new(lin, deg)))
+
+
 STAGED_SHAPES = [
     ((17,), (9,), (20,)),                                  # rank 1: rows only, axis 0 is the staged axis
     ((300,), (300,), (300,)),                              # more than one chunk per row
