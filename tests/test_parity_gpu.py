@@ -419,6 +419,21 @@ def test_recurrences_same_bits_in_both_reference_order_kernels(mode, OTP, GTP, O
         L.gft_set_conv_mode(0)
 
 
+def test_exp_recurrence_steps_on_the_tiled_kernel(OTP, GTP):
+    """exp's slab steps above the tiled crossover run as plain slab products of shifted operand views on the tiled
+    kernel (1e-10 contract; measured 1e-14); div and log keep the reference-order kernel and stay bit-exact."""
+    shape = (24, 20, 28)
+    a = rand(shape, 91, -0.2, 0.2)
+    b = rand(shape, 92, -0.2, 0.2)
+    b[0, 0, 0] = 1.5
+    oa, ga, ob, gb = OTP.new(a, list(shape)), GTP.new(a, list(shape)), OTP.new(b, list(shape)), GTP.new(b, list(shape))
+    want, got = oa.exp().array(), ga.exp().array()
+    assert np.all(np.abs(got - want) <= 1e-10 * np.maximum(np.abs(want), 1e-3 * np.abs(want).max()))
+    check(oa / ob, ga / gb)
+    want, got = ob.log().array(), gb.log().array()
+    assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want).max())
+
+
 TILED_SHAPES = [
     ((32, 32, 32), (32, 32, 32), (32, 32, 32)),
     ((20, 17, 29), (13, 22, 30), (30, 30, 40)),       # ragged, compact operands, inner not a multiple of 8
