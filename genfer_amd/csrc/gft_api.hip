@@ -1583,10 +1583,25 @@ struct Ops {
 
 static Dims dims(const size_t* p, size_t n) { return Dims(p, p + n); }
 
+// GFT_TRACE_API=1: calls per entry point, printed at exit
+struct ApiTrace {
+    bool on = getenv("GFT_TRACE_API") != nullptr;
+    std::map<std::string, size_t> counts;
+    void hit(const char* fn) {
+        if (on) counts[fn]++;
+    }
+    ~ApiTrace() {
+        if (!on) return;
+        for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %zu\n", kv.first.c_str(), kv.second);
+    }
+};
+static ApiTrace g_api_trace;
+
 template <class F>
-static gft_poly* guard(F&& f) {
+static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
         require_ready();
+        g_api_trace.hit(fn);
         return new gft_poly(f());
     } catch (const std::exception& e) {
         g_err = e.what();
@@ -1594,9 +1609,10 @@ static gft_poly* guard(F&& f) {
     }
 }
 template <class F>
-static int guard_int(F&& f) {
+static int guard_int(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
         require_ready();
+        g_api_trace.hit(fn);
         return f();
     } catch (const std::exception& e) {
         g_err = e.what();
