@@ -991,7 +991,13 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
                               size_t plane, const HornerLoopArgs& args, unsigned lines) {
     if (args.nsteps == 0 || lines == 0) return;
     const unsigned lw = args.fs[args.w];
-    unsigned threads = std::min<unsigned>(1024, (lw + 63) / 64 * 64);
+    // one position per thread up to 1024-long lines (measured: two per thread is 10 % slower — the element chains
+    // are not interleaved by the compiler, more waves hide the latency better)
+    static const unsigned per_thread = [] {
+        const char* e = getenv("GFT_HORNER_EPT");  // A/B knob: positions per thread the launch aims for (1 or 2)
+        return (unsigned)(e ? std::max(1, std::min(2, atoi(e))) : 1);
+    }();
+    unsigned threads = std::min<unsigned>(1024, ((lw + per_thread - 1) / per_thread + 63) / 64 * 64);
     size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
     hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args);
 }
