@@ -571,6 +571,46 @@ def test_full_size_c2_properties():
     assert abs(got[0, 0, 1] - (x[0, 0, 0] * y[0, 0, 1] + x[0, 0, 1] * y[0, 0, 0])) <= 1e-15
 
 
+def test_full_size_c4_properties():
+    """BASELINE configs[3] at full size (64^4, the 8-GPU workload) on one GPU: size-independent properties of the
+    tiled result (commutativity, exact power-of-two scaling, corner known answers, slab additivity) and the first
+    leading slab against the reference-order kernel."""
+    shape = (64, 64, 64, 64)
+    x, y = rand(shape, 3), rand(shape, 4)
+    got = _conv_raw_gpu(2, x, y, shape)
+    comm = _conv_raw_gpu(2, y, x, shape)
+    assert np.all(np.abs(got - comm) <= 1e-10 * np.abs(got))
+    assert np.array_equal(_conv_raw_gpu(2, 0.5 * x, y, shape), 0.5 * got)
+    assert got[0, 0, 0, 0] == x[0, 0, 0, 0] * y[0, 0, 0, 0]
+    assert abs(got[0, 0, 0, 1] - (x[0, 0, 0, 0] * y[0, 0, 0, 1] + x[0, 0, 0, 1] * y[0, 0, 0, 0])) <= 1e-15
+    # output sharding (SURVEY 8e): two disjoint slab ranges written into one buffer reproduce the full product
+    z = np.full(shape, np.nan)
+    a = _conv_raw_gpu(2, x, y, shape, slab=(0, 40), z0=z)
+    b = _conv_raw_gpu(2, x, y, shape, slab=(40, 64), z0=a)
+    assert np.all(np.abs(b - got) <= 1e-10 * np.abs(got))
+    # leading slab vs the reference-order kernel (9e9 MACs)
+    want0 = _conv_raw_gpu(3, x, y, shape, slab=(0, 1), z0=np.zeros(shape))[0]
+    assert np.all(np.abs(got[0] - want0) <= 1e-10 * np.abs(want0))
+
+
+def test_many_variables_few_nontrivial_axes(OTP, GTP):
+    """20 variables of which three carry coefficients: unit axes are collapsed on the host, so the kernels see
+    rank 3 (the reference's 8-variable programs have this shape pattern)."""
+    nd = 20
+    shape = [1] * nd
+    shape[2], shape[9], shape[17] = 5, 6, 4
+    deg = [3] * nd
+    deg[2], deg[9], deg[17] = 7, 8, 6
+    x, y = rand(shape, 95, -1, 1), rand(shape, 96, -1, 1)
+    ox, gx, oy, gy = OTP.new(x, deg), GTP.new(x, deg), OTP.new(y, deg), GTP.new(y, deg)
+    check(ox * oy, gx * gy)
+    check(ox + oy, gx + gy)
+    check(ox.derivative(9, 2), gx.derivative(9, 2))
+    check(ox.shift_down(17, 1), gx.shift_down(17, 1))
+    check(ox.subst_var(2, oy), gx.subst_var(2, gy))
+    check((ox * oy) / (oy + OTP.from_scalar(3.0)), (gx * gy) / (gy + GTP.from_scalar(3.0)))
+
+
 @pytest.mark.parametrize("xs,ys,deg", SHAPES)
 def test_observe_step_fused_equals_reference_sequence(OTP, GTP, xs, ys, deg):
     """gft_observe_step (one kernel) == derivative -> truncate -> * var -> * const (three reference calls),
