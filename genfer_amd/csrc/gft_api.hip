@@ -59,7 +59,7 @@ struct Runtime {
     double* h_mail = nullptr;    // mailbox (mapped coherent pinned memory): 8 doubles payload + sequence word
     double* d_mail = nullptr;    // the same slot as the device sees it
     unsigned long long mail_seq = 0;
-    hipEvent_t events[16] = {};
+    hipEvent_t events[64] = {};
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
@@ -1720,7 +1720,7 @@ void gft_pool_stats(size_t out[3]) {
 }
 int gft_event_record(int slot) {
     return guard_int([&] {
-        if (slot < 0 || slot >= 16) throw Error("event slot out of range");
+        if (slot < 0 || slot >= 64) throw Error("event slot out of range");
         HIP_OK(hipEventRecord(R.events[slot], R.stream));
         return 0;
     });
@@ -1728,6 +1728,7 @@ int gft_event_record(int slot) {
 float gft_event_elapsed_ms(int a, int b) {
     try {
         require_ready();
+        if (a < 0 || a >= 64 || b < 0 || b >= 64) throw Error("event slot out of range");
         HIP_OK(hipEventSynchronize(R.events[b]));
         float ms = 0;
         HIP_OK(hipEventElapsedTime(&ms, R.events[a], R.events[b]));

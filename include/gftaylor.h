@@ -58,7 +58,7 @@ void gft_pool_stats(size_t out[3]);
  * 1-element value read-backs, coefficient() read-backs, products on the tiled kernel, on the LDS-staged
  * reference-order kernel, on the one-thread-per-output kernel, reserved, reserved}.  Diagnostics. */
 void gft_op_stats(size_t out[8]);
-/* hipEvent timing on the library's stream: record into slot 0..15, elapsed in ms (syncs on b). */
+/* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
 float gft_event_elapsed_ms(int slot_a, int slot_b);
 /* Which convolution kernel `mul` may use: 0 = auto, 1 = force the simple one-thread-per-output
