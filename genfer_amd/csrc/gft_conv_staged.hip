@@ -39,6 +39,8 @@ struct StagedArgs {
     unsigned long long sub_lo, sub_hi;  // linear output range inside the staged subspace
     unsigned sxa, sxb, sya, syb, na, nb;  // staged extents (S == 1: sxa = sya = na = 1)
     unsigned xcap, ycap;     // LDS plane sizes (doubles) of the x / y regions
+    unsigned batch;          // S == 1: consecutive rows of the LAST outer axis staged per barrier pair (>= 1)
+    unsigned rw;             // S == 1 with inner-from-zero sums: thread groups that split the rows of a batch (>= 1)
 };
 
 template <class E, bool INNER0, int S>
@@ -50,7 +52,14 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
     if (a.guard && *a.guard != a.guard_epoch) return;
     double* xl = smem;                         // [W][xcap]
     double* yl = smem + (size_t)E::W * g.xcap;  // [W][ycap]
-    const unsigned CH = blockDim.x, tid = threadIdx.x;
+    // The block is NT threads: CH outputs x rw "row groups".  The reference forms every row's partial sum from zero
+    // and adds the sums in row order (mt:971-982), so the row sums of a batch are independent: group q computes the
+    // rows t = q, q + rw, .. of the batch for the block's CH outputs, the sums go through LDS and group 0 adds them
+    // in ascending row order — same operations per output, 1/rw of the serial chain (a recurrence row step has 64
+    // outputs and thousands of MACs each: nothing else is parallel).
+    const unsigned NT = blockDim.x, tid = threadIdx.x;
+    const unsigned rw = (S == 1 && INNER0) ? g.rw : 1;
+    const unsigned CH = NT / rw, q = tid / CH, otid = tid - q * CH;
 
     // ---- which outputs --------------------------------------------------------------------------
     const unsigned long long b = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest first
@@ -83,8 +92,25 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
             steps *= cnt[ax];
         }
     }
+    // S == 1: the rows x[.., j, :] for consecutive j of the last outer axis are contiguous in HBM (and so are the
+    // rows y[.., K - j, :]), so `batch` of them are staged per barrier pair — the global-load latency of a step is
+    // paid once per batch instead of once per row (a recurrence slab step is one wave per block: nothing else
+    // hides it).  The rows of a batch are consumed in ascending j, i.e. in the reference's order.
+    const int lastax = (S == 1) ? g.no - 1 : -1;
+    unsigned nbatch = 1, cnt_last = 1, lo_last = 0, K_last = 0;
+#pragma unroll
+    for (int ax = 0; ax < MAXO; ++ax)
+        if (ax == lastax) {
+            cnt_last = cnt[ax];
+            lo_last = lo[ax];
+            K_last = K[ax];
+        }
+    if (lastax >= 0 && cnt_last > 0) {
+        nbatch = (cnt_last + g.batch - 1) / g.batch;
+        steps = steps / cnt_last * nbatch;
+    }
     const unsigned long long first = g.sub_lo + (unsigned long long)chunk * CH;
-    const unsigned long long lin = first + tid;
+    const unsigned long long lin = first + otid;
     const bool active = lin < g.sub_hi;
     unsigned long long last = first + CH - 1;
     if (last > g.sub_hi - 1) last = g.sub_hi - 1;
@@ -133,40 +159,85 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
 
     for (unsigned long long step = 0; step < steps; ++step) {
         // offsets of the staged sub-tensors for the current outer j
-        size_t xoff = 0, yoff = 0;
+        size_t xoff = 0, yoff = 0, xpitch = 0, ypitch = 0;
+        unsigned rows = 1;  // rows of this batch (S == 1)
 #pragma unroll
         for (int ax = 0; ax < MAXO; ++ax) {
             if (ax < g.no) {
-                unsigned j = (ax == 0 && desc_0) ? (lo[ax] + cnt[ax] - 1 - pos[ax]) : (lo[ax] + pos[ax]);
-                xoff += (size_t)j * a.xstr[ax];
-                yoff += (size_t)(K[ax] - j) * a.ystr[ax];
+                if (ax == lastax) {
+                    // descending j0 (log): batches are taken from the top and their rows consumed downwards
+                    rows = cnt_last - pos[ax] * g.batch < g.batch ? cnt_last - pos[ax] * g.batch : g.batch;
+                    const unsigned jlo = (ax == 0 && desc_0) ? (lo_last + cnt_last - pos[ax] * g.batch - rows)
+                                                            : (lo_last + pos[ax] * g.batch);
+                    xoff += (size_t)jlo * a.xstr[ax];
+                    yoff += (size_t)(K_last - (jlo + rows - 1)) * a.ystr[ax];  // lowest y row of the batch
+                    xpitch = a.xstr[ax];
+                    ypitch = a.ystr[ax];
+                } else {
+                    unsigned j = (ax == 0 && desc_0) ? (lo[ax] + cnt[ax] - 1 - pos[ax]) : (lo[ax] + pos[ax]);
+                    xoff += (size_t)j * a.xstr[ax];
+                    yoff += (size_t)(K[ax] - j) * a.ystr[ax];
+                }
             }
         }
+        const bool rows_desc = lastax == 0 && desc_0;
         __syncthreads();  // everyone is done with the previous sub-tensors
-        for (unsigned i = tid; i < nx; i += CH) {
+        if (S == 1 && rows > 1) {
+            for (unsigned i = tid; i < rows * xcols; i += NT) {
+                unsigned r = i / xcols, c = i - r * xcols;
+                E::st(xl, g.xcap, i, E::ld(x, xp, xoff + (size_t)r * xpitch + c));
+            }
+            for (unsigned i = tid; i < rows * ycols; i += NT) {
+                unsigned r = i / ycols, c = i - r * ycols;
+                E::st(yl, g.ycap, i, E::ld(y, yp, yoff + (size_t)r * ypitch + c));
+            }
+        } else {
+        for (unsigned i = tid; i < nx; i += NT) {
             V v = E::ld(x, xp, xoff + i);
             E::st(xl, g.xcap, i, v);
         }
         if (S == 2 && g.syb != g.nb) {
-            for (unsigned i = tid; i < ny; i += CH) {
+            for (unsigned i = tid; i < ny; i += NT) {
                 unsigned r = i / g.syb, c = i - r * g.syb;
                 V v = E::ld(y, yp, yoff + i);
                 E::st(yl, g.ycap, (size_t)r * g.nb + c, v);
             }
         } else {
-            for (unsigned i = tid; i < ny; i += CH) {
+            for (unsigned i = tid; i < ny; i += NT) {
                 V v = E::ld(y, yp, yoff + i);
                 E::st(yl, g.ycap, i, v);
             }
         }
+        }
         __syncthreads();
 
+        if (S == 1 && INNER0 && rw > 1) {
+            double* sums = yl + (size_t)E::W * g.ycap;  // [plane][batch][CH]
+            const size_t splane = (size_t)g.batch * CH;
+            const bool nonempty = hi_b > lo_b;
+            if (active && nonempty) {
+                for (unsigned t = q; t < rows; t += rw) {  // t-th row in consumption order
+                    const unsigned xr = rows_desc ? rows - 1 - t : t;
+                    const unsigned xb = xr * xcols, yb = (rows - 1 - xr) * ycols + kb;
+                    V inner = E::zero();
+#pragma unroll 4
+                    for (unsigned j = lo_b; j < hi_b; ++j)
+                        inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                    E::st(sums, splane, (size_t)t * CH + otid, inner);
+                }
+            }
+            __syncthreads();
+            if (active && nonempty && q == 0)
+                for (unsigned t = 0; t < rows; ++t) acc = E::add(acc, E::ld(sums, splane, (size_t)t * CH + otid));
+        } else
         if (active) {
-            const unsigned cnt_a = hi_a > lo_a ? hi_a - lo_a : 0;
+            // S == 2: t walks the staged plane's rows j_a; S == 1: t walks the rows of the batch (ascending outer j)
+            const unsigned cnt_a = S == 2 ? (hi_a > lo_a ? hi_a - lo_a : 0) : rows;
             for (unsigned t = 0; t < cnt_a; ++t) {
                 const unsigned ja = desc_a ? (hi_a - 1 - t) : (lo_a + t);
-                const unsigned xb = ja * g.sxb;                       // wave-uniform when the wave shares ja
-                const unsigned yb = (S == 2 ? (ka - ja) * g.nb : 0) + kb;
+                const unsigned xr = rows_desc ? rows - 1 - t : t;     // S == 1: staged row consumed t-th
+                const unsigned xb = S == 2 ? ja * g.sxb : xr * xcols;  // wave-uniform when the wave shares ja
+                const unsigned yb = (S == 2 ? (ka - ja) * g.nb : (rows - 1 - xr) * ycols) + kb;
                 if (hi_b > lo_b) {
                     if (INNER0) {
                         V inner = E::zero();
@@ -190,12 +261,12 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
 #pragma unroll
         for (int ax = MAXO - 1; ax >= 0; --ax) {
             if (ax < g.no && carry) {
-                if (++pos[ax] == cnt[ax]) pos[ax] = 0;
+                if (++pos[ax] == (ax == lastax ? nbatch : cnt[ax])) pos[ax] = 0;
                 else carry = false;
             }
         }
     }
-    if (active) E::st(z, zp, zlin, acc);
+    if (active && q == 0) E::st(z, zp, zlin, acc);
 }
 
 template <class E, bool INNER0, int S>
@@ -248,13 +319,23 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     else if (a.zs[nd - 1] >= 32 && fits(1, LDS_MAX)) S = 1;
     else if (nd >= 2 && fits(2, LDS_MAX)) S = 2;
     else if (fits(1, LDS_MAX)) S = 1;
+    g.batch = 1;
     if (S) {
         g.S = S;
         g.sxa = S == 2 ? a.xs[nd - 2] : 1; g.sya = S == 2 ? a.ys[nd - 2] : 1; g.na = S == 2 ? a.zs[nd - 2] : 1;
         g.sxb = a.xs[nd - 1]; g.syb = a.ys[nd - 1]; g.nb = a.zs[nd - 1];
         g.xcap = g.sxa * g.sxb;
         g.ycap = g.sya * (S == 2 ? g.nb : g.syb);
+        if (S == 1 && nd >= 2) {  // rows of the last outer axis, `batch` per barrier pair
+            size_t row_bytes = (size_t)(g.sxb + g.syb) * 8 * W;
+            size_t b = std::min<size_t>(8, std::max<size_t>(1, (40 * 1024) / std::max<size_t>(row_bytes, 1)));
+            b = std::min<size_t>(b, std::max<unsigned>(1u, std::min(a.xs[nd - 2], a.ys[nd - 2])));
+            g.batch = (unsigned)b;
+            g.xcap *= g.batch;
+            g.ycap *= g.batch;
+        }
     }
+    g.rw = 1;
     if (S == 0) return false;
     g.no = nd - S;
     unsigned long long sub = (unsigned long long)g.na * g.nb, n_outer = 1;
@@ -274,7 +355,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
         // interval MACs are ~130 VALU instructions: staging only pays once the rows fill a good part of a wave
         if (W == 2 && g.nb < 24) return false;
     }
-    const size_t lds = (size_t)(g.xcap + g.ycap) * 8 * W;
+    size_t lds = (size_t)(g.xcap + g.ycap) * 8 * W;
     unsigned threads = lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
     // do not use more threads than one balanced chunk needs
     unsigned long long chunks = (span + threads - 1) / threads;
@@ -283,10 +364,19 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     if (need < threads && lds <= 40 * 1024) threads = need;
     chunks = (span + threads - 1) / threads;
     g.chunks = (unsigned)chunks;
+    // row groups (see the kernel): as many as the batch has rows and the block has room for
+    if (S == 1 && a.inner_from_zero && g.batch > 1) {
+        unsigned rw = std::min<unsigned>(g.batch, 1024u / threads);
+        if (rw > 1 && lds + (size_t)g.batch * threads * 8 * W <= 64 * 1024) {
+            g.rw = rw;
+            lds += (size_t)g.batch * threads * 8 * W;
+        }
+    }
+    const unsigned block_threads = threads * g.rw;
     unsigned long long blocks = n_outer * chunks;
     if (blocks == 0) return true;
     if (blocks > 0x7fffffffULL) return false;
-#define GFT_ST(I0, SS) launch<E, I0, SS>(st, x, xp, y, yp, z, zp, a, g, (unsigned)blocks, threads, lds)
+#define GFT_ST(I0, SS) launch<E, I0, SS>(st, x, xp, y, yp, z, zp, a, g, (unsigned)blocks, block_threads, lds)
     if (a.inner_from_zero) return S == 2 ? GFT_ST(true, 2) : GFT_ST(true, 1);
     return S == 2 ? GFT_ST(false, 2) : GFT_ST(false, 1);
 #undef GFT_ST
