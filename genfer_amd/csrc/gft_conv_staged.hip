@@ -58,7 +58,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
     // in ascending row order — same operations per output, 1/rw of the serial chain (a recurrence row step has 64
     // outputs and thousands of MACs each: nothing else is parallel).
     const unsigned NT = blockDim.x, tid = threadIdx.x;
-    const unsigned rw = (S == 1 && INNER0) ? g.rw : 1;
+    const unsigned rw = INNER0 ? g.rw : 1;
     const unsigned CH = NT / rw, q = tid / CH, otid = tid - q * CH;
 
     // ---- which outputs --------------------------------------------------------------------------
@@ -211,6 +211,32 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
         }
         __syncthreads();
 
+        if (S == 2 && INNER0 && rw > 1) {
+            // plane mode: the rows j_a of the staged plane play the role of the batch rows, 8 at a time
+            double* sums = yl + (size_t)E::W * g.ycap;  // [plane][8][CH]
+            const unsigned RB = 8;
+            const size_t splane = (size_t)RB * CH;
+            const bool nonempty = hi_b > lo_b;
+            const unsigned cnt_a = hi_a > lo_a ? hi_a - lo_a : 0;
+            for (unsigned c0 = 0; c0 < xrows; c0 += RB) {  // xrows bounds every thread's cnt_a (uniform loop)
+                const unsigned cend = c0 + RB < cnt_a ? c0 + RB : cnt_a;
+                if (active && nonempty) {
+                    for (unsigned t = c0 + q; t < cend; t += rw) {
+                        const unsigned ja = desc_a ? (hi_a - 1 - t) : (lo_a + t);
+                        const unsigned xb = ja * g.sxb, yb = (ka - ja) * g.nb + kb;
+                        V inner = E::zero();
+#pragma unroll 4
+                        for (unsigned j = lo_b; j < hi_b; ++j)
+                            inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                        E::st(sums, splane, (size_t)(t - c0) * CH + otid, inner);
+                    }
+                }
+                __syncthreads();
+                if (active && nonempty && q == 0)
+                    for (unsigned t = c0; t < cend; ++t) acc = E::add(acc, E::ld(sums, splane, (size_t)(t - c0) * CH + otid));
+                __syncthreads();
+            }
+        } else
         if (S == 1 && INNER0 && rw > 1) {
             double* sums = yl + (size_t)E::W * g.ycap;  // [plane][batch][CH]
             const size_t splane = (size_t)g.batch * CH;
@@ -351,10 +377,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     }
     const unsigned long long span = g.sub_hi - g.sub_lo;
     if (span == 0 || n_outer == 0) return true;
-    if (!force) {
-        // interval MACs are ~130 VALU instructions: staging only pays once the rows fill a good part of a wave
-        if (W == 2 && g.nb < 24) return false;
-    }
+    (void)force;  // every supported shape is at least as fast here as on the one-thread-per-output kernel
     size_t lds = (size_t)(g.xcap + g.ycap) * 8 * W;
     unsigned threads = lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
     // do not use more threads than one balanced chunk needs
@@ -370,6 +393,13 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
         if (rw > 1 && lds + (size_t)g.batch * threads * 8 * W <= 64 * 1024) {
             g.rw = rw;
             lds += (size_t)g.batch * threads * 8 * W;
+        }
+    }
+    if (S == 2 && a.inner_from_zero && std::min(g.sxa, g.sya) >= 4) {
+        unsigned rw = std::min<unsigned>(8u, 1024u / threads);
+        if (rw > 1 && lds + (size_t)8 * threads * 8 * W <= 64 * 1024) {
+            g.rw = rw;
+            lds += (size_t)8 * threads * 8 * W;
         }
     }
     const unsigned block_threads = threads * g.rw;
