@@ -31,6 +31,10 @@ namespace gft {
 namespace {
 
 constexpr int MAXO = MAXD - 1;  // max number of outer axes
+static const size_t R_BATCH_MAX = [] {
+    const char* e = getenv("GFT_STAGED_BATCH");  // tuning knob: rows per batch in row mode
+    return (size_t)(e ? std::max(1, atoi(e)) : 8);
+}();
 
 struct StagedArgs {
     int S;                   // staged axes (1 or 2)
@@ -354,7 +358,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
         g.ycap = g.sya * (S == 2 ? g.nb : g.syb);
         if (S == 1 && nd >= 2) {  // rows of the last outer axis, `batch` per barrier pair
             size_t row_bytes = (size_t)(g.sxb + g.syb) * 8 * W;
-            size_t b = std::min<size_t>(8, std::max<size_t>(1, (40 * 1024) / std::max<size_t>(row_bytes, 1)));
+            size_t b = std::min<size_t>(R_BATCH_MAX, std::max<size_t>(1, (40 * 1024) / std::max<size_t>(row_bytes, 1)));
             b = std::min<size_t>(b, std::max<unsigned>(1u, std::min(a.xs[nd - 2], a.ys[nd - 2])));
             g.batch = (unsigned)b;
             g.xcap *= g.batch;
