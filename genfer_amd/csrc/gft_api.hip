@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -23,8 +24,66 @@
 #include "gft_kernels.hpp"
 
 using namespace gft;
-typedef std::vector<size_t> Dims;
 static const size_t UMAX = SIZE_MAX;
+
+// Shape / degree lists.  A std::vector here cost ~20 heap round trips per operation — visible when a whole
+// operation is a 4 us kernel launch (Genfer programs are 10^5-10^6 tiny operations) — so the list lives inline:
+// the reference's programs have <= 8 variables, the ABI admits 32.
+struct Dims {
+    static constexpr size_t CAP = 32;
+    size_t n = 0;
+    size_t v[CAP];
+    Dims() {}
+    Dims(size_t count, size_t val) {
+        grow(count);
+        for (size_t i = 0; i < count; ++i) v[i] = val;
+        n = count;
+    }
+    Dims(std::initializer_list<size_t> l) {
+        grow(l.size());
+        for (size_t x : l) v[n++] = x;
+    }
+    template <class It>
+    Dims(It a, It b) {
+        for (; a != b; ++a) push_back((size_t)*a);
+    }
+    static void grow(size_t want) {
+        if (want > CAP) throw std::runtime_error("more than 32 variables are not supported");
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    size_t& operator[](size_t i) { return v[i]; }
+    const size_t& operator[](size_t i) const { return v[i]; }
+    size_t* begin() { return v; }
+    size_t* end() { return v + n; }
+    const size_t* begin() const { return v; }
+    const size_t* end() const { return v + n; }
+    size_t& back() { return v[n - 1]; }
+    const size_t& back() const { return v[n - 1]; }
+    void push_back(size_t x) {
+        grow(n + 1);
+        v[n++] = x;
+    }
+    void pop_back() { --n; }
+    void clear() { n = 0; }
+    void resize(size_t m, size_t val = 0) {
+        grow(m);
+        for (size_t i = n; i < m; ++i) v[i] = val;
+        n = m;
+    }
+    template <class It>
+    void insert(const size_t* pos, It a, It b) {  // only appending is used
+        (void)pos;
+        for (; a != b; ++a) push_back((size_t)*a);
+    }
+    bool operator==(const Dims& o) const {
+        if (n != o.n) return false;
+        for (size_t i = 0; i < n; ++i)
+            if (v[i] != o.v[i]) return false;
+        return true;
+    }
+    bool operator!=(const Dims& o) const { return !(*this == o); }
+};
 
 // ------------------------------------------------------------------------------------------
 // runtime
@@ -1486,7 +1545,7 @@ struct Ops {
         if (order >= a.shape[v]) return zero_with(a.deg);
         return slab_range(a, v, order, order + 1, a.deg);
     }
-    static P taylor_polynomial_terms(const P& a, size_t v, const Dims& orders) {
+    static P taylor_polynomial_terms(const P& a, size_t v, const std::vector<size_t>& orders) {  // a list of orders, not a shape
         size_t max_order_p1 = 1;
         for (size_t o : orders) max_order_p1 = std::max(max_order_p1, o + 1);
         bool has0 = std::find(orders.begin(), orders.end(), (size_t)0) != orders.end();
@@ -1927,7 +1986,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::coefficients_of_term(*a, v, o); });                                 \
     }                                                                                                         \
     gft_poly* PFX##taylor_polynomial_terms(const gft_poly* a, size_t v, const size_t* orders, size_t n) {     \
-        return guard([&] { return Ops<E>::taylor_polynomial_terms(*a, v, dims(orders, n)); });                \
+        return guard([&] { return Ops<E>::taylor_polynomial_terms(*a, v, std::vector<size_t>(orders, orders + n)); });                \
     }                                                                                                         \
     gft_poly* PFX##truncate_to_degree_p1(const gft_poly* a, size_t d) {                                       \
         return guard([&] { return Ops<E>::truncate_to_degree_p1(*a, d); });                                   \
