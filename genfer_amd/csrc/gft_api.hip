@@ -29,61 +29,64 @@ static const size_t UMAX = SIZE_MAX;
 // Shape / degree lists.  A std::vector here cost ~20 heap round trips per operation — visible when a whole
 // operation is a 4 us kernel launch (Genfer programs are 10^5-10^6 tiny operations) — so the list lives inline:
 // the reference's programs have <= 8 variables, the ABI admits 32.
-struct Dims {
+template <class T>
+struct SmallVecT {
     static constexpr size_t CAP = 32;
     size_t n = 0;
-    size_t v[CAP];
-    Dims() {}
-    Dims(size_t count, size_t val) {
+    T v[CAP];
+    SmallVecT() {}
+    SmallVecT(size_t count, T val) {
         grow(count);
         for (size_t i = 0; i < count; ++i) v[i] = val;
         n = count;
     }
-    Dims(std::initializer_list<size_t> l) {
+    SmallVecT(std::initializer_list<T> l) {
         grow(l.size());
-        for (size_t x : l) v[n++] = x;
+        for (T x : l) v[n++] = x;
     }
     template <class It>
-    Dims(It a, It b) {
-        for (; a != b; ++a) push_back((size_t)*a);
+    SmallVecT(It a, It b) {
+        for (; a != b; ++a) push_back((T)*a);
     }
     static void grow(size_t want) {
         if (want > CAP) throw std::runtime_error("more than 32 variables are not supported");
     }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
-    size_t& operator[](size_t i) { return v[i]; }
-    const size_t& operator[](size_t i) const { return v[i]; }
-    size_t* begin() { return v; }
-    size_t* end() { return v + n; }
-    const size_t* begin() const { return v; }
-    const size_t* end() const { return v + n; }
-    size_t& back() { return v[n - 1]; }
-    const size_t& back() const { return v[n - 1]; }
-    void push_back(size_t x) {
+    T& operator[](size_t i) { return v[i]; }
+    const T& operator[](size_t i) const { return v[i]; }
+    T* begin() { return v; }
+    T* end() { return v + n; }
+    const T* begin() const { return v; }
+    const T* end() const { return v + n; }
+    T& back() { return v[n - 1]; }
+    const T& back() const { return v[n - 1]; }
+    void push_back(T x) {
         grow(n + 1);
         v[n++] = x;
     }
     void pop_back() { --n; }
     void clear() { n = 0; }
-    void resize(size_t m, size_t val = 0) {
+    void resize(size_t m, T val = 0) {
         grow(m);
         for (size_t i = n; i < m; ++i) v[i] = val;
         n = m;
     }
     template <class It>
-    void insert(const size_t* pos, It a, It b) {  // only appending is used
+    void insert(const T* pos, It a, It b) {  // only appending is used
         (void)pos;
-        for (; a != b; ++a) push_back((size_t)*a);
+        for (; a != b; ++a) push_back((T)*a);
     }
-    bool operator==(const Dims& o) const {
+    bool operator==(const SmallVecT& o) const {
         if (n != o.n) return false;
         for (size_t i = 0; i < n; ++i)
             if (v[i] != o.v[i]) return false;
         return true;
     }
-    bool operator!=(const Dims& o) const { return !(*this == o); }
+    bool operator!=(const SmallVecT& o) const { return !(*this == o); }
 };
+typedef SmallVecT<size_t> Dims;
+typedef SmallVecT<long long> Shifts;  // per-axis source offsets of a gather
 
 // ------------------------------------------------------------------------------------------
 // runtime
@@ -110,7 +113,7 @@ struct Runtime {
     hipStream_t stream = nullptr;
     // size-class pool: freed blocks are reused immediately — legal because every kernel, memset and
     // copy of this library is ordered on the one stream.
-    std::multimap<size_t, void*> free_blocks;
+    std::map<size_t, std::vector<void*>> free_blocks;  // size class -> free device blocks (vectors: no node churn)
     size_t in_use = 0, cached = 0, peak = 0;
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
     double* d_scratch = nullptr; // small device scratch for packed read-backs
@@ -145,16 +148,17 @@ static size_t size_class(size_t bytes) {
 static void* pool_alloc(size_t bytes, size_t* cls_out) {
     size_t cls = size_class(bytes);
     *cls_out = cls;
-    auto it = R.free_blocks.find(cls);
+    std::vector<void*>& fl = R.free_blocks[cls];
     void* p;
-    if (it != R.free_blocks.end()) {
-        p = it->second;
-        R.free_blocks.erase(it);
+    if (!fl.empty()) {
+        p = fl.back();
+        fl.pop_back();
         R.cached -= cls;
     } else {
         hipError_t e = hipMalloc(&p, cls);
         if (e != hipSuccess) {  // release the cache and retry once
-            for (auto& kv : R.free_blocks) (void)hipFree(kv.second);
+            for (auto& kv : R.free_blocks)
+                for (void* q : kv.second) (void)hipFree(q);
             R.free_blocks.clear();
             R.cached = 0;
             HIP_OK(hipMalloc(&p, cls));
@@ -168,7 +172,7 @@ static void* pool_alloc(size_t bytes, size_t* cls_out) {
 static void pool_free(void* p, size_t cls) {
     R.in_use -= cls;
     R.cached += cls;
-    R.free_blocks.emplace(cls, p);
+    R.free_blocks[cls].push_back(p);
 }
 
 struct Buf {
@@ -506,7 +510,7 @@ struct Ops {
 
     // ---- structured copies -----------------------------------------------------------------------
     // General gather of `src` into a fresh tensor of shape `out_shape`; per-axis shift and valid length.
-    static P gather(const P& src, const Dims& out_shape, const Dims& out_deg, const std::vector<long long>& shift,
+    static P gather(const P& src, const Dims& out_shape, const Dims& out_deg, const Shifts& shift,
                     const Dims& src_len, int op = OP_COPY, const double* s = nullptr, int tab_axis = -1,
                     const double* tab = nullptr, size_t tab_plane = 0, const unsigned char* keep = nullptr) {
         P out = make(out_shape, out_deg);
@@ -572,14 +576,14 @@ struct Ops {
     }
     static P lead_block(const P& p, const Dims& lens, const Dims& deg) {  // slice 0..lens per axis
         if (lens == p.shape) return with_meta(p, p.shape, deg);
-        std::vector<long long> shift(lens.size(), 0);
+        Shifts shift(lens.size(), 0);
         return gather(p, lens, deg, shift, p.shape);
     }
     static P slab_range(const P& p, size_t v, size_t lo, size_t hi, const Dims& deg, int op = OP_COPY,
                         int tab_axis = -1, const double* tab = nullptr, size_t tab_plane = 0) {
         Dims out = p.shape;
         out[v] = hi - lo;
-        std::vector<long long> shift(out.size(), 0);
+        Shifts shift(out.size(), 0);
         shift[v] = (long long)lo;
         return gather(p, out, deg, shift, p.shape, op, nullptr, tab_axis, tab, tab_plane);
     }
@@ -600,7 +604,7 @@ struct Ops {
             K<E>::scalar_imm(R.stream, kind, Scalar2{p.cv[0], p.cv[1]}, b, dp<E>(out), out.numel);
             return out;
         }
-        std::vector<long long> shift(p.shape.size(), 0);
+        Shifts shift(p.shape.size(), 0);
         return gather(p, p.shape, p.deg, shift, p.shape, op, s);
     }
 
@@ -986,7 +990,7 @@ struct Ops {
     static P mul_var(const P& self, const double* m, size_t v, const Dims& shape, const Dims& deg) {  // mt:589-608
         if (v >= self.shape.size() || shape.size() != self.shape.size()) throw Error("mul_var: bad axis/shape");
         size_t upper = std::min(shape[v] - 1, self.shape[v]);
-        std::vector<long long> shift(shape.size(), 0);
+        Shifts shift(shape.size(), 0);
         shift[v] = -1;
         Dims src_len = self.shape;
         src_len[v] = upper;
@@ -1388,7 +1392,7 @@ struct Ops {
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 Dims sst = c_strides(subst.shape);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
-                std::vector<long long> shift(lens.size(), 0);
+                Shifts shift(lens.size(), 0);
                 return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v]);
             }
         }
@@ -1408,7 +1412,7 @@ struct Ops {
             Dims out = cshape;
             out[v] = 1;
             for (size_t ax = 0; ax < out.size(); ++ax) out[ax] = std::min(out[ax], deg[ax]);
-            std::vector<long long> shift(out.size(), 0);
+            Shifts shift(out.size(), 0);
             shift[v] = (long long)i;
             P coeff = gather(ca, out, deg, shift, cshape);
             res = addsub(R.fuse_horner ? mul_horner(res, subst) : mul(res, subst), coeff, false);
@@ -1558,7 +1562,7 @@ struct Ops {
         HIP_OK(hipStreamSynchronize(R.stream));
         Dims out = a.shape;
         out[v] = upper;
-        std::vector<long long> shift(out.size(), 0);
+        Shifts shift(out.size(), 0);
         return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, (const unsigned char*)kb->p);
     }
 
@@ -1577,7 +1581,7 @@ struct Ops {
         for (size_t v = 0; v < s.size(); ++v)
             if (s[v] > ns[v]) throw Error("extend: shape exceeds new size");
         P src = with_meta_unchecked(a, s);
-        std::vector<long long> shift(ns.size(), 0);
+        Shifts shift(ns.size(), 0);
         return gather(src, ns, ns, shift, s);
     }
     static P remove_last_variable(const P& a) {
@@ -1737,7 +1741,8 @@ int gft_init(int device) {
 void gft_shutdown(void) {
     if (!R.ready) return;
     (void)hipStreamSynchronize(R.stream);
-    for (auto& kv : R.free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : R.free_blocks)
+        for (void* q : kv.second) (void)hipFree(q);
     R.free_blocks.clear();
     R.cached = 0;
     if (R.conv_ws) (void)hipFree(R.conv_ws);
