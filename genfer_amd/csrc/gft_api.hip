@@ -1273,6 +1273,27 @@ struct Ops {
         return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len);
     }
 
+    // derivative(a, v, n).truncate_to_degree_p1(d) — what the evaluator does for every Derivative node
+    // (generating_function.rs Derivative arm: the operand is evaluated to degree_p1 + n and cut back) — as ONE
+    // gather: truncation is pure slicing, so the values are those of the two-step form bit for bit.
+    static P derivative_truncated(const P& a, size_t v, size_t n, size_t d) {
+        size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+        if (!(v < a.deg.size() && n < len_of) || v >= a.shape.size() || n >= a.shape[v])
+            return truncate_to_degree_p1(deriv_like(a, v, n, TAB_DERIV, "derivative"), d);  // assertion / zero paths
+        Dims deg = a.deg, out = a.shape;
+        deg[v] -= n;
+        out[v] -= n;
+        const size_t len = out[v];
+        for (size_t ax = 0; ax < deg.size(); ++ax) {
+            deg[ax] = std::min(deg[ax], d);
+            out[ax] = std::min(out[ax], deg[ax]);
+        }
+        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, n, len);
+        Shifts shift(out.size(), 0);
+        shift[v] = (long long)n;
+        return gather(a, out, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, len);
+    }
+
     // ---- fused observation step ------------------------------------------------------------------------
     // (a.derivative(v, 1).truncate_to_degree_p1(d) * var(v, x, d)) * from(c) — the body of the reference's
     // compound-Poisson observation loop (gf.rs:684-689) — in one launch, no dispatch read-backs.
@@ -1981,6 +2002,9 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::deriv_like(*a, v, n, TAB_COEFF, "taylor_expansion_of_coeff"); });   \
     }                                                                                                         \
     gft_poly* PFX##shift_down(const gft_poly* a, size_t v, size_t n) { return guard([&] { return Ops<E>::shift_down(*a, v, n); }); } \
+    gft_poly* PFX##derivative_truncated(const gft_poly* a, size_t v, size_t n, size_t d) {                    \
+        return guard([&] { return Ops<E>::derivative_truncated(*a, v, n, d); });                              \
+    }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
         return guard([&] { return Ops<E>::observe_step(*a, v, x, c, d); });                                   \
     }                                                                                                         \

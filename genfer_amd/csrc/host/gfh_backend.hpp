@@ -53,6 +53,7 @@ struct Api {
     void* (*shift_down)(const void*, size_t, size_t);
     void* (*subst_var)(const void*, size_t, const void*);
     void* (*observe_step)(const void*, size_t, const double*, const double*, size_t);
+    void* (*derivative_truncated)(const void*, size_t, size_t, size_t);
     void* (*coefficients_of_term)(const void*, size_t, size_t);
     void* (*taylor_polynomial_terms)(const void*, size_t, const size_t*, size_t);
     void* (*truncate_to_degree_p1)(const void*, size_t);
@@ -77,7 +78,7 @@ struct Api {
         GFH_BIND(shape); GFH_BIND(degrees_p1); GFH_BIND(to_host); GFH_BIND(is_zero); GFH_BIND(is_one);
         GFH_BIND(constant_term); GFH_BIND(extract_constant); GFH_BIND(coefficient); GFH_BIND(add); GFH_BIND(sub);
         GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
-        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step);
+        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derivative_truncated);
         GFH_BIND(coefficients_of_term); GFH_BIND(taylor_polynomial_terms); GFH_BIND(truncate_to_degree_p1);
         GFH_BIND(remove_last_variable); GFH_BIND(extend_to_dim);
 #undef GFH_BIND
@@ -173,6 +174,7 @@ class Poly {
     Poly log() const { return wrap(api().log(h())); }
     Poly pow(uint32_t e) const { return wrap(api().pow(h(), e)); }
     Poly derivative(size_t v, size_t n) const { return wrap(api().derivative(h(), v, n)); }
+    Poly derivative_truncated(size_t v, size_t n, size_t d) const { return wrap(api().derivative_truncated(h(), v, n, d)); }
     Poly taylor_expansion_of_coeff(size_t v, size_t n) const { return wrap(api().taylor_expansion_of_coeff(h(), v, n)); }
     Poly shift_down(size_t v, size_t n) const { return wrap(api().shift_down(h(), v, n)); }
     Poly subst_var(size_t v, const Poly& s) const { return wrap(api().subst_var(h(), v, s.h())); }

@@ -249,7 +249,7 @@ struct GenFun {
                 }
                 return result;
             }
-            case Derivative: return x.a.eval_with(inputs, degree_p1 + x.order, cache).derivative(x.var, x.order).truncate_to_degree_p1(degree_p1);
+            case Derivative: return x.a.eval_with(inputs, degree_p1 + x.order, cache).derivative_truncated(x.var, x.order, degree_p1);  // = .derivative(v, n).truncate_to_degree_p1(d), one call
             case TaylorPolynomial: {
                 std::vector<T> ni = inputs;
                 ni.at(x.var) = T::zero();

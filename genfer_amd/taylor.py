@@ -76,6 +76,7 @@ HANDLE_API = {
     "shift_down": (_VP, [_VP, C.c_size_t, C.c_size_t]),
     "subst_var": (_VP, [_VP, C.c_size_t, _VP]),
     "observe_step": (_VP, [_VP, C.c_size_t, _DP, _DP, C.c_size_t]),
+    "derivative_truncated": (_VP, [_VP, C.c_size_t, C.c_size_t, C.c_size_t]),
     "coefficients_of_term": (_VP, [_VP, C.c_size_t, C.c_size_t]),
     "taylor_polynomial_terms": (_VP, [_VP, C.c_size_t, _SP, C.c_size_t]),
     "truncate_to_degree_p1": (_VP, [_VP, C.c_size_t]),
@@ -285,6 +286,10 @@ def bind(lib: C.CDLL, prefix: str):
 
         def shift_down(self, v: int, n: int):
             return type(self)(fn.shift_down(self._h, v, n))
+
+        def derivative_truncated(self, v: int, n: int, degree_p1: int):
+            """Fused derivative(v, n).truncate_to_degree_p1(degree_p1) (the evaluator's Derivative arm)."""
+            return type(self)(fn.derivative_truncated(self._h, v, n, degree_p1))
 
         def observe_step(self, v: int, x, c, degree_p1: int):
             """Fused (derivative(v,1).truncate(d) * var(v,x,d)) * c  (gf.rs:684-689)."""

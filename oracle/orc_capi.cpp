@@ -133,6 +133,9 @@ static P<S>* from_host(const double* data, const size_t* shape, const size_t* de
         ORC_TRY((void*)new P<S>(((const P<S>*)a)->taylor_expansion_of_coeff(v, n)))                        \
     }                                                                                                      \
     void* PFX##shift_down(const void* a, size_t v, size_t n) { ORC_TRY((void*)new P<S>(((const P<S>*)a)->shift_down(v, n))) } \
+    void* PFX##derivative_truncated(const void* a, size_t v, size_t n, size_t d) {                         \
+        ORC_TRY((void*)new P<S>(((const P<S>*)a)->derivative(v, n).truncate_to_degree_p1(d)))               \
+    }                                                                                                      \
     void* PFX##observe_step(const void* a, size_t v, const double* x, const double* c, size_t d) {         \
         /* the unfused reference sequence, literally (generating_function.rs:684-689 evaluated by :557-566, :628-632) */ \
         ORC_TRY((void*)new P<S>(P<S>::mul(P<S>::mul(((const P<S>*)a)->derivative(v, 1).truncate_to_degree_p1(d),   \

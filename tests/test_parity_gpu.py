@@ -593,6 +593,24 @@ def test_full_size_c4_properties():
     assert np.all(np.abs(got[0] - want0) <= 1e-10 * np.abs(want0))
 
 
+@pytest.mark.parametrize("interval", [False, True])
+def test_derivative_truncated_equals_two_step_form(interval, OTP, GTP, OTPI, GTPI):
+    """gft_derivative_truncated == derivative(v, n).truncate_to_degree_p1(d) of the oracle (generating_function.rs
+    Derivative arm), bit for bit, including the zero / assertion-free edge cases."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + 1e-8])) if interval else (lambda a: a)
+    for shape, deg in (((6, 5, 7), [9, 8, 9]), ((4, 9), [6, 12]), ((5,), [7]), ((3, 1, 4), [5, 3, 6])):
+        base = rand(shape, 97, -1.0, 1.0)
+        o, g = O.new(mk(base), deg), G.new(mk(base), deg)
+        for v in range(len(shape)):
+            for n in (0, 1, 2, 4):
+                if n >= deg[v]:
+                    continue
+                for d in (1, 3, 5, 20):
+                    check(o.derivative(v, n).truncate_to_degree_p1(d), g.derivative_truncated(v, n, d))
+                    check(o.derivative_truncated(v, n, d), g.derivative_truncated(v, n, d))
+
+
 def test_many_variables_few_nontrivial_axes(OTP, GTP):
     """20 variables of which three carry coefficients: unit axes are collapsed on the host, so the kernels see
     rank 3 (the reference's 8-variable programs have this shape pattern)."""
