@@ -1410,10 +1410,12 @@ struct Ops {
                 Dims lens = a.shape;
                 for (size_t i = 0; i < lens.size(); ++i) lens[i] = std::min(lens[i], deg[i]);
                 if (m_known && val_is_one(m)) return lead_block(a, lens, deg);  // powers of one: x * 1 == x, nothing to compute
-                std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 Dims sst = c_strides(subst.shape);
-                K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
                 Shifts shift(lens.size(), 0);
+                if (lens[v] <= 256)  // short axis: every thread forms its own m^k (same running product), no table launch
+                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel);
+                std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
+                K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
                 return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v]);
             }
         }

@@ -47,6 +47,13 @@ __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, 
                 case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
                 case OP_NEG: v = E::neg(v); break;
                 case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                case OP_MUL_POW: {
+                    const V mv = E::ld(a.tab, a.tab_plane, 0);
+                    V f = E::one();
+                    for (unsigned i = 0; i < kaxis; ++i) f = E::mul(f, mv);
+                    v = E::mul(v, f);
+                    break;
+                }
                 default: break;
             }
         }
@@ -87,6 +94,14 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
                 case OP_LMUL_S: v.x = a.s.a * v.x; v.y = a.s.a * v.y; break;
                 case OP_NEG: v.x = -v.x; v.y = -v.y; break;
                 case OP_MUL_TAB: { double f = a.tab[kaxis]; v.x = v.x * f; v.y = v.y * f; break; }
+                case OP_MUL_POW: {
+                    const double m = a.tab[0];
+                    double f = 1.0;
+                    for (unsigned i = 0; i < kaxis; ++i) f = f * m;
+                    v.x = v.x * f;
+                    v.y = v.y * f;
+                    break;
+                }
                 default: break;
             }
         }

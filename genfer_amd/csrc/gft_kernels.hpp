@@ -27,7 +27,7 @@ struct DView {
     Shape sh;
 };
 
-enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB = 4, OP_LMUL_S = 5 };
+enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB = 4, OP_LMUL_S = 5, OP_MUL_POW = 6 };
 enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_DIV_S = 4, MAP_LMUL_S = 5 };
 enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1, FIRST_SUB_NEG_ALL = 2 };
 enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
@@ -43,7 +43,9 @@ struct GatherArgs {
     int op;                     // GatherOp
     Scalar2 s;
     int tab_axis;               // axis whose OUTPUT index selects tab[] / keep[]
-    const double* tab;          // OP_MUL_TAB: x * tab[k_axis]  (interval: two planes, tab_plane apart)
+    const double* tab;          // OP_MUL_TAB: x * tab[k_axis]  (interval: two planes, tab_plane apart);
+                                // OP_MUL_POW: x * m^k_axis with m = tab[0], the power formed as ((1*m)*m)*.. in the thread
+                                // (the reference's running product, mt:557-565: no table launch for short axes)
     size_t tab_plane;
     const unsigned char* keep;  // optional: keep[k_axis] == 0 -> write zero
 };
