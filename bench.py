@@ -100,6 +100,44 @@ def cpu_baseline(shape, x, y, budget_hint_s=20.0):
     }, res, slabs
 
 
+def cpu_baseline_all_cores(shape, x, y, max_threads=64):
+    """The stronger CPU baseline of SURVEY §8d: the same oracle loop nest, different leading-axis output slabs on
+    different host threads (slabs are independent; per-element operation order unchanged).  One of the heaviest
+    slabs per thread, so the sample is ~4 s of wall time.  ctypes releases the GIL during the call."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
+    lib.orc_mul_slabs_timed.restype = ctypes.c_double
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    lib.orc_mul_slabs_timed.argtypes = [ctypes.c_void_p, szp, ctypes.c_void_p, szp, ctypes.c_void_p, szp,
+                                        ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_double)]
+    nd, n0 = len(shape), shape[0]
+    threads = max(1, min(max_threads, os.cpu_count() or 1, n0))
+    sz = (ctypes.c_size_t * nd)(*shape)
+    res = np.zeros(shape)
+    slabs = list(range(n0 - threads, n0))
+
+    def one(k):
+        m = ctypes.c_double(0.0)
+        lib.orc_mul_slabs_timed(x.ctypes.data_as(ctypes.c_void_p), sz, y.ctypes.data_as(ctypes.c_void_p), sz,
+                                res.ctypes.data_as(ctypes.c_void_p), sz, nd, k, k + 1, ctypes.byref(m))
+        return m.value
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        macs = sum(ex.map(one, slabs))
+    wall = time.perf_counter() - t0
+    return {
+        "value": macs / wall / 1e9,
+        "unit": "GMAC/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"leading-axis output slabs k0 in [{slabs[0]}, {slabs[-1]}] of the same product, one per thread "
+                  f"({macs:.3e} MACs, {wall:.1f} s wall, host has {os.cpu_count()} cores)",
+    }
+
+
 def pmc_traffic(world):
     """HBM-side bytes per product launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r01/pmc_k_conv_tiled.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH_SIZE
@@ -248,6 +286,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref_slabs, slabs = cpu_baseline(shape, xh, yh)
         out["cpu_baseline"] = base
+        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(shape, xh, yh)
         # the timed sample doubles as an end-of-run parity check of the full-size result
         zh = z.cpu().numpy()
         worst = 0.0
