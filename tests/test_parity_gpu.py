@@ -611,6 +611,22 @@ def test_derivative_truncated_equals_two_step_form(interval, OTP, GTP, OTPI, GTP
                     check(o.derivative_truncated(v, n, d), g.derivative_truncated(v, n, d))
 
 
+def test_full_size_c5_interval_product_encloses_f64(GTP, GTPI):
+    """BASELINE configs[4] at the C2 size: point intervals [x, x] of the 128^3 data through the interval product
+    (LDS-staged reference-order kernel).  Soundness at full size: every f64 coefficient of the (tiled) f64 product
+    lies inside its interval, the intervals are thin (<= a few thousand ulps for 2e6-term sums), lo <= hi."""
+    shape = (128, 128, 128)
+    x, y = rand(shape, 1), rand(shape, 2)
+    iv = (GTPI.new(np.stack([x, x]), list(shape)) * GTPI.new(np.stack([y, y]), list(shape))).array()
+    lo, hi = np.asarray(iv[0]), np.asarray(iv[1])
+    mid = (GTP.new(x, list(shape)) * GTP.new(y, list(shape))).array()
+    assert np.all(lo <= hi)
+    slack = 1e-10 * np.abs(mid)  # the f64 product itself is only 1e-10-close to the exactly rounded sum
+    assert np.all(lo - slack <= mid) and np.all(mid <= hi + slack)
+    assert np.all(hi - lo <= 1e-9 * np.abs(mid))
+    assert lo[0, 0, 0] == hi[0, 0, 0] == x[0, 0, 0] * y[0, 0, 0] or lo[0, 0, 0] < x[0, 0, 0] * y[0, 0, 0] < hi[0, 0, 0]
+
+
 def test_many_variables_few_nontrivial_axes(OTP, GTP):
     """20 variables of which three carry coefficients: unit axes are collapsed on the host, so the kernels see
     rank 3 (the reference's 8-variable programs have this shape pattern)."""
