@@ -229,6 +229,48 @@ __device__ inline void block_fast(double (&acc)[8], unsigned c, cptr_t xr, const
     }
 }
 
+// The same pipeline for COMPACT operands (fewer x / y chunks than output blocks: the inner-split products, Horner
+// steps with a small substitution): x chunks q in [q_lo, q_hi) with q_lo = max(0, c - nyc), q_hi = min(c, nxc), the
+// diagonal triangle only if c < nxc, and the first window is zero when it would lie beyond y's last chunk.
+// A separate function (and instantiation, VAR bit 8) so that the full-extent kernel's code is untouched.
+template <int VAR>
+__device__ inline void block_fast_gen(double (&acc)[8], unsigned c, cptr_t xr, const double* yrow, unsigned nxc,
+                                      unsigned nyc) {
+    constexpr bool NO_LDS = (VAR & 16) != 0;
+    constexpr bool NO_X = (VAR & 32) != 0;
+    constexpr bool B128 = (VAR & 2) != 0;
+    const unsigned q_lo = c > nyc ? c - nyc : 0, q_hi = c < nxc ? c : nxc;
+    const bool tri = c < nxc;
+    if (q_hi <= q_lo && !tri) return;
+    const double* w0 = yrow + 8 * c;  // W[t] = w0 - 8t = y chunk c - t
+    double A[8], B[8], C[8], X0[8], X1[8], X2[8];
+    if (c - q_lo < nyc) {
+        if (B128) load8_b128(A, w0 - 8 * (int)q_lo); else load8(A, w0 - 8 * (int)q_lo);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i] = 0.0;
+    }
+    if (B128) load8_b128(B, w0 - 8 * (int)(q_lo + 1)); else load8(B, w0 - 8 * (int)(q_lo + 1));
+    loadx(X0, xr + 8 * q_lo);
+    unsigned q = q_lo;
+    for (; q + 3 <= q_hi; q += 3) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
+        GFT_STEP(X2, C, A, X0, q + 3, B, q + 4);
+    }
+    const unsigned rem = q_hi - q;
+    if (rem == 2) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
+        if (tri) fma_tri(acc, X2, C);
+    } else if (rem == 1) {
+        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
+        if (tri) fma_tri(acc, X1, B);
+    } else if (tri) {
+        fma_tri(acc, X0, A);
+    }
+}
+
 struct TileGeom {
     unsigned julo, n_ju, j0lo, n_j0, j1lo, n_j1;
 };
@@ -351,7 +393,10 @@ k_conv_tiled(TiledArgs A) {
                 const bool valid = lane_in && j0 <= k0 && (k0 - j0) < A.y0 && j1 <= k1 && (k1 - j1) < A.y1;
                 if (valid) {
                     const double* yrow = lds + l0 * A.P0 + ((k1 - j1) & 7u) * A.P1 + YPAD;
-                    if constexpr (FAST) {  // host guarantees nxc, nyc >= nb for this instantiation
+                    if constexpr (FAST && (VAR & 8)) {  // pipelined path for compact operands
+                        if (has1) block_fast_gen<VAR>(acc1, c1, xr, yrow, A.nxc, A.nyc);
+                        if (has2) block_fast_gen<VAR>(acc2, c2, xr, yrow, A.nxc, A.nyc);
+                    } else if constexpr (FAST) {  // host guarantees nxc, nyc >= nb for this instantiation
                         if (has1) block_fast<VAR>(acc1, c1, xr, yrow);
                         if (has2) block_fast<VAR>(acc2, c2, xr, yrow);
                     } else {
@@ -832,7 +877,14 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     if (a.variant < 0) a.variant = GFT_TILED_DEFAULT_VARIANT;
     if (a.nd == 3 || a.nd == 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
         unsigned nb = (a.zs[a.nd - 1] + 7) / 8;
-        if ((a.xs[a.nd - 1] + 7) / 8 < nb || (a.ys[a.nd - 1] + 7) / 8 < nb) a.variant &= ~3;
+        if ((a.xs[a.nd - 1] + 7) / 8 < nb || (a.ys[a.nd - 1] + 7) / 8 < nb) {
+            static const bool compact_fast = [] {
+                const char* e = getenv("GFT_TILED_COMPACT_FAST");  // A/B knob: 0 = unpipelined general path
+                return e ? atoi(e) != 0 : true;
+            }();
+            if (compact_fast && (a.variant & 3) == 3) a.variant = (a.variant & ~0xff) | (a.variant & 7) | 8;  // pipelined path for compact operands
+            else a.variant &= ~3;
+        }
     }
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
@@ -898,7 +950,14 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     hipError_t e = hipSuccess;
     constexpr int DEF = GFT_TILED_DEFAULT_VARIANT;
     int variant = a.variant;
-    if (P.NW == 8) {
+    if (variant & 8) {  // compact operands, pipelined
+        switch (P.NW) {
+            case 1: e = launch_main<1, 11>(st, P, T); break;
+            case 2: e = launch_main<2, 11>(st, P, T); break;
+            case 4: e = launch_main<4, 11>(st, P, T); break;
+            default: e = launch_main<8, 11>(st, P, T); break;
+        }
+    } else if (P.NW == 8) {
         switch (variant) {
             case 0: case 4: e = launch_main<8, 0>(st, P, T); break;
             case 1: e = launch_main<8, 1>(st, P, T); break;
