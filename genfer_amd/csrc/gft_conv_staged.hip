@@ -231,7 +231,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                         V inner = E::zero();
 #pragma unroll 4
                         for (unsigned j = lo_b; j < hi_b; ++j)
-                            inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                            inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
                         E::st(sums, splane, (size_t)(t - c0) * CH + otid, inner);
                     }
                 }
@@ -252,7 +252,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                     V inner = E::zero();
 #pragma unroll 4
                     for (unsigned j = lo_b; j < hi_b; ++j)
-                        inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                        inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
                     E::st(sums, splane, (size_t)t * CH + otid, inner);
                 }
             }
@@ -273,13 +273,13 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                         V inner = E::zero();
 #pragma unroll 4
                         for (unsigned j = lo_b; j < hi_b; ++j)
-                            inner = E::add(inner, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                            inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
                         acc = E::add(acc, inner);
                     } else {
                         const unsigned cnt_b = hi_b - lo_b;
                         for (unsigned u = 0; u < cnt_b; ++u) {
                             const unsigned j = desc_b ? (hi_b - 1 - u) : (lo_b + u);
-                            acc = E::add(acc, E::mul(E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j)));
+                            acc = E::mac(acc, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
                         }
                     }
                 }

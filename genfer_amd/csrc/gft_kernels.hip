@@ -867,15 +867,15 @@ __global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict_
             // A = mul_var(res, m, w): res[k - e_w] * m inside the shifted source box, zero elsewhere
             bool in_src = kw >= 1 && kw - 1 < g.upper;
             if (in_src) {  // the other axes of the source box are res's own extents == sh's
-                V A = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);
+                V A = E::mulw(E::ld(res, rp, roff - g.rstr[g.w]), mv);
                 p = A;
             }
             if (!g.c_zero) {
-                p = E::add(E::zero(), p);
+                p = E::add0(p);
                 if (in_r) {
                     V x = E::ld(res, rp, roff);
-                    V B = g.c_one ? x : E::mul(cv, x);
-                    p = E::add(p, B);
+                    V B = g.c_one ? x : E::mulw(cv, x);
+                    p = E::addw(p, B);
                 }
             }
         }
@@ -885,8 +885,8 @@ __global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict_
             if (lin == 0) v = E::add(p, E::ld(a, ap, g.a_base));
         } else {
             v = E::zero();
-            if (in_p) v = E::add(v, p);
-            if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+            if (in_p) v = E::add0(p);
+            if (in_c) v = E::addw(v, E::ld(a, ap, aoff));
         }
         E::st(out, op, lin, v);
     }
@@ -974,12 +974,12 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             V p = E::zero();
             if (in_p) {
                 if (kw[e] >= 1 && kw[e] - 1 < upper)
-                    p = E::mul(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
+                    p = E::mulw(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
                 if (!g.c_zero) {
-                    p = E::add(E::zero(), p);
+                    p = E::add0(p);
                     if (in_r) {
                         V x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
-                        p = E::add(p, g.c_one ? x : E::mul(cv, x));
+                        p = E::addw(p, g.c_one ? x : E::mulw(cv, x));
                     }
                 }
             }
@@ -989,8 +989,8 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                 if (blockIdx.x == 0 && kw[e] == 0) v = E::add(p, coef[e]);
             } else {
                 v = E::zero();
-                if (in_p) v = E::add(v, p);
-                if (takes_c[e]) v = E::add(v, coef[e]);
+                if (in_p) v = E::add0(p);
+                if (takes_c[e]) v = E::addw(v, coef[e]);
             }
             if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
             else E::st(dst_l, lw_pad, kw[e], v);
