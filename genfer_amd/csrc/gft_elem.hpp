@@ -118,6 +118,14 @@ struct EIv {
         g.hi = z ? 0.0 : g.hi;
         return g;
     }
+    // General product formula for FINITE operands: no product can be NaN (only finite * finite), so the
+    // reference's compare-and-select min/max (f64.rs:68-83) equals the hardware min/max up to the sign of a zero,
+    // and widen() maps +0 and -0 to the same neighbour.
+    __device__ static V mul_general_finite(V a, V b) {
+        const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
+        return widen(__builtin_fmin(__builtin_fmin(p, q), __builtin_fmin(r, s)),
+                     __builtin_fmax(__builtin_fmax(p, q), __builtin_fmax(r, s)));
+    }
     // acc + a*b as the reference computes it (mul, then add, each with its short-circuits).  When NO lane of the
     // wave holds an operand that can trigger a short-circuit (exact 0 / 1 / -1, inf/NaN, an exactly zero
     // accumulator) the general formulas are the whole story and the ~50 selects and compares of the branch-free
@@ -130,18 +138,14 @@ struct EIv {
     __device__ static V mac(V acc, V a, V b) {
         const bool sp = maybe_special(a) || maybe_special(b) || is_zero(acc);
         if (__builtin_amdgcn_ballot_w64(sp) == 0) {
-            const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
-            const V m = widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
+            const V m = mul_general_finite(a, b);
             return widen(acc.lo + m.lo, acc.hi + m.hi);
         }
         return add(acc, mul(a, b));
     }
     // mul / add with the same wave-uniform shortcut as mac(): the general formula when no lane can short-circuit
     __device__ static V mulw(V a, V b) {
-        if (__builtin_amdgcn_ballot_w64(maybe_special(a) || maybe_special(b)) == 0) {
-            const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
-            return widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
-        }
+        if (__builtin_amdgcn_ballot_w64(maybe_special(a) || maybe_special(b)) == 0) return mul_general_finite(a, b);
         return mul(a, b);
     }
     __device__ static V addw(V a, V b) {
