@@ -6,7 +6,8 @@ Every output slab ``z[k0, ...]`` of the truncated product depends only on ``x[0.
 without any reduction: operands are replicated (``broadcast_operands`` when they originate on one
 rank), every rank computes its own leading-axis slabs — assigned by the folded plan of
 ``gft_plan_slabs`` so that the triangular work is balanced — and the result slabs are exchanged with
-two all-gathers (low groups, mirrored high groups).  When the leading axis does not divide evenly
+two all-gathers (low groups, mirrored high groups); the first one is started asynchronously as soon as its
+group is computed and overlaps the second group's kernels.  When the leading axis does not divide evenly
 the fallback is an all-reduce of zero-initialised tensors (adding zeros is exact, so the result is
 bit-identical to the single-GPU one).
 
@@ -57,17 +58,30 @@ def sharded_conv(
         z.zero_()
     if before_local:
         before_local()
+    works = []
+    if world > 1 and even:
+        plans = [plan_slabs(n0, world, r) for r in range(world)]
+        pending = [(0, g0), (1, g1)]  # slab groups whose exchange has not been started yet
     for lo, hi in launches:
         conv_slabs(x, y, z, lo, hi)
+        if world > 1 and even:
+            # start the exchange of every group this launch completed while the next group is still computing: the
+            # collective (on the backend's own stream, ordered after the launch) writes the OTHER ranks' slabs only
+            while pending and pending[0][1][1] <= hi and pending[0][1][0] >= lo:
+                g, mine = pending.pop(0)
+                outs = [z[plans[r][g][0]:plans[r][g][1]] for r in range(world)]
+                works.append(dist.all_gather(outs, z[mine[0]:mine[1]], group=group, async_op=True))
     if after_local:  # e.g. record a HIP event: kernel time is reported separately from the exchange
         after_local()
     if world == 1:
         return z
     if even:
-        plans = [plan_slabs(n0, world, r) for r in range(world)]
-        for g, mine in ((0, g0), (1, g1)):
+        while pending:  # (not reached: every group lies inside one launch)
+            g, mine = pending.pop(0)
             outs = [z[plans[r][g][0]:plans[r][g][1]] for r in range(world)]
-            dist.all_gather(outs, z[mine[0]:mine[1]], group=group)
+            works.append(dist.all_gather(outs, z[mine[0]:mine[1]], group=group, async_op=True))
+        for w in works:
+            w.wait()
     else:
         dist.all_reduce(z, group=group)
     return z
