@@ -627,6 +627,41 @@ def test_full_size_c5_interval_product_encloses_f64(GTP, GTPI):
     assert lo[0, 0, 0] == hi[0, 0, 0] == x[0, 0, 0] * y[0, 0, 0] or lo[0, 0, 0] < x[0, 0, 0] * y[0, 0, 0] < hi[0, 0, 0]
 
 
+def test_interval_edge_values_bit_exact(OTPI, GTPI):
+    """Interval add / sub / mul / div on the edge values of f64 (signed zeros, smallest subnormals, largest finite,
+    infinities, NaN, exact 0 / 1 / -1 points): the outward widening (f64.rs:127-171 next_up / next_down) and every
+    short-circuit of interval.rs must agree with the oracle bit for bit, NaN payloads aside."""
+    tiny, big, inf, nan = 5e-324, 1.7976931348623157e308, np.inf, np.nan
+    vals = [0.0, -0.0, tiny, -tiny, 2.2250738585072014e-308, 1.0, -1.0, 0.5, -3.0, big, -big, inf, -inf, nan]
+    pts = [(a, a) for a in vals] + [(-1.0, 1.0), (0.0, 1.0), (-tiny, tiny), (1.0, inf), (-inf, -1.0), (-0.0, 0.0), (0.25, 0.75)]
+    lo = np.array([p[0] for p in pts])
+    hi = np.array([p[1] for p in pts])
+    n = len(pts)
+    # all ordered pairs as two 1-d tensors (element-wise ops act per coefficient; products via the [n] x [1] trick)
+    A = np.stack([np.repeat(lo, n), np.repeat(hi, n)])
+    B = np.stack([np.tile(lo, n), np.tile(hi, n)])
+    oa, ga, ob, gb = OTPI.new(A, [n * n]), GTPI.new(A, [n * n]), OTPI.new(B, [n * n]), GTPI.new(B, [n * n])
+
+    def same(o, g):
+        a, b = np.asarray(o.array()), np.asarray(g.array())
+        assert a.shape == b.shape
+        ok = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+        assert np.all(ok), (a[~ok][:4], b[~ok][:4])
+
+    same(oa + ob, ga + gb)
+    same(oa - ob, ga - gb)
+    same(-oa, -ga)
+    for i, (l, h) in enumerate(pts):  # scalar * tensor, tensor / scalar, tensor * scalar: every pair through mul / div
+        so, sg = OTPI.from_scalar((l, h)), GTPI.from_scalar((l, h))
+        same(so * oa, sg * ga)
+        same(oa * so, ga * sg)
+        same(oa / so, ga / sg)
+    # general products (convolution MAC path incl. the wave-uniform fast path and its fallback)
+    x = np.stack([lo.reshape(3, 7), hi.reshape(3, 7)])
+    y = np.stack([lo[::-1].reshape(3, 7), hi[::-1].reshape(3, 7)])
+    same(OTPI.new(x, [3, 7]) * OTPI.new(y, [3, 7]), GTPI.new(x, [3, 7]) * GTPI.new(y, [3, 7]))
+
+
 def test_many_variables_few_nontrivial_axes(OTP, GTP):
     """20 variables of which three carry coefficients: unit axes are collapsed on the host, so the kernels see
     rank 3 (the reference's 8-variable programs have this shape pattern)."""
