@@ -42,24 +42,18 @@ struct EF64 {
 };
 
 // f64.rs:127-171 — integer arithmetic on the bits.
-// Branch-free: bits + (+1 | -1 by sign) is right for every input except -0.0 (-> smallest subnormal of the
-// target sign) and NaN / the infinity in the direction of travel (-> unchanged); two selects fix those.
+// next_up(x): bits + (+1 | -1 by sign) is right for every input except -0.0, NaN and +inf.  Canonicalising the
+// zero first (x + 0.0 == +0.0 for both zeros) removes one fix-up, and !(x < +inf) covers NaN and +inf with a single
+// compare; next_down(x) == -next_up(-x) for every input (f64.rs:127-171 is symmetric), so one routine serves both.
 __device__ inline double next_up(double x) {
-    const long long bits = __double_as_longlong(x);
+    const double t = x + 0.0;  // -0 -> +0 (NaN stays NaN, everything else unchanged)
+    const long long bits = __double_as_longlong(t);
     const long long step = (bits >> 63) | 1LL;  // +1 for the positive half, -1 for the negative half
-    long long r = bits + step;
-    r = (x == 0.0) ? 0x1LL : r;
-    r = (x != x || bits == 0x7ff0000000000000LL) ? bits : r;
-    return __longlong_as_double(r);
+    const long long r = bits + step;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    return !(t < inf) ? x : __longlong_as_double(r);  // NaN / +inf: unchanged (the reference returns x itself)
 }
-__device__ inline double next_down(double x) {
-    const long long bits = __double_as_longlong(x);
-    const long long step = (bits >> 63) | 1LL;
-    long long r = bits - step;
-    r = (x == 0.0) ? (long long)0x8000000000000001ULL : r;
-    r = (x != x || bits == (long long)0xfff0000000000000ULL) ? bits : r;
-    return __longlong_as_double(r);
-}
+__device__ inline double next_down(double x) { return -next_up(-x); }
 __device__ inline double fmin_ref(double a, double b) { return a < b ? a : b; }  // f64.rs:68-74
 __device__ inline double fmax_ref(double a, double b) { return a > b ? a : b; }  // f64.rs:77-83
 __device__ inline bool finite_d(double x) { return (x - x) == 0.0; }
