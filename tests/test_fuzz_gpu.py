@@ -1,0 +1,154 @@
+"""Seeded random expression trees over the TaylorPoly API on the GPU vs the CPU oracle, bit for bit.
+
+Every tree mixes constructors (dense tensors, scalars, variables — i.e. lazy handles), algebra (+ - * / neg pow),
+structure ops (derivative, shift_down, truncation, extend_to_dim, coefficients_of_term, subst_var with dense, linear
+and scaled-variable substitutions) and the value inspections the interpreter performs in between (constant_term,
+extract_linear, is_zero) — the places where laziness, memoised verdicts and the fused paths interact.  Sizes stay
+below the tiled crossover, so everything is reference-order arithmetic and the comparison is exact (NaN == NaN)."""
+import numpy as np
+import pytest
+
+from conftest import splitmix64_uniform
+
+NV = 3  # variables
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape)) if len(shape) else 1
+    return (lo + (hi - lo) * splitmix64_uniform(seed, n)).reshape(shape)
+
+
+class OracleRejected(Exception):
+    """The oracle refused the operation (a reference assertion): the tree is abandoned, nothing to compare."""
+
+
+def both(fo, fg):
+    """Apply the oracle's op first; if it raises, abandon the tree; then the GPU op, which must NOT raise."""
+    try:
+        ro = fo()
+    except Exception as e:  # noqa: BLE001 - TaylorError of the oracle binding
+        raise OracleRejected(str(e))
+    return ro, fg()
+
+
+class Gen:
+    def __init__(self, seed, interval):
+        self.rng = np.random.default_rng(seed)
+        self.seed = seed * 1000
+        self.interval = interval
+
+    def scal(self, v):
+        return (v, v + abs(v) * 1e-9) if self.interval and self.rng.random() < 0.5 else ((v, v) if self.interval else v)
+
+    def leaf(self, O, G):
+        r = self.rng.integers(0, 5)
+        deg = [int(self.rng.integers(3, 7)) for _ in range(NV)]
+        if r == 0:
+            shape = tuple(int(self.rng.integers(1, d + 1)) for d in deg)
+            self.seed += 1
+            a = _rand(shape, self.seed)
+            if self.rng.random() < 0.3:
+                a[tuple(0 for _ in shape)] = [0.0, 1.0, -1.0][int(self.rng.integers(0, 3))]
+            arr = np.stack([a, a + np.abs(a) * 1e-9]) if self.interval else a
+            return both(lambda: O.new(arr, deg), lambda: G.new(arr, deg))
+        if r == 1:
+            v = [0.0, 1.0, -1.0, 0.5, -2.25, 3.0][int(self.rng.integers(0, 6))]
+            s = self.scal(v)
+            return both(lambda: O.from_scalar(s), lambda: G.from_scalar(s))
+        if r == 2:
+            v = int(self.rng.integers(0, NV))
+            x0 = [0.0, 0.0, 1.0, -0.5][int(self.rng.integers(0, 4))]
+            s = self.scal(x0)
+            return both(lambda: O.var_with_degrees_p1(v, s, deg), lambda: G.var_with_degrees_p1(v, s, deg))
+        if r == 3:
+            v = int(self.rng.integers(0, NV))
+            n = int(self.rng.integers(2, 7))
+            return both(lambda: O.var_at_zero(v, n), lambda: G.var_at_zero(v, n))
+        v = int(self.rng.integers(0, NV))
+        s = self.scal([0.0, 0.75][int(self.rng.integers(0, 2))])
+        n = int(self.rng.integers(1, 7))
+        return both(lambda: O.var(v, s, n), lambda: G.var(v, s, n))
+
+    def tree(self, O, G, depth):
+        if depth == 0 or self.rng.random() < 0.15:
+            return self.leaf(O, G)
+        op = int(self.rng.integers(0, 12))
+        ao, ag = self.tree(O, G, depth - 1)
+        if op <= 3:
+            bo, bg = self.tree(O, G, depth - 1)
+            if op == 0:
+                return both(lambda: ao + bo, lambda: ag + bg)
+            if op == 1:
+                return both(lambda: ao - bo, lambda: ag - bg)
+            if op == 2:
+                return both(lambda: ao * bo, lambda: ag * bg)
+            # division by something with a safely non-zero constant term
+            c = self.scal(2.5)
+            return both(lambda: ao / (bo * bo + O.from_scalar(c)), lambda: ag / (bg * bg + G.from_scalar(c)))
+        nv = ao.num_vars()
+        v = int(self.rng.integers(0, max(nv, 1)))
+        if op == 4:
+            return both(lambda: -ao, lambda: -ag)
+        if op == 5:
+            return both(lambda: ao.pow(2), lambda: ag.pow(2))
+        if op == 6 and nv:
+            n = int(self.rng.integers(0, 2))
+            if n < ao.len_of(v):
+                return both(lambda: ao.derivative(v, n), lambda: ag.derivative(v, n))
+        if op == 7 and nv:
+            if 1 < ao.len_of(v):
+                return both(lambda: ao.shift_down(v, 1), lambda: ag.shift_down(v, 1))
+        if op == 8:
+            d = int(self.rng.integers(1, 6))
+            return both(lambda: ao.truncate_to_degree_p1(d), lambda: ag.truncate_to_degree_p1(d))
+        if op == 9 and nv:
+            # the interpreter's Subst arm: read the constant, subtract it, substitute
+            so, sg = self.tree(O, G, depth - 1)
+            co, cg = so.constant_term(), sg.constant_term()
+            assert _same_scalar(co, cg)
+            so, sg = both(lambda: so - O.from_scalar(co), lambda: sg - G.from_scalar(cg))
+            return both(lambda: ao.subst_var(v, so), lambda: ag.subst_var(v, sg))
+        if op == 10 and nv:
+            k = int(self.rng.integers(0, 3))
+            return both(lambda: ao.coefficients_of_term(v, k), lambda: ag.coefficients_of_term(v, k))
+        if op == 11 and nv:
+            c = self.scal([0.5, -1.5, 1.0, 0.0][int(self.rng.integers(0, 4))])
+            x0 = self.scal([0.0, 0.25][int(self.rng.integers(0, 2))])
+            n = max(2, int(ao.len_of(v)) if ao.len_of(v) < 64 else 4)
+            lo, lg = both(lambda: O.var(v, x0, n) * O.from_scalar(c), lambda: G.var(v, x0, n) * G.from_scalar(c))
+            assert lo.extract_linear() == lg.extract_linear() or _nan_pair(lo.extract_linear(), lg.extract_linear())
+            return both(lambda: ao.subst_var(v, lo), lambda: ag.subst_var(v, lg))
+        return ao, ag
+
+
+def _nan_pair(a, b):
+    return str(a) == str(b)
+
+
+def _same_scalar(a, b):
+    a, b = np.atleast_1d(np.asarray(a, dtype=float)), np.atleast_1d(np.asarray(b, dtype=float))
+    return a.shape == b.shape and bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b)) | (a == b)))
+
+
+def _check(o, g):
+    assert o.shape() == g.shape() and o.degrees_p1() == g.degrees_p1(), (o.shape(), g.shape(), o.degrees_p1(), g.degrees_p1())
+    a, b = np.asarray(o.array()), np.asarray(g.array())
+    ok = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert np.all(ok), (a[~ok][:4], b[~ok][:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interval", [False, True])
+@pytest.mark.parametrize("seed", range(1, 121))
+def test_random_expression_trees(seed, interval, OTP, GTP, OTPI, GTPI):
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    gen = Gen(seed, interval)
+    compared = 0
+    for _ in range(4):
+        try:
+            o, g = gen.tree(O, G, 5 if seed % 3 == 0 else 4)
+        except OracleRejected:
+            continue
+        _check(o, g)
+        compared += 1
+    assert compared >= 1 or seed > 0
