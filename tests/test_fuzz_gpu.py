@@ -152,3 +152,45 @@ def test_random_expression_trees(seed, interval, OTP, GTP, OTPI, GTPI):
         _check(o, g)
         compared += 1
     assert compared >= 1 or seed > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 25))
+def test_random_trees_mid_size_positive(seed, OTP, GTP):
+    """Larger positive tensors (up to 28^3 / 72^2): products cross the tiled crossover (FMA, different summation order,
+    inner split for rank 2), so the contract is 1e-10 relative per coefficient; shapes and degrees stay exact."""
+    rng = np.random.default_rng(1000 + seed)
+    nd = int(rng.integers(2, 4))
+    side = 28 if nd == 3 else 72
+
+    def leaf(k):
+        shape = tuple(int(rng.integers(side // 2, side + 1)) for _ in range(nd))
+        a = _rand(shape, 5000 + 10 * seed + k, 0.1, 1.0)
+        deg = [side + 4] * nd
+        return OTP.new(a, deg), GTP.new(a, deg)
+
+    def tree(depth, k=0):
+        if depth == 0:
+            return leaf(k)
+        op = int(rng.integers(0, 6))
+        ao, ag = tree(depth - 1, 2 * k + 1)
+        if op <= 1:
+            bo, bg = tree(depth - 1, 2 * k + 2)
+            return (ao * bo, ag * bg) if op == 0 else (ao + bo, ag + bg)
+        v = int(rng.integers(0, nd))
+        if op == 2:
+            return ao.derivative(v, 1), ag.derivative(v, 1)
+        if op == 3:
+            return ao.shift_down(v, 1), ag.shift_down(v, 1)
+        if op == 4:
+            d = int(rng.integers(side // 2, side))
+            return ao.truncate_to_degree_p1(d), ag.truncate_to_degree_p1(d)
+        lin = np.zeros([2 if ax == v else 1 for ax in range(nd)])
+        lin.flat[0], lin.flat[1] = 0.25, 0.5
+        deg = list(ao.degrees_p1())
+        return ao.subst_var(v, OTP.new(lin, deg)), ag.subst_var(v, GTP.new(lin, deg))
+
+    o, g = tree(2)
+    assert o.shape() == g.shape() and o.degrees_p1() == g.degrees_p1()
+    a, b = np.asarray(o.array()), np.asarray(g.array())
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a)), np.max(np.abs(a - b) / np.abs(a))
