@@ -1425,8 +1425,19 @@ struct Ops {
         P ca = with_meta_unchecked(a, cshape);
         // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
         const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2 && R.fuse_horner;
+        // The reference asks on every step whether the ACCUMULATOR is linear (and then multiplies the other way
+        // round, which compacts its stored shape).  That happens while the top coefficient slabs are zero or
+        // scalar-like; once the accumulator has been seen non-linear it stays so short of an exact cancellation.
+        // So: generic steps (with the scan) until the first "not linear" verdict, fused / scan-free steps after it.
+        bool res_nonlinear_seen = false;
         for (size_t i = cshape[v]; i-- > 0;) {
-            if (lin_known && res.numel > 1 && res.shape.size() == deg.size()) {
+            if (R.fuse_horner && !res_nonlinear_seen && res.numel > 1) {
+                double c_[2], m_[2];
+                size_t u_;
+                ScanCtx sc_res("subst_var.accumulator");
+                if (!extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // memoised: the generic mul reuses it
+            }
+            if (lin_known && res_nonlinear_seen && res.numel > 1 && res.shape.size() == deg.size()) {
                 // small tensors: every remaining step in one single-workgroup launch
                 if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res)) break;
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
@@ -1438,14 +1449,15 @@ struct Ops {
             Shifts shift(out.size(), 0);
             shift[v] = (long long)i;
             P coeff = gather(ca, out, deg, shift, cshape);
-            res = addsub(R.fuse_horner ? mul_horner(res, subst) : mul(res, subst), coeff, false);
+            res = addsub(R.fuse_horner && res_nonlinear_seen ? mul_horner(res, subst) : mul(res, subst), coeff, false);
         }
         return res;
     }
-    // res * subst inside the Horner loop.  The generic mul first asks whether `res` is linear (device scan + host
-    // round trip on every step, because res is new each time) before it looks at `subst`, whose verdict is
-    // memoised.  Multiplying the other way round gives the same products and sums (see horner_linear_step), so
-    // here only subst's verdict is consulted; shapes with a 1-element operand keep the generic value dispatch.
+    // res * subst inside the Horner loop once the accumulator has been seen non-linear.  The generic mul would ask
+    // again on every step whether `res` is linear (device scan + host round trip, because res is new each time)
+    // before it looks at `subst`, whose verdict is memoised; here only subst's verdict is consulted.  Should the
+    // accumulator turn exactly linear again by cancellation, the products and sums are still the same
+    // (commutativity, see horner_linear_step) — only its stored shape would keep explicit zeros.
     static P mul_horner(const P& res, const P& subst) {
         if (res.numel == 1 || subst.numel == 1) return mul(res, subst);
         P self = res, other = subst;

@@ -21,8 +21,9 @@
  *     is_zero/is_one/extract_*, equal) — and data-dependent dispatch inside mul/div/subst_var
  *     (mt:1021-1061), which the reference also performs.
  *   - Stored (compact) shapes equal the reference's, with one documented exception: inside subst_var's Horner
- *     loop the accumulator is never asked whether it happens to be exactly linear (the reference would then
- *     multiply the other way round and compact it); the coefficients are the same products and sums, only
+ *     loop the accumulator is asked whether it is linear (the reference does so on every step, and then
+ *     multiplies the other way round, which compacts it) only until it has been seen NON-linear once; should it
+ *     turn exactly linear again by cancellation, the coefficients are still the same products and sums, but
  *     explicit zeros may be stored where the reference's shape would have ended.
  *   - Errors: functions returning a handle return NULL, functions returning int return a
  *     negative value; gft_last_error() holds the message.  Reference panics (assert!/unwrap,

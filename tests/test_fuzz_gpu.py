@@ -72,7 +72,7 @@ class Gen:
     def tree(self, O, G, depth):
         if depth == 0 or self.rng.random() < 0.15:
             return self.leaf(O, G)
-        op = int(self.rng.integers(0, 12))
+        op = int(self.rng.integers(0, 16))
         ao, ag = self.tree(O, G, depth - 1)
         if op <= 3:
             bo, bg = self.tree(O, G, depth - 1)
@@ -118,6 +118,18 @@ class Gen:
             lo, lg = both(lambda: O.var(v, x0, n) * O.from_scalar(c), lambda: G.var(v, x0, n) * G.from_scalar(c))
             assert lo.extract_linear() == lg.extract_linear() or _nan_pair(lo.extract_linear(), lg.extract_linear())
             return both(lambda: ao.subst_var(v, lo), lambda: ag.subst_var(v, lg))
+        if op == 12 and nv:
+            orders = sorted({int(t) for t in self.rng.integers(0, 4, size=2)})
+            return both(lambda: ao.taylor_polynomial_terms(v, orders), lambda: ag.taylor_polynomial_terms(v, orders))
+        if op == 13:
+            d = int(self.rng.integers(2, 6))
+            return both(lambda: ao.extend_to_dim(nv + 1, d), lambda: ag.extend_to_dim(nv + 1, d))
+        if op == 14 and nv:
+            return both(lambda: ao.remove_last_variable(), lambda: ag.remove_last_variable())
+        if op == 15 and nv:
+            n, d = int(self.rng.integers(0, 3)), int(self.rng.integers(1, 6))
+            if n < ao.len_of(v):
+                return both(lambda: ao.derivative(v, n).truncate_to_degree_p1(d), lambda: ag.derivative_truncated(v, n, d))
         return ao, ag
 
 
