@@ -5,6 +5,8 @@ structure ops (derivative, shift_down, truncation, extend_to_dim, coefficients_o
 and scaled-variable substitutions) and the value inspections the interpreter performs in between (constant_term,
 extract_linear, is_zero) — the places where laziness, memoised verdicts and the fused paths interact.  Sizes stay
 below the tiled crossover, so everything is reference-order arithmetic and the comparison is exact (NaN == NaN)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -151,7 +153,7 @@ def _check(o, g):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("interval", [False, True])
-@pytest.mark.parametrize("seed", range(1, 121))
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("GFT_FUZZ_SEEDS", "120"))))
 def test_random_expression_trees(seed, interval, OTP, GTP, OTPI, GTPI):
     O, G = (OTPI, GTPI) if interval else (OTP, GTP)
     gen = Gen(seed, interval)
