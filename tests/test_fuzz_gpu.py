@@ -208,3 +208,55 @@ def test_random_trees_mid_size_positive(seed, OTP, GTP):
     assert o.shape() == g.shape() and o.degrees_p1() == g.degrees_p1()
     a, b = np.asarray(o.array()), np.asarray(g.array())
     assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a)), np.max(np.abs(a - b) / np.abs(a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("GFT_FUZZ_SHAPES", "60"))))
+def test_conv_tiled_random_shapes(seed):
+    """The tiled kernel (forced, incl. the inner split for rank 2 / long last axes and compact operands) against the
+    reference-order kernel on random ragged shapes of rank 2-4, mixed-sign data, slab range + accumulate:
+    |err| <= 1e-10 * (|x| (*) |y|) coefficient-wise (SURVEY 8d normwise bound)."""
+    import torch
+
+    import genfer_amd
+
+    rng = np.random.default_rng(9000 + seed)
+    nd = int(rng.integers(2, 5))
+    hi = {2: 160, 3: 36, 4: 14}[nd]
+    zs = [int(rng.integers(1, hi + 1)) for _ in range(nd)]
+    if nd == 2:
+        zs[1] = int(rng.integers(96, 260))  # rank 2 needs a last axis the split accepts
+    xs = [int(rng.integers(1, z + 1)) for z in zs]
+    ys = [int(rng.integers(1, z + 1)) for z in zs]
+    x = _rand(xs, 100 + seed)
+    y = _rand(ys, 200 + seed)
+    L = genfer_amd.lib()
+    tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ax, ay = tx.abs(), ty.abs()
+    lo = int(rng.integers(0, zs[0]))
+    hi_s = int(rng.integers(lo + 1, zs[0] + 1))
+    z0 = torch.from_numpy(_rand(zs, 300 + seed)).cuda()
+
+    def run(mode, a, b, acc):
+        out = z0.clone() if acc else torch.full(zs, float("nan"), dtype=torch.float64, device="cuda")
+        L.gft_set_conv_mode(mode)
+        try:
+            genfer_amd.conv_raw(a.data_ptr(), xs, b.data_ptr(), ys, out.data_ptr(), zs, lo if acc else 0, hi_s if acc else zs[0], acc)
+        finally:
+            L.gft_set_conv_mode(0)
+        L.gft_synchronize()
+        return out
+
+    torch.cuda.synchronize()
+    try:
+        got = run(2, tx, ty, False)
+    except genfer_amd.TaylorError as e:
+        assert "not supported" in str(e)
+        pytest.skip("shape outside the tiled kernel's domain")
+    want = run(1, tx, ty, False)
+    bound = run(1, ax, ay, False)
+    assert bool(torch.all((got - want).abs() <= 1e-10 * bound + 0.0))
+    got = run(2, tx, ty, True)
+    want = run(1, tx, ty, True)
+    assert bool(torch.equal(got[:lo], z0[:lo])) and bool(torch.equal(got[hi_s:], z0[hi_s:]))
+    assert bool(torch.all((got[lo:hi_s] - want[lo:hi_s]).abs() <= 1e-10 * (bound[lo:hi_s] + z0[lo:hi_s].abs())))
