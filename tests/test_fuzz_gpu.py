@@ -239,6 +239,7 @@ def test_conv_tiled_random_shapes(seed):
 
     def run(mode, a, b, acc):
         out = z0.clone() if acc else torch.full(zs, float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()  # torch fills on ITS stream; the library runs on its own non-blocking stream
         L.gft_set_conv_mode(mode)
         try:
             genfer_amd.conv_raw(a.data_ptr(), xs, b.data_ptr(), ys, out.data_ptr(), zs, lo if acc else 0, hi_s if acc else zs[0], acc)
