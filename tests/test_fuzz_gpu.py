@@ -186,8 +186,18 @@ def test_random_trees_mid_size_positive(seed, OTP, GTP):
     def tree(depth, k=0):
         if depth == 0:
             return leaf(k)
-        op = int(rng.integers(0, 6))
+        op = int(rng.integers(0, 9))
         ao, ag = tree(depth - 1, 2 * k + 1)
+        if op >= 6:
+            # exp / log / div recurrences on a well-conditioned argument: c0 + t / (8 * max-norm bound)
+            so, sg = OTP.from_scalar(1.0 / (8.0 * side ** nd)), GTP.from_scalar(1.0 / (8.0 * side ** nd))
+            to, tg = ao * so, ag * sg
+            if op == 6:
+                return to.exp(), tg.exp()
+            one_o, one_g = OTP.from_scalar(1.0), GTP.from_scalar(1.0)
+            if op == 7:
+                return (one_o + to).log(), (one_g + tg).log()
+            return ao / (one_o + to), ag / (one_g + tg)
         if op <= 1:
             bo, bg = tree(depth - 1, 2 * k + 2)
             return (ao * bo, ag * bg) if op == 0 else (ao + bo, ag + bg)
