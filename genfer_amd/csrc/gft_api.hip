@@ -1,8 +1,9 @@
 // Host side of libgftaylor: runtime (device, stream, memory pool), the TaylorPoly bookkeeping
 // of src/multivariate_taylor.rs (compact shapes, degrees_p1, broadcast, shortcut dispatch) and
-// the C ABI of include/gftaylor.h.  All VALUE arithmetic is done by the kernels in
-// gft_kernels.hip / gft_conv_tiled.hip; the host never computes a coefficient.  There is no CPU
-// fallback: without a usable gfx950 device every entry point fails with an error message.
+// the C ABI of include/gftaylor.h.  Value arithmetic is done by the kernels in gft_kernels.hip /
+// gft_conv_*.hip — and, below the size threshold of SURVEY §8f-2, by the host tier of gft_host.hpp
+// (same element functors, same bits; the reference computes everything on the host).  There is no CPU
+// fallback for a missing device: without a usable gfx950 every entry point fails with an error message.
 //
 // Citations `mt:<lines>` refer to /root/reference/src/multivariate_taylor.rs.
 #include <hip/hip_runtime.h>
@@ -22,6 +23,7 @@
 
 #include "../../include/gftaylor.h"
 #include "gft_kernels.hpp"
+#include "gft_host.hpp"
 
 using namespace gft;
 static const size_t UMAX = SIZE_MAX;
@@ -117,6 +119,7 @@ struct Runtime {
     size_t in_use = 0, cached = 0, peak = 0;
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
     double* d_scratch = nullptr; // small device scratch for packed read-backs
+    unsigned* d_wit = nullptr;   // sticky non-linearity witnesses of a speculative Horner loop (Ops::WIT_SLOTS words)
     double* h_pinned = nullptr;  // pinned staging for small D2H reads
     double* h_mail = nullptr;    // mailbox (mapped coherent pinned memory): 8 doubles payload + sequence word
     double* d_mail = nullptr;    // the same slot as the device sees it
@@ -131,6 +134,12 @@ struct Runtime {
     int conv_variant = -1;
     void* conv_ws = nullptr;
     size_t conv_ws_bytes = 0;
+    // size-threshold dispatch: an operation whose operands are all host-resident runs on the host
+    // tier (gft_host.hpp) if its result has at most host_max_elems elements (and, for a general product, at most
+    // host_max_macs multiply-adds); 0 = everything on the device.  Crossovers measured with tools/xover_host.py.
+    size_t host_max_elems = 1024;
+    double host_max_macs = 16384;
+    std::map<size_t, std::vector<void*>> host_blocks;  // free host-tier blocks by size class
 };
 Runtime R;
 
@@ -175,10 +184,27 @@ static void pool_free(void* p, size_t cls) {
     R.free_blocks[cls].push_back(p);
 }
 
+static void* host_alloc(size_t bytes, size_t* cls_out) {
+    size_t cls = size_class(bytes);
+    *cls_out = cls;
+    std::vector<void*>& fl = R.host_blocks[cls];
+    if (!fl.empty()) {
+        void* p = fl.back();
+        fl.pop_back();
+        return p;
+    }
+    void* p = std::malloc(cls);
+    if (!p) throw std::runtime_error("out of host memory");
+    return p;
+}
+static void host_free(void* p, size_t cls) { R.host_blocks[cls].push_back(p); }
+
 struct Buf {
     double* p = nullptr;
     size_t cls = 0;
     bool borrowed = false;
+    bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
+    std::shared_ptr<Buf> dev;
     // memoised extract_linear() verdict: buffers are immutable once their polynomial is returned, and the
     // metadata-only reshapes that share a buffer (extend_to_dim, dropping a trailing unit axis) keep the
     // indices of all non-unit axes, so the verdict is a property of the buffer
@@ -186,7 +212,9 @@ struct Buf {
     double lin_c[2] = {0, 0}, lin_m[2] = {0, 0};
     size_t lin_var = 0;
     ~Buf() {
-        if (p && !borrowed && R.ready) pool_free(p, cls);
+        if (!p || borrowed) return;
+        if (host) host_free(p, cls);
+        else if (R.ready) pool_free(p, cls);
     }
 };
 
@@ -195,6 +223,13 @@ static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     b->p = (double*)pool_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
     return b;
 }
+static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
+    auto b = std::make_shared<Buf>();
+    b->host = true;
+    b->p = (double*)host_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
+    return b;
+}
+static std::shared_ptr<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
 
 static void require_ready() {
     if (!R.ready) {
@@ -313,8 +348,41 @@ static double* dp(const gft_poly& p) {
             K<E>::set_small(R.stream, p.buf.get()->p, p.numel, 1, v, v);
         }
     }
-    return p.buf.get()->p;
+    Buf* b = p.buf.get();
+    if (b->host) {  // a host-tier tensor meets a device operand: mirror it once (values travel as kernel arguments)
+        if (!b->dev) {
+            b->dev = alloc_doubles(p.numel * E::W);
+            upload_small(R.stream, b->dev->p, b->p, p.numel * E::W);
+            R.stats[7]++;
+        }
+        return b->dev->p;
+    }
+    return b->p;
 }
+// true iff every value of the polynomial is host-resident (host-tier buffer, or a lazy handle without a buffer)
+static inline bool on_host(const gft_poly& p) { return !p.buf || p.buf->host; }
+// Host pointer of a host-resident polynomial (lazy handles are materialised in host memory).
+template <class E>
+static double* hp(const gft_poly& p) {
+    if (!p.buf) {
+        p.buf = alloc_host_doubles(p.numel * E::W);
+        Buf* b = p.buf.get();
+        b->p[0] = p.cv[0];
+        if (E::W == 2) b->p[p.numel] = p.cv[1];
+        if (p.lazy_lin) {
+            b->p[1] = p.cv1[0];
+            if (E::W == 2) b->p[p.numel + 1] = p.cv1[1];
+            b->lin_state = 2;
+            b->lin_c[0] = p.cv[0]; b->lin_c[1] = p.cv[1];
+            b->lin_m[0] = p.cv1[0]; b->lin_m[1] = p.cv1[1];
+            b->lin_var = p.lazy_var;
+        }
+    }
+    if (!p.buf->host) throw Error("internal: host pointer of a device tensor requested");
+    return p.buf->p;
+}
+template <class E>
+static double* tp(const gft_poly& p, bool host) { return host ? hp<E>(p) : dp<E>(p); }
 
 static size_t prod(const Dims& s) {
     size_t n = 1;
@@ -367,6 +435,7 @@ static Dims c_strides(const Dims& s) {
 template <class E>
 struct Ops {
     typedef gft_poly P;
+    typedef Scalar2 V2;
     static constexpr int W = E::W;
 
     // A contiguous device view used inside the recurrences.
@@ -374,6 +443,7 @@ struct Ops {
         double* p;
         size_t plane;
         Dims shape;
+        bool host = false;  // p is host memory (host tier)
         size_t numel() const { return prod(shape); }
         HV index0(size_t k) const {
             HV r;
@@ -381,10 +451,41 @@ struct Ops {
             r.p = p + k * prod(sub);
             r.plane = plane;
             r.shape = sub;
+            r.host = host;
             return r;
         }
     };
-    static HV view(const P& p) { return HV{dp<E>(p), p.numel, p.shape}; }
+    static HV view(const P& p, bool host = false) { return HV{tp<E>(p, host), p.numel, p.shape, host}; }
+
+    // ---- size-threshold dispatch ------------------------------------------------------------
+    // An operation runs on the host tier iff every operand is host-resident and its result is small.
+    static bool tier_host(size_t out_numel, const P& a) {
+        return R.host_max_elems && out_numel <= R.host_max_elems && on_host(a);
+    }
+    static bool tier_host(size_t out_numel, const P& a, const P& b) { return tier_host(out_numel, a) && on_host(b); }
+    // 1-element results of the host tier become lazy scalars (value in the handle, no buffer at all)
+    static P seal(P r) {
+        if (r.buf && r.buf->host) {
+            R.stats[6]++;
+            if (r.numel == 1) {
+                r.cv[0] = r.buf->p[0];
+                r.cv[1] = W == 2 ? r.buf->p[1] : 0.0;
+                r.cached = true;
+                r.lazy_lin = false;
+                r.buf = nullptr;
+            }
+        }
+        return r;
+    }
+    static V2 hv(const double v[2]) { return V2{v[0], W == 2 ? v[1] : 0.0}; }
+    static void copy_elems(bool host, double* dst, const double* src, size_t n) {
+        if (host) std::memcpy(dst, src, sizeof(double) * n);
+        else HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
+    }
+    static void zero_elems(bool host, double* dst, size_t n) {
+        if (host) std::memset(dst, 0, sizeof(double) * n);
+        else HIP_OK(hipMemsetAsync(dst, 0, sizeof(double) * n, R.stream));
+    }
     static DView dview(const HV& v, const Dims* keep = nullptr) {
         DView d;
         d.p = v.p;
@@ -394,14 +495,14 @@ struct Ops {
     }
 
     // ---- allocation ------------------------------------------------------------------------
-    static P make(const Dims& shape, const Dims& deg) {
+    static P make(const Dims& shape, const Dims& deg, bool host = false) {
         check_invariants(shape, deg);
         P r;
         r.width = W;
         r.shape = shape;
         r.deg = deg;
         r.numel = prod(shape);
-        r.buf = alloc_doubles(r.numel * W);
+        r.buf = alloc_tier(host, r.numel * W);
         return r;
     }
     static P with_meta(const P& src, const Dims& shape, const Dims& deg) {  // metadata-only reshape
@@ -410,6 +511,12 @@ struct Ops {
         r.shape = shape;
         r.deg = deg;
         return r;
+    }
+    static P from_host_value(typename E::V v, const Dims& shape, const Dims& deg) {
+        double x[2] = {0.0, 0.0};
+        E::st(x, 1, 0, v);
+        R.stats[6]++;
+        return from_host_scalar(x, shape, deg);
     }
     static P from_host_scalar(const double* x, const Dims& shape, const Dims& deg) {
         check_invariants(shape, deg);
@@ -439,6 +546,11 @@ struct Ops {
         if (p.c0_known) {
             out[0] = p.c0[0];
             out[1] = p.c0[1];
+            return;
+        }
+        if (p.buf && p.buf->host) {
+            out[0] = p.buf->p[0];
+            out[1] = W == 2 ? p.buf->p[p.numel] : 0.0;
             return;
         }
         double tmp[2] = {0, 0};
@@ -510,10 +622,14 @@ struct Ops {
 
     // ---- structured copies -----------------------------------------------------------------------
     // General gather of `src` into a fresh tensor of shape `out_shape`; per-axis shift and valid length.
+    // `tier`: -1 = decide here; callers that pass `tab` / `keep` pointers decide first (gather_tier) and pass the
+    // pointers of that side.
+    static bool gather_tier(const P& src, const Dims& out_shape) { return tier_host(prod(out_shape), src); }
     static P gather(const P& src, const Dims& out_shape, const Dims& out_deg, const Shifts& shift,
                     const Dims& src_len, int op = OP_COPY, const double* s = nullptr, int tab_axis = -1,
-                    const double* tab = nullptr, size_t tab_plane = 0, const unsigned char* keep = nullptr) {
-        P out = make(out_shape, out_deg);
+                    const double* tab = nullptr, size_t tab_plane = 0, const unsigned char* keep = nullptr, int tier = -1) {
+        const bool host = tier < 0 ? gather_tier(src, out_shape) : tier != 0;
+        P out = make(out_shape, out_deg, host);
         if (out.numel == 0) return out;
         Dims sst = c_strides(src.shape);
         // collapse axes that are trivial in the output and read index 0 (+shift) of the source
@@ -526,8 +642,8 @@ struct Ops {
             if (out_shape[ax] == 1 && (int)ax != tab_axis) {
                 long long si = shift[ax];
                 if (si < 0 || (size_t)si >= src_len[ax]) {  // whole output is outside the source box
-                    HIP_OK(hipMemsetAsync(dp<E>(out), 0, sizeof(double) * out.numel * W, R.stream));
-                    return out;
+                    zero_elems(host, tp<E>(out, host), out.numel * W);
+                    return seal(out);
                 }
                 base += (size_t)si * sst[ax];
                 continue;
@@ -571,6 +687,10 @@ struct Ops {
         a.tab = tab;
         a.tab_plane = tab_plane;
         a.keep = keep;
+        if (host) {
+            HK<E>::gather(hp<E>(src) + base, src.numel, hp<E>(out), out.numel, a);
+            return seal(out);
+        }
         K<E>::gather(R.stream, dp<E>(src) + base, src.numel, dp<E>(out), out.numel, a);
         return out;
     }
@@ -580,12 +700,12 @@ struct Ops {
         return gather(p, lens, deg, shift, p.shape);
     }
     static P slab_range(const P& p, size_t v, size_t lo, size_t hi, const Dims& deg, int op = OP_COPY,
-                        int tab_axis = -1, const double* tab = nullptr, size_t tab_plane = 0) {
+                        int tab_axis = -1, const double* tab = nullptr, size_t tab_plane = 0, int tier = -1) {
         Dims out = p.shape;
         out[v] = hi - lo;
         Shifts shift(out.size(), 0);
         shift[v] = (long long)lo;
-        return gather(p, out, deg, shift, p.shape, op, nullptr, tab_axis, tab, tab_plane);
+        return gather(p, out, deg, shift, p.shape, op, nullptr, tab_axis, tab, tab_plane, nullptr, tier);
     }
     static P truncate_degrees(const P& p, const Dims& degs) {  // mt:195-204
         Dims nd = p.deg, lens = p.shape;
@@ -596,13 +716,12 @@ struct Ops {
         return lead_block(p, lens, nd);
     }
     static P map_copy(const P& p, int op, const double* s) {  // fresh tensor = f(p) elementwise
-        if (p.numel == 1 && p.cached && !p.buf && (op == OP_LMUL_S || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG)) {
-            // both operands are host-cached scalars: they travel as kernel arguments, nothing is materialised first
-            P out = make(p.shape, p.deg);
+        if (p.numel == 1 && p.cached && (op == OP_LMUL_S || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG)) {
+            // both operands are host-known scalars: one IEEE operation on the host (what the reference does,
+            // mt:1033-1047), no launch, no buffer — the result is again a lazy scalar
             int kind = op == OP_LMUL_S ? IMM_LMUL : (op == OP_MUL_S ? IMM_MUL : (op == OP_DIV_S ? IMM_DIV : IMM_NEG));
             Scalar2 b{s ? s[0] : 0.0, (s && W == 2) ? s[1] : 0.0};
-            K<E>::scalar_imm(R.stream, kind, Scalar2{p.cv[0], p.cv[1]}, b, dp<E>(out), out.numel);
-            return out;
+            return from_host_value(HK<E>::scalar_imm(kind, E::from(Scalar2{p.cv[0], p.cv[1]}), E::from(b)), p.shape, p.deg);
         }
         Shifts shift(p.shape.size(), 0);
         return gather(p, p.shape, p.deg, shift, p.shape, op, s);
@@ -692,12 +811,16 @@ struct Ops {
             // zero), so `Var(x) + Const(d)` substitutions never touch the device before they are consumed.
             if (!self.buf && self.lazy_lin && other.cached && !other.buf && self.deg == rd && lazy_zero_plus(self, other, subtract, &self))
                 return self;
-            P out = make(self.shape, rd);
-            if (self.numel == 1 && self.cached && !self.buf && other.cached && !other.buf) {
-                K<E>::scalar_imm(R.stream, subtract ? IMM_SUB : IMM_ADD, Scalar2{self.cv[0], self.cv[1]},
-                                 Scalar2{other.cv[0], other.cv[1]}, dp<E>(out), out.numel);
-                return out;
+            if (self.numel == 1 && self.cached && other.cached)  // two host-known scalars (mt:862-869): host arithmetic
+                return from_host_value(HK<E>::scalar_imm(subtract ? IMM_SUB : IMM_ADD, E::from(Scalar2{self.cv[0], self.cv[1]}),
+                                                         E::from(Scalar2{other.cv[0], other.cv[1]})), self.shape, rd);
+            if (other.cached && tier_host(self.numel, self)) {
+                P out = make(self.shape, rd, true);
+                HK<E>::copy_first(hp<E>(self), self.numel, hp<E>(out), out.numel, self.numel, subtract ? FIRST_SUB : FIRST_ADD,
+                                  Scalar2{other.cv[0], other.cv[1]});
+                return seal(out);
             }
+            P out = make(self.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
                              subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
             if (W == 1 && subtract && self.c0_known && other.cached && std::isfinite(self.c0[0]) &&
@@ -711,15 +834,26 @@ struct Ops {
             if (!subtract && !other.buf && other.lazy_lin && self.cached && !self.buf && other.deg == rd &&
                 lazy_zero_plus(other, self, false, &other))
                 return other;
+            if (self.cached && tier_host(other.numel, other)) {
+                P out = make(other.shape, rd, true);
+                HK<E>::copy_first(hp<E>(other), other.numel, hp<E>(out), out.numel, other.numel,
+                                  subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, Scalar2{self.cv[0], self.cv[1]});
+                return seal(out);
+            }
             P out = make(other.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(other), other.numel, dp<E>(out), out.numel, other.numel,
                              subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, sptr(self), self.numel, Scalar2{self.cv[0], self.cv[1]});
             return out;
         }
         Dims shape = max_shape(self, other);
-        P out = make(shape, rd);
+        const bool host = tier_host(prod(shape), self, other);
+        P out = make(shape, rd, host);
         Dims keep = collapse_mask({&shape}, false);
-        HV vo = view(out), va = view(self), vb = view(other);
+        HV vo = view(out, host), va = view(self, host), vb = view(other, host);
+        if (host) {
+            HK<E>::addsub_padded(dview(vo, &keep), dview(va, &keep), dview(vb, &keep), subtract ? 1 : 0);
+            return seal(out);
+        }
         K<E>::addsub_padded(R.stream, dview(vo, &keep), dview(va, &keep), dview(vb, &keep), subtract ? 1 : 0);
         return out;
     }
@@ -749,14 +883,19 @@ struct Ops {
         unsigned cmask = 0;
         for (size_t i = 0; i < keep.size(); ++i)
             if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
-        HV v = view(p);
-        DView dv = dview(v, &keep);
-        Mailbox mb = next_mail();
-        K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, mb);  // one launch (state words 8, 9), result by mailbox
-        R.stats[0]++;
-        g_scan_trace.hit(p.numel, keep.size());
         double res[5];
-        wait_mail(mb, res, 5);
+        if (p.buf->host) {
+            HV v = view(p, true);
+            res[0] = (double)HK<E>::linear_scan(dview(v, &keep), cmask, res + 1, res + 3);  // {mask, c.lo, c.hi, m.lo, m.hi}
+        } else {
+            HV v = view(p);
+            DView dv = dview(v, &keep);
+            Mailbox mb = next_mail();
+            K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, mb);  // one launch (state words 8, 9), result by mailbox
+            R.stats[0]++;
+            g_scan_trace.hit(p.numel, keep.size());
+            wait_mail(mb, res, 5);
+        }
         unsigned got = (unsigned)res[0];
         if (!got) {
             p.buf->lin_state = 1;
@@ -860,6 +999,13 @@ struct Ops {
             if (a.zs[i] != 1) nonunit++;
         a.inner_from_zero = nonunit >= 1 ? 1 : 0;
 
+        if (z.host) {  // host tier: the reference's loop nest, operands and result in host memory
+            if (!x.host || !y.host) throw Error("internal: host-tier product with a device operand");
+            HK<E>::conv_naive(x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
+            return;
+        }
+        if (x.host || y.host) throw Error("internal: device product with a host operand");
+
         bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
         // A recurrence step (one output slab k with j0 >= j0_min and/or j0 < k) is a plain slab product of shifted
         // operand views:  sum_{j0 >= m, j0 <= k - e} x[j0] y[k - j0]  =  slab k - m - e of  x[m:] (*) y[e:]  (e = 1
@@ -906,9 +1052,12 @@ struct Ops {
             unsigned B = 0;
             const bool split = plan_inner_split(ash, at, &B);
             size_t need = 0;
-            bool ok = conv_tiled_f64(R.stream, tx, ty, tz, at, nullptr, 0, &need, nullptr, 0);
-            if (ok && R.conv_mode == 0) {
-                // auto: below this the bit-exact reference-order kernels are as fast (fixed costs dominate)
+            bool ok = true;
+            if (R.conv_mode == 0) {
+                // auto: below this the bit-exact reference-order kernels are as fast (fixed costs dominate).  Decided
+                // from the shapes alone, BEFORE the tiled planner is asked: a plan query builds tables, takes an arena
+                // slice and a cache entry, which small ever-changing shapes (Genfer's supports grow statement by
+                // statement) would pay for nothing.
                 double macs = 1.0;
                 for (int i = 0; i < ash.nd; ++i) {
                     double f = 0.5 * (double)ash.zs[i] * (double)std::min(ash.xs[i], ash.ys[i]);
@@ -917,6 +1066,7 @@ struct Ops {
                 }
                 if (macs < R.tiled_min_macs * (split ? 10.0 : 1.0)) ok = false;
             }
+            if (ok) ok = conv_tiled_f64(R.stream, tx, ty, tz, at, nullptr, 0, &need, nullptr, 0);
             if (ok) {
                 if (need > R.conv_ws_bytes) {  // grow geometrically: supports (and workspaces) grow statement by statement
                     size_t want = std::max(need, std::min<size_t>(2 * R.conv_ws_bytes, (size_t)1 << 32));
@@ -1059,9 +1209,16 @@ struct Ops {
             sh[v] = std::min(deg[v], sh[v] + 1);
             return mul_linear(self, c, m, v, sh, deg);
         }
-        P out = make(shape, deg);
-        conv(view(self), view(other), view(out), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
-        return out;
+        const bool host = tier_host(prod(shape), self, other) && est_macs(self.shape, other.shape, shape) <= R.host_max_macs;
+        P out = make(shape, deg, host);
+        conv(view(self, host), view(other, host), view(out, host), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
+        return seal(out);
+    }
+    // multiply-adds of a full product, estimated from the shapes (the dispatch criterion for general products)
+    static double est_macs(const Dims& xs, const Dims& ys, const Dims& zs) {
+        double macs = 1.0;
+        for (size_t i = 0; i < zs.size(); ++i) macs *= 0.5 * (double)zs[i] * (double)std::min(xs[i], ys[i]) + 0.5;
+        return macs;
     }
 
     // ---- division (mt:1162-1231) -----------------------------------------------------------------------------
@@ -1071,15 +1228,39 @@ struct Ops {
             if (x != 1) n++;
         return n;
     }
+    // tier-dispatched launches used by the recurrences (views carry their side)
+    static void x_map_inplace(const HV& v, int op, unsigned u) {
+        if (v.host) HK<E>::map_inplace(v.p, v.plane, v.numel(), op, u, Scalar2{0, 0});
+        else K<E>::map_inplace(R.stream, v.p, v.plane, v.numel(), op, u, Scalar2{0, 0});
+    }
+    static void x_block_op(const HV& dst, const HV& src, int op, unsigned u) {
+        Dims keep = collapse_mask({&dst.shape}, false);
+        if (dst.host) HK<E>::block_op(dview(dst, &keep), dview(src, &keep), op, u);
+        else K<E>::block_op(R.stream, dview(dst, &keep), dview(src, &keep), op, u);
+    }
+    static void x_set_scalar(const HV& dst, Scalar2 v) {
+        if (dst.host) E::st(dst.p, dst.plane, 0, E::from(v));
+        else K<E>::set_small(R.stream, dst.p, dst.plane, 1, v, v);
+    }
+    static void copy_planes(bool host, double* dst, size_t dplane, const double* src, size_t splane, size_t n) {
+        copy_elems(host, dst, src, n);
+        if (W == 2) copy_elems(host, dst + dplane, src + splane, n);
+    }
     static void div_rec(const HV& xs, const HV& ys, const HV& res) {
         if (xs.numel() == 0) return;
+        const bool host = res.host;
         if (res.shape.empty()) {
-            K<E>::scalar_op(R.stream, SC_DIV, xs.p, xs.plane, ys.p, ys.plane, res.p, res.plane);
+            if (host) E::st(res.p, res.plane, 0, E::div(E::ld(xs.p, xs.plane, 0), E::ld(ys.p, ys.plane, 0)));
+            else K<E>::scalar_op(R.stream, SC_DIV, xs.p, xs.plane, ys.p, ys.plane, res.p, res.plane);
             return;
         }
         if (res.shape.size() == 1) {  // last level: fused sequential recurrence
-            K<E>::div_1d(R.stream, xs.p, xs.plane, (unsigned)xs.shape[0], ys.p, ys.plane, (unsigned)ys.shape[0], res.p,
-                         res.plane, (unsigned)res.shape[0]);
+            if (host)
+                HK<E>::div_1d(xs.p, xs.plane, (unsigned)xs.shape[0], ys.p, ys.plane, (unsigned)ys.shape[0], res.p, res.plane,
+                              (unsigned)res.shape[0]);
+            else
+                K<E>::div_1d(R.stream, xs.p, xs.plane, (unsigned)xs.shape[0], ys.p, ys.plane, (unsigned)ys.shape[0], res.p,
+                             res.plane, (unsigned)res.shape[0]);
             return;
         }
         size_t n0 = res.shape[0];
@@ -1087,18 +1268,11 @@ struct Ops {
         for (size_t k = 0; k < n0; ++k) {
             HV cur = res.index0(k);
             conv(res, ys, res, k, k + 1, false, true, 0, 1, 0);  // cur = sum_{j<k} res[j] (*) ys[k-j]
-            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_NEG, 0, Scalar2{0, 0});
-            if (k < xs.shape[0]) {
-                HV xk = xs.index0(k);
-                Dims keep = collapse_mask({&cur.shape}, false);
-                K<E>::block_op(R.stream, dview(cur, &keep), dview(xk, &keep), BLK_ADD, 0);
-            }
-            std::shared_ptr<Buf> tmp = alloc_doubles(cur.numel() * W);
-            HV copy{tmp->p, cur.numel(), cur.shape};
-            HIP_OK(hipMemcpyAsync(copy.p, cur.p, sizeof(double) * cur.numel(), hipMemcpyDeviceToDevice, R.stream));
-            if (W == 2)
-                HIP_OK(hipMemcpyAsync(copy.p + copy.plane, cur.p + cur.plane, sizeof(double) * cur.numel(),
-                                      hipMemcpyDeviceToDevice, R.stream));
+            x_map_inplace(cur, MAP_NEG, 0);
+            if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD, 0);
+            std::shared_ptr<Buf> tmp = alloc_tier(host, cur.numel() * W);
+            HV copy{tmp->p, cur.numel(), cur.shape, host};
+            copy_planes(host, copy.p, copy.plane, cur.p, cur.plane, cur.numel());
             div_rec(copy, y0, cur);
         }
     }
@@ -1118,16 +1292,18 @@ struct Ops {
             if (other.shape[i] == 1) rs[i] = self.shape[i];
         for (size_t i = 0; i < rs.size(); ++i)
             if (rs[i] == UMAX) throw Error("div: untruncated result shape (degrees_p1 == usize::MAX)");
-        P out = make(rs, deg);
-        div_rec(view(self), view(other), view(out));
-        return out;
+        const bool host = tier_host(prod(rs), self, other) && est_macs(rs, other.shape, rs) <= R.host_max_macs;
+        P out = make(rs, deg, host);
+        div_rec(view(self, host), view(other, host), view(out, host));
+        return seal(out);
     }
 
     // ---- exp / log (mt:406-430, 1270-1386) ---------------------------------------------------------------------
     // xs scaled slab-wise by T::from(j) along axis 0 (mt:1308-1310): xs[j] * j
     static std::shared_ptr<Buf> scaled_by_index(const HV& xs, HV* out) {
-        std::shared_ptr<Buf> buf = alloc_doubles(xs.numel() * W);
-        std::shared_ptr<Buf> tab = cached_table(TAB_INDEX, 0, xs.shape[0]);
+        const bool host = xs.host;
+        std::shared_ptr<Buf> buf = alloc_tier(host, xs.numel() * W);
+        std::shared_ptr<Buf> tab = cached_table(TAB_INDEX, 0, xs.shape[0], host);
         GatherArgs a;
         std::memset(&a, 0, sizeof(a));
         size_t inner = xs.numel() / std::max<size_t>(xs.shape[0], 1);
@@ -1142,28 +1318,33 @@ struct Ops {
         a.tab_axis = 0;
         a.tab = tab->p;
         a.tab_plane = xs.shape[0];
-        *out = HV{buf->p, xs.numel(), xs.shape};
-        K<E>::gather(R.stream, xs.p, xs.plane, buf->p, xs.numel(), a);
+        *out = HV{buf->p, xs.numel(), xs.shape, host};
+        if (host) HK<E>::gather(xs.p, xs.plane, buf->p, xs.numel(), a);
+        else K<E>::gather(R.stream, xs.p, xs.plane, buf->p, xs.numel(), a);
         return buf;
     }
-    static void exp_rec(const HV& xs, const HV& res) {
+    // The scalar seeds exp(xs[0]) / ln(xs[0]) (mt:1286-1289, 1336-1339; f64.rs:54-61 = the platform libm) are formed on
+    // the host from the constant term — one value, SURVEY §8a row S — so that they are the same libm result whichever
+    // side runs the recurrence; every coefficient operation after the seed is device (or host-tier) arithmetic.
+    static void exp_rec(const HV& xs, const HV& res, Scalar2 seed) {
         if (xs.numel() == 0) return;
         if (res.shape.empty()) {
-            K<E>::scalar_op(R.stream, SC_EXP, xs.p, xs.plane, nullptr, 0, res.p, res.plane);
+            x_set_scalar(res, seed);
             return;
         }
         if (nonunit_axes(res.shape) == 1) {
-            K<E>::exp_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel());
+            if (res.host) HK<E>::exp_1d(xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
+            else K<E>::exp_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
             return;
         }
-        exp_rec(xs.index0(0), res.index0(0));
+        exp_rec(xs.index0(0), res.index0(0), seed);
         if (res.shape[0] <= 1) return;
         HV xsc;
         std::shared_ptr<Buf> hold = scaled_by_index(xs, &xsc);
         for (size_t k = 1; k < res.shape[0]; ++k) {
             HV cur = res.index0(k);
             conv(xsc, res, res, k, k + 1, false, true, 1, 0, 0);
-            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_DIV_U32, (unsigned)k, Scalar2{0, 0});
+            x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
         }
     }
     static Dims explog_shape(const P& a) {
@@ -1174,62 +1355,80 @@ struct Ops {
         }
         return rs;
     }
+    static Scalar2 seed_of(const P& a, bool is_exp) {
+        double c[2];
+        first_value(a, c);
+        typename E::V r = is_exp ? E::exp(E::from(hv(c))) : E::log(E::from(hv(c)));
+        double o[2] = {0.0, 0.0};
+        E::st(o, 1, 0, r);
+        return Scalar2{o[0], o[1]};
+    }
     static P exp(const P& a) {
-        P out = make(explog_shape(a), a.deg);
-        exp_rec(view(a), view(out));
-        return out;
+        Dims rs = explog_shape(a);
+        const bool host = tier_host(prod(rs), a) && est_macs(a.shape, rs, rs) <= R.host_max_macs;
+        P out = make(rs, a.deg, host);
+        exp_rec(view(a, host), view(out, host), seed_of(a, true));
+        return seal(out);
     }
 
-    static void log_rec(const HV& xs, const HV& res) {
+    static void log_rec(const HV& xs, const HV& res, Scalar2 seed) {
         if (xs.numel() == 0) return;
+        const bool host = res.host;
         if (res.shape.empty()) {
-            K<E>::scalar_op(R.stream, SC_LOG, xs.p, xs.plane, nullptr, 0, res.p, res.plane);
+            x_set_scalar(res, seed);
             return;
         }
         if (nonunit_axes(xs.shape) == 1) {
             if (nonunit_axes(res.shape) != 1) throw Error("log: called `Option::unwrap()` on a `None` value (mt:1346)");
-            K<E>::log_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel());
+            if (host) HK<E>::log_1d(xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
+            else K<E>::log_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
             return;
         }
-        log_rec(xs.index0(0), res.index0(0));
+        log_rec(xs.index0(0), res.index0(0), seed);
         size_t n0 = res.shape[0];
         if (n0 <= 1) return;
         // rs[j] = res[j] * j, filled slab by slab as res becomes known (mt:1362-1365)
-        std::shared_ptr<Buf> rsbuf = alloc_doubles(res.numel() * W);
-        HV rs{rsbuf->p, res.numel(), res.shape};
-        HIP_OK(hipMemsetAsync(rs.p, 0, sizeof(double) * res.numel() * W, R.stream));
+        std::shared_ptr<Buf> rsbuf = alloc_tier(host, res.numel() * W);
+        HV rs{rsbuf->p, res.numel(), res.shape, host};
+        zero_elems(host, rs.p, res.numel() * W);
         Dims sub(res.shape.begin() + 1, res.shape.end());
         HV x0 = xs.index0(0);
         for (size_t k = 1; k < n0; ++k) {
             HV cur = res.index0(k);
             conv(xs, rs, res, k, k + 1, false, true, 1, 1, 1);  // sum_{j} xs[k-j] (*) (res[j]*j), j ascending
-            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_NEG, 0, Scalar2{0, 0});
-            if (k < xs.shape[0]) {
-                HV xk = xs.index0(k);
-                Dims keep = collapse_mask({&cur.shape}, false);
-                K<E>::block_op(R.stream, dview(cur, &keep), dview(xk, &keep), BLK_ADD_U32_TIMES, (unsigned)k);
-            }
+            x_map_inplace(cur, MAP_NEG, 0);
+            if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD_U32_TIMES, (unsigned)k);
             // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
-            P num = make(sub, sub), den = make(x0.shape, sub);
-            copy_planes(dp<E>(num), num.numel, cur.p, cur.plane, cur.numel());
-            copy_planes(dp<E>(den), den.numel, x0.p, x0.plane, x0.numel());
-            P q = div(num, den);
+            P num = make(sub, sub, host), den = make(x0.shape, sub, host);
+            copy_planes(host, tp<E>(num, host), num.numel, cur.p, cur.plane, cur.numel());
+            copy_planes(host, tp<E>(den, host), den.numel, x0.p, x0.plane, x0.numel());
+            P q = div_same_tier(num, den, host);
             if (q.shape != sub) throw Error("log: internal shape mismatch after division");
-            copy_planes(cur.p, cur.plane, dp<E>(q), q.numel, cur.numel());
-            K<E>::map_inplace(R.stream, cur.p, cur.plane, cur.numel(), MAP_DIV_U32, (unsigned)k, Scalar2{0, 0});
+            copy_planes(host, cur.p, cur.plane, tp<E>(q, host), q.numel, cur.numel());
+            x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
             HV rk = rs.index0(k);
-            copy_planes(rk.p, rk.plane, cur.p, cur.plane, cur.numel());
-            K<E>::map_inplace(R.stream, rk.p, rk.plane, rk.numel(), MAP_MUL_U32, (unsigned)k, Scalar2{0, 0});
+            copy_planes(host, rk.p, rk.plane, cur.p, cur.plane, cur.numel());
+            x_map_inplace(rk, MAP_MUL_U32, (unsigned)k);
         }
     }
-    static void copy_planes(double* dst, size_t dplane, const double* src, size_t splane, size_t n) {
-        HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
-        if (W == 2) HIP_OK(hipMemcpyAsync(dst + dplane, src + splane, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
+    // Div's dispatcher (mt:1194-1231) for the slab division inside log.  tp<E>() serves a device caller whatever side
+    // the quotient is on; a host caller needs it in host memory.
+    static P div_same_tier(const P& num, const P& den, bool host) {
+        P q = div(num, den);
+        if (host && !on_host(q)) {  // cannot happen while the dispatch criterion is monotone in the shapes; stay correct anyway
+            P h = make(q.shape, q.deg, true);
+            HIP_OK(hipMemcpyAsync(hp<E>(h), dp<E>(q), sizeof(double) * q.numel * W, hipMemcpyDeviceToHost, R.stream));
+            HIP_OK(hipStreamSynchronize(R.stream));
+            return h;
+        }
+        return q;
     }
     static P log(const P& a) {
-        P out = make(explog_shape(a), a.deg);
-        log_rec(view(a), view(out));
-        return out;
+        Dims rs = explog_shape(a);
+        const bool host = tier_host(prod(rs), a) && est_macs(a.shape, rs, rs) <= R.host_max_macs;
+        P out = make(rs, a.deg, host);
+        log_rec(view(a, host), view(out, host), seed_of(a, false));
+        return seal(out);
     }
 
     static P pow(const P& a, uint32_t e) {  // mt:433-451
@@ -1248,14 +1447,16 @@ struct Ops {
 
     // Device-resident factor tables for derivative / coefficient expansion / index scaling depend only on
     // (kind, n, len): computed once by k_factor_table (reference operation order) and reused.
-    static std::shared_ptr<Buf> cached_table(int table_op, size_t n, size_t len) {
-        static std::map<std::tuple<int, size_t, size_t>, std::shared_ptr<Buf>> cache;
+    static std::shared_ptr<Buf> cached_table(int table_op, size_t n, size_t len, bool host = false) {
+        static std::map<std::tuple<int, size_t, size_t>, std::shared_ptr<Buf>> caches[2];
+        auto& cache = caches[host ? 1 : 0];
         auto key = std::make_tuple(table_op, n, len);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
         if (cache.size() > 4096) cache.clear();
-        std::shared_ptr<Buf> tab = alloc_doubles(len * W);
-        K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        std::shared_ptr<Buf> tab = alloc_tier(host, len * W);
+        if (host) HK<E>::factor_table(table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        else K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
         cache[key] = tab;
         return tab;
     }
@@ -1269,8 +1470,9 @@ struct Ops {
         d[v] = d[v] > n ? d[v] - n : 0;
         if (n >= a.shape[v]) return zero_with(d);
         size_t len = a.shape[v] - n;
-        std::shared_ptr<Buf> tab = cached_table(table_op, n, len);
-        return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len);
+        const bool host = tier_host(a.numel / a.shape[v] * len, a);
+        std::shared_ptr<Buf> tab = cached_table(table_op, n, len, host);
+        return slab_range(a, v, n, a.shape[v], d, OP_MUL_TAB, (int)v, tab->p, len, host);
     }
 
     // derivative(a, v, n).truncate_to_degree_p1(d) — what the evaluator does for every Derivative node
@@ -1288,10 +1490,11 @@ struct Ops {
             deg[ax] = std::min(deg[ax], d);
             out[ax] = std::min(out[ax], deg[ax]);
         }
-        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, n, len);
+        const bool host = gather_tier(a, out);
+        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, n, len, host);
         Shifts shift(out.size(), 0);
         shift[v] = (long long)n;
-        return gather(a, out, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, len);
+        return gather(a, out, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, len, nullptr, host);
     }
 
     // ---- fused observation step ------------------------------------------------------------------------
@@ -1307,6 +1510,7 @@ struct Ops {
         if (!(v < a.deg.size() && 1 < len_of)) return generic();          // reference assertion path
         if (v >= a.shape.size() || a.shape[v] < 2 || d < 2) return generic();  // zero_with / constant var
         if (val_is_zero(c)) return generic();                             // -> zero_with(deg)
+        if (tier_host(a.numel, a)) return generic();                      // host tier: the reference's own op sequence
         for (int i = 0; i < W; ++i)
             if (!(x[i] - x[i] == 0.0) || !(c[i] - c[i] == 0.0)) return generic();  // inf/NaN scalars: keep the exact dispatch
         Dims dshape = a.shape, ddeg = a.deg;
@@ -1348,13 +1552,18 @@ struct Ops {
     }
 
     // ---- shift_down (mt:514-536) -------------------------------------------------------------------------------------
-    static void sum_axis_into(const P& a, size_t v, size_t upto, double* out, size_t out_plane) {
+    static void sum_axis_into(const P& a, size_t v, size_t upto, double* out, size_t out_plane, bool host) {
         size_t outer = 1, inner = 1;
         for (size_t i = 0; i < v; ++i) outer *= a.shape[i];
         for (size_t i = v + 1; i < a.shape.size(); ++i) inner *= a.shape[i];
         int mode = SUM_SEQ;
         // ndarray 0.15.6 sum_axis: 2-d array whose summed axis has unit stride => per-lane 8-way fold
         if (a.shape.size() == 2 && inner == 1) mode = SUM_UNROLL8;
+        if (host) {
+            HK<E>::sum_axis(hp<E>(a), a.numel, (unsigned)outer, (unsigned)upto, (unsigned)inner, a.shape[v] * inner, out,
+                            out_plane, mode);
+            return;
+        }
         if (W == 1 && inner == 1 && upto >= 128) mode = SUM_WAVE;  // long rows: wavefront-shuffle reduction
         K<E>::sum_axis(R.stream, dp<E>(a), a.numel, (unsigned)outer, (unsigned)upto, (unsigned)inner,
                        a.shape[v] * inner, out, out_plane, mode);
@@ -1365,23 +1574,28 @@ struct Ops {
         if (v >= a.shape.size()) return a;
         Dims d = a.deg;
         d[v] = d[v] > n ? d[v] - n : 0;
+        const bool host = tier_host(a.numel, a);
         if (a.shape[v] <= n + 1) {
             Dims rs = a.shape;
             rs[v] = 1;
-            P out = make(rs, d);
-            sum_axis_into(a, v, a.shape[v], dp<E>(out), out.numel);
-            return out;
+            P out = make(rs, d, host);
+            sum_axis_into(a, v, a.shape[v], tp<E>(out, host), out.numel, host);
+            return seal(out);
         }
-        P out = slab_range(a, v, n, a.shape[v], d);
+        Dims os = a.shape;
+        os[v] = a.shape[v] - n;
+        Shifts sh0(os.size(), 0);
+        sh0[v] = (long long)n;
+        P out = gather(a, os, d, sh0, a.shape, OP_COPY, nullptr, -1, nullptr, 0, nullptr, host);
         Dims ss = a.shape;
         ss[v] = 1;
-        std::shared_ptr<Buf> s = alloc_doubles(prod(ss) * W);
-        sum_axis_into(a, v, n, s->p, prod(ss));
-        Dims keep = collapse_mask({&out.shape}, false);
-        HV vo = view(out), vs{s->p, prod(ss), ss};
-        K<E>::block_op(R.stream, dview(vo, &keep), dview(vs, &keep), BLK_ADD, 0);
-        return out;
+        std::shared_ptr<Buf> s = alloc_tier(host, prod(ss) * W);
+        sum_axis_into(a, v, n, s->p, prod(ss), host);
+        HV vo = view(out, host), vs{s->p, prod(ss), ss, host};
+        x_block_op(vo, vs, BLK_ADD, 0);
+        return seal(out);
     }
+
 
     // ---- subst_var (mt:540-580) -----------------------------------------------------------------------------------------
     static P subst_var(const P& a, size_t v, const P& subst) {
@@ -1394,7 +1608,7 @@ struct Ops {
         // A 2-element tensor is linear by structure; if the host also knows its constant term (see gft_poly::c0_known)
         // the verdict needs no device scan.  m stays on the device (the power table reads it from there).
         bool have_lin = false, m_known = true;
-        if (subst.buf && !subst.buf->lin_state && subst.numel == 2 && subst.c0_known && val_is_zero(subst.c0)) {
+        if (subst.buf && !subst.buf->host && !subst.buf->lin_state && subst.numel == 2 && subst.c0_known && val_is_zero(subst.c0)) {
             for (size_t ax = 0; ax < subst.shape.size(); ++ax)
                 if (subst.shape[ax] == 2) w = ax;
             if (v == w) {
@@ -1412,52 +1626,109 @@ struct Ops {
                 if (m_known && val_is_one(m)) return lead_block(a, lens, deg);  // powers of one: x * 1 == x, nothing to compute
                 Dims sst = c_strides(subst.shape);
                 Shifts shift(lens.size(), 0);
+                if (m_known && gather_tier(a, lens)) {  // host tier: the running product m^k per element (mt:557-565)
+                    const double mm[2] = {m[0], m[1]};
+                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, mm, 1, nullptr, 1);
+                }
                 if (lens[v] <= 256)  // short axis: every thread forms its own m^k (same running product), no table launch
-                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel);
+                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel, nullptr, 0);
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
-                return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v]);
+                return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v], nullptr, 0);
             }
         }
-        P res = zero_with(deg);
         Dims cshape = a.shape;
         while (cshape.size() < deg.size()) cshape.push_back(1);
         P ca = with_meta_unchecked(a, cshape);
         // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
-        const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2 && R.fuse_horner;
-        // The reference asks on every step whether the ACCUMULATOR is linear (and then multiplies the other way
-        // round, which compacts its stored shape).  That happens while the top coefficient slabs are zero or
-        // scalar-like; once the accumulator has been seen non-linear it stays so short of an exact cancellation.
-        // So: generic steps (with the scan) until the first "not linear" verdict, fused / scan-free steps after it.
+        const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2;
+        P res;
+        if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res)) return res;
+        return horner_exact(ca, v, subst, deg);
+    }
+    // One Horner coefficient: a[.., i, ..] clipped to deg (mt:571-576)
+    static P horner_coeff(const P& ca, size_t v, size_t i, const Dims& deg) {
+        Dims out = ca.shape;
+        out[v] = 1;
+        for (size_t ax = 0; ax < out.size(); ++ax) out[ax] = std::min(out[ax], deg[ax]);
+        Shifts shift(out.size(), 0);
+        shift[v] = (long long)i;
+        return gather(ca, out, deg, shift, ca.shape);
+    }
+    // The reference's loop, operation for operation (mt:569-579): every product goes through Mul's dispatcher, which asks
+    // on every step whether the accumulator is linear (a device scan + host round trip for device tensors, free on the
+    // host tier).
+    static P horner_exact(const P& ca, size_t v, const P& subst, const Dims& deg) {
+        P res = zero_with(deg);
+        for (size_t i = ca.shape[v]; i-- > 0;) res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
+        return res;
+    }
+    // The same loop without a host round trip per step.  The reference asks on every step whether the ACCUMULATOR is
+    // linear (and then multiplies the other way round, which compacts its stored shape).  That is the case while the top
+    // coefficient slabs are zero or scalar-like; once the accumulator has been seen non-linear it stays so short of an
+    // exact cancellation.  So: reference steps (with the scan) until the first "not linear" verdict, then fused /
+    // scan-free steps that SPECULATE "still not linear" — and prove it: every accumulator produced on the way is
+    // checked on the device for a witness of non-linearity (a non-zero coefficient at an index with two non-zero
+    // coordinates or a coordinate >= 2), one sticky word per step, and ONE verdict read-back at the end of the loop.
+    // A step without a witness (exact cancellation, or a support on unit positions of two axes) makes the function
+    // return false and the caller redoes the loop with horner_exact: the stored shapes are the reference's in every
+    // case, the extra cost is one round trip per subst_var instead of one per step.
+    static constexpr size_t WIT_SLOTS = 8192;
+    static bool horner_speculative(const P& ca, size_t v, const P& subst, const Dims& deg, bool lin_known, const double c[2],
+                                   const double m[2], size_t w, P* result) {
+        P res = zero_with(deg);
         bool res_nonlinear_seen = false;
-        for (size_t i = cshape[v]; i-- > 0;) {
-            if (R.fuse_horner && !res_nonlinear_seen && res.numel > 1) {
-                double c_[2], m_[2];
-                size_t u_;
-                ScanCtx sc_res("subst_var.accumulator");
-                if (!extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // memoised: the generic mul reuses it
+        unsigned slots = 0;  // speculated accumulators so far (sticky witness words R.d_wit[0 .. slots))
+        for (size_t i = ca.shape[v]; i-- > 0;) {
+            bool speculate = false;
+            if (!on_host(res) && res.numel > 1) {
+                if (!res_nonlinear_seen) {  // device accumulator: scan until the first "not linear" verdict
+                    double c_[2], m_[2];
+                    size_t u_;
+                    ScanCtx sc_res("subst_var.accumulator");
+                    if (!extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // memoised: the generic mul reuses it
+                }
+                speculate = res_nonlinear_seen;
             }
-            if (lin_known && res_nonlinear_seen && res.numel > 1 && res.shape.size() == deg.size()) {
-                // small tensors: every remaining step in one single-workgroup launch
-                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res)) break;
-                res = horner_linear_step(res, ca, v, i, c, m, w, deg);
+            if (!speculate) {  // reference step; on the host tier the accumulator's scan is free
+                res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
                 continue;
             }
-            Dims out = cshape;
-            out[v] = 1;
-            for (size_t ax = 0; ax < out.size(); ++ax) out[ax] = std::min(out[ax], deg[ax]);
-            Shifts shift(out.size(), 0);
-            shift[v] = (long long)i;
-            P coeff = gather(ca, out, deg, shift, cshape);
-            res = addsub(R.fuse_horner && res_nonlinear_seen ? mul_horner(res, subst) : mul(res, subst), coeff, false);
+            if (slots == 0) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
+            if (lin_known && res.shape.size() == deg.size()) {
+                // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, R.d_wit + slots)) {
+                    slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
+                    break;
+                }
+                res = horner_linear_step(res, ca, v, i, c, m, w, deg);
+            } else {
+                res = addsub(mul_horner(res, subst), horner_coeff(ca, v, i, deg), false);
+            }
+            if (on_host(res) || res.numel == 1) return false;  // left the speculated regime: take the exact loop
+            if (i == 0) break;  // the last accumulator is the result: nothing is speculated about it
+            {
+                Dims keep = collapse_mask({&res.shape}, false);
+                HV rv = view(res);
+                K<E>::witness(R.stream, dview(rv, &keep), R.d_wit + slots);
+            }
+            slots++;
         }
-        return res;
+        if (slots) {
+            Mailbox mb = next_mail();
+            witness_verdict(R.stream, R.d_wit, slots, mb);
+            R.stats[0]++;
+            double missing = 0.0;
+            wait_mail(mb, &missing, 1);
+            if (missing != 0.0) return false;
+        }
+        *result = res;
+        return true;
     }
     // res * subst inside the Horner loop once the accumulator has been seen non-linear.  The generic mul would ask
     // again on every step whether `res` is linear (device scan + host round trip, because res is new each time)
-    // before it looks at `subst`, whose verdict is memoised; here only subst's verdict is consulted.  Should the
-    // accumulator turn exactly linear again by cancellation, the products and sums are still the same
-    // (commutativity, see horner_linear_step) — only its stored shape would keep explicit zeros.
+    // before it looks at `subst`, whose verdict is memoised; here only subst's verdict is consulted, and the
+    // speculation "res is not linear" is verified by horner_speculative's witnesses.
     static P mul_horner(const P& res, const P& subst) {
         if (res.numel == 1 || subst.numel == 1) return mul(res, subst);
         P self = res, other = subst;
@@ -1481,12 +1752,12 @@ struct Ops {
     // res * (c + m*eps_w) + a[.., i, ..] in one launch (k_horner_linear), element for element the sequence
     // mul -> mul_linear -> mul_var / scale / add -> add that the generic loop above performs.  The generic mul
     // would first ask whether `res` itself is linear (a device scan + host round trip per step) and, if so,
-    // multiply the other way round — the same products and sums (commutativity), so only the stored shape of an
-    // accumulator that happens to be exactly linear can differ (explicit zeros instead of a compact shape).
+    // multiply the other way round; these kernels speculate that it is not and raise a witness per step
+    // (horner_speculative), so a step where the speculation fails is redone by the exact loop.
     // Steps i, i-1, .., 0 in one launch (k_horner_linear_loop) when the final tensor is small enough for a single
     // workgroup to be the faster machine (a launch per step costs ~4 us of host time + ~4 us on the device).
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
-                                   const Dims& deg, P* result) {
+                                   const Dims& deg, P* result, unsigned* wit) {
         const size_t nd = deg.size();
         Dims oc = ca.shape;
         oc[v] = 1;
@@ -1529,7 +1800,7 @@ struct Ops {
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
         g.lw_pad = (unsigned)((fs[w] + 7) / 8 * 8);
-        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]));
+        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
         *result = out;
         return true;
     }
@@ -1592,13 +1863,14 @@ struct Ops {
         size_t upper = std::min(a.shape[v], max_order_p1);
         std::vector<unsigned char> keep(max_order_p1, 0);
         for (size_t o : orders) keep[o] = 1;
-        std::shared_ptr<Buf> kb = alloc_doubles((upper + 7) / 8 + 1);
-        HIP_OK(hipMemcpyAsync(kb->p, keep.data(), upper, hipMemcpyHostToDevice, R.stream));
-        HIP_OK(hipStreamSynchronize(R.stream));
         Dims out = a.shape;
         out[v] = upper;
         Shifts shift(out.size(), 0);
-        return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, (const unsigned char*)kb->p);
+        if (gather_tier(a, out)) return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, keep.data(), 1);
+        std::shared_ptr<Buf> kb = alloc_doubles((upper + 7) / 8 + 1);
+        HIP_OK(hipMemcpyAsync(kb->p, keep.data(), upper, hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, (const unsigned char*)kb->p, 0);
     }
 
     // ---- metadata ops (mt:81-112, 172-193) -------------------------------------------------------------------------------------
@@ -1664,12 +1936,19 @@ struct Ops {
         }
         if (consumed != a.shape.size()) throw Error("index is too short");
         out[1] = 0.0;
+        if (on_host(a)) {
+            const double* h = hp<E>(a);
+            out[0] = h[off];
+            if (W == 2) out[1] = h[a.numel + off];
+            return;
+        }
         R.stats[2]++;
         peek(out, dp<E>(a) + off, a.numel, W);
     }
 
     static bool equal(const P& a, const P& b) {
         if (a.deg != b.deg || a.shape != b.shape) return false;
+        if (on_host(a) && on_host(b)) return HK<E>::count_neq(hp<E>(a), a.numel, hp<E>(b), b.numel, a.numel) == 0;
 
         HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 1), 0, 1, R.stream));
         K<E>::count_neq(R.stream, dp<E>(a), a.numel, dp<E>(b), b.numel, a.numel, R.d_flag + 1);
@@ -1749,6 +2028,7 @@ int gft_init(int device) {
             HIP_OK(hipMemcpy(R.d_flag, init, sizeof(init), hipMemcpyHostToDevice));
         }
         HIP_OK(hipMalloc((void**)&R.d_scratch, 256));
+        HIP_OK(hipMalloc((void**)&R.d_wit, sizeof(unsigned) * 8192));
         HIP_OK(hipHostMalloc((void**)&R.h_pinned, 4096, hipHostMallocDefault));
         HIP_OK(hipHostMalloc((void**)&R.h_mail, 4096, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(R.h_mail, 0, 4096);
@@ -1760,6 +2040,8 @@ int gft_init(int device) {
             if (v >= 0) R.tiled_min_macs = v;
         }
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
+        if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
+        if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
@@ -1785,6 +2067,7 @@ void gft_shutdown(void) {
     R.conv_ws_bytes = 0;
     (void)hipFree(R.d_flag);
     (void)hipFree(R.d_scratch);
+    (void)hipFree(R.d_wit);
     (void)hipHostFree(R.h_pinned);
     (void)hipHostFree(R.h_mail);
     R.h_mail = R.d_mail = nullptr;
@@ -1842,6 +2125,8 @@ int gft_set_option(const char* name, double value) {
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
+    else if (n == "host_max_elems") R.host_max_elems = value < 0 ? 0 : (size_t)value;
+    else if (n == "host_max_macs") R.host_max_macs = value;
     else return -1;
     return 0;
 }
@@ -1920,7 +2205,14 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     int PFX##width(void) { return E::W; }                                                                     \
     gft_poly* PFX##from_host(const double* c, const size_t* sh, const size_t* dg, size_t nd) {                \
         return guard([&] {                                                                                    \
-            gft_poly r = Ops<E>::make(dims(sh, nd), dims(dg, nd));                                            \
+            Dims shape = dims(sh, nd);                                                                        \
+            const size_t n = prod(shape);                                                                     \
+            const bool host = R.host_max_elems && n <= R.host_max_elems;  /* small: stays host-resident */    \
+            gft_poly r = Ops<E>::make(shape, dims(dg, nd), host);                                             \
+            if (host) {                                                                                       \
+                std::memcpy(hp<E>(r), c, sizeof(double) * n * E::W);                                          \
+                return Ops<E>::seal(r);                                                                       \
+            }                                                                                                 \
             HIP_OK(hipMemcpyAsync(dp<E>(r), c, sizeof(double) * r.numel * E::W, hipMemcpyHostToDevice, R.stream)); \
             HIP_OK(hipStreamSynchronize(R.stream));                                                           \
             return r;                                                                                         \
@@ -1955,6 +2247,10 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     void PFX##degrees_p1(const gft_poly* p, size_t* out) { std::copy(p->deg.begin(), p->deg.end(), out); }    \
     int PFX##to_host(const gft_poly* p, double* out) {                                                        \
         return guard_int([&] {                                                                                \
+            if (on_host(*p)) {                                                                                \
+                std::memcpy(out, hp<E>(*p), sizeof(double) * p->numel * E::W);                                \
+                return 0;                                                                                     \
+            }                                                                                                 \
             HIP_OK(hipMemcpyAsync(out, dp<E>(*p), sizeof(double) * p->numel * E::W, hipMemcpyDeviceToHost, R.stream)); \
             HIP_OK(hipStreamSynchronize(R.stream));                                                           \
             return 0;                                                                                         \

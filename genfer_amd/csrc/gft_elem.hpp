@@ -8,10 +8,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 
+// Every element operation is one source for both sides of the size-threshold dispatch: the device
+// kernels and the host tier of gft_host.hpp call the same functions, so a tensor computed on either side carries the
+// same bits (IEEE f64 + - * / and integer bit steps; -ffp-contract=off on both passes).
+#define GFT_HD __host__ __device__
+
 namespace gft {
+
+GFT_HD inline long long f64_bits(double x) { return __builtin_bit_cast(long long, x); }
+GFT_HD inline double bits_f64(long long b) { return __builtin_bit_cast(double, b); }
+// true iff some lane of the wave (device) / this element (host) raises `p`
+GFT_HD inline bool any_lane(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+    return p;
+#endif
+}
 
 struct Scalar2 {  // a scalar crossing the host->kernel boundary: {v,unused} or {lo,hi}
     double a, b;
@@ -20,43 +37,43 @@ struct Scalar2 {  // a scalar crossing the host->kernel boundary: {v,unused} or 
 struct EF64 {
     typedef double V;
     static constexpr int W = 1;
-    __device__ static V ld(const double* p, size_t, size_t i) { return p[i]; }
-    __device__ static void st(double* p, size_t, size_t i, V v) { p[i] = v; }
-    __device__ static V from(Scalar2 s) { return s.a; }
-    __device__ static V zero() { return 0.0; }
-    __device__ static V one() { return 1.0; }
-    __device__ static V from_u32(unsigned u) { return (double)u; }  // f64.rs:19-24
-    __device__ static bool is_zero(V x) { return x == 0.0; }        // f64.rs:181-183
-    __device__ static bool eq(V a, V b) { return a == b; }
-    __device__ static V neg(V a) { return -a; }
-    __device__ static V add(V a, V b) { return a + b; }
-    __device__ static V sub(V a, V b) { return a - b; }
-    __device__ static V mul(V a, V b) { return a * b; }
-    __device__ static V div(V a, V b) { return a / b; }
-    __device__ static V mac(V acc, V a, V b) { return acc + a * b; }  // separate multiply and add (-ffp-contract=off)
-    __device__ static V mulw(V a, V b) { return a * b; }   // "wave-checked" variants: plain ops for f64
-    __device__ static V addw(V a, V b) { return a + b; }
-    __device__ static V add0(V b) { return 0.0 + b; }      // (0 + b): turns -0 into +0, so it is not skipped
-    __device__ static V exp(V a) { return ::exp(a); }  // f64.rs:54-56
-    __device__ static V log(V a) { return ::log(a); }  // f64.rs:59-61
+    GFT_HD static V ld(const double* p, size_t, size_t i) { return p[i]; }
+    GFT_HD static void st(double* p, size_t, size_t i, V v) { p[i] = v; }
+    GFT_HD static V from(Scalar2 s) { return s.a; }
+    GFT_HD static V zero() { return 0.0; }
+    GFT_HD static V one() { return 1.0; }
+    GFT_HD static V from_u32(unsigned u) { return (double)u; }  // f64.rs:19-24
+    GFT_HD static bool is_zero(V x) { return x == 0.0; }        // f64.rs:181-183
+    GFT_HD static bool eq(V a, V b) { return a == b; }
+    GFT_HD static V neg(V a) { return -a; }
+    GFT_HD static V add(V a, V b) { return a + b; }
+    GFT_HD static V sub(V a, V b) { return a - b; }
+    GFT_HD static V mul(V a, V b) { return a * b; }
+    GFT_HD static V div(V a, V b) { return a / b; }
+    GFT_HD static V mac(V acc, V a, V b) { return acc + a * b; }  // separate multiply and add (-ffp-contract=off)
+    GFT_HD static V mulw(V a, V b) { return a * b; }   // "wave-checked" variants: plain ops for f64
+    GFT_HD static V addw(V a, V b) { return a + b; }
+    GFT_HD static V add0(V b) { return 0.0 + b; }      // (0 + b): turns -0 into +0, so it is not skipped
+    GFT_HD static V exp(V a) { return ::exp(a); }  // f64.rs:54-56
+    GFT_HD static V log(V a) { return ::log(a); }  // f64.rs:59-61
 };
 
 // f64.rs:127-171 — integer arithmetic on the bits.
 // next_up(x): bits + (+1 | -1 by sign) is right for every input except -0.0, NaN and +inf.  Canonicalising the
 // zero first (x + 0.0 == +0.0 for both zeros) removes one fix-up, and !(x < +inf) covers NaN and +inf with a single
 // compare; next_down(x) == -next_up(-x) for every input (f64.rs:127-171 is symmetric), so one routine serves both.
-__device__ inline double next_up(double x) {
+GFT_HD inline double next_up(double x) {
     const double t = x + 0.0;  // -0 -> +0 (NaN stays NaN, everything else unchanged)
-    const long long bits = __double_as_longlong(t);
+    const long long bits = f64_bits(t);
     const long long step = (bits >> 63) | 1LL;  // +1 for the positive half, -1 for the negative half
     const long long r = bits + step;
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    return !(t < inf) ? x : __longlong_as_double(r);  // NaN / +inf: unchanged (the reference returns x itself)
+    const double inf = bits_f64(0x7ff0000000000000LL);
+    return !(t < inf) ? x : bits_f64(r);  // NaN / +inf: unchanged (the reference returns x itself)
 }
-__device__ inline double next_down(double x) { return -next_up(-x); }
-__device__ inline double fmin_ref(double a, double b) { return a < b ? a : b; }  // f64.rs:68-74
-__device__ inline double fmax_ref(double a, double b) { return a > b ? a : b; }  // f64.rs:77-83
-__device__ inline bool finite_d(double x) { return (x - x) == 0.0; }
+GFT_HD inline double next_down(double x) { return -next_up(-x); }
+GFT_HD inline double fmin_ref(double a, double b) { return a < b ? a : b; }  // f64.rs:68-74
+GFT_HD inline double fmax_ref(double a, double b) { return a > b ? a : b; }  // f64.rs:77-83
+GFT_HD inline bool finite_d(double x) { return (x - x) == 0.0; }
 
 struct Iv {
     double lo, hi;
@@ -65,25 +82,25 @@ struct Iv {
 struct EIv {
     typedef Iv V;
     static constexpr int W = 2;
-    __device__ static V ld(const double* p, size_t plane, size_t i) { return Iv{p[i], p[plane + i]}; }
-    __device__ static void st(double* p, size_t plane, size_t i, V v) {
+    GFT_HD static V ld(const double* p, size_t plane, size_t i) { return Iv{p[i], p[plane + i]}; }
+    GFT_HD static void st(double* p, size_t plane, size_t i, V v) {
         p[i] = v.lo;
         p[plane + i] = v.hi;
     }
-    __device__ static V from(Scalar2 s) { return Iv{s.a, s.b}; }
-    __device__ static V zero() { return Iv{0.0, 0.0}; }
-    __device__ static V one() { return Iv{1.0, 1.0}; }
-    __device__ static V from_u32(unsigned u) { return Iv{(double)u, (double)u}; }  // interval.rs:80-85
-    __device__ static V widen(double lo, double hi) { return Iv{next_down(lo), next_up(hi)}; }  // :28-31
-    __device__ static bool is_zero(V x) { return x.lo == 0.0 && x.hi == 0.0; }   // :100-103
-    __device__ static bool is_one(V x) { return x.lo == 1.0 && x.hi == 1.0; }    // :112-115
-    __device__ static bool is_finite(V x) { return finite_d(x.lo) && finite_d(x.hi); }
-    __device__ static bool is_nan(V x) { return x.lo != x.lo || x.hi != x.hi; }
-    __device__ static bool eq(V a, V b) { return a.lo == b.lo && a.hi == b.hi; }
-    __device__ static V neg(V a) { return Iv{-a.hi, -a.lo}; }                     // :117-124
+    GFT_HD static V from(Scalar2 s) { return Iv{s.a, s.b}; }
+    GFT_HD static V zero() { return Iv{0.0, 0.0}; }
+    GFT_HD static V one() { return Iv{1.0, 1.0}; }
+    GFT_HD static V from_u32(unsigned u) { return Iv{(double)u, (double)u}; }  // interval.rs:80-85
+    GFT_HD static V widen(double lo, double hi) { return Iv{next_down(lo), next_up(hi)}; }  // :28-31
+    GFT_HD static bool is_zero(V x) { return x.lo == 0.0 && x.hi == 0.0; }   // :100-103
+    GFT_HD static bool is_one(V x) { return x.lo == 1.0 && x.hi == 1.0; }    // :112-115
+    GFT_HD static bool is_finite(V x) { return finite_d(x.lo) && finite_d(x.hi); }
+    GFT_HD static bool is_nan(V x) { return x.lo != x.lo || x.hi != x.hi; }
+    GFT_HD static bool eq(V a, V b) { return a.lo == b.lo && a.hi == b.hi; }
+    GFT_HD static V neg(V a) { return Iv{-a.hi, -a.lo}; }                     // :117-124
     // add / mul are written as "compute the general result, then select" (no control flow): the hot
     // convolution loops run them once per MAC and divergent early returns cost more than the selects.
-    __device__ static V add(V a, V b) {                                           // :126-139
+    GFT_HD static V add(V a, V b) {                                           // :126-139
         V g = widen(a.lo + b.lo, a.hi + b.hi);
         const bool za = is_zero(a), zb = is_zero(b);
         g.lo = zb ? a.lo : g.lo;
@@ -92,8 +109,8 @@ struct EIv {
         g.hi = za ? b.hi : g.hi;
         return g;
     }
-    __device__ static V sub(V a, V b) { return add(a, neg(b)); }                  // :148-155
-    __device__ static V mul(V a, V b) {                                           // :164-190
+    GFT_HD static V sub(V a, V b) { return add(a, neg(b)); }                  // :148-155
+    GFT_HD static V mul(V a, V b) {                                           // :164-190
         const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
         V g = widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
         // the reference's short-circuits, lowest priority first so that the first match of its if-chain wins
@@ -115,7 +132,7 @@ struct EIv {
     // General product formula for FINITE operands: no product can be NaN (only finite * finite), so the
     // reference's compare-and-select min/max (f64.rs:68-83) equals the hardware min/max up to the sign of a zero,
     // and widen() maps +0 and -0 to the same neighbour.
-    __device__ static V mul_general_finite(V a, V b) {
+    GFT_HD static V mul_general_finite(V a, V b) {
         const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
         return widen(__builtin_fmin(__builtin_fmin(p, q), __builtin_fmin(r, s)),
                      __builtin_fmax(__builtin_fmax(p, q), __builtin_fmax(r, s)));
@@ -124,37 +141,37 @@ struct EIv {
     // wave holds an operand that can trigger a short-circuit (exact 0 / 1 / -1, inf/NaN, an exactly zero
     // accumulator) the general formulas are the whole story and the ~50 selects and compares of the branch-free
     // versions are skipped: 135 -> ~80 VALU instructions per interval MAC.  One wave-uniform branch (ballot).
-    __device__ static bool maybe_special(V v) {
+    GFT_HD static bool maybe_special(V v) {
         const bool point = v.lo == v.hi;
         const bool unitish = v.lo == 0.0 || __builtin_fabs(v.lo) == 1.0;
         return (point && unitish) || !is_finite(v);
     }
-    __device__ static V mac(V acc, V a, V b) {
+    GFT_HD static V mac(V acc, V a, V b) {
         const bool sp = maybe_special(a) || maybe_special(b) || is_zero(acc);
-        if (__builtin_amdgcn_ballot_w64(sp) == 0) {
+        if (!any_lane(sp)) {
             const V m = mul_general_finite(a, b);
             return widen(acc.lo + m.lo, acc.hi + m.hi);
         }
         return add(acc, mul(a, b));
     }
     // mul / add with the same wave-uniform shortcut as mac(): the general formula when no lane can short-circuit
-    __device__ static V mulw(V a, V b) {
-        if (__builtin_amdgcn_ballot_w64(maybe_special(a) || maybe_special(b)) == 0) return mul_general_finite(a, b);
+    GFT_HD static V mulw(V a, V b) {
+        if (!any_lane(maybe_special(a) || maybe_special(b))) return mul_general_finite(a, b);
         return mul(a, b);
     }
-    __device__ static V addw(V a, V b) {
-        if (__builtin_amdgcn_ballot_w64(is_zero(a) || is_zero(b)) == 0) return widen(a.lo + b.lo, a.hi + b.hi);
+    GFT_HD static V addw(V a, V b) {
+        if (!any_lane(is_zero(a) || is_zero(b))) return widen(a.lo + b.lo, a.hi + b.hi);
         return add(a, b);
     }
-    __device__ static V add0(V b) { return b; }  // [0,0] + b returns b unchanged (interval.rs:126-139)
-    __device__ static V div(V a, V b) {                                           // :199-234
+    GFT_HD static V add0(V b) { return b; }  // [0,0] + b returns b unchanged (interval.rs:126-139)
+    GFT_HD static V div(V a, V b) {                                           // :199-234
         if (is_nan(a) || is_nan(b)) {
-            double n = __longlong_as_double(0x7ff8000000000000LL);
+            double n = bits_f64(0x7ff8000000000000LL);
             return Iv{n, n};
         }
         if (is_zero(a) && !is_zero(b)) return a;
         if (is_one(b)) return a;
-        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        const double inf = bits_f64(0x7ff0000000000000LL);
         double lo = inf, hi = -inf;
         if (b.lo <= 0.0 && 0.0 <= b.hi) {
             if (0.0 <= a.lo) hi = inf; else lo = -inf;
@@ -165,11 +182,11 @@ struct EIv {
         hi = fmax_ref(fmax_ref(fmax_ref(fmax_ref(hi, p), q), r), s);
         return widen(lo, hi);
     }
-    __device__ static V exp(V a) {                                                // :264-269
+    GFT_HD static V exp(V a) {                                                // :264-269
         if (is_zero(a)) return one();
         return widen(::exp(a.lo), ::exp(a.hi));
     }
-    __device__ static V log(V a) {                                                // :271-276
+    GFT_HD static V log(V a) {                                                // :271-276
         if (is_one(a)) return zero();
         return widen(::log(a.lo), ::log(a.hi));
     }

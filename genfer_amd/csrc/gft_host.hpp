@@ -1,0 +1,358 @@
+// Host tier of the size-threshold dispatch (reference: every TaylorPoly operation is host code,
+// src/multivariate_taylor.rs).  Genfer programs issue 10^5-10^6 operations on tensors of a few hundred elements
+// (switchpoint: 3.8e5 operations, almost all <= 512 elements); a kernel launch costs ~4 us and a host round trip
+// ~15 us, the same operation on 256 elements costs the host ~0.3 us.  So tensors whose operands are all host-resident
+// and whose result stays below the crossover (gft_set_option "host_max_elems" / "host_max_macs") are computed right
+// here, by plain loops over the SAME element functors the kernels use (gft_elem.hpp, one source for both passes,
+// -ffp-contract=off): a result carries the same bits whichever side produced it.  Signatures mirror K<E> in
+// gft_kernels.hpp without the stream; every loop runs in the order the corresponding kernel documents.
+//
+// This is part of the product (libgftaylor), not of the test oracle; nothing here includes oracle/.  The library
+// still refuses to initialise without a gfx950 device.
+#pragma once
+#include <cstring>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+template <class E>
+struct HK {
+    typedef typename E::V V;
+
+    static size_t numel(const Shape& s) {
+        size_t n = 1;
+        for (int i = 0; i < s.nd; ++i) n *= s.d[i];
+        return n;
+    }
+
+    // k_gather
+    static void gather(const double* src, size_t src_plane, double* out, size_t out_plane, const GatherArgs& a) {
+        const size_t total = numel(a.out);
+        for (size_t lin = 0; lin < total; ++lin) {
+            size_t r = lin, soff = 0;
+            bool valid = true;
+            unsigned kaxis = 0;
+            for (int ax = a.out.nd - 1; ax >= 0; --ax) {
+                const unsigned d = a.out.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                const long long si = (long long)k + a.shift[ax];
+                if (si < 0 || si >= (long long)a.src_len[ax]) valid = false;
+                soff += (size_t)(si < 0 ? 0 : si) * a.src_stride[ax];
+                if (ax == a.tab_axis) kaxis = k;
+            }
+            if (valid && a.keep && !a.keep[kaxis]) valid = false;
+            V v = E::zero();
+            if (valid) {
+                v = E::ld(src, src_plane, soff);
+                switch (a.op) {
+                    case OP_MUL_S: v = E::mul(v, E::from(a.s)); break;
+                    case OP_DIV_S: v = E::div(v, E::from(a.s)); break;
+                    case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
+                    case OP_NEG: v = E::neg(v); break;
+                    case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                    case OP_MUL_POW: {
+                        const V mv = E::ld(a.tab, a.tab_plane, 0);
+                        V f = E::one();
+                        for (unsigned i = 0; i < kaxis; ++i) f = E::mul(f, mv);
+                        v = E::mul(v, f);
+                        break;
+                    }
+                    default: break;
+                }
+            }
+            E::st(out, out_plane, lin, v);
+        }
+    }
+
+    // k_addsub_padded: (0 + a) (+|-) b on leading blocks
+    static void addsub_padded(const DView& out, const DView& a, const DView& b, int subtract) {
+        const size_t total = numel(out.sh);
+        for (size_t lin = 0; lin < total; ++lin) {
+            size_t r = lin, aoff = 0, boff = 0, astr = 1, bstr = 1;
+            bool ina = true, inb = true;
+            for (int ax = out.sh.nd - 1; ax >= 0; --ax) {
+                const unsigned d = out.sh.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                if (k >= a.sh.d[ax]) ina = false;
+                if (k >= b.sh.d[ax]) inb = false;
+                aoff += k * astr;
+                boff += k * bstr;
+                astr *= a.sh.d[ax];
+                bstr *= b.sh.d[ax];
+            }
+            V v = E::zero();
+            if (ina) v = E::add(v, E::ld(a.p, a.plane, aoff));
+            if (inb) {
+                const V w = E::ld(b.p, b.plane, boff);
+                v = subtract ? E::sub(v, w) : E::add(v, w);
+            }
+            E::st(out.p, out.plane, lin, v);
+        }
+    }
+
+    // k_copy_first
+    static void copy_first(const double* src, size_t sp, double* dst, size_t dp, size_t n, int op, Scalar2 sv) {
+        for (size_t i = 0; i < n; ++i) {
+            V x = E::ld(src, sp, i);
+            if (i == 0) {
+                const V y = E::from(sv);
+                x = (op == FIRST_ADD) ? E::add(x, y) : E::sub(x, y);
+            }
+            if (op == FIRST_SUB_NEG_ALL) x = E::neg(x);
+            E::st(dst, dp, i, x);
+        }
+    }
+
+    // two host scalars (k_scalar_imm's table)
+    static V scalar_imm(int kind, V x, V y) {
+        switch (kind) {
+            case IMM_LMUL: return E::mul(y, x);
+            case IMM_MUL: return E::mul(x, y);
+            case IMM_DIV: return E::div(x, y);
+            case IMM_NEG: return E::neg(x);
+            case IMM_ADD: return E::add(x, y);
+            case IMM_SUB: return E::sub(x, y);
+            default: return E::neg(E::sub(x, y));
+        }
+    }
+
+    // k_linear_scan: mask of the axes the tensor is "linear in"; c = t[0], m = t[e_v] of the first surviving axis
+    static unsigned linear_scan(const DView& t, unsigned axes_mask, double c[2], double m[2]) {
+        const size_t total = numel(t.sh);
+        unsigned local = axes_mask;
+        for (size_t lin = 0; lin < total && local != 0; ++lin) {
+            if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
+            size_t r = lin;
+            int nonzero_axes = 0, which = -1;
+            bool unit = true;
+            for (int ax = t.sh.nd - 1; ax >= 0; --ax) {
+                const unsigned d = t.sh.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                if (k != 0) {
+                    nonzero_axes++;
+                    which = ax;
+                    if (k != 1) unit = false;
+                }
+            }
+            if (nonzero_axes == 0) continue;
+            if (nonzero_axes == 1 && unit) local &= (1u << which);
+            else local = 0;
+        }
+        c[0] = c[1] = m[0] = m[1] = 0.0;
+        if (local) {
+            const int ax = __builtin_ffs((int)local) - 1;
+            size_t stride = 1;
+            for (int i = t.sh.nd - 1; i > ax; --i) stride *= t.sh.d[i];
+            c[0] = t.p[0];
+            m[0] = t.p[stride];
+            if (E::W == 2) {
+                c[1] = t.p[t.plane];
+                m[1] = t.p[t.plane + stride];
+            }
+        }
+        return local;
+    }
+
+    static V apply_map(V x, int op, unsigned u, V s) {
+        switch (op) {
+            case MAP_NEG: return E::neg(x);
+            case MAP_DIV_U32: return E::div(x, E::from_u32(u));
+            case MAP_MUL_U32: return E::mul(x, E::from_u32(u));
+            case MAP_MUL_S: return E::mul(x, s);
+            case MAP_DIV_S: return E::div(x, s);
+            case MAP_LMUL_S: return E::mul(s, x);
+            default: return x;
+        }
+    }
+    static void map_inplace(double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s) {
+        const V sv = E::from(s);
+        for (size_t i = 0; i < n; ++i) E::st(p, plane, i, apply_map(E::ld(p, plane, i), op, u, sv));
+    }
+
+    // k_block_op
+    static void block_op(const DView& dst, const DView& src, int op, unsigned u) {
+        const size_t total = numel(src.sh);
+        for (size_t lin = 0; lin < total; ++lin) {
+            size_t r = lin, doff = 0, dstr = 1;
+            for (int ax = src.sh.nd - 1; ax >= 0; --ax) {
+                const unsigned d = src.sh.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                doff += k * dstr;
+                dstr *= dst.sh.d[ax];
+            }
+            const V x = E::ld(src.p, src.plane, lin);
+            V rv;
+            if (op == BLK_ASSIGN) rv = x;
+            else {
+                const V cur = E::ld(dst.p, dst.plane, doff);
+                rv = (op == BLK_ADD) ? E::add(cur, x) : E::add(cur, E::mul(E::from_u32(u), x));
+            }
+            E::st(dst.p, dst.plane, doff, rv);
+        }
+    }
+
+    // k_exp_1d / k_log_1d (seed = exp / ln of xs[0], formed by the caller)
+    static void exp_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n, Scalar2 seed) {
+        if (n == 0) return;
+        E::st(res, rp, 0, E::from(seed));
+        for (unsigned k = 1; k < n; ++k) {
+            V sum = E::zero();
+            const unsigned hi = nx < k + 1 ? nx : k + 1;
+            for (unsigned j = 1; j < hi; ++j)
+                sum = E::add(sum, E::mul(E::mul(E::ld(xs, xp, j), E::from_u32(j)), E::ld(res, rp, k - j)));
+            E::st(res, rp, k, E::div(sum, E::from_u32(k)));
+        }
+    }
+    static void log_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n, Scalar2 seed) {
+        if (n == 0) return;
+        const V x0 = E::ld(xs, xp, 0);
+        E::st(res, rp, 0, E::from(seed));
+        for (unsigned k = 1; k < n; ++k) {
+            V sum = E::zero();
+            unsigned lo = (k + 1 > nx) ? (k + 1 - nx) : 0;
+            if (lo < 1) lo = 1;
+            for (unsigned j = lo; j < k; ++j)
+                sum = E::add(sum, E::mul(E::mul(E::ld(xs, xp, k - j), E::ld(res, rp, j)), E::from_u32(j)));
+            const V xk = k < nx ? E::ld(xs, xp, k) : E::zero();
+            const V num = E::sub(E::mul(xk, E::from_u32(k)), sum);
+            E::st(res, rp, k, E::div(E::div(num, x0), E::from_u32(k)));
+        }
+    }
+    // k_div_1d_serial
+    static void div_1d(const double* xs, size_t xp, unsigned nx, const double* ys, size_t yp, unsigned ny, double* res,
+                       size_t rp, unsigned n) {
+        const V y0 = E::ld(ys, yp, 0);
+        for (unsigned k = 0; k < n; ++k) {
+            V cur = E::zero();
+            const unsigned lo = (k + 1 > ny) ? (k + 1 - ny) : 0;
+            for (unsigned j = lo; j < k; ++j) cur = E::add(cur, E::mul(E::ld(res, rp, j), E::ld(ys, yp, k - j)));
+            cur = E::neg(cur);
+            if (k < nx) cur = E::add(cur, E::ld(xs, xp, k));
+            E::st(res, rp, k, E::div(cur, y0));
+        }
+    }
+
+    // k_factor_table
+    static void factor_table(int op, unsigned n, unsigned len, const double* m, size_t mp, double* tab, size_t tp) {
+        if (op == TAB_DERIV) {
+            V ff = E::one();
+            for (unsigned i = 1; i <= n; ++i) ff = E::mul(ff, E::from_u32(i));
+            for (unsigned k = 0; k < len; ++k) {
+                E::st(tab, tp, k, ff);
+                ff = E::mul(ff, E::div(E::from_u32(n + k + 1), E::from_u32(k + 1)));
+            }
+        } else if (op == TAB_COEFF) {
+            V f = E::one();
+            E::st(tab, tp, 0, f);
+            for (unsigned k = 1; k < len; ++k) {
+                f = E::mul(f, E::div(E::from_u32(n + k), E::from_u32(k)));
+                E::st(tab, tp, k, f);
+            }
+        } else if (op == TAB_POW) {
+            V f = E::one();
+            const V mv = E::ld(m, mp, 0);
+            for (unsigned k = 0; k < len; ++k) {
+                E::st(tab, tp, k, f);
+                f = E::mul(f, mv);
+            }
+        } else {
+            for (unsigned k = 0; k < len; ++k) E::st(tab, tp, k, E::from_u32(k));
+        }
+    }
+
+    // k_sum_axis_seq (SUM_SEQ / SUM_UNROLL8)
+    static void sum_axis(const double* in, size_t ip, unsigned outer, unsigned len, unsigned inner, size_t outer_stride,
+                         double* out, size_t op, int mode) {
+        const size_t total = (size_t)outer * inner;
+        for (size_t lin = 0; lin < total; ++lin) {
+            const unsigned i = (unsigned)(lin % inner);
+            const size_t o = lin / inner;
+            const size_t base = o * outer_stride + i;
+            V acc = E::zero();
+            if (mode == SUM_UNROLL8) {
+                V p[8];
+                for (int u = 0; u < 8; ++u) p[u] = E::zero();
+                unsigned k = 0;
+                for (; k + 8 <= len; k += 8)
+                    for (int u = 0; u < 8; ++u) p[u] = E::add(p[u], E::ld(in, ip, base + (size_t)(k + u) * inner));
+                acc = E::add(acc, E::add(p[0], p[4]));
+                acc = E::add(acc, E::add(p[1], p[5]));
+                acc = E::add(acc, E::add(p[2], p[6]));
+                acc = E::add(acc, E::add(p[3], p[7]));
+                for (; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
+            } else {
+                for (unsigned k = 0; k < len; ++k) acc = E::add(acc, E::ld(in, ip, base + (size_t)k * inner));
+            }
+            E::st(out, op, lin, acc);
+        }
+    }
+
+    static size_t count_neq(const double* a, size_t ap, const double* b, size_t bp, size_t n) {
+        size_t c = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (!E::eq(E::ld(a, ap, i), E::ld(b, bp, i))) c++;
+        return c;
+    }
+
+    // k_conv_naive: the reference's loop nest (mt:971-1012) per output element
+    static void conv_axis(const ConvArgs& a, int ax, const unsigned* k, const double* x, size_t xp, const double* y, size_t yp,
+                          size_t xoff, size_t yoff, V& acc) {
+        const unsigned kk = k[ax];
+        unsigned lo = (kk + 1 > a.ys[ax]) ? (kk + 1 - a.ys[ax]) : 0;
+        unsigned hi = (kk + 1 < a.xs[ax]) ? (kk + 1) : a.xs[ax];
+        bool desc = false;
+        if (ax == 0) {
+            if (lo < (unsigned)a.j0_min) lo = (unsigned)a.j0_min;
+            if (a.j0_excl && hi > kk) hi = kk;
+            desc = a.j0_desc != 0;
+        }
+        if (hi <= lo) return;
+        const unsigned cnt = hi - lo;
+        if (ax == a.nd - 1) {
+            if (a.inner_from_zero) {
+                V inner = E::zero();
+                for (unsigned j = lo; j < hi; ++j)
+                    inner = E::add(inner, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[ax]),
+                                                 E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[ax])));
+                acc = E::add(acc, inner);
+            } else {
+                for (unsigned t = 0; t < cnt; ++t) {
+                    const unsigned j = desc ? (hi - 1 - t) : (lo + t);
+                    acc = E::add(acc, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[ax]),
+                                             E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[ax])));
+                }
+            }
+        } else {
+            for (unsigned t = 0; t < cnt; ++t) {
+                const unsigned j = desc ? (hi - 1 - t) : (lo + t);
+                conv_axis(a, ax + 1, k, x, xp, y, yp, xoff + (size_t)j * a.xstr[ax], yoff + (size_t)(kk - j) * a.ystr[ax], acc);
+            }
+        }
+    }
+    static void conv_naive(const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a) {
+        size_t slab = 1;
+        for (int i = 1; i < a.nd; ++i) slab *= a.zs[i];
+        const size_t total = (a.nd == 0) ? 1 : (size_t)(a.slab_hi - a.slab_lo) * slab;
+        for (size_t lin = 0; lin < total; ++lin) {
+            const size_t zlin = lin + (size_t)a.slab_lo * slab;
+            unsigned k[MAXD > 0 ? MAXD : 1];
+            size_t r = zlin;
+            for (int ax = a.nd - 1; ax >= 0; --ax) {
+                const unsigned d = a.zs[ax];
+                k[ax] = (unsigned)(r % d);
+                r /= d;
+            }
+            V acc = a.accumulate ? E::ld(z, zp, zlin) : E::zero();
+            if (a.nd == 0) acc = E::add(acc, E::mul(E::ld(x, xp, 0), E::ld(y, yp, 0)));
+            else conv_axis(a, 0, k, x, xp, y, yp, 0, 0, acc);
+            E::st(z, zp, zlin, acc);
+        }
+    }
+};
+
+}  // namespace gft

@@ -4,6 +4,9 @@
 // compute-bound product lives in gft_conv_tiled.hip.
 #include "gft_kernels.hpp"
 
+#include <algorithm>
+#include <cstring>
+
 namespace gft {
 
 static inline unsigned grid_for(size_t n, unsigned block = 256) {
@@ -223,26 +226,6 @@ __global__ void k_set_small(double* p, size_t plane, unsigned n, Scalar2 v0, Sca
     if (n > 1) E::st(p, plane, 1, E::from(v1));
 }
 template <class E>
-__global__ void k_scalar_imm(int kind, Scalar2 a, Scalar2 b, double* out, size_t plane) {
-    typedef typename E::V V;
-    const V x = E::from(a), y = E::from(b);
-    V v;
-    switch (kind) {
-        case IMM_LMUL: v = E::mul(y, x); break;
-        case IMM_MUL: v = E::mul(x, y); break;
-        case IMM_DIV: v = E::div(x, y); break;
-        case IMM_NEG: v = E::neg(x); break;
-        case IMM_ADD: v = E::add(x, y); break;
-        case IMM_SUB: v = E::sub(x, y); break;
-        default: v = E::neg(E::sub(x, y)); break;
-    }
-    E::st(out, plane, 0, v);
-}
-template <class E>
-void K<E>::scalar_imm(hipStream_t st, int kind, Scalar2 a, Scalar2 b, double* out, size_t out_plane) {
-    hipLaunchKernelGGL(k_scalar_imm<E>, dim3(1), dim3(1), 0, st, kind, a, b, out, out_plane);
-}
-template <class E>
 void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1) {
     hipLaunchKernelGGL(k_set_small<E>, dim3(1), dim3(1), 0, st, p, plane, n, v0, v1);
 }
@@ -379,12 +362,8 @@ void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double*
 template <class E>
 __global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b, size_t bp, double* out,
                             size_t op_plane) {
-    typename E::V x = E::ld(a, ap, 0);
-    typename E::V r;
-    if (op == SC_EXP) r = E::exp(x);
-    else if (op == SC_LOG) r = E::log(x);
-    else r = E::div(x, E::ld(b, bp, 0));
-    E::st(out, op_plane, 0, r);
+    (void)op;  // SC_DIV
+    E::st(out, op_plane, 0, E::div(E::ld(a, ap, 0), E::ld(b, bp, 0)));
 }
 template <class E>
 void K<E>::scalar_op(hipStream_t st, int op, const double* a, size_t a_plane, const double* b, size_t b_plane,
@@ -465,10 +444,10 @@ void K<E>::block_op(hipStream_t st, const DView& dst, const DView& src, int op, 
 // sequential 1-D recurrences (one lane; n is a few hundred at most in the reference's workloads)
 // ------------------------------------------------------------------------------------------
 template <class E>
-__global__ void k_exp_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n) {
+__global__ void k_exp_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n, Scalar2 seed) {
     typedef typename E::V V;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    E::st(res, rp, 0, E::exp(E::ld(xs, xp, 0)));
+    E::st(res, rp, 0, E::from(seed));
     for (unsigned k = 1; k < n; ++k) {
         V sum = E::zero();
         unsigned hi = nx < k + 1 ? nx : k + 1;
@@ -479,16 +458,16 @@ __global__ void k_exp_1d(const double* xs, size_t xp, unsigned nx, double* res, 
 }
 template <class E>
 void K<E>::exp_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
-                  unsigned n) {
-    hipLaunchKernelGGL(k_exp_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n);
+                  unsigned n, Scalar2 seed) {
+    hipLaunchKernelGGL(k_exp_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
 }
 
 template <class E>
-__global__ void k_log_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n) {
+__global__ void k_log_1d(const double* xs, size_t xp, unsigned nx, double* res, size_t rp, unsigned n, Scalar2 seed) {
     typedef typename E::V V;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     V x0 = E::ld(xs, xp, 0);
-    E::st(res, rp, 0, E::log(x0));
+    E::st(res, rp, 0, E::from(seed));
     for (unsigned k = 1; k < n; ++k) {
         V sum = E::zero();
         unsigned lo = (k + 1 > nx) ? (k + 1 - nx) : 0;
@@ -502,8 +481,8 @@ __global__ void k_log_1d(const double* xs, size_t xp, unsigned nx, double* res, 
 }
 template <class E>
 void K<E>::log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
-                  unsigned n) {
-    hipLaunchKernelGGL(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n);
+                  unsigned n, Scalar2 seed) {
+    hipLaunchKernelGGL(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
 }
 
 // 1-d division recurrence (mt:1162-1185 base case): res[k] = (xs[k] - sum_{j<k} res[j] * ys[k-j]) / ys[0], the sum
@@ -910,7 +889,8 @@ constexpr int HL_EPT = 2;  // positions along w per thread: lines up to 2048 lon
 template <class E>
 __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __restrict__ res0, size_t rp0,
                                                              const double* __restrict__ a, size_t ap,
-                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g) {
+                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                             unsigned* __restrict__ wit) {
     typedef typename E::V V;
     extern __shared__ double hl_lds[];  // [buffer][plane][lw_pad]
     const unsigned lw = g.fs[g.w], lw_pad = g.lw_pad;
@@ -918,8 +898,13 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
     // this block's line: position on the axes other than w
     size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
     bool off_p0 = true, off_o0 = true, in_c_b = true;  // step 0 / coefficient box, axes other than w
+    // Non-linearity witnesses (K<E>::witness): on this line a non-zero at position kw is one if the index has two
+    // non-zero coordinates or a coordinate >= 2 — from position wit_from on, given the line's other coordinates.
+    unsigned wit_from = 2;
     {
         size_t r = blockIdx.x;
+        unsigned nz_coords = 0;
+        bool big = false;
 #pragma unroll
         for (int ax = MAXD - 1; ax >= 0; --ax) {
             if (ax < g.nd && ax != g.w) {
@@ -933,8 +918,12 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                 if (k >= r0) off_p0 = false;
                 if (k >= o0) off_o0 = false;
                 if (k >= g.oc[ax]) in_c_b = false;
+                if (k) nz_coords++;
+                if (k >= 2) big = true;
             }
         }
+        if (big || nz_coords >= 2) wit_from = 0;
+        else if (nz_coords == 1) wit_from = 1;
     }
     const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w], wstr_a = g.astr[g.w];
     const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
@@ -964,6 +953,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
         const double* src_l = hl_lds + (size_t)((t + 1) & 1u) * E::W * lw_pad;  // written by step t-1
         double* dst_l = hl_lds + (size_t)(t & 1u) * E::W * lw_pad;
         const bool last = t + 1 == g.nsteps, first = t == 0;
+        int witness = 0;
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) {
             if (!have[e]) continue;
@@ -994,16 +984,19 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             }
             if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
             else E::st(dst_l, lw_pad, kw[e], v);
+            if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
         }
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e) coef[e] = next[e];
         rsw = osw;
-        __syncthreads();
+        const int any = __syncthreads_or(witness);
+        if (wit && !last && any && threadIdx.x == 0 && __hip_atomic_load(&wit[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
-                              size_t plane, const HornerLoopArgs& args, unsigned lines) {
+                              size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit) {
     if (args.nsteps == 0 || lines == 0) return;
     const unsigned lw = args.fs[args.w];
     // one position per thread up to 1024-long lines (measured: two per thread is 10 % slower — the element chains
@@ -1014,7 +1007,67 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
     }();
     unsigned threads = std::min<unsigned>(1024, ((lw + per_thread - 1) / per_thread + 63) / 64 * 64);
     size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
-    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args);
+    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+}
+
+template <class E>
+__global__ void __launch_bounds__(256) k_witness(DView t, unsigned* flag, size_t total) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // another block was faster
+    int found = 0;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total && !found;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
+        size_t r = lin;
+        int nz = 0;
+        bool big = false;
+#pragma unroll 1
+        for (int ax = t.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = t.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k) nz++;
+            if (k >= 2) big = true;
+        }
+        if (big || nz >= 2) found = 1;
+    }
+    if (__syncthreads_or(found) && threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class E>
+void K<E>::witness(hipStream_t st, const DView& t, unsigned* flag) {
+    size_t total = 1;
+    for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
+    if (total == 0) return;
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 64);  // dense tensors are settled by the first elements
+    hipLaunchKernelGGL(k_witness<E>, dim3(blocks), dim3(256), 0, st, t, flag, total);
+}
+
+__global__ void __launch_bounds__(256) k_witness_verdict(const unsigned* __restrict__ flags, unsigned n, Mailbox mb) {
+    int missing = 0;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+        if (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) missing = 1;
+    const int any = __syncthreads_or(missing);
+    if (threadIdx.x == 0) {
+        mb.payload[0] = any ? 1.0 : 0.0;
+        mailbox_publish(mb);
+    }
+}
+void witness_verdict(hipStream_t st, const unsigned* flags, unsigned n, const Mailbox& mb) {
+    hipLaunchKernelGGL(k_witness_verdict, dim3(1), dim3(256), 0, st, flags, n, mb);
+}
+
+struct UploadChunk {
+    double v[480];
+};
+__global__ void __launch_bounds__(256) k_upload_small(double* __restrict__ dst, UploadChunk c, unsigned n) {
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = c.v[i];
+}
+void upload_small(hipStream_t st, double* dst, const double* host_src, size_t n) {
+    for (size_t off = 0; off < n; off += 480) {
+        UploadChunk c;
+        const unsigned cnt = (unsigned)std::min<size_t>(480, n - off);
+        std::memcpy(c.v, host_src + off, sizeof(double) * cnt);
+        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, st, dst + off, c, cnt);
+    }
 }
 
 __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n, Mailbox mb) {

@@ -32,7 +32,7 @@ enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_D
 enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1, FIRST_SUB_NEG_ALL = 2 };
 enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
 enum ImmOp { IMM_LMUL = 0 /* b*a */, IMM_MUL = 1 /* a*b */, IMM_DIV = 2, IMM_NEG = 3, IMM_ADD = 4, IMM_SUB = 5, IMM_SUB_NEG = 6 /* -(a-b) */ };
-enum ScalarOp { SC_EXP = 0, SC_LOG = 1, SC_DIV = 2 };
+enum ScalarOp { SC_DIV = 2 };
 enum TableOp { TAB_DERIV = 0, TAB_COEFF = 1, TAB_POW = 2, TAB_INDEX = 3 };
 
 struct GatherArgs {
@@ -120,6 +120,11 @@ __device__ inline void mailbox_publish(const Mailbox& mb) {
 }
 // copies n <= 7 doubles (src[i * stride]) into the mailbox
 void peek_to_mailbox(hipStream_t st, const double* src, size_t stride, unsigned n, const Mailbox& mb);
+// payload[0] = number of zero words among flags[0 .. n): the verdict of a speculative Horner loop (K<E>::witness)
+void witness_verdict(hipStream_t st, const unsigned* flags, unsigned n, const Mailbox& mb);
+// dst[0 .. n) = src[0 .. n) for a host-tier tensor that meets a device operand: the values travel as kernel
+// arguments (480 doubles per launch), so the host block may be reused the moment this returns
+void upload_small(hipStream_t st, double* dst, const double* host_src, size_t n);
 
 struct ConvArgs {
     int nd;
@@ -148,8 +153,6 @@ struct K {
     static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,
                            int op, const double* s, size_t s_plane, Scalar2 s_value);  // s == nullptr: use s_value
     // p[0] = v0, p[1] = v1 (if n == 2): constants and `var` constructors without a host->device copy
-    // out[0] = a (op) b for two immediates (both operands are lazy host-cached scalars): kind = ImmOp
-    static void scalar_imm(hipStream_t st, int kind, Scalar2 a, Scalar2 b, double* out, size_t out_plane);
     static void set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1);
     // extract_linear (mt:275-294) for all axes in ONE launch.  Bit a of the mask survives iff the tensor is
     // "linear in axis a" (every non-zero entry sits at index 0 or at e_a); blocks AND their verdicts into
@@ -161,8 +164,12 @@ struct K {
     static void horner_linear(hipStream_t st, const double* res, size_t res_plane, const double* a, size_t a_plane, double* out,
                               size_t out_plane, const HornerArgs& args);
     static constexpr unsigned HORNER_LINE_MAX = 2048;  // longest line along the substitution axis of horner_linear_loop
+    // `wit` (optional): wit[t] = 1 if the accumulator after in-kernel step t < nsteps-1 has a non-linearity witness
     static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
-                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines);
+                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit);
+    // *flag = 1 if `t` holds a non-zero coefficient at an index with two non-zero coordinates or a coordinate >= 2:
+    // such a tensor is not of the form c + m*x_v (extract_linear, mt:275-294, would say None).  Sticky, no read-back.
+    static void witness(hipStream_t st, const DView& t, unsigned* flag);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     // in-place elementwise map over n contiguous elements
@@ -172,14 +179,15 @@ struct K {
                                 size_t s_plane);
     // dst (contiguous, shape D) leading block of src's shape: BLK_ADD r += x ; BLK_ADD_U32_TIMES r += u*x ; BLK_ASSIGN r = x
     static void block_op(hipStream_t st, const DView& dst, const DView& src, int op, unsigned u);
-    // 0-dim ops: out = exp(a) | log(a) | a / b
+    // 0-dim op: out = a / b (SC_DIV)
     static void scalar_op(hipStream_t st, int op, const double* a, size_t a_plane, const double* b, size_t b_plane,
                           double* out, size_t out_plane);
     // sequential 1-D recurrences (mt:1270-1283, 1319-1333)
+    // `seed` = exp(xs[0]) / ln(xs[0]), formed by the caller on the host (one libm value)
     static void exp_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
-                       unsigned n);
+                       unsigned n, Scalar2 seed);
     static void log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
-                       unsigned n);
+                       unsigned n, Scalar2 seed);
     // last-axis level of the division recurrence (mt:1162-1192 with 0-dim base): res = xs / ys, 1-D
     static void div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys,
                        size_t y_plane, unsigned ny, double* res, size_t r_plane, unsigned n);

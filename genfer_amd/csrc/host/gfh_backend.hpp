@@ -5,8 +5,12 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <cstddef>
 #include <cstdint>
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -87,6 +91,23 @@ struct Api {
     }
 };
 
+// GFH_TRACE_SIZES=1: histogram of TaylorPoly operations by (op, power-of-two bucket of the largest tensor involved),
+// printed at exit — the op / size mix a program really issues (what the size-threshold dispatch is tuned on).
+struct SizeTrace {
+    bool on = getenv("GFH_TRACE_SIZES") != nullptr;
+    std::map<std::pair<std::string, size_t>, size_t> counts;
+    void hit(const char* op, size_t n) {
+        size_t b = 1;
+        while (b < n) b <<= 1;
+        counts[{op, b}]++;
+    }
+    ~SizeTrace() {
+        if (!on) return;
+        for (auto& kv : counts) fprintf(stderr, "[gfh sizes] %-28s <=%-9zu %zu\n", kv.first.first.c_str(), kv.first.second, kv.second);
+    }
+};
+inline SizeTrace& size_trace() { static SizeTrace t; return t; }
+
 // The value type: shared immutable handle (clone = refcount, like the ABI's O(1) clone).
 template <class T>
 class Poly {
@@ -110,6 +131,11 @@ class Poly {
         return r;
     }
     void* h() const { return p_->h; }
+    static size_t nel(const Poly& p) { return api().numel(p.h()); }
+    static Poly traced(const char* op, size_t n_in, Poly r) {
+        if (size_trace().on) size_trace().hit(op, std::max(n_in, nel(r)));
+        return r;
+    }
 
   public:
     static void bind(std::shared_ptr<Api> a) {
@@ -165,30 +191,30 @@ class Poly {
         return out;
     }
 
-    Poly operator+(const Poly& o) const { return wrap(api().add(h(), o.h())); }
-    Poly operator-(const Poly& o) const { return wrap(api().sub(h(), o.h())); }
-    Poly operator*(const Poly& o) const { return wrap(api().mul(h(), o.h())); }
-    Poly operator/(const Poly& o) const { return wrap(api().div(h(), o.h())); }
-    Poly operator-() const { return wrap(api().neg(h())); }
-    Poly exp() const { return wrap(api().exp(h())); }
-    Poly log() const { return wrap(api().log(h())); }
-    Poly pow(uint32_t e) const { return wrap(api().pow(h(), e)); }
-    Poly derivative(size_t v, size_t n) const { return wrap(api().derivative(h(), v, n)); }
-    Poly derivative_truncated(size_t v, size_t n, size_t d) const { return wrap(api().derivative_truncated(h(), v, n, d)); }
-    Poly taylor_expansion_of_coeff(size_t v, size_t n) const { return wrap(api().taylor_expansion_of_coeff(h(), v, n)); }
-    Poly shift_down(size_t v, size_t n) const { return wrap(api().shift_down(h(), v, n)); }
-    Poly subst_var(size_t v, const Poly& s) const { return wrap(api().subst_var(h(), v, s.h())); }
+    Poly operator+(const Poly& o) const { return traced("add", std::max(nel(*this), nel(o)), wrap(api().add(h(), o.h()))); }
+    Poly operator-(const Poly& o) const { return traced("sub", std::max(nel(*this), nel(o)), wrap(api().sub(h(), o.h()))); }
+    Poly operator*(const Poly& o) const { return traced("mul", std::max(nel(*this), nel(o)), wrap(api().mul(h(), o.h()))); }
+    Poly operator/(const Poly& o) const { return traced("div", std::max(nel(*this), nel(o)), wrap(api().div(h(), o.h()))); }
+    Poly operator-() const { return traced("neg", nel(*this), wrap(api().neg(h()))); }
+    Poly exp() const { return traced("exp", nel(*this), wrap(api().exp(h()))); }
+    Poly log() const { return traced("log", nel(*this), wrap(api().log(h()))); }
+    Poly pow(uint32_t e) const { return traced("pow", nel(*this), wrap(api().pow(h(), e))); }
+    Poly derivative(size_t v, size_t n) const { return traced("derivative", nel(*this), wrap(api().derivative(h(), v, n))); }
+    Poly derivative_truncated(size_t v, size_t n, size_t d) const { return traced("derivative_truncated", nel(*this), wrap(api().derivative_truncated(h(), v, n, d))); }
+    Poly taylor_expansion_of_coeff(size_t v, size_t n) const { return traced("taylor_expansion_of_coeff", nel(*this), wrap(api().taylor_expansion_of_coeff(h(), v, n))); }
+    Poly shift_down(size_t v, size_t n) const { return traced("shift_down", nel(*this), wrap(api().shift_down(h(), v, n))); }
+    Poly subst_var(size_t v, const Poly& s) const { return traced("subst_var", std::max(nel(*this), nel(s)), wrap(api().subst_var(h(), v, s.h()))); }
     Poly observe_step(size_t v, const T& x, const T& c, size_t d) const {
         double xb[2], cb[2];
         x.store(xb);
         c.store(cb);
         return wrap(api().observe_step(h(), v, xb, cb, d));
     }
-    Poly coefficients_of_term(size_t v, size_t o) const { return wrap(api().coefficients_of_term(h(), v, o)); }
+    Poly coefficients_of_term(size_t v, size_t o) const { return traced("coefficients_of_term", nel(*this), wrap(api().coefficients_of_term(h(), v, o))); }
     Poly taylor_polynomial_terms(size_t v, const Dims& orders) const {
         return wrap(api().taylor_polynomial_terms(h(), v, orders.data(), orders.size()));
     }
-    Poly truncate_to_degree_p1(size_t d) const { return wrap(api().truncate_to_degree_p1(h(), d)); }
+    Poly truncate_to_degree_p1(size_t d) const { return traced("truncate", nel(*this), wrap(api().truncate_to_degree_p1(h(), d))); }
     Poly remove_last_variable() const { return wrap(api().remove_last_variable(h())); }
     Poly extend_to_dim(size_t nd, size_t d) const { return wrap(api().extend_to_dim(h(), nd, d)); }
 };

@@ -11,8 +11,15 @@
  *   - A polynomial is an opaque handle (`gft_poly*`).  Its coefficient tensor lives in HBM as a
  *     contiguous row-major f64 array of the *compact* stored shape (mt:13-19); `degrees_p1`
  *     (conceptual truncation orders, SIZE_MAX = untruncated) lives on the host.
- *   - All value arithmetic runs in HIP kernels on gfx950.  There is no CPU fallback: if no
- *     device / code object is available every call fails and gft_last_error() says why.
+ *   - Value arithmetic runs in HIP kernels on gfx950.  There is no CPU fallback: if no device /
+ *     code object is available every call fails and gft_last_error() says why.
+ *   - Size-threshold dispatch: Genfer issues 10^5-10^6 operations on tensors of a
+ *     few hundred elements, each far below a kernel launch.  A tensor with at most
+ *     "host_max_elems" elements whose operands are all host-resident (built from host data or by
+ *     such operations) stays in host memory and is computed there by the same element functions
+ *     the kernels use (one source, same bits, -ffp-contract=off); scalars never leave the host.
+ *     A host-resident tensor that meets a device operand is mirrored to the device once.
+ *     gft_set_option("host_max_elems", 0) keeps every tensor on the device.
  *   - The ABI is NON-consuming: `out = op(a, b)` never frees or mutates its inputs (the Rust
  *     operators consume by value, mt:857,914,1017,1197; a shim maps that to "call, then drop").
  *     Handles are immutable values; gft_clone is O(1) (shared device buffer).
@@ -20,11 +27,10 @@
  *     The host only synchronises when a VALUE is inspected (to_host, coefficient, constant_term,
  *     is_zero/is_one/extract_*, equal) — and data-dependent dispatch inside mul/div/subst_var
  *     (mt:1021-1061), which the reference also performs.
- *   - Stored (compact) shapes equal the reference's, with one documented exception: inside subst_var's Horner
- *     loop the accumulator is asked whether it is linear (the reference does so on every step, and then
- *     multiplies the other way round, which compacts it) only until it has been seen NON-linear once; should it
- *     turn exactly linear again by cancellation, the coefficients are still the same products and sums, but
- *     explicit zeros may be stored where the reference's shape would have ended.
+ *   - Stored (compact) shapes and degrees_p1 equal the reference's in every case (integer
+ *     bookkeeping is bit-exact); subst_var's Horner loop speculates on the data-dependent dispatch
+ *     of mt:1052-1061 on the device, verifies the speculation with one read-back per call and
+ *     redoes the loop step by step if it failed.
  *   - Errors: functions returning a handle return NULL, functions returning int return a
  *     negative value; gft_last_error() holds the message.  Reference panics (assert!/unwrap,
  *     `panic = "abort"`, Cargo.toml:29) map to such errors; IEEE inf/NaN propagate as values.
@@ -57,7 +63,8 @@ const char* gft_last_error(void);
 void gft_pool_stats(size_t out[3]);
 /* Cumulative operation counters since gft_init: {extract_linear device scans (each a host round trip),
  * 1-element value read-backs, coefficient() read-backs, products on the tiled kernel, on the LDS-staged
- * reference-order kernel, on the one-thread-per-output kernel, reserved, reserved}.  Diagnostics. */
+ * reference-order kernel, on the one-thread-per-output kernel, operations computed on the host tier,
+ * host-resident tensors mirrored to the device}.  Diagnostics. */
 void gft_op_stats(size_t out[8]);
 /* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
@@ -69,7 +76,9 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
 int gft_set_conv_mode(int mode);
 /* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
  * tiled product), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
- * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step). */
+ * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
+ * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
+ * product, in multiply-adds, computed on the host tier; 0 = everything on the device). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);
