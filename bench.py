@@ -138,19 +138,62 @@ def cpu_baseline_all_cores(shape, x, y, max_threads=64):
     }
 
 
-def pmc_traffic(world):
-    """HBM-side bytes per product launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01/pmc_k_conv_tiled.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH_SIZE
-    doubled per MI355X_MICROARCH.md §HBM — gfx950 reports half of wide coalesced reads).  PMC counters
-    cannot be read from inside this process; null when no matching profile is committed (N > 1)."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_k_conv_tiled.json")
-    if world != 1 or not os.path.exists(path):
+PROFILE_ROUNDS = ("r02", "r01")  # newest first
+
+
+def pmc_traffic(world, workload):
+    """HBM-side bytes per product launch from the committed rocprofv3 PMC passes of this same command AND workload
+    (profiles/rNN/pmc_k_conv_tiled_<workload>.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md §HBM — gfx950 reports half of wide coalesced reads).  PMC counters cannot be
+    read from inside this process; null when no profile of this workload is committed (and for N > 1)."""
+    if world != 1:
         return None
-    d = json.load(open(path))
-    try:
-        return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
-    except KeyError:
-        return None
+    for rnd in PROFILE_ROUNDS:
+        names = [f"pmc_k_conv_tiled_{workload}.json"] + (["pmc_k_conv_tiled.json"] if workload == "c2" else [])
+        for name in names:
+            path = os.path.join(ROOT, "profiles", rnd, name)
+            if not os.path.exists(path):
+                continue
+            d = json.load(open(path))
+            if d.get("workload", "c2") != workload:
+                continue
+            try:
+                return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+            except KeyError:
+                continue
+    return None
+
+
+E2E_PROGRAMS = ("approx/hmm/hmm", "approx/mixture/mixture", "approx/two_populations/two_populations", "approx/switchpoint/switchpoint")
+
+
+def e2e_seconds(gpu_runs=5):
+    """BASELINE's second metric: end-to-end seconds ("Total inference time", best of N — the protocol of the
+    reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105) on NeurIPS'23 programs at --limit 100: the host
+    interpreter over libgftaylor (GPU, best of 5) and, beside it, the same interpreter over the CPU oracle on this
+    box's host (1 thread; best of 2, a single run for the 20-second mixture)."""
+    import genfer_amd
+
+    oracle = os.path.join(ROOT, "oracle", "liborc.so")
+    rows = {}
+    for prog in E2E_PROGRAMS:
+        path = os.path.join(ROOT, "tests", "golden", "sgcl", "neurips2023", prog + ".sgcl")
+        src = open(path).read()
+        name = prog.split("/")[-1]
+        row = {}
+        for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs), ("cpu_oracle_s", oracle, "orc_", 1 if name == "mixture" else 2)):
+            best = None
+            for _ in range(runs):
+                rc, text, t = genfer_amd.run_sgcl_with_backend(src, "--limit 100", lib, prefix)
+                if rc != 0:
+                    row[key + "_error"] = text[-200:]
+                    best = None
+                    break
+                best = t["time_infer"] if best is None else min(best, t["time_infer"])
+            row[key] = best
+            row[key.replace("_s", "_runs")] = runs
+        rows[name] = row
+    return {"unit": "s", "flags": "--limit 100", "protocol": "best-of-N Total inference time", "programs": rows}
 
 
 def main():
@@ -160,6 +203,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end seconds of the NeurIPS'23 programs (N = 1 only)")
     ap.add_argument("--conv-mode", type=int, default=0, help="0 auto, 1 reference-order kernel, 2 tiled kernel")
     args = ap.parse_args()
 
@@ -265,11 +309,13 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
+            "bound_detail": "FP64 FMA issue rate of the vector pipe (v_fma_f64); no MFMA instruction is issued — on gfx950 "
+                            "the FP64 matrix peak is the same 78.6 TFLOP/s and measured lower (profiles/r02/microbench_fp64.txt)",
             "achieved": achieved_tflops,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / FP64_PEAK_TFLOPS,
-            "traffic": pmc_traffic(world),
+            "traffic": pmc_traffic(world, args.workload),
             "note": "FP64 FMA roof (vector == matrix FP64 peak on gfx950, 78.6 TFLOP/s); flops = 2*MACs of the "
                     "slabs this rank computes / mean HIP-event duration of the product launch(es) on its stream",
             "kernel_ms": k_ms,
@@ -314,10 +360,15 @@ def main():
                 if float(err.item()) > 1e-10:
                     out["parity_failed"] = True
 
+    if rank == 0 and world == 1 and not args.no_e2e and args.workload == "c2":
+        out["e2e"] = e2e_seconds()
+    bad = bool(out.get("parity_failed")) or any(t < 0 for t in kern_ms)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if bad:  # a wrong product (or a failed event query) must not look like a successful run
+        sys.exit(1)
 
 
 if __name__ == "__main__":

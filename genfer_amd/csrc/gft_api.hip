@@ -137,8 +137,10 @@ struct Runtime {
     // size-threshold dispatch: an operation whose operands are all host-resident runs on the host
     // tier (gft_host.hpp) if its result has at most host_max_elems elements (and, for a general product, at most
     // host_max_macs multiply-adds); 0 = everything on the device.  Crossovers measured with tools/xover_host.py.
-    size_t host_max_elems = 1024;
-    double host_max_macs = 16384;
+    static constexpr size_t HOST_MAX_ELEMS_DEFAULT = 1024;
+    static constexpr double HOST_MAX_MACS_DEFAULT = 16384;
+    size_t host_max_elems = HOST_MAX_ELEMS_DEFAULT;
+    double host_max_macs = HOST_MAX_MACS_DEFAULT;
     std::map<size_t, std::vector<void*>> host_blocks;  // free host-tier blocks by size class
 };
 Runtime R;
@@ -2125,8 +2127,8 @@ int gft_set_option(const char* name, double value) {
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
-    else if (n == "host_max_elems") R.host_max_elems = value < 0 ? 0 : (size_t)value;
-    else if (n == "host_max_macs") R.host_max_macs = value;
+    else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
+    else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;
     else return -1;
     return 0;
 }

@@ -308,4 +308,24 @@ int gfh_run(const char* source, const char* flags, const char* backend_lib, cons
 }
 
 void gfh_free(char* p) { free(p); }
+
+// One raw Interval<F64> operation of the interpreter's own number type (gfh_number.hpp, interval.rs:117-234,
+// 264-276): op 0 add, 1 sub, 2 mul, 3 div, 4 neg, 5 exp, 6 log.  Used by tests/test_interval_pins.py to check that
+// the three independent restatements of interval.rs in this repository (this one, the kernels' gft_elem.hpp and the
+// test oracle) agree bit for bit.
+int gfh_interval_op(int op, const double* a, const double* b, double* out) {
+    Interval x = Interval::load(a), y = b ? Interval::load(b) : Interval(), r;
+    switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x / y; break;
+        case 4: r = -x; break;
+        case 5: r = x.exp(); break;
+        case 6: r = x.log(); break;
+        default: return -1;
+    }
+    r.store(out);
+    return 0;
+}
 }

@@ -88,7 +88,18 @@ def sharded_conv(
 
 
 def gpu_conv_slabs(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, lo: int, hi: int) -> None:
-    """The product's local compute: HIP kernels on the caller's tensors (no CPU path)."""
-    from . import conv_raw
+    """The product's local compute: HIP kernels on the caller's tensors (no CPU path).
 
+    Stream contract: torch's fills / uploads of x, y, z and the collectives of ``sharded_conv`` are ordered on
+    torch's CURRENT stream, the library launches on its own stream unless told otherwise — so the library adopts
+    torch's current stream here (``gft_set_stream`` synchronises the old one once when the stream changes)."""
+    import ctypes
+
+    from . import conv_raw, lib
+
+    L = lib()
+    cur = torch.cuda.current_stream().cuda_stream
+    if (L.gft_get_stream() or 0) != (cur or 0):
+        if L.gft_set_stream(ctypes.c_void_p(cur)) != 0:
+            raise RuntimeError((L.gft_last_error() or b"gft_set_stream failed").decode())
     conv_raw(x.data_ptr(), tuple(x.shape), y.data_ptr(), tuple(y.shape), z.data_ptr(), tuple(z.shape), lo, hi)

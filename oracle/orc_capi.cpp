@@ -228,4 +228,23 @@ double orc_mul_slabs_timed(const double* xs, const size_t* xshape, const double*
     *macs = total;
     return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// One raw Interval<F64> operation (iv:117-234, 264-276) on scalars, for the interval pin tests: op 0 add, 1 sub,
+// 2 mul, 3 div, 4 neg, 5 exp, 6 log.
+int orci_scalar_op(int op, const double* a, const double* b, double* out) {
+    Interval x(a[0], a[1]), y = b ? Interval(b[0], b[1]) : Interval(), r;
+    switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x / y; break;
+        case 4: r = -x; break;
+        case 5: r = x.exp(); break;
+        case 6: r = x.log(); break;
+        default: return -1;
+    }
+    out[0] = r.lo;
+    out[1] = r.hi;
+    return 0;
+}
 }

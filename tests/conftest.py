@@ -73,6 +73,39 @@ def GTPI():
 BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
+# ---- size-threshold dispatch in the tests --------------------------------------------
+# The library keeps small host-built tensors on its host tier.  The GPU tests exist to check the HIP kernels on
+# small shapes too, so by default every `gpu` test runs with the dispatch OFF (everything on the device).  The tests
+# of TIERED_MODULES that go through the handle API run twice: [device] = kernels only, [host] = the default dispatch
+# (host tier below the crossover) — same assertions, same oracle.
+TIERED_MODULES = {"test_fuzz_gpu", "test_parity_gpu", "test_reference_unit_vectors", "test_exact_kats", "test_e2e_snapshots",
+                  "test_horner_shapes_gpu", "test_interval_pins"}
+DEVICE_ONLY = ("conv_raw", "conv_tiled", "conv_staged", "full_size", "reference_order_kernels", "on_the_tiled", "oracle_byte_exact",
+               "mid_size", "test_oracle_", "limit100")
+
+
+def _set_tier(name):
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    assert L.gft_set_option(b"host_max_elems", 0.0 if name == "device" else -1.0) == 0
+    assert L.gft_set_option(b"host_max_macs", -1.0) == 0
+
+
+@pytest.fixture(autouse=True)
+def tier(request):
+    name = getattr(request, "param", "device")
+    if request.node.get_closest_marker("gpu") is not None:
+        _set_tier(name)
+    yield name
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.split(".")[-1]
+    if mod in TIERED_MODULES and not any(p in metafunc.function.__name__ for p in DEVICE_ONLY):
+        metafunc.parametrize("tier", ["device", pytest.param("host", marks=pytest.mark.gpu)], indirect=True)
+
+
 @pytest.fixture(params=BACKENDS)
 def backend(request):
     return request.param

@@ -13,11 +13,17 @@ Case kinds:
              summation order is exact => expected results are bit-exact targets.
   add/sub    ditto.
   div/exp/log/subst   rational results => compared with a tolerance.
+  iv_chain   q = (x*y + w) / d on small dyadic-rational tensors, exact.  The known answer is stored as the two doubles
+             that bracket each exact coefficient (r_down <= r <= r_up, adjacent or equal) plus a magnitude scale: an
+             Interval<F64> evaluation of the same chain on point intervals must ENCLOSE r (lo <= r_down, r_up <= hi —
+             soundness of interval.rs's widen-by-one-ulp arithmetic) and be at most ~1e-12 * mag wide (tightness).
+             Independent of the reference code, of the oracle and of every Interval implementation in this repo.
 
 Run:  python tests/golden/make_exact_kats.py   (deterministic; seed fixed)
 """
 import itertools
 import json
+import math
 import os
 import random
 from fractions import Fraction
@@ -188,6 +194,41 @@ def cases():
             spow = trunc_mul(spow, full, s, full, full)
         out.append(dict(kind="subst", p=to_nested(p, full), s=to_nested(s, full), v=v, deg=list(full),
                         r=to_nested(res, full), exact=True))
+    # ---- interval enclosure chains: q = (x*y + w) / d, exact -------------------------------------
+    def bracket(r):
+        f = float(r)  # nearest double
+        lo = f if Fraction(f) <= r else math.nextafter(f, -math.inf)
+        hi = f if Fraction(f) >= r else math.nextafter(f, math.inf)
+        assert Fraction(lo) <= r <= Fraction(hi)
+        return lo, hi
+
+    for full in [(6,), (4, 3), (3, 3, 2), (2, 2, 2, 2)]:
+        x = rand_poly(full, lo=-6, hi=7, denom=8)
+        y = rand_poly(full, lo=-6, hi=7, denom=4)
+        w = rand_poly(full, lo=-9, hi=9, denom=16)
+        d = rand_poly(full, lo=-3, hi=4, denom=2)
+        zero = tuple(0 for _ in full)
+        d[zero] = Fraction(rng.choice([3, -5, 7]), 2)
+        num = trunc_mul(x, full, y, full, full)
+        absnum = trunc_mul({k: abs(v) for k, v in x.items()}, full, {k: abs(v) for k, v in y.items()}, full, full)
+        for k in num:
+            num[k] += w[k]
+            absnum[k] += abs(w[k])
+        q = series_div(num, d, full)
+        mag = zeros(full)
+        for k in indices(full):
+            acc = absnum[k]
+            for j in indices(tuple(kk + 1 for kk in k)):
+                if j == k:
+                    continue
+                m = tuple(a - b for a, b in zip(k, j))
+                acc += mag[j] * abs(d[m])
+            mag[k] = acc / abs(d[zero])
+        lo, hi = zeros(full), zeros(full)
+        for k in indices(full):
+            lo[k], hi[k] = bracket(q[k])
+        out.append(dict(kind="iv_chain", x=to_nested(x, full), y=to_nested(y, full), w=to_nested(w, full), d=to_nested(d, full),
+                        deg=list(full), r_down=to_nested(lo, full), r_up=to_nested(hi, full), mag=to_nested(mag, full), exact=False))
     return out
 
 

@@ -195,3 +195,35 @@ def test_bounds_hip_matches_oracle(prog, oracle_path):
     rc, got = run_flags(path, genfer_amd.LIB_PATH, "gfti_", flags)
     assert rc == 0, got
     compare_reports(got, want)
+
+
+# ---- BASELINE configs[2] at its benchmarked size: `--limit 100` (tensors of side ~ 100 + sum of observations) ----------
+# The `.expect` snapshots were generated at the programs' auto-limit, so at --limit 100 the checker is the oracle
+# itself, run here on the host beside the HIP run of the same program (the shipped configuration: default
+# size-threshold dispatch, products above the crossover on the tiled kernel).
+C3_LIMIT100 = [
+    ("approx/hmm/hmm", False), ("approx/two_populations/two_populations", False), ("approx/mixture/mixture", False),
+    ("approx/switchpoint/switchpoint", False), ("approx/population/population", False),
+    ("approx/hmm/hmm", True), ("approx/two_populations/two_populations", True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,bounds", C3_LIMIT100, ids=[p.split("/")[-1] + ("-bounds" if b else "") for p, b in C3_LIMIT100])
+def test_c3_limit100_hip_matches_oracle(prog, bounds, oracle_path):
+    import conftest
+    import genfer_amd
+
+    genfer_amd.lib()
+    conftest._set_tier("host")  # the library's default dispatch
+    path = os.path.join(SGCL, "neurips2023", prog + ".sgcl")
+    flags = "--no-timing --limit 100" + (" --bounds" if bounds else "")
+    try:
+        rc, got = run_flags(path, genfer_amd.LIB_PATH, "gfti_" if bounds else "gft_", flags)
+        assert rc == 0, got
+    finally:
+        conftest._set_tier("device")
+    rc, want = run_flags(path, oracle_path, "orci_" if bounds else "orc_", flags)
+    assert rc == 0, want
+    assert want.count("p(") >= 100
+    compare_reports(got, want)

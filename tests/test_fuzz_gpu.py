@@ -232,10 +232,17 @@ def test_conv_tiled_random_shapes(seed):
 
     rng = np.random.default_rng(9000 + seed)
     nd = int(rng.integers(2, 5))
+    # shapes are drawn INSIDE the tiled kernel's domain (rank 3/4 directly, rank 2 and long last axes through the
+    # inner split; unit axes are collapsed by the library first, so a rank-4 shape with one unit axis is a rank-3
+    # problem); what lies outside is covered by test_conv_outside_tiled_domain_falls_back_bit_exactly
     hi = {2: 160, 3: 36, 4: 14}[nd]
-    zs = [int(rng.integers(1, hi + 1)) for _ in range(nd)]
+    zs = [int(rng.integers(2, hi + 1)) for _ in range(nd)]
     if nd == 2:
         zs[1] = int(rng.integers(96, 260))  # rank 2 needs a last axis the split accepts
+    if nd == 3 and seed % 5 == 0:
+        zs = [int(rng.integers(2, 10)), int(rng.integers(2, 12)), int(rng.integers(129, 200))]  # rank-3 inner split
+    if nd == 4 and seed % 4 == 0:
+        zs[int(rng.integers(0, 3))] = 1  # collapses to rank 3
     xs = [int(rng.integers(1, z + 1)) for z in zs]
     ys = [int(rng.integers(1, z + 1)) for z in zs]
     x = _rand(xs, 100 + seed)
@@ -259,11 +266,7 @@ def test_conv_tiled_random_shapes(seed):
         return out
 
     torch.cuda.synchronize()
-    try:
-        got = run(2, tx, ty, False)
-    except genfer_amd.TaylorError as e:
-        assert "not supported" in str(e)
-        pytest.skip("shape outside the tiled kernel's domain")
+    got = run(2, tx, ty, False)  # raises if the shape were outside the tiled domain: the draw above must not leave it
     want = run(1, tx, ty, False)
     bound = run(1, ax, ay, False)
     assert bool(torch.all((got - want).abs() <= 1e-10 * bound + 0.0))
@@ -271,3 +274,38 @@ def test_conv_tiled_random_shapes(seed):
     want = run(1, tx, ty, True)
     assert bool(torch.equal(got[:lo], z0[:lo])) and bool(torch.equal(got[hi_s:], z0[hi_s:]))
     assert bool(torch.all((got[lo:hi_s] - want[lo:hi_s]).abs() <= 1e-10 * (bound[lo:hi_s] + z0[lo:hi_s].abs())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xs,ys,zs", [
+    ((300,), (250,), (400,)),                                    # rank 1
+    ((40, 60), (50, 70), (64, 90)),                              # rank 2, last axis below the split's 96
+    ((1, 33, 1, 80), (1, 40, 1, 64), (1, 48, 1, 95)),            # collapses to rank 2, short last axis
+    ((3, 4, 5, 6, 7), (4, 4, 4, 4, 4), (5, 6, 7, 8, 9)),         # rank 5
+    ((2, 3, 2, 3, 2, 3), (3, 2, 3, 2, 3, 2), (4, 4, 4, 4, 4, 4)),  # rank 6
+])
+def test_conv_outside_tiled_domain_falls_back_bit_exactly(xs, ys, zs):
+    """Shapes the tiled kernel does not take: forcing it is an error, and the automatic dispatch computes them on the
+    reference-order kernels — bit-identical to the one-thread-per-output kernel (itself bit-exact against the oracle)."""
+    import torch
+
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    x, y = _rand(xs, 71), _rand(ys, 72)
+    tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def run(mode):
+        out = torch.full(zs, float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        L.gft_set_conv_mode(mode)
+        try:
+            genfer_amd.conv_raw(tx.data_ptr(), xs, ty.data_ptr(), ys, out.data_ptr(), zs)
+        finally:
+            L.gft_set_conv_mode(0)
+        L.gft_synchronize()
+        return out
+
+    with pytest.raises(genfer_amd.TaylorError, match="not supported"):
+        run(2)
+    assert bool(torch.equal(run(0), run(1)))
