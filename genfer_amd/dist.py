@@ -99,7 +99,15 @@ def gpu_conv_slabs(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, lo: int, h
 
     L = lib()
     cur = torch.cuda.current_stream().cuda_stream
-    if (L.gft_get_stream() or 0) != (cur or 0):
+    args = (x.data_ptr(), tuple(x.shape), y.data_ptr(), tuple(y.shape), z.data_ptr(), tuple(z.shape), lo, hi)
+    if not cur:
+        # torch's legacy default stream (handle 0) cannot be adopted (0 means "the library's own stream"): order the
+        # launch with explicit synchronisation on both sides instead — correct, just not asynchronous
+        torch.cuda.current_stream().synchronize()
+        conv_raw(*args)
+        L.gft_synchronize()
+        return
+    if (L.gft_get_stream() or 0) != cur:
         if L.gft_set_stream(ctypes.c_void_p(cur)) != 0:
             raise RuntimeError((L.gft_last_error() or b"gft_set_stream failed").decode())
-    conv_raw(x.data_ptr(), tuple(x.shape), y.data_ptr(), tuple(y.shape), z.data_ptr(), tuple(z.shape), lo, hi)
+    conv_raw(*args)
