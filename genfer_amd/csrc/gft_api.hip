@@ -130,6 +130,7 @@ struct Runtime {
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
+    bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
@@ -207,6 +208,10 @@ struct Buf {
     bool borrowed = false;
     bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
     std::shared_ptr<Buf> dev;
+    // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
+    // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
+    std::shared_ptr<Buf> host_copy;
+    unsigned coef_reads = 0;
     // memoised extract_linear() verdict: buffers are immutable once their polynomial is returned, and the
     // metadata-only reshapes that share a buffer (extend_to_dim, dropping a trailing unit axis) keep the
     // indices of all non-unit axes, so the verdict is a property of the buffer
@@ -1265,11 +1270,24 @@ struct Ops {
                              res.plane, (unsigned)res.shape[0]);
             return;
         }
+        if (!host && R.div2d && res.shape.size() == 2 &&
+            K<E>::div_2d(R.stream, xs.p, xs.plane, (unsigned)xs.shape[0], (unsigned)xs.shape[1], xs.shape[1], ys.p, ys.plane,
+                         (unsigned)ys.shape[0], (unsigned)ys.shape[1], res.p, res.plane, (unsigned)res.shape[0], (unsigned)res.shape[1], 0))
+            return;  // the last two axes in one launch (gft_div2d.hip), same bits
         size_t n0 = res.shape[0];
         HV y0 = ys.index0(0);
         for (size_t k = 0; k < n0; ++k) {
             HV cur = res.index0(k);
             conv(res, ys, res, k, k + 1, false, true, 0, 1, 0);  // cur = sum_{j<k} res[j] (*) ys[k-j]
+            if (!host && R.div2d && cur.shape.size() == 2) {
+                // neg, += xs[k], copy and the whole 2-d division of the slab fused into one launch
+                const bool have_x = k < xs.shape[0];
+                HV xk = have_x ? xs.index0(k) : HV{nullptr, 0, Dims{0, 0}, false};
+                if (K<E>::div_2d(R.stream, xk.p, xk.plane, have_x ? (unsigned)xk.shape[0] : 0u, have_x ? (unsigned)xk.shape[1] : 0u,
+                                 have_x ? xk.shape[1] : 0, y0.p, y0.plane, (unsigned)y0.shape[0], (unsigned)y0.shape[1], cur.p, cur.plane,
+                                 (unsigned)cur.shape[0], (unsigned)cur.shape[1], 1))
+                    continue;
+            }
             x_map_inplace(cur, MAP_NEG, 0);
             if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD, 0);
             std::shared_ptr<Buf> tmp = alloc_tier(host, cur.numel() * W);
@@ -1944,8 +1962,22 @@ struct Ops {
             if (W == 2) out[1] = h[a.numel + off];
             return;
         }
+        const double* d = dp<E>(a);
+        Buf* b = a.buf.get();
+        if (!b->host_copy && ++b->coef_reads >= 2 && a.numel * W * sizeof(double) <= ((size_t)32 << 20)) {
+            std::shared_ptr<Buf> m = alloc_host_doubles(a.numel * W);
+            HIP_OK(hipMemcpyAsync(m->p, d, sizeof(double) * a.numel * W, hipMemcpyDeviceToHost, R.stream));
+            HIP_OK(hipStreamSynchronize(R.stream));
+            b->host_copy = m;
+            R.stats[2]++;
+        }
+        if (b->host_copy) {
+            out[0] = b->host_copy->p[off];
+            if (W == 2) out[1] = b->host_copy->p[a.numel + off];
+            return;
+        }
         R.stats[2]++;
-        peek(out, dp<E>(a) + off, a.numel, W);
+        peek(out, d + off, a.numel, W);
     }
 
     static bool equal(const P& a, const P& b) {
@@ -2042,6 +2074,7 @@ int gft_init(int device) {
             if (v >= 0) R.tiled_min_macs = v;
         }
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
+        if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
@@ -2126,6 +2159,7 @@ int gft_set_option(const char* name, double value) {
     std::string n = name ? name : "";
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
+    else if (n == "div2d") R.div2d = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
     else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;

@@ -1,0 +1,138 @@
+// Blocked power-series division: the whole (last two axes) level of the division recurrence (mt:1162-1192) in ONE
+// launch.  The reference divides slab by slab: for every leading index k0 it forms `cur = xs[k0] - sum_{j<k0} res[j] (*)
+// ys[k0-j]` and then divides `cur` by ys[0] — a (d-1)-dimensional division that recurses the same way down to 1-d rows.
+// Driving that recursion from the host costs one launch per row and level (4096 k_div_1d launches + 4 x 4160 helper
+// launches for a 64^3 quotient, 0.08 % of the FP64 roof, profiles/r01/recurrences.txt).  Here one workgroup owns a 2-d
+// slab: divisor and quotient rows live in LDS, the inner 1-d products of a row are formed by 16 waves in parallel and
+// ADDED IN THE REFERENCE'S ORDER (mt:971-982: every row's partial sum from zero, sums added by ascending row), the 1-d
+// division (mt:1162-1185 with 0-dim base) runs in lock step over j exactly like k_div_1d.  Same operations per element
+// in the same order as the host-driven recursion => bit-identical quotients; only the launch count changes
+// (64^3: 20 000 -> 128).
+//
+// The dividend of the slab is either a tensor (plain 2-d division) or, fused, `(-acc) + x` where `acc` is the slab of
+// partial sums the leading-axis step just wrote into the quotient's own memory (the reference's neg + add + copy,
+// mt:1186-1189) — the quotient row overwrites it in place.
+#include <algorithm>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+struct Div2dArgs {
+    unsigned n1, n2;        // quotient slab shape (rows, row length)
+    unsigned ny1, ny2;      // divisor shape (compact: <= n1, n2)
+    unsigned nx1, nx2;      // box of the dividend tensor x (0, 0: none)
+    size_t x_rstride;       // row stride of x
+    int fused;              // 1: dividend row = (-res_in_place[k1][k2]) (+ x[k1][k2] inside x's box)
+    unsigned n2p, ny2p;     // LDS row pitches
+};
+
+constexpr int D2_NW = 16;  // waves per workgroup
+
+template <class E>
+__global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+                                                 double* res, size_t rp, Div2dArgs g) {
+    typedef typename E::V V;
+    extern __shared__ double d2_lds[];
+    // layout: [y: W x ny1 x ny2p][r: W x n1 x n2p][part: W x NW x n2p][row: W x n2p]
+    const size_t ysz = (size_t)g.ny1 * g.ny2p, rsz = (size_t)g.n1 * g.n2p, psz = (size_t)D2_NW * g.n2p;
+    double* yl = d2_lds;
+    double* rl = yl + E::W * ysz;
+    double* pl = rl + E::W * rsz;
+    double* tl = pl + E::W * psz;
+    const unsigned tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+    for (size_t i = tid; i < (size_t)g.ny1 * g.ny2; i += nthr) {
+        const unsigned a = (unsigned)(i / g.ny2), b = (unsigned)(i - (size_t)a * g.ny2);
+        E::st(yl, ysz, (size_t)a * g.ny2p + b, E::ld(y, yp, i));
+    }
+    __syncthreads();
+    const V y00 = E::ld(yl, ysz, 0);
+    const bool owner = tid < g.n2;
+    const unsigned k2 = tid;
+    const unsigned lo2 = (k2 + 1 > g.ny2) ? (k2 + 1 - g.ny2) : 0;  // 1-d level: first j whose y[k2 - j] exists
+    for (unsigned k1 = 0; k1 < g.n1; ++k1) {
+        // ---- sum_{j1 < k1} (res[j1, :] (*) y[k1 - j1, :])[k2]: each term's row product from zero, terms added by ascending j1
+        const unsigned lo1 = (k1 + 1 > g.ny1) ? (k1 + 1 - g.ny1) : 0;
+        V acc = E::zero();
+        for (unsigned base = lo1; base < k1; base += nwaves) {
+            const unsigned j1 = base + wave;
+            if (j1 < k1) {
+                const size_t rrow = (size_t)j1 * g.n2p, yrow = (size_t)(k1 - j1) * g.ny2p;
+                for (unsigned c = lane; c < g.n2; c += 64) {
+                    const unsigned jl = (c + 1 > g.ny2) ? (c + 1 - g.ny2) : 0;
+                    V inner = E::zero();
+                    for (unsigned j2 = jl; j2 <= c; ++j2)
+                        inner = E::add(inner, E::mul(E::ld(rl, rsz, rrow + j2), E::ld(yl, ysz, yrow + (c - j2))));
+                    E::st(pl, psz, (size_t)wave * g.n2p + c, inner);
+                }
+            }
+            __syncthreads();
+            if (owner) {
+                const unsigned cnt = (k1 - base < nwaves) ? (k1 - base) : nwaves;
+                for (unsigned w = 0; w < cnt; ++w) acc = E::add(acc, E::ld(pl, psz, (size_t)w * g.n2p + k2));
+            }
+            __syncthreads();
+        }
+        // ---- dividend row: cur = -acc; cur += x[k1]  (mt:1186-1188 at this level), x itself possibly the fused outer step
+        V cur1 = E::zero();  // the 1-d level's running sum of res[j] * y[0][k2 - j]
+        V t = E::zero();
+        if (owner) {
+            t = E::neg(acc);
+            if (g.fused) {
+                V xv = E::neg(E::ld(res, rp, (size_t)k1 * g.n2 + k2));
+                if (k1 < g.nx1 && k2 < g.nx2) xv = E::add(xv, E::ld(x, xp, (size_t)k1 * g.x_rstride + k2));
+                t = E::add(t, xv);
+            } else if (k1 < g.nx1 && k2 < g.nx2) {
+                t = E::add(t, E::ld(x, xp, (size_t)k1 * g.x_rstride + k2));
+            }
+        }
+        // ---- 1-d division of the row by y[0, :], lock step over j (k_div_1d): lane j finalises res[j], then every lane
+        // k2 > j adds res[j] * y[0][k2 - j]
+        for (unsigned j = 0; j < g.n2; ++j) {
+            if (owner && k2 == j) {
+                const V r = E::div(E::add(E::neg(cur1), t), y00);
+                E::st(tl, g.n2p, j, r);
+                E::st(rl, rsz, (size_t)k1 * g.n2p + j, r);
+                E::st(res, rp, (size_t)k1 * g.n2 + j, r);
+            }
+            if (g.n2 > 64) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"), __builtin_amdgcn_wave_barrier();
+            if (owner && k2 > j && j >= lo2) cur1 = E::add(cur1, E::mul(E::ld(tl, g.n2p, j), E::ld(yl, ysz, k2 - j)));
+            if (g.n2 <= 64) __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();  // row k1 of the quotient is in LDS for the next rows
+    }
+}
+
+template <class E>
+bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
+                  size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused) {
+    if (n1 == 0 || n2 < 2 || n2 > 1024 || ny1 > n1 || ny2 > n2) return false;
+    Div2dArgs g;
+    g.n1 = n1; g.n2 = n2; g.ny1 = ny1; g.ny2 = ny2; g.nx1 = nx1; g.nx2 = nx2;
+    g.x_rstride = x_rstride;
+    g.fused = fused;
+    g.n2p = n2 | 1;   // odd pitches: rows of one column do not share a bank
+    g.ny2p = ny2 | 1;
+    const size_t lds = sizeof(double) * E::W * ((size_t)ny1 * g.ny2p + (size_t)n1 * g.n2p + (size_t)D2_NW * g.n2p + g.n2p);
+    if (lds > 150 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_div_2d<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    // threads: one per row element, at least enough waves to form the row products in parallel
+    unsigned threads = std::max<unsigned>((n2 + 63) / 64 * 64, std::min<unsigned>(1024, 64 * (unsigned)std::min<unsigned>(D2_NW, std::max(1u, n1))));
+    hipLaunchKernelGGL(k_div_2d<E>, dim3(1), dim3(threads), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
+    return true;
+}
+
+template bool K<EF64>::div_2d(hipStream_t, const double*, size_t, unsigned, unsigned, size_t, const double*, size_t, unsigned, unsigned,
+                              double*, size_t, unsigned, unsigned, int);
+template bool K<EIv>::div_2d(hipStream_t, const double*, size_t, unsigned, unsigned, size_t, const double*, size_t, unsigned, unsigned,
+                             double*, size_t, unsigned, unsigned, int);
+
+}  // namespace gft

@@ -88,8 +88,11 @@ def _set_tier(name):
     import genfer_amd
 
     L = genfer_amd.lib()
-    assert L.gft_set_option(b"host_max_elems", 0.0 if name == "device" else -1.0) == 0
-    assert L.gft_set_option(b"host_max_macs", -1.0) == 0
+    # GFT_TEST_HOST_LIMITS="elems,macs": override the [host] tier's thresholds (debugging aid: lift them to run whole
+    # suites on the host tier)
+    elems, macs = (float(t) for t in os.environ.get("GFT_TEST_HOST_LIMITS", "-1,-1").split(","))
+    assert L.gft_set_option(b"host_max_elems", 0.0 if name == "device" else elems) == 0
+    assert L.gft_set_option(b"host_max_macs", macs) == 0
 
 
 @pytest.fixture(autouse=True)

@@ -243,8 +243,10 @@ def test_conv_tiled_random_shapes(seed):
         zs = [int(rng.integers(2, 10)), int(rng.integers(2, 12)), int(rng.integers(129, 200))]  # rank-3 inner split
     if nd == 4 and seed % 4 == 0:
         zs[int(rng.integers(0, 3))] = 1  # collapses to rank 3
+    # compact operands, but never a result larger than the product's support (xs + ys - 1): `Mul` cannot produce
+    # that (sum_shape, mt:150-170), and the tiled planner refuses output tiles nothing contributes to
     xs = [int(rng.integers(1, z + 1)) for z in zs]
-    ys = [int(rng.integers(1, z + 1)) for z in zs]
+    ys = [int(rng.integers(max(1, z - a + 1), z + 1)) for z, a in zip(zs, xs)]
     x = _rand(xs, 100 + seed)
     y = _rand(ys, 200 + seed)
     L = genfer_amd.lib()

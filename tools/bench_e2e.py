@@ -57,7 +57,7 @@ for f in files:
         row[name + "_s"] = best
     st = (ctypes.c_size_t * 8)()
     genfer_amd.lib().gft_op_stats(st)
-    row["gpu_op_stats_cumulative"] = dict(zip(("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "scans_other_known_linear"), list(st)[:7]))
+    row["gpu_op_stats_cumulative"] = dict(zip(("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops", "host_to_device_mirrors"), list(st)[:8]))
     rows.append(row)
     print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}", flush=True)
 print(json.dumps({"limit": limit, "runs": runs, "host_cores": os.cpu_count(), "rows": rows}))
