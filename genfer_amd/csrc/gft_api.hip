@@ -138,8 +138,11 @@ struct Runtime {
     // size-threshold dispatch: an operation whose operands are all host-resident runs on the host
     // tier (gft_host.hpp) if its result has at most host_max_elems elements (and, for a general product, at most
     // host_max_macs multiply-adds); 0 = everything on the device.  Crossovers measured with tools/xover_host.py.
-    static constexpr size_t HOST_MAX_ELEMS_DEFAULT = 1024;
-    static constexpr double HOST_MAX_MACS_DEFAULT = 16384;
+    // Measured on MI355X + its host (profiles/r02/xover_host.txt): a streaming operation costs the device ~4 us whatever
+    // its size and the host ~2.4 us per 1024 elements; a general product costs the device >= 15-20 us (launches + the
+    // dispatcher's two extract_linear read-backs) and the host 0.4 / 0.55 / 1.1 ns per multiply-add at rank 1 / 2 / >= 3.
+    static constexpr size_t HOST_MAX_ELEMS_DEFAULT = 2048;
+    static constexpr double HOST_MAX_MACS_DEFAULT = 65536;  // in rank-1 equivalents (est_macs weighs the rank)
     size_t host_max_elems = HOST_MAX_ELEMS_DEFAULT;
     double host_max_macs = HOST_MAX_MACS_DEFAULT;
     std::map<size_t, std::vector<void*>> host_blocks;  // free host-tier blocks by size class
@@ -1224,8 +1227,12 @@ struct Ops {
     // multiply-adds of a full product, estimated from the shapes (the dispatch criterion for general products)
     static double est_macs(const Dims& xs, const Dims& ys, const Dims& zs) {
         double macs = 1.0;
-        for (size_t i = 0; i < zs.size(); ++i) macs *= 0.5 * (double)zs[i] * (double)std::min(xs[i], ys[i]) + 0.5;
-        return macs;
+        int rank = 0;
+        for (size_t i = 0; i < zs.size(); ++i) {
+            macs *= 0.5 * (double)zs[i] * (double)std::min(xs[i], ys[i]) + 0.5;
+            if (zs[i] > 1) rank++;
+        }
+        return macs * (rank <= 1 ? 1.0 : (rank == 2 ? 1.4 : 2.8));  // host cost in rank-1 multiply-adds (xover_host.txt)
     }
 
     // ---- division (mt:1162-1231) -----------------------------------------------------------------------------

@@ -47,6 +47,34 @@ struct StagedArgs {
     unsigned rw;             // S == 1 with inner-from-zero sums: thread groups that split the rows of a batch (>= 1)
 };
 
+// One row product  sum_{j = lo}^{hi - 1} x[xb + j] * y[yb - j]  formed from zero in ascending j (mul_1d, mt:971-982).
+// `pos`: every staged element is in the interval functor's positive regime — the sum is then formed with mac_pos and
+// recomputed with the general mac if some lane of the wave hit a case mac_pos cannot represent.
+template <class E>
+__device__ inline typename E::V inner_sum(const double* xl, size_t xcap, const double* yl, size_t ycap, unsigned xb, unsigned yb,
+                                          unsigned lo, unsigned hi, bool pos) {
+    typedef typename E::V V;
+    if constexpr (E::HAS_POS) {
+        if (pos) {
+            bool bad = false;
+            V inner = E::zero();
+            if (lo < hi) {
+                inner = E::mul_pos(E::ld(xl, xcap, xb + lo), E::ld(yl, ycap, yb - lo));  // [0,0] + m returns m unchanged
+                bad = !E::pos_first_ok(inner);
+#pragma unroll 4
+                for (unsigned j = lo + 1; j < hi; ++j)
+                    inner = E::mac_pos(inner, E::ld(xl, xcap, xb + j), E::ld(yl, ycap, yb - j), bad);
+                bad = bad || !E::pos_result_ok(inner);
+            }
+            if (!any_lane(bad)) return inner;
+        }
+    }
+    V inner = E::zero();
+#pragma unroll 4
+    for (unsigned j = lo; j < hi; ++j) inner = E::mac(inner, E::ld(xl, xcap, xb + j), E::ld(yl, ycap, yb - j));
+    return inner;
+}
+
 template <class E, bool INNER0, int S>
 __global__ void __launch_bounds__(1024)
 k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
@@ -186,34 +214,45 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
         }
         const bool rows_desc = lastax == 0 && desc_0;
         __syncthreads();  // everyone is done with the previous sub-tensors
+        // Interval tensors: while staging, note whether every staged element is in the positive regime
+        // (gft_elem.hpp EIv::pos_ok); the block then runs its inner sums with mac_pos (same bits, ~1/4 of the
+        // instructions) and falls back to the general mac for the sums mac_pos cannot represent.
+        int not_pos = 0;
         if (S == 1 && rows > 1) {
             for (unsigned i = tid; i < rows * xcols; i += NT) {
                 unsigned r = i / xcols, c = i - r * xcols;
-                E::st(xl, g.xcap, i, E::ld(x, xp, xoff + (size_t)r * xpitch + c));
+                V v = E::ld(x, xp, xoff + (size_t)r * xpitch + c);
+                if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                E::st(xl, g.xcap, i, v);
             }
             for (unsigned i = tid; i < rows * ycols; i += NT) {
                 unsigned r = i / ycols, c = i - r * ycols;
-                E::st(yl, g.ycap, i, E::ld(y, yp, yoff + (size_t)r * ypitch + c));
+                V v = E::ld(y, yp, yoff + (size_t)r * ypitch + c);
+                if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                E::st(yl, g.ycap, i, v);
             }
         } else {
         for (unsigned i = tid; i < nx; i += NT) {
             V v = E::ld(x, xp, xoff + i);
+            if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
             E::st(xl, g.xcap, i, v);
         }
         if (S == 2 && g.syb != g.nb) {
             for (unsigned i = tid; i < ny; i += NT) {
                 unsigned r = i / g.syb, c = i - r * g.syb;
                 V v = E::ld(y, yp, yoff + i);
+                if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
                 E::st(yl, g.ycap, (size_t)r * g.nb + c, v);
             }
         } else {
             for (unsigned i = tid; i < ny; i += NT) {
                 V v = E::ld(y, yp, yoff + i);
+                if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
                 E::st(yl, g.ycap, i, v);
             }
         }
         }
-        __syncthreads();
+        const bool regime_pos = E::HAS_POS ? (__syncthreads_or(not_pos) == 0) : (__syncthreads(), false);
 
         if (S == 2 && INNER0 && rw > 1) {
             // plane mode: the rows j_a of the staged plane play the role of the batch rows, 8 at a time
@@ -228,10 +267,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                     for (unsigned t = c0 + q; t < cend; t += rw) {
                         const unsigned ja = desc_a ? (hi_a - 1 - t) : (lo_a + t);
                         const unsigned xb = ja * g.sxb, yb = (ka - ja) * g.nb + kb;
-                        V inner = E::zero();
-#pragma unroll 4
-                        for (unsigned j = lo_b; j < hi_b; ++j)
-                            inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
+                        V inner = inner_sum<E>(xl, g.xcap, yl, g.ycap, xb, yb, lo_b, hi_b, regime_pos);
                         E::st(sums, splane, (size_t)(t - c0) * CH + otid, inner);
                     }
                 }
@@ -249,10 +285,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                 for (unsigned t = q; t < rows; t += rw) {  // t-th row in consumption order
                     const unsigned xr = rows_desc ? rows - 1 - t : t;
                     const unsigned xb = xr * xcols, yb = (rows - 1 - xr) * ycols + kb;
-                    V inner = E::zero();
-#pragma unroll 4
-                    for (unsigned j = lo_b; j < hi_b; ++j)
-                        inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
+                    V inner = inner_sum<E>(xl, g.xcap, yl, g.ycap, xb, yb, lo_b, hi_b, regime_pos);
                     E::st(sums, splane, (size_t)t * CH + otid, inner);
                 }
             }
@@ -270,10 +303,7 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                 const unsigned yb = (S == 2 ? (ka - ja) * g.nb : (rows - 1 - xr) * ycols) + kb;
                 if (hi_b > lo_b) {
                     if (INNER0) {
-                        V inner = E::zero();
-#pragma unroll 4
-                        for (unsigned j = lo_b; j < hi_b; ++j)
-                            inner = E::mac(inner, E::ld(xl, g.xcap, xb + j), E::ld(yl, g.ycap, yb - j));
+                        V inner = inner_sum<E>(xl, g.xcap, yl, g.ycap, xb, yb, lo_b, hi_b, regime_pos);
                         acc = E::add(acc, inner);
                     } else {
                         const unsigned cnt_b = hi_b - lo_b;

@@ -54,6 +54,13 @@ struct EF64 {
     GFT_HD static V mulw(V a, V b) { return a * b; }   // "wave-checked" variants: plain ops for f64
     GFT_HD static V addw(V a, V b) { return a + b; }
     GFT_HD static V add0(V b) { return 0.0 + b; }      // (0 + b): turns -0 into +0, so it is not skipped
+    // positive-regime interface of the interval functor (no such regime for plain f64)
+    static constexpr bool HAS_POS = false;
+    GFT_HD static bool pos_ok(V) { return false; }
+    GFT_HD static V mul_pos(V a, V b) { return a * b; }
+    GFT_HD static V mac_pos(V acc, V a, V b, bool&) { return acc + a * b; }
+    GFT_HD static bool pos_first_ok(V) { return true; }
+    GFT_HD static bool pos_result_ok(V) { return true; }
     GFT_HD static V exp(V a) { return ::exp(a); }  // f64.rs:54-56
     GFT_HD static V log(V a) { return ::log(a); }  // f64.rs:59-61
 };
@@ -164,6 +171,27 @@ struct EIv {
         return add(a, b);
     }
     GFT_HD static V add0(V b) { return b; }  // [0,0] + b returns b unchanged (interval.rs:126-139)
+    // ---- positive regime ------------------------------------------------------------------------------------------
+    // Probability-like tensors are strictly positive.  For operands with 0 < lo <= hi < inf that are not the point
+    // interval [1,1] the reference's product (interval.rs:164-190) takes no short-circuit, its min / max of the four
+    // products are lo*lo and hi*hi (round-to-nearest multiplication is monotone), and every bound that follows is
+    // positive, where next_down / next_up are the integer steps bits-1 / bits+1.  mac_pos is that arithmetic — the
+    // same operations on the same values, so the same bits — for acc != [0,0]; the two cases it cannot represent
+    // (a lower bound that rounds down to 0, an upper bound that overflows) are reported through `bad` /
+    // pos_result_ok and the caller recomputes the sum with the general mac().
+    static constexpr bool HAS_POS = true;
+    GFT_HD static bool pos_ok(V v) { return v.lo > 0.0 && v.lo <= v.hi && v.hi < bits_f64(0x7ff0000000000000LL) && !(v.lo == 1.0 && v.hi == 1.0); }
+    GFT_HD static double dec_pos(double x) { return bits_f64(f64_bits(x) - 1); }  // next_down for x > 0
+    GFT_HD static double inc_pos(double x) { return bits_f64(f64_bits(x) + 1); }  // next_up for 0 <= x < inf
+    GFT_HD static V mul_pos(V a, V b) { return Iv{dec_pos(a.lo * b.lo), inc_pos(a.hi * b.hi)}; }
+    GFT_HD static V mac_pos(V acc, V a, V b, bool& bad) {
+        const double p = a.lo * b.lo;
+        const double mlo = dec_pos(p);
+        bad = bad || !(mlo > 0.0);  // p underflowed to 0 or to the least subnormal: next_down leaves the positive half
+        return Iv{dec_pos(acc.lo + mlo), inc_pos(acc.hi + inc_pos(a.hi * b.hi))};
+    }
+    GFT_HD static bool pos_first_ok(V m) { return m.lo > 0.0; }  // the first product's lower bound stayed positive
+    GFT_HD static bool pos_result_ok(V v) { return v.hi < bits_f64(0x7ff0000000000000LL); }  // no overflow on the way (NaN fails too)
     GFT_HD static V div(V a, V b) {                                           // :199-234
         if (is_nan(a) || is_nan(b)) {
             double n = bits_f64(0x7ff8000000000000LL);
