@@ -29,6 +29,51 @@ struct Div2dArgs {
 
 constexpr int D2_NW = 16;  // waves per workgroup
 
+// Division by a divisor that stays the same for a whole slab (y[0, 0]): the f64 quotient n / d as the compiler expands
+// it on gfx950 (v_div_scale, v_rcp, two Newton steps on the reciprocal, q = n*r, one residual step, v_div_fmas,
+// v_div_fixup — a ~30-instruction dependent chain) spends most of its length on the reciprocal of d, which does not
+// change.  With |d| and |n| in [2^-300, 2^300] the scale factors are 1 and the fix-up passes through, so the quotient is
+// exactly  q = n*r; e = fma(-d, q, n); fma(e, r, q)  with the refined reciprocal r formed once: the same operations on
+// the same values as the full expansion, hence the same (correctly rounded) bits, on a 3-instruction chain.  Outside
+// the window the full division runs.  (The 1-d recurrence is one dependent chain of n2 divisions per row: this is the
+// critical path of the whole quotient.)
+struct FastDiv {
+    double d, r;
+    bool ok;
+};
+__device__ inline bool fd_mid(double v) {
+    const unsigned e = (unsigned)((f64_bits(v) >> 52) & 0x7ff);
+    return e > 1023 - 300 && e < 1023 + 300;
+}
+__device__ inline FastDiv fd_make(double d) {
+    FastDiv f;
+    f.d = d;
+    f.ok = fd_mid(d);
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double r1 = __builtin_fma(r0, __builtin_fma(-d, r0, 1.0), r0);
+    f.r = __builtin_fma(r1, __builtin_fma(-d, r1, 1.0), r1);
+    return f;
+}
+__device__ inline double fd_div(double n, const FastDiv& f) {
+    if (f.ok && fd_mid(n)) {
+        const double q = n * f.r;
+        return __builtin_fma(__builtin_fma(-f.d, q, n), f.r, q);
+    }
+    return n / f.d;
+}
+template <class E>
+struct SlabDiv {  // generic element type: the functor's own division
+    typename E::V d;
+    __device__ explicit SlabDiv(typename E::V y) : d(y) {}
+    __device__ typename E::V operator()(typename E::V n) const { return E::div(n, d); }
+};
+template <>
+struct SlabDiv<EF64> {
+    FastDiv f;
+    __device__ explicit SlabDiv(double y) : f(fd_make(y)) {}
+    __device__ double operator()(double n) const { return fd_div(n, f); }
+};
+
 template <class E>
 __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
                                                  double* res, size_t rp, Div2dArgs g) {
@@ -46,7 +91,7 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
         E::st(yl, ysz, (size_t)a * g.ny2p + b, E::ld(y, yp, i));
     }
     __syncthreads();
-    const V y00 = E::ld(yl, ysz, 0);
+    const SlabDiv<E> div_y00(E::ld(yl, ysz, 0));
     const bool owner = tid < g.n2;
     const unsigned k2 = tid;
     const unsigned lo2 = (k2 + 1 > g.ny2) ? (k2 + 1 - g.ny2) : 0;  // 1-d level: first j whose y[k2 - j] exists
@@ -61,6 +106,7 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
                 for (unsigned c = lane; c < g.n2; c += 64) {
                     const unsigned jl = (c + 1 > g.ny2) ? (c + 1 - g.ny2) : 0;
                     V inner = E::zero();
+#pragma unroll 4
                     for (unsigned j2 = jl; j2 <= c; ++j2)
                         inner = E::add(inner, E::mul(E::ld(rl, rsz, rrow + j2), E::ld(yl, ysz, yrow + (c - j2))));
                     E::st(pl, psz, (size_t)wave * g.n2p + c, inner);
@@ -90,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
         // k2 > j adds res[j] * y[0][k2 - j]
         for (unsigned j = 0; j < g.n2; ++j) {
             if (owner && k2 == j) {
-                const V r = E::div(E::add(E::neg(cur1), t), y00);
+                const V r = div_y00(E::add(E::neg(cur1), t));
                 E::st(tl, g.n2p, j, r);
                 E::st(rl, rsz, (size_t)k1 * g.n2p + j, r);
                 E::st(res, rp, (size_t)k1 * g.n2 + j, r);
