@@ -24,6 +24,7 @@
 #include "../../include/gftaylor.h"
 #include "gft_kernels.hpp"
 #include "gft_host.hpp"
+#include "gft_fmt.hpp"
 
 using namespace gft;
 static const size_t UMAX = SIZE_MAX;
@@ -1987,6 +1988,48 @@ struct Ops {
         peek(out, d + off, a.numel, W);
     }
 
+    // `impl Display for TaylorPoly` = fmt_polynomial (mt:694-730): non-zero coefficients in row-major order, each
+    // followed by its variables ("a".."z", then x_<i>; "^e" above 1), joined by " + "; "0" if there is none.
+    // `debug`: `impl Debug` (mt:632-636), "TaylorPoly([degrees_p1], <polynomial>)" with the coefficients in the same
+    // polynomial form (the reference prints ndarray's nested-list Display there; the information is the same).
+    static std::string format(const P& a, bool debug) {
+        std::vector<double> h(a.numel * W);
+        if (on_host(a)) std::memcpy(h.data(), hp<E>(a), sizeof(double) * h.size());
+        else {
+            HIP_OK(hipMemcpyAsync(h.data(), dp<E>(a), sizeof(double) * h.size(), hipMemcpyDeviceToHost, R.stream));
+            HIP_OK(hipStreamSynchronize(R.stream));
+        }
+        auto num = [&](size_t i) {
+            if (W == 1) return gftfmt::fmt_f64(h[i]);
+            return "[" + gftfmt::fmt_f64(h[i]) + ", " + gftfmt::fmt_f64(h[a.numel + i]) + "]";  // interval.rs:243-247
+        };
+        std::string out;
+        bool first = true;
+        Dims idx(a.shape.size(), 0);
+        for (size_t lin = 0; lin < a.numel; ++lin) {
+            const bool zero = W == 1 ? h[lin] == 0.0 : (h[lin] == 0.0 && h[a.numel + lin] == 0.0);
+            if (!zero) {
+                if (!first) out += " + ";
+                first = false;
+                out += num(lin);
+                for (size_t i = 0; i < idx.size(); ++i) {
+                    if (idx[i] == 0) continue;
+                    out += i < 26 ? std::string(1, (char)('a' + i)) : "x_" + std::to_string(i);  // ppl.rs:107-117
+                    if (idx[i] > 1) out += "^" + std::to_string(idx[i]);
+                }
+            }
+            for (size_t ax = idx.size(); ax-- > 0;) {
+                if (++idx[ax] < a.shape[ax]) break;
+                idx[ax] = 0;
+            }
+        }
+        if (first) out = "0";
+        if (!debug) return out;
+        std::string d = "TaylorPoly([";
+        for (size_t i = 0; i < a.deg.size(); ++i) d += (i ? ", " : "") + std::to_string(a.deg[i]);
+        return d + "], " + out + ")";
+    }
+
     static bool equal(const P& a, const P& b) {
         if (a.deg != b.deg || a.shape != b.shape) return false;
         if (on_host(a) && on_host(b)) return HK<E>::count_neq(hp<E>(a), a.numel, hp<E>(b), b.numel, a.numel) == 0;
@@ -2304,6 +2347,20 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     int PFX##is_zero(const gft_poly* p) { return guard_int([&] { return (int)Ops<E>::is_zero(*p); }); }       \
     int PFX##is_one(const gft_poly* p) { return guard_int([&] { return (int)Ops<E>::is_one(*p); }); }         \
     int PFX##equal(const gft_poly* a, const gft_poly* b) { return guard_int([&] { return (int)Ops<E>::equal(*a, *b); }); } \
+    long PFX##format(const gft_poly* p, int debug, char* out, size_t cap) {                                   \
+        long need = -1;                                                                                       \
+        (void)guard_int([&] {                                                                                 \
+            std::string s = Ops<E>::format(*p, debug != 0);                                                   \
+            need = (long)s.size();                                                                            \
+            if (out && cap) {                                                                                 \
+                size_t n = std::min(cap - 1, s.size());                                                       \
+                std::memcpy(out, s.data(), n);                                                                \
+                out[n] = 0;                                                                                   \
+            }                                                                                                 \
+            return 0;                                                                                         \
+        });                                                                                                   \
+        return need;                                                                                          \
+    }                                                                                                         \
     int PFX##constant_term(const gft_poly* p, double* out) {                                                  \
         return guard_int([&] {                                                                                \
             double v[2];                                                                                      \

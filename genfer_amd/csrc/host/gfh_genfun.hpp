@@ -59,6 +59,77 @@ struct GenFun {
     friend GenFun operator*(const GenFun& a, const GenFun& b) { return bin(Mul, a, b); }
     friend GenFun operator/(const GenFun& a, const GenFun& b) { return bin(Div, a, b); }
 
+    // ---- Display (generating_function.rs:330-432, precedence :451-470; `--print-gf`) ---------------------------------
+    static std::string var_name(size_t i) {  // ppl.rs:107-117
+        if (i < 26) return std::string(1, (char)('a' + i));
+        return "x_" + std::to_string(i);
+    }
+    // fmt_polynomial (multivariate_taylor.rs:694-724): non-zero coefficients in row-major order, "c" then every
+    // variable with a non-zero exponent ("^e" above 1), joined by " + "; "0" for the zero polynomial
+    static std::string fmt_polynomial(const std::vector<T>& coeffs, const Dims& shape) {
+        std::string out;
+        bool first = true;
+        Dims idx(shape.size(), 0);
+        for (size_t lin = 0; lin < coeffs.size(); ++lin) {
+            if (!coeffs[lin].is_zero()) {
+                if (!first) out += " + ";
+                first = false;
+                out += coeffs[lin].str();
+                for (size_t i = 0; i < idx.size(); ++i) {
+                    if (idx[i] == 0) continue;
+                    out += var_name(i);
+                    if (idx[i] > 1) out += "^" + std::to_string(idx[i]);
+                }
+            }
+            for (size_t ax = idx.size(); ax-- > 0;) {
+                if (++idx[ax] < shape[ax]) break;
+                idx[ax] = 0;
+            }
+        }
+        return first ? "0" : out;
+    }
+    static int precedence(Kind k) {
+        switch (k) {
+            case Add: case Neg: case Polynomial: return 0;
+            case Mul: case Div: return 1;
+            case Pow: return 2;
+            default: return 10;
+        }
+    }
+    std::string str(int parent_prec = 0) const {
+        const Node& x = *p;
+        const int cur = precedence(x.kind);
+        std::string o;
+        if (cur < parent_prec) o += "(";
+        auto list = [](const Dims& v) {  // {:?} of a Vec<usize>
+            std::string r = "[";
+            for (size_t i = 0; i < v.size(); ++i) r += (i ? ", " : "") + std::to_string(v[i]);
+            return r + "]";
+        };
+        switch (x.kind) {
+            case Var: o += var_name(x.var); break;
+            case Const: o += x.c.str(); break;
+            case Add: o += x.a.str(cur) + " + " + x.b.str(cur); break;
+            case Neg: o += "-" + x.a.str(cur + 1); break;
+            case Mul: o += x.a.str(cur) + " * " + x.b.str(cur); break;
+            case Div: o += x.a.str(cur) + " / " + x.b.str(cur + 1); break;
+            case Polynomial: o += fmt_polynomial(x.coeffs, x.shape); break;
+            case Exp: o += "exp(" + x.a.str(0) + ")"; break;
+            case Log: o += "log(" + x.a.str(0) + ")"; break;
+            case Pow: o += x.a.str(cur + 1) + "^" + std::to_string(x.n); break;
+            case Max: o += "max(" + x.a.str(0) + ", " + x.b.str(0) + ")"; break;
+            case UniformMgf: o += "uniform_mgf(" + x.a.str(0) + ")"; break;
+            case Subst: o += "[" + var_name(x.var) + " -> " + x.b.str(0) + " in " + x.a.str(0) + "]"; break;
+            case Derivative: o += "d_" + var_name(x.var) + "^" + std::to_string(x.order) + "(" + x.a.str(0) + ")"; break;
+            case TaylorPolynomial: o += "taylor(" + x.a.str(0) + " of " + var_name(x.var) + "^i with i ∈ " + list(x.orders) + ")"; break;
+            case TaylorCoeffAtZero: o += "coeff_at_zero(" + x.a.str(0) + " of " + var_name(x.var) + "^" + std::to_string(x.order) + ")"; break;
+            case TaylorCoeff: o += "coeff(" + x.a.str(0) + " of " + var_name(x.var) + "^" + std::to_string(x.order) + ")"; break;
+            case ShiftTaylorAtZero: o += "shift(" + x.a.str(0) + " of " + var_name(x.var) + " by " + std::to_string(x.order) + ")"; break;
+        }
+        if (cur < parent_prec) o += ")";
+        return o;
+    }
+
     // derived PartialEq (structural)
     bool operator==(const GenFun& o) const {
         if (p == o.p) return true;

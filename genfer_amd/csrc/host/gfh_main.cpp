@@ -6,7 +6,10 @@
 //                             const char* backend_prefix, char** out_text, char** out_timings_json)
 // `backend_lib`/`backend_prefix` select the library that implements the TaylorPoly C ABI
 // (include/gftaylor.h): the product passes libgftaylor.so + "gft_" (or "gfti_" with --bounds).
+#include <charconv>
 #include <chrono>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <sstream>
@@ -23,6 +26,9 @@ struct Args {
     size_t unroll = 8;
     bool has_limit = false;
     size_t limit = 0;
+    bool print_gf = false;
+    std::string json_path;           // --json <path> (main.rs:91-93)
+    std::string model_name = "model";  // file stem of the program (main.rs:603); set by the `genfer` executable
 };
 
 Args parse_flags(const std::string& flags) {
@@ -43,8 +49,12 @@ Args parse_flags(const std::string& flags) {
         else if (tok == "-l" || tok == "--limit") { a.has_limit = true; a.limit = next_num(tok); }
         else if (tok.rfind("--limit=", 0) == 0) { a.has_limit = true; a.limit = std::stoull(tok.substr(8)); }
         else if (tok.rfind("--unroll=", 0) == 0) a.unroll = std::stoull(tok.substr(9));
+        else if (tok == "--print-gf") a.print_gf = true;
+        else if (tok == "--json") { if (!(is >> a.json_path)) throw std::runtime_error("missing value for --json"); }
+        else if (tok.rfind("--json=", 0) == 0) a.json_path = tok.substr(7);
+        else if (tok == "--model-name") { if (!(is >> a.model_name)) throw std::runtime_error("missing value for --model-name"); }
         else if (tok == "-r" || tok == "--rational" || tok == "-s" || tok == "--symbolic" || tok == "--big-float" || tok == "-p" ||
-                 tok == "--precision" || tok == "--json" || tok == "--print-program" || tok == "--print-gf")
+                 tok == "--precision" || tok == "--print-program")
             throw std::runtime_error("flag " + tok + " selects a part of the reference that is out of scope here (f64 / interval Taylor path only)");
         else throw std::runtime_error("unknown flag " + tok);
     }
@@ -53,10 +63,38 @@ Args parse_flags(const std::string& flags) {
 
 typedef std::chrono::steady_clock Clock;
 
+// Rust's `{}` of an f64 (the durations of print_json, main.rs:629-640): shortest round-trip digits, never scientific
+// notation, no trailing ".0".
+std::string fmt_rust_f64(double x) {
+    if (std::isnan(x)) return "NaN";
+    if (std::isinf(x)) return x < 0 ? "-inf" : "inf";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);
+    std::string s(buf, r.ptr);
+    bool neg = s[0] == '-';
+    if (neg) s = s.substr(1);
+    size_t epos = s.find('e');
+    std::string digits;
+    for (char c : s.substr(0, epos))
+        if (c != '.') digits.push_back(c);
+    int exp10 = std::stoi(s.substr(epos + 1));
+    int kk = exp10 + 1;  // position of the decimal point relative to the digit string
+    std::string out;
+    if (x == 0.0) out = "0";
+    else if (kk <= 0) out = "0." + std::string(-kk, '0') + digits;
+    else if ((size_t)kk >= digits.size()) out = digits + std::string(kk - digits.size(), '0');
+    else out = digits.substr(0, kk) + "." + digits.substr(kk);
+    return neg ? "-" + out : out;
+}
+
 struct Report {
     std::ostringstream out;
+    std::ostringstream err;
     Args args;
     double t_gf = 0, t_moments = 0, t_probs = 0, t_total = 0;
+    // what print_json needs (main.rs:595-645)
+    bool json_ok = false;
+    std::string j_total, j_mean, j_variance, j_stddev, j_skewness, j_kurtosis, j_masses;
     void elapsed(Clock::time_point start, const char* text, double* store) {  // main.rs:579-593
         double e = std::chrono::duration<double>(Clock::now() - start).count();
         if (store) *store = e;
@@ -128,7 +166,7 @@ void print_moments(Report& R, const Moments& m, bool pi) {  // main.rs:548-577
 
 const size_t MAX_PROB_LIMIT = 1000;
 
-void print_probs(Report& R, const Interval& rest, const Interval& total_without_rest, const std::vector<Interval>& moments,
+std::vector<Interval> print_probs(Report& R, const Interval& rest, const Interval& total_without_rest, const std::vector<Interval>& moments,
                  const SupportSet& var_info, const SupportSet& rest_info, bool uses_observe,
                  const std::function<std::vector<Interval>(size_t)>& probs_fn, Clock::time_point probs_start) {  // main.rs:384-473
     auto& o = R.out;
@@ -182,6 +220,7 @@ void print_probs(Report& R, const Interval& rest, const Interval& total_without_
         o << "Normalized:   p(n) / Z <= " << mm_n.str() << " for all n >= " << limit << "\n";
     }
     R.elapsed(probs_start, "Time to compute probability masses: ", &R.t_probs);
+    return probs;
 }
 
 void print_moments_and_probs_interval(Report& R, const std::function<Interval()>& rest_fn,
@@ -214,9 +253,31 @@ void print_moments_and_probs_interval(Report& R, const std::function<Interval()>
     ms.kurtosis = ms.kurtosis.ensure_lower_bound(F64::zero());
     print_moments(R, ms, R.args.bounds || !rest.is_zero());
     R.elapsed(moment_start, "Time to compute moments: ", &R.t_moments);
+    std::vector<Interval> probs;
     if (!(R.args.no_probs || !var_info.is_discrete() || total.is_zero()))
-        print_probs(R, rest, total_without_rest, moments, var_info, rest_info, uses_observe, probs_fn, Clock::now());
+        probs = print_probs(R, rest, total_without_rest, moments, var_info, rest_info, uses_observe, probs_fn, Clock::now());
     R.elapsed(inference_start, "Total inference time: ", &R.t_total);
+    if (!R.args.json_path.empty()) {  // main.rs:364-382: point values (interval centres), only without loop bounds
+        if (rest.is_zero()) {
+            R.json_ok = true;
+            R.j_total = ms.total.center().str(); R.j_mean = ms.mean.center().str(); R.j_variance = ms.variance.center().str();
+            R.j_stddev = ms.stddev.center().str(); R.j_skewness = ms.skewness.center().str(); R.j_kurtosis = ms.kurtosis.center().str();
+            for (auto& p : probs) R.j_masses += p.center().str() + ", ";
+            double total_s = std::chrono::duration<double>(Clock::now() - inference_start).count();
+            std::ostringstream j;  // the reference's literal layout, trailing commas and all (main.rs:617-633)
+            j << "\n{\n    \"model\": \"" << R.args.model_name << "\",\n    \"system\": \"genfer\",\n    \"time_gf_translation\": "
+              << fmt_rust_f64(R.t_gf) << ",\n    \"total\": " << R.j_total << ",\n    \"mean\": " << R.j_mean << ",\n    \"variance\": "
+              << R.j_variance << ",\n    \"stddev\": " << R.j_stddev << ",\n    \"skewness\": " << R.j_skewness << ",\n    \"kurtosis\": "
+              << R.j_kurtosis << ",\n    \"time_moments\": " << fmt_rust_f64(R.t_moments) << ",\n    \"masses\": [" << R.j_masses
+              << "],\n    \"time_probs\": " << fmt_rust_f64(R.t_probs) << ",\n    \"time_infer\": " << fmt_rust_f64(total_s) << ",\n}\n";
+            FILE* f = fopen(R.args.json_path.c_str(), "w");
+            if (!f) throw std::runtime_error("failed to write JSON file");
+            fputs(j.str().c_str(), f);
+            fclose(f);
+        } else {
+            R.err << "Could not write JSON file because results are only bounds due to the presence of loops.\n";
+        }
+    }
 }
 
 template <class T>
@@ -229,6 +290,10 @@ GfTranslation<T> translate(Report& R, const Program& program) {  // main.rs:229-
     if (!R.args.no_simplify_gf) {
         t.gf = t.gf.simplify();
         t.rest = t.rest.simplify();
+    }
+    if (R.args.print_gf) {  // main.rs:248-251
+        R.out << "Generating function:\n" << t.gf.str() << "\n\n";
+        R.out << "Remaining mass:\n" << t.rest.str() << "\n\n";
     }
     R.elapsed(start, "Time to construct the generating function: ", &R.t_gf);
     return t;
@@ -274,7 +339,12 @@ char* dup(const std::string& s) {
 
 }  // namespace
 
+static std::string g_last_stderr;
+
 extern "C" {
+
+// What the last gfh_run would have written to stderr (the reference's eprintln! lines).
+const char* gfh_last_stderr() { return g_last_stderr.c_str(); }
 
 // Returns 0 on success (*out_text = the report, exactly the reference's stdout), non-zero on error
 // (*out_text = the message: parse errors and reference panics).  Caller frees with gfh_free.
@@ -292,6 +362,7 @@ int gfh_run(const char* source, const char* flags, const char* backend_lib, cons
             Poly<F64>::bind(api);
             run_f64(R, program);
         }
+        g_last_stderr = R.err.str();
         *out_text = dup(R.out.str());
         if (out_timings_json) {
             std::ostringstream j;

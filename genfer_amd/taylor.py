@@ -59,6 +59,7 @@ HANDLE_API = {
     "is_zero": (C.c_int, [_VP]),
     "is_one": (C.c_int, [_VP]),
     "equal": (C.c_int, [_VP, _VP]),
+    "format": (C.c_long, [_VP, C.c_int, C.c_char_p, C.c_size_t]),
     "constant_term": (C.c_int, [_VP, _DP]),
     "extract_constant": (C.c_int, [_VP, _DP]),
     "extract_linear": (C.c_int, [_VP, _DP, _DP, _SP]),
@@ -347,8 +348,19 @@ def bind(lib: C.CDLL, prefix: str):
 
         __hash__ = None
 
-        def __repr__(self):
-            return f"TaylorPoly({list(self.degrees_p1())}, {self.array().tolist()})"
+        def _format(self, debug: bool) -> str:
+            n = fn.format(self._h, int(debug), None, 0)
+            if n < 0:
+                raise TaylorError((fn.last_error() or b"format failed").decode())
+            buf = C.create_string_buffer(n + 1)
+            fn.format(self._h, int(debug), buf, n + 1)
+            return buf.value.decode()
+
+        def __str__(self):  # impl Display (fmt_polynomial, mt:694-730)
+            return self._format(False)
+
+        def __repr__(self):  # impl Debug (mt:632-636)
+            return self._format(True)
 
     TaylorPoly.__qualname__ = f"TaylorPoly[{prefix}]"
     return TaylorPoly

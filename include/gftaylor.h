@@ -125,6 +125,10 @@ int gft_is_constant(const gft_poly* p);                                 /* is_co
 int gft_is_zero(const gft_poly* p);                                     /* Zero::is_zero          mt:643-645 */
 int gft_is_one(const gft_poly* p);                                      /* One::is_one            mt:653-655 */
 int gft_equal(const gft_poly* a, const gft_poly* b);                    /* PartialEq              mt:10      */
+/* Display (debug == 0: fmt_polynomial, mt:694-730, e.g. "1.0 + 2.0b + 3.0a^2") or Debug (debug != 0: "TaylorPoly([degrees_p1],
+ * <polynomial>)", mt:632-636) as NUL-terminated UTF-8 into out[0..cap); returns the full length (call with cap 0 to size
+ * the buffer), -1 on error.  Floats print like the reference's F64 (ryu shortest round-trip, f64.rs:41-45). */
+long gft_format(const gft_poly* p, int debug, char* out, size_t cap);   /* Display / Debug        mt:632-636,694-730 */
 int gft_constant_term(const gft_poly* p, double* out);                  /* constant_term          mt:296-299 */
 int gft_extract_constant(const gft_poly* p, double* out);               /* extract_constant       mt:262-269 */
 int gft_extract_linear(const gft_poly* p, double* c, double* m, size_t* v); /* extract_linear     mt:275-294 */
@@ -189,6 +193,7 @@ int gfti_is_constant(const gft_poly* p);
 int gfti_is_zero(const gft_poly* p);
 int gfti_is_one(const gft_poly* p);
 int gfti_equal(const gft_poly* a, const gft_poly* b);
+long gfti_format(const gft_poly* p, int debug, char* out, size_t cap);
 int gfti_constant_term(const gft_poly* p, double* out);
 int gfti_extract_constant(const gft_poly* p, double* out);
 int gfti_extract_linear(const gft_poly* p, double* c, double* m, size_t* v);

@@ -53,6 +53,65 @@ static P<S>* from_host(const double* data, const size_t* shape, const size_t* de
     return new P<S>(std::move(a), vec(degs, ndim));
 }
 
+// Display / Debug of a TaylorPoly (mt:632-636, 694-730).  Floats: shortest decimal that round-trips (searched with
+// printf precision 1..17 — independent of the product's std::to_chars route), laid out like ryu's format64 (f64:41-45).
+static std::string fmt_num(double x) {
+    if (std::isnan(x)) return "NaN";
+    if (std::isinf(x)) return x < 0 ? "-inf" : "inf";
+    if (x == 0.0) return std::signbit(x) ? "-0.0" : "0.0";
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; ++prec) {
+        snprintf(buf, sizeof buf, "%.*e", prec - 1, x);
+        if (strtod(buf, nullptr) == x) break;
+    }
+    std::string s(buf);
+    bool neg = s[0] == '-';
+    if (neg) s = s.substr(1);
+    size_t e = s.find('e');
+    std::string digits;
+    for (char c : s.substr(0, e))
+        if (c != '.') digits.push_back(c);
+    int exp10 = atoi(s.c_str() + e + 1), len = (int)digits.size(), k = exp10 - (len - 1), kk = len + k;
+    std::string out;
+    if (0 <= k && kk <= 16) out = digits + std::string(k, '0') + ".0";
+    else if (0 < kk && kk <= 16) out = digits.substr(0, kk) + "." + digits.substr(kk);
+    else if (-5 < kk && kk <= 0) out = "0." + std::string(-kk, '0') + digits;
+    else if (len == 1) out = digits + "e" + std::to_string(kk - 1);
+    else out = digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+    return neg ? "-" + out : out;
+}
+static std::string fmt_scalar(const F64& s) { return fmt_num(s.v); }
+static std::string fmt_scalar(const Interval& s) { return "[" + fmt_num(s.lo) + ", " + fmt_num(s.hi) + "]"; }
+template <class S>
+static std::string format_poly(const P<S>& p, bool debug) {
+    std::string out;
+    bool first = true;
+    const std::vector<usize>& shape = p.coeffs.shape;
+    std::vector<usize> idx(shape.size(), 0);
+    for (usize lin = 0; lin < p.coeffs.data.size(); ++lin) {
+        if (!p.coeffs.data[lin].is_zero()) {
+            if (!first) out += " + ";
+            first = false;
+            out += fmt_scalar(p.coeffs.data[lin]);
+            for (usize i = 0; i < idx.size(); ++i) {
+                if (!idx[i]) continue;
+                out += i < 26 ? std::string(1, (char)('a' + i)) : "x_" + std::to_string(i);
+                if (idx[i] > 1) out += "^" + std::to_string(idx[i]);
+            }
+        }
+        for (usize ax = idx.size(); ax-- > 0;) {
+            if (++idx[ax] < shape[ax]) break;
+            idx[ax] = 0;
+        }
+    }
+    if (first) out = "0";
+    if (!debug) return out;
+    std::string d = "TaylorPoly([";
+    for (usize i = 0; i < p.degrees_p1.size(); ++i) d += (i ? ", " : "") + std::to_string(p.degrees_p1[i]);
+    return d + "], " + out + ")";
+}
+
 #define DEFINE_API(PFX, S)                                                                                 \
     extern "C" {                                                                                           \
     const char* PFX##last_error() { return g_err.c_str(); }                                                \
@@ -92,6 +151,15 @@ static P<S>* from_host(const double* data, const size_t* shape, const size_t* de
     int PFX##is_zero(const void* p) { return ((const P<S>*)p)->is_zero(); }                                \
     int PFX##is_one(const void* p) { return ((const P<S>*)p)->is_one(); }                                  \
     int PFX##equal(const void* a, const void* b) { return *(const P<S>*)a == *(const P<S>*)b; }            \
+    long PFX##format(const void* p, int debug, char* out, size_t cap) {                                    \
+        std::string s = format_poly(*(const P<S>*)p, debug != 0);                                          \
+        if (out && cap) {                                                                                  \
+            size_t n = std::min(cap - 1, s.size());                                                        \
+            std::memcpy(out, s.data(), n);                                                                 \
+            out[n] = 0;                                                                                    \
+        }                                                                                                  \
+        return (long)s.size();                                                                             \
+    }                                                                                                      \
     int PFX##constant_term(const void* p, double* out) {                                                   \
         Tr<S>::store(((const P<S>*)p)->constant_term(), out);                                              \
         return 0;                                                                                          \
