@@ -1525,6 +1525,34 @@ struct Ops {
         return gather(a, out, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, len, nullptr, host);
     }
 
+    // ---- fused continuous-Poisson observation step -------------------------------------------------------
+    // a.derivative(v, 1).truncate_to_degree_p1(d) * from(c) — the body of the reference's loop for observations from a
+    // Poisson with a continuous rate (gf.rs:703-706: `gf.derive(param_var, 1) * constant(lambda / k)`) — as ONE gather:
+    // element for element  c * (x * ff)  in the reference's order (derivative scaling x * ff, mt:471-479, then the
+    // constant on the left, mt:1041-1047).
+    static P derive_scale(const P& a, size_t v, const double* c, size_t d) {
+        auto generic = [&]() { return mul(derivative_truncated(a, v, 1, d), scalar(c)); };
+        size_t len_of = v < a.deg.size() ? a.deg[v] : UMAX;
+        if (!(v < a.deg.size() && 1 < len_of) || v >= a.shape.size() || 1 >= a.shape[v]) return generic();  // assertion / zero paths
+        if (val_is_zero(c) || val_is_one(c)) return generic();  // Mul's zero / one shortcuts
+        for (int i = 0; i < W; ++i)
+            if (!(c[i] - c[i] == 0.0)) return generic();  // inf / NaN constant: keep the exact dispatch
+        Dims deg = a.deg, out = a.shape;
+        deg[v] -= 1;
+        out[v] -= 1;
+        const size_t len = out[v];
+        for (size_t ax = 0; ax < deg.size(); ++ax) {
+            deg[ax] = std::min(deg[ax], d);
+            out[ax] = std::min(out[ax], deg[ax]);
+        }
+        if (prod(out) < 2) return generic();  // a 1-element derivative takes Mul's scalar paths
+        const bool host = gather_tier(a, out);
+        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, 1, len, host);
+        Shifts shift(out.size(), 0);
+        shift[v] = 1;
+        return gather(a, out, deg, shift, a.shape, OP_MUL_TAB_LMUL_S, c, (int)v, tab->p, len, nullptr, host);
+    }
+
     // ---- fused observation step ------------------------------------------------------------------------
     // (a.derivative(v, 1).truncate_to_degree_p1(d) * var(v, x, d)) * from(c) — the body of the reference's
     // compound-Poisson observation loop (gf.rs:684-689) — in one launch, no dispatch read-backs.
@@ -1707,6 +1735,24 @@ struct Ops {
         P res = zero_with(deg);
         bool res_nonlinear_seen = false;
         unsigned slots = 0;  // speculated accumulators so far (sticky witness words R.d_wit[0 .. slots))
+        // Interval tensors with a substitution whose constant term c is a non-zero finite interval: interval arithmetic
+        // cannot cancel — a product of two non-zero intervals and a sum with a non-zero term are widened, never [0,0]
+        // (interval.rs:126-190) — and every step's out[k] contains the term c * res[k], so a non-zero coefficient of the
+        // accumulator stays non-zero at its position for the rest of the loop.  The witness the initial scan found
+        // therefore persists: the speculation is PROVEN and needs no per-step witnesses and no verdict read-back.
+        bool proven = false;
+        if (W == 2) {
+            double c0[2];
+            bool have = false;
+            if (lin_known) { c0[0] = c[0]; c0[1] = c[1]; have = true; }
+            else if (on_host(subst) || subst.c0_known || (subst.numel == 1 && subst.cached)) { first_value(subst, c0); have = true; }
+            proven = have && !val_is_zero(c0) && (c0[0] - c0[0] == 0.0) && (c0[1] - c0[1] == 0.0);
+        }
+        static const bool verify = [] {
+            const char* e = getenv("GFT_HORNER_VERIFY");  // A/B knob (0 = skip the verdict; measurement only)
+            return e ? atoi(e) != 0 : true;
+        }();
+        if (!verify) proven = true;
         for (size_t i = ca.shape[v]; i-- > 0;) {
             bool speculate = false;
             if (!on_host(res) && res.numel > 1) {
@@ -1722,11 +1768,11 @@ struct Ops {
                 res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
                 continue;
             }
-            if (slots == 0) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
+            if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
             if (lin_known && res.shape.size() == deg.size()) {
                 // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
-                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, R.d_wit + slots)) {
-                    slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots)) {
+                    if (!proven) slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
                     break;
                 }
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
@@ -1735,12 +1781,12 @@ struct Ops {
             }
             if (on_host(res) || res.numel == 1) return false;  // left the speculated regime: take the exact loop
             if (i == 0) break;  // the last accumulator is the result: nothing is speculated about it
-            {
+            if (!proven) {
                 Dims keep = collapse_mask({&res.shape}, false);
                 HV rv = view(res);
                 K<E>::witness(R.stream, dview(rv, &keep), R.d_wit + slots);
+                slots++;
             }
-            slots++;
         }
         if (slots) {
             Mailbox mb = next_mail();
@@ -2417,6 +2463,9 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
         return guard([&] { return Ops<E>::observe_step(*a, v, x, c, d); });                                   \
+    }                                                                                                         \
+    gft_poly* PFX##derive_scale(const gft_poly* a, size_t v, const double* c, size_t d) {                     \
+        return guard([&] { return Ops<E>::derive_scale(*a, v, c, d); });                                      \
     }                                                                                                         \
     gft_poly* PFX##subst_var(const gft_poly* a, size_t v, const gft_poly* s) {                                \
         return guard([&] { return Ops<E>::subst_var(*a, v, *s); });                                           \

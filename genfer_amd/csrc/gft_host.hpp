@@ -52,6 +52,7 @@ struct HK {
                     case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
                     case OP_NEG: v = E::neg(v); break;
                     case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                    case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
                     case OP_MUL_POW: {
                         const V mv = E::ld(a.tab, a.tab_plane, 0);
                         V f = E::one();

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, 
                 case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
                 case OP_NEG: v = E::neg(v); break;
                 case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
                 case OP_MUL_POW: {
                     const V mv = E::ld(a.tab, a.tab_plane, 0);
                     V f = E::one();
@@ -97,6 +98,7 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
                 case OP_LMUL_S: v.x = a.s.a * v.x; v.y = a.s.a * v.y; break;
                 case OP_NEG: v.x = -v.x; v.y = -v.y; break;
                 case OP_MUL_TAB: { double f = a.tab[kaxis]; v.x = v.x * f; v.y = v.y * f; break; }
+                case OP_MUL_TAB_LMUL_S: { double f = a.tab[kaxis]; v.x = a.s.a * (v.x * f); v.y = a.s.a * (v.y * f); break; }
                 case OP_MUL_POW: {
                     const double m = a.tab[0];
                     double f = 1.0;

@@ -57,6 +57,7 @@ struct Api {
     void* (*shift_down)(const void*, size_t, size_t);
     void* (*subst_var)(const void*, size_t, const void*);
     void* (*observe_step)(const void*, size_t, const double*, const double*, size_t);
+    void* (*derive_scale)(const void*, size_t, const double*, size_t);
     void* (*derivative_truncated)(const void*, size_t, size_t, size_t);
     void* (*coefficients_of_term)(const void*, size_t, size_t);
     void* (*taylor_polynomial_terms)(const void*, size_t, const size_t*, size_t);
@@ -82,7 +83,7 @@ struct Api {
         GFH_BIND(shape); GFH_BIND(degrees_p1); GFH_BIND(to_host); GFH_BIND(is_zero); GFH_BIND(is_one);
         GFH_BIND(constant_term); GFH_BIND(extract_constant); GFH_BIND(coefficient); GFH_BIND(add); GFH_BIND(sub);
         GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
-        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derivative_truncated);
+        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derive_scale); GFH_BIND(derivative_truncated);
         GFH_BIND(coefficients_of_term); GFH_BIND(taylor_polynomial_terms); GFH_BIND(truncate_to_degree_p1);
         GFH_BIND(remove_last_variable); GFH_BIND(extend_to_dim);
 #undef GFH_BIND
@@ -209,6 +210,11 @@ class Poly {
         x.store(xb);
         c.store(cb);
         return wrap(api().observe_step(h(), v, xb, cb, d));
+    }
+    Poly derive_scale(size_t v, const T& c, size_t d) const {
+        double cb[2];
+        c.store(cb);
+        return traced("derive_scale", nel(*this), wrap(api().derive_scale(h(), v, cb, d)));
     }
     Poly coefficients_of_term(size_t v, size_t o) const { return traced("coefficients_of_term", nel(*this), wrap(api().coefficients_of_term(h(), v, o))); }
     Poly taylor_polynomial_terms(size_t v, const Dims& orders) const {

@@ -266,6 +266,13 @@ struct GenFun {
                         return t.observe_step(v, inputs.at(v), x.b.p->c, degree_p1);
                     }
                 }
+                // (d/dv G) * const — one level of the continuous-rate Poisson observation chain (gf.rs:703-706): the
+                // backend's fused derive_scale = derivative / truncate (the Derivative arm below) and the constant factor
+                if (x.b.p->kind == Const && x.a.p->kind == Derivative && x.a.p->order == 1) {
+                    size_t v = x.a.p->var;
+                    TP t = x.a.p->a.eval_with(inputs, degree_p1 + 1, cache);
+                    return t.derive_scale(v, x.b.p->c, degree_p1);
+                }
                 TP g = x.a.eval_with(inputs, degree_p1, cache);
                 TP h = x.b.eval_with(inputs, degree_p1, cache);
                 return g * h;

@@ -77,6 +77,7 @@ HANDLE_API = {
     "shift_down": (_VP, [_VP, C.c_size_t, C.c_size_t]),
     "subst_var": (_VP, [_VP, C.c_size_t, _VP]),
     "observe_step": (_VP, [_VP, C.c_size_t, _DP, _DP, C.c_size_t]),
+    "derive_scale": (_VP, [_VP, C.c_size_t, _DP, C.c_size_t]),
     "derivative_truncated": (_VP, [_VP, C.c_size_t, C.c_size_t, C.c_size_t]),
     "coefficients_of_term": (_VP, [_VP, C.c_size_t, C.c_size_t]),
     "taylor_polynomial_terms": (_VP, [_VP, C.c_size_t, _SP, C.c_size_t]),
@@ -295,6 +296,10 @@ def bind(lib: C.CDLL, prefix: str):
         def observe_step(self, v: int, x, c, degree_p1: int):
             """Fused (derivative(v,1).truncate(d) * var(v,x,d)) * c  (gf.rs:684-689)."""
             return type(self)(fn.observe_step(self._h, v, scal(x), scal(c), degree_p1))
+
+        def derive_scale(self, v: int, c, degree_p1: int):
+            """Fused derivative(v,1).truncate(d) * c  (continuous-Poisson observation step, gf.rs:703-706)."""
+            return type(self)(fn.derive_scale(self._h, v, scal(c), degree_p1))
 
         def subst_var(self, v: int, subst: "TaylorPoly"):
             return type(self)(fn.subst_var(self._h, v, subst._h))

@@ -152,6 +152,9 @@ gft_poly* gft_shift_down(const gft_poly* a, size_t v, size_t n);        /* shift
  * * from(c) — one step of the compound-Poisson observation loop, generating_function.rs:684-689 — same
  * per-element operation order, one kernel launch, no dispatch read-backs. */
 gft_poly* gft_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
+/* The same for observations from a Poisson with a CONTINUOUS rate (generating_function.rs:703-706):
+ * derivative(a, v, 1).truncate_to_degree_p1(d) * from(c), i.e. c * (x * ff) per element, in one launch. */
+gft_poly* gft_derive_scale(const gft_poly* a, size_t v, const double* c, size_t degree_p1);
 /* Fused form of derivative(a, v, n).truncate_to_degree_p1(degree_p1) — the evaluator's Derivative arm
  * (generating_function.rs:628-633: operand evaluated to degree_p1 + n, differentiated, cut back): one launch,
  * same values (truncation is slicing). */
@@ -210,6 +213,7 @@ gft_poly* gfti_derivative(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_shift_down(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
+gft_poly* gfti_derive_scale(const gft_poly* a, size_t v, const double* c, size_t degree_p1);
 gft_poly* gfti_derivative_truncated(const gft_poly* a, size_t v, size_t n, size_t degree_p1);
 gft_poly* gfti_subst_var(const gft_poly* a, size_t v, const gft_poly* subst);
 gft_poly* gfti_coefficients_of_term(const gft_poly* a, size_t v, size_t order);

@@ -210,6 +210,11 @@ static std::string format_poly(const P<S>& p, bool debug) {
                                                    P<S>::var(v, Tr<S>::load(x), d)),                            \
                                         P<S>::from_scalar(Tr<S>::load(c)))))                                  \
     }                                                                                                      \
+    void* PFX##derive_scale(const void* a, size_t v, const double* c, size_t d) {                          \
+        /* the unfused reference sequence (generating_function.rs:703-706 evaluated by :628-632 and Mul) */   \
+        ORC_TRY((void*)new P<S>(P<S>::mul(((const P<S>*)a)->derivative(v, 1).truncate_to_degree_p1(d),       \
+                                        P<S>::from_scalar(Tr<S>::load(c)))))                                  \
+    }                                                                                                      \
     void* PFX##subst_var(const void* a, size_t v, const void* s) {                                         \
         ORC_TRY((void*)new P<S>(((const P<S>*)a)->subst_var(v, *(const P<S>*)s)))                          \
     }                                                                                                      \
