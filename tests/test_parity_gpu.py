@@ -715,3 +715,33 @@ def test_observe_step_interval(OTPI, GTPI):
             for xv, c in (((0.0, 0.0), (0.5, 0.5)), ((1.0, 1.0), (1.0, 1.0)), ((0.3, 0.31), (0.2, 0.21))):
                 want = (ox.derivative(v, 1).truncate_to_degree_p1(3) * OTPI.var(v, xv, 3)) * OTPI.from_scalar(c)
                 check(want, gx.observe_step(v, xv, c, 3))
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_derive_scale_fused_equals_reference_sequence(interval, OTP, GTP, OTPI, GTPI):
+    """gft_derive_scale = derivative(v, 1).truncate_to_degree_p1(d) * from(c) in one gather (the continuous-rate Poisson
+    observation step, generating_function.rs:703-706): bit-identical to the oracle's unfused sequence, including Mul's
+    zero / one shortcuts, non-finite constants and the 1-element cases."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + np.abs(a) * 1e-12])) if interval else (lambda a: a)
+    sc = (lambda c: (c, c + abs(c) * 1e-12)) if interval else (lambda c: c)
+    for shape, deg in [((7,), [9]), ((5, 6), [6, 8]), ((3, 4, 5), [4, 4, 7]), ((2, 1, 6), [3, 2, 6]), ((1, 5), [4, 5]), ((40, 50), [40, 50])]:
+        a = rand(shape, 77, -1, 1)
+        o, g = O.new(mk(a), deg), G.new(mk(a), deg)
+        for v in range(len(shape)):
+            for c in (0.3, -2.5, 1.0, 0.0, float("inf"), float("nan")):
+                for d in (1, 2, 3, max(deg) + 1):
+                    if not 1 < o.len_of(v):
+                        continue
+                    check(o.derive_scale(v, sc(c), d), g.derive_scale(v, sc(c), d))
+    # inside a whole program: continuous-rate Poisson observations
+    src = "rate ~ Exponential(1);\nobserve 3 ~ Poisson(2 * rate);\nobserve 1 ~ Poisson(rate);\nreturn rate;\n"
+    import genfer_amd
+    import os
+    from conftest import ROOT
+
+    flags = "--no-timing" + (" --bounds" if interval else "")
+    rc, want, _ = genfer_amd.run_sgcl_with_backend(src, flags, os.path.join(ROOT, "oracle", "liborc.so"), "orci_" if interval else "orc_")
+    assert rc == 0, want
+    got, _ = genfer_amd.run_sgcl(src, flags)
+    assert got == want
