@@ -247,6 +247,24 @@ def main():
 
     from genfer_amd.dist import gpu_conv_slabs, local_ranges, sharded_conv
 
+    # N > 1: the sharded product runs behind the C ABI (gft_conv_raw_sharded: the library's own RCCL communicator,
+    # in-place all-gather + point-to-point exchange on its stream; torch.distributed only hands the 128-byte unique id
+    # to the ranks and times the job).  GFT_BENCH_EXCHANGE=torch selects the torch.distributed exchange of
+    # genfer_amd/dist.py instead; it is also the fallback if the library's communicator cannot be created.
+    exchange = "none" if world == 1 else os.environ.get("GFT_BENCH_EXCHANGE", "abi")
+    exchange_note = None
+    if exchange == "abi":
+        try:
+            ids = [genfer_amd.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            genfer_amd.dist_init(rank, world, ids[0])
+        except Exception as e:  # noqa: BLE001 - any failure here means "use the other exchange", loudly noted
+            exchange, exchange_note = "torch", f"C-ABI RCCL communicator failed ({e}); torch.distributed exchange used"
+        ok = torch.tensor([1 if exchange == "abi" else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and exchange == "abi":
+            exchange, exchange_note = "torch", "another rank could not create the C-ABI communicator; torch.distributed exchange used"
+
     g0, g1, even, launches = local_ranges(shape[0], world, rank)
     local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in (g0, g1) if b > a)
 
@@ -257,9 +275,13 @@ def main():
     def step(timed):
         i = timed_steps[0]
         rec = timed and i < EV_PAIRS
-        sharded_conv(x, y, z, gpu_conv_slabs,
-                     before_local=(lambda: L.gft_event_record(2 * i)) if rec else None,
-                     after_local=(lambda: L.gft_event_record(2 * i + 1)) if rec else None)
+        if exchange == "abi":
+            L.gft_set_option(b"dist_event_slot", float(2 * i) if rec else -1.0)
+            genfer_amd.conv_raw_sharded(x.data_ptr(), shape, y.data_ptr(), shape, z.data_ptr(), shape)
+        else:
+            sharded_conv(x, y, z, gpu_conv_slabs,
+                         before_local=(lambda: L.gft_event_record(2 * i)) if rec else None,
+                         after_local=(lambda: L.gft_event_record(2 * i + 1)) if rec else None)
         if timed:
             timed_steps[0] += 1
 
@@ -305,7 +327,8 @@ def main():
             "shape": shape,
             "macs": total_macs,
             "parallelism": "single GPU" if world == 1 else f"leading output axis folded-sharded over {world} GPUs, "
-                           f"operands replicated, RCCL {'all-gather' if even else 'all-reduce'} of result slabs",
+                           f"operands replicated, RCCL {'all-gather + point-to-point' if even else 'all-reduce'} of result slabs "
+                           f"({'inside libgftaylor (gft_conv_raw_sharded)' if exchange == 'abi' else 'torch.distributed'})",
         },
         "roofline": {
             "bound": "mfma",
@@ -360,6 +383,16 @@ def main():
                 if float(err.item()) > 1e-10:
                     out["parity_failed"] = True
 
+    if world > 1:
+        # proof that RCCL saw every rank: ncclCommCount of the library's communicator on every rank (C-ABI exchange),
+        # gathered to rank 0
+        counts = [None] * world
+        dist.all_gather_object(counts, int(L.gft_dist_comm_count()))
+        if rank == 0:
+            out["exchange"] = exchange
+            out["rccl_comm_count_per_rank"] = counts
+            if exchange_note:
+                out["exchange_note"] = exchange_note
     if rank == 0 and world == 1 and not args.no_e2e and args.workload == "c2":
         out["e2e"] = e2e_seconds()
     bad = bool(out.get("parity_failed")) or any(t < 0 for t in kern_ms)

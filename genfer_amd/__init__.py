@@ -70,6 +70,15 @@ def _declare_runtime(L):
     L.gft_conv_macs.argtypes = [sz, sz, sz, c.c_size_t, c.c_size_t, c.c_size_t]
     L.gft_plan_slabs.restype = c.c_int
     L.gft_plan_slabs.argtypes = [c.c_size_t, c.c_int, c.c_int, sz]
+    L.gft_dist_unique_id.restype, L.gft_dist_unique_id.argtypes = c.c_int, [c.c_void_p]
+    L.gft_dist_init.restype, L.gft_dist_init.argtypes = c.c_int, [c.c_int, c.c_int, c.c_void_p]
+    L.gft_dist_world.restype, L.gft_dist_world.argtypes = c.c_int, []
+    L.gft_dist_rank.restype, L.gft_dist_rank.argtypes = c.c_int, []
+    L.gft_dist_comm_count.restype, L.gft_dist_comm_count.argtypes = c.c_int, []
+    L.gft_dist_shutdown.restype, L.gft_dist_shutdown.argtypes = c.c_int, []
+    L.gft_dist_broadcast.restype, L.gft_dist_broadcast.argtypes = c.c_int, [c.c_void_p, c.c_size_t, c.c_int]
+    L.gft_conv_raw_sharded.restype = c.c_int
+    L.gft_conv_raw_sharded.argtypes = [c.c_void_p, sz, c.c_void_p, sz, c.c_void_p, sz, c.c_size_t]
 
 
 def init(device: int = -1) -> None:
@@ -151,6 +160,27 @@ def conv_raw(x_ptr: int, xshape, y_ptr: int, yshape, z_ptr: int, zshape, slab_lo
         slab_hi = zshape[0] if nd else 1
     rc = L.gft_conv_raw(x_ptr, _sz(xshape), y_ptr, _sz(yshape), z_ptr, _sz(zshape), nd, slab_lo, slab_hi, int(accumulate))
     if rc != 0:
+        raise TaylorError((L.gft_last_error() or b"").decode())
+
+
+def dist_unique_id() -> bytes:
+    """Rank 0: the 128-byte RCCL unique id to hand to every rank's :func:`dist_init`."""
+    buf = ctypes.create_string_buffer(128)
+    if lib().gft_dist_unique_id(buf) != 0:
+        raise TaylorError((lib().gft_last_error() or b"").decode())
+    return buf.raw
+
+
+def dist_init(rank: int, world: int, unique_id: bytes) -> None:
+    """Join the library's own RCCL communicator (one process per GPU; call after :func:`init`)."""
+    if lib().gft_dist_init(rank, world, ctypes.create_string_buffer(unique_id, 128)) != 0:
+        raise TaylorError((lib().gft_last_error() or b"").decode())
+
+
+def conv_raw_sharded(x_ptr: int, xshape, y_ptr: int, yshape, z_ptr: int, zshape):
+    """``gft_conv_raw_sharded``: the product with its leading output axis sharded over the library's communicator."""
+    L = lib()
+    if L.gft_conv_raw_sharded(x_ptr, _sz(xshape), y_ptr, _sz(yshape), z_ptr, _sz(zshape), len(zshape)) != 0:
         raise TaylorError((L.gft_last_error() or b"").decode())
 
 

@@ -7,6 +7,8 @@
 //
 // Citations `mt:<lines>` refer to /root/reference/src/multivariate_taylor.rs.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed by gft_dist_init (single-GPU users never load it)
 
 #include <algorithm>
 #include <atomic>
@@ -1222,9 +1224,11 @@ struct Ops {
         }
         const bool host = tier_host(prod(shape), self, other) && est_macs(self.shape, other.shape, shape) <= R.host_max_macs;
         P out = make(shape, deg, host);
+        if (!host && W == 1 && dist_shard(self, other, out)) return out;  // multi-GPU: leading axis sharded (gft_dist_init)
         conv(view(self, host), view(other, host), view(out, host), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
         return seal(out);
     }
+    static bool dist_shard(const P& self, const P& other, const P& out);  // defined after the RCCL plumbing
     // multiply-adds of a full product, estimated from the shapes (the dispatch criterion for general products)
     static double est_macs(const Dims& xs, const Dims& ys, const Dims& zs) {
         double macs = 1.0;
@@ -2104,6 +2108,9 @@ struct ApiTrace {
 };
 static ApiTrace g_api_trace;
 
+void dist_set_min_macs(double v);  // multi-GPU section below
+void dist_set_event_slot(double v);
+
 template <class F>
 static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
@@ -2259,6 +2266,8 @@ int gft_set_option(const char* name, double value) {
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
     else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;
+    else if (n == "dist_min_macs") dist_set_min_macs(value);
+    else if (n == "dist_event_slot") dist_set_event_slot(value);
     else return -1;
     return 0;
 }
@@ -2306,6 +2315,197 @@ double gft_conv_macs(const size_t* xs, const size_t* ys, const size_t* rs, size_
     double total = 0;
     for (size_t k = slab_lo; k < slab_hi && k < rs[0]; ++k) total += pairs(xs[0], ys[0], k) * inner;
     return total;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU behind the C ABI: one process per GPU, RCCL over xGMI, no torch on the path
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    double min_macs = 1.0e10;  // gft_mul shards a general product at or above this many multiply-adds ("dist_min_macs")
+    int ev_slot = -1;          // "dist_event_slot": the next sharded products bracket their LOCAL kernels with the event
+                               // slots s, s+1 (then s += 2, up to 62): kernel time apart from the exchange (bench.py)
+};
+Rccl D;
+void dist_set_min_macs(double v) { D.min_macs = v; }
+void dist_set_event_slot(double v) { D.ev_slot = (v >= 0 && v <= 62) ? (int)v : -1; }
+
+static void rccl_load() {
+    if (D.lib) return;
+    // the copy a host process already loaded (PyTorch-ROCm bundles one) wins; else ROCm's
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        D.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (D.lib) break;
+    }
+    if (!D.lib) throw Error(std::string("cannot load RCCL: ") + dlerror());
+#define GFT_NCCL(f)                                                          \
+    D.f = reinterpret_cast<decltype(D.f)>(dlsym(D.lib, "nccl" #f));          \
+    if (!D.f) throw Error("RCCL does not export nccl" #f)
+    GFT_NCCL(GetUniqueId); GFT_NCCL(CommInitRank); GFT_NCCL(CommCount); GFT_NCCL(CommDestroy); GFT_NCCL(AllGather);
+    GFT_NCCL(AllReduce); GFT_NCCL(Broadcast); GFT_NCCL(Send); GFT_NCCL(Recv); GFT_NCCL(GroupStart); GFT_NCCL(GroupEnd);
+    GFT_NCCL(GetErrorString);
+#undef GFT_NCCL
+}
+#define NCCL_OK(call)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) throw Error(std::string("RCCL error: ") + D.GetErrorString(r_) + " in " #call); \
+    } while (0)
+
+// Exchange of a sharded result whose leading axis has n0 slabs of `slab` doubles each: every rank has computed the
+// slab groups gft_plan_slabs gives it and ends up with all of them.  Even split: the low groups lie in rank order (an
+// in-place all-gather); the mirrored high groups lie in REVERSE rank order, exchanged as grouped point-to-point
+// sends/receives (xGMI is point-to-point; each rank pushes its group to its 7 peers on 7 links).  Uneven split:
+// zero-filled all-reduce (adding zeros is exact).  `even` and the ranges come from gft_plan_slabs.
+static void dist_exchange(double* z, size_t n0, size_t slab, bool zeroed_outside) {
+    if (D.world <= 1) return;
+    size_t mine[4];
+    const bool even = gft_plan_slabs(n0, D.world, D.rank, mine) != 0;
+    if (!even) {
+        if (!zeroed_outside) throw Error("internal: uneven sharded product without a zeroed result");
+        NCCL_OK(D.AllReduce(z, z, n0 * slab, ncclDouble, ncclSum, D.comm, R.stream));
+        return;
+    }
+    const size_t b0 = mine[1] - mine[0], b1 = mine[3] - mine[2];
+    if (b0) NCCL_OK(D.AllGather(z + mine[0] * slab, z, b0 * slab, ncclDouble, D.comm, R.stream));  // in place: rank r's group at r * b0
+    if (b1) {
+        NCCL_OK(D.GroupStart());
+        for (int peer = 0; peer < D.world; ++peer) {
+            if (peer == D.rank) continue;
+            size_t theirs[4];
+            gft_plan_slabs(n0, D.world, peer, theirs);
+            NCCL_OK(D.Send(z + mine[2] * slab, b1 * slab, ncclDouble, peer, D.comm, R.stream));
+            NCCL_OK(D.Recv(z + theirs[2] * slab, (theirs[3] - theirs[2]) * slab, ncclDouble, peer, D.comm, R.stream));
+        }
+        NCCL_OK(D.GroupEnd());
+    }
+}
+
+// z = x (*) y, leading output axis sharded over the communicator (operands replicated on every rank)
+template <class O>
+static void dist_conv(const typename O::HV& x, const typename O::HV& y, const typename O::HV& z) {
+    const size_t n0 = z.shape[0];
+    size_t slab = 1;
+    for (size_t i = 1; i < z.shape.size(); ++i) slab *= z.shape[i];
+    size_t mine[4];
+    const bool even = gft_plan_slabs(n0, D.world, D.rank, mine) != 0;
+    if (!even) HIP_OK(hipMemsetAsync(z.p, 0, sizeof(double) * n0 * slab, R.stream));
+    const int ev = D.ev_slot;
+    if (ev >= 0) HIP_OK(hipEventRecord(R.events[ev], R.stream));
+    struct AfterLocal {
+        int ev;
+        ~AfterLocal() {
+            if (ev >= 0) {
+                (void)hipEventRecord(R.events[ev + 1], R.stream);
+                D.ev_slot = ev + 2 <= 62 ? ev + 2 : -1;
+            }
+        }
+    };
+    {
+    AfterLocal after{ev};
+    if (mine[1] == mine[2]) {  // the two groups touch: one launch
+        O::conv(x, y, z, mine[0], mine[3], false, false, 0, 0, 0);
+    } else {
+        O::conv(x, y, z, mine[0], mine[1], false, false, 0, 0, 0);
+        O::conv(x, y, z, mine[2], mine[3], false, false, 0, 0, 0);
+    }
+    }
+    dist_exchange(z.p, n0, slab, !even);
+}
+}  // namespace
+
+template <class E>
+bool Ops<E>::dist_shard(const P& self, const P& other, const P& out) {
+    // Every rank runs the same program on replicated operands ("replicas" outside this one operation), so
+    // every rank reaches this product with the same shapes and takes the same decision.
+    if (!D.comm || D.world <= 1 || out.shape.empty() || out.shape[0] < (size_t)(2 * D.world)) return false;
+    if (gft_conv_macs(self.shape.begin(), other.shape.begin(), out.shape.begin(), out.shape.size(), 0, out.shape[0]) < D.min_macs) return false;
+    dist_conv<Ops<E>>(view(self), view(other), view(out));
+    return true;
+}
+
+extern "C" {
+
+int gft_dist_unique_id(void* out128) {
+    return guard_int([&] {
+        rccl_load();
+        ncclUniqueId id;
+        NCCL_OK(D.GetUniqueId(&id));
+        static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+        std::memcpy(out128, &id, sizeof id);
+        return 0;
+    });
+}
+int gft_dist_init(int rank, int world, const void* unique_id128) {
+    return guard_int([&] {
+        if (world < 1 || rank < 0 || rank >= world) throw Error("gft_dist_init: bad rank / world");
+        if (D.comm) throw Error("gft_dist_init: already initialised");
+        rccl_load();
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id128, sizeof id);
+        NCCL_OK(D.CommInitRank(&D.comm, world, id, rank));
+        D.rank = rank;
+        D.world = world;
+        return 0;
+    });
+}
+int gft_dist_world(void) { return D.world; }
+int gft_dist_rank(void) { return D.rank; }
+int gft_dist_comm_count(void) {
+    int n = 0;
+    if (D.comm && D.CommCount(D.comm, &n) != ncclSuccess) return -1;
+    return D.comm ? n : 0;
+}
+int gft_dist_shutdown(void) {
+    return guard_int([&] {
+        if (D.comm) {
+            HIP_OK(hipStreamSynchronize(R.stream));
+            NCCL_OK(D.CommDestroy(D.comm));
+        }
+        D.comm = nullptr;
+        D.rank = 0;
+        D.world = 1;
+        return 0;
+    });
+}
+int gft_dist_broadcast(double* buf, size_t count, int root) {
+    return guard_int([&] {
+        if (!D.comm) throw Error("gft_dist_broadcast: gft_dist_init has not been called");
+        NCCL_OK(D.Broadcast(buf, buf, count, ncclDouble, root, D.comm, R.stream));
+        return 0;
+    });
+}
+int gft_conv_raw_sharded(const double* x, const size_t* xshape, const double* y, const size_t* yshape, double* res,
+                         const size_t* rshape, size_t ndim) {
+    return guard_int([&] {
+        typedef Ops<EF64> O;
+        if (ndim == 0) throw Error("conv_raw_sharded: a scalar product does not shard");
+        for (size_t i = 0; i < ndim; ++i)
+            if (xshape[i] > rshape[i] || yshape[i] > rshape[i] || xshape[i] == 0 || yshape[i] == 0)
+                throw Error("conv_raw_sharded: operand shapes must be non-empty and not exceed the result shape");
+        O::HV xv{const_cast<double*>(x), 0, dims(xshape, ndim)};
+        O::HV yv{const_cast<double*>(y), 0, dims(yshape, ndim)};
+        O::HV zv{res, 0, dims(rshape, ndim)};
+        dist_conv<O>(xv, yv, zv);
+        return 0;
+    });
 }
 
 int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {

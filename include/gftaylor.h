@@ -78,7 +78,8 @@ int gft_set_conv_mode(int mode);
  * tiled product), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
- * product, in multiply-adds, computed on the host tier; 0 = everything on the device). */
+ * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div2d" (0: host-driven division
+ * recursion down to 1-d rows), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);
@@ -99,6 +100,29 @@ double gft_conv_macs(const size_t* xshape, const size_t* yshape, const size_t* r
  * {lo0,hi0,lo1,hi1} (folded: low group + mirrored high group).  Pure integer logic; needs no GPU.
  * Returns 1 if every rank's two groups have equal sizes (all-gather friendly), 0 otherwise. */
 int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI, collectives internal to the library --------
+ * The reference is single-process; a host that wants one large product spread over the GPUs of a node starts one
+ * process per GPU (each with its own gft_init(device)), lets rank 0 call gft_dist_unique_id, hands the 128 bytes to
+ * the other ranks by whatever means it has (MPI, torch.distributed, a file), and has every rank call gft_dist_init.
+ * From then on every rank runs the SAME program on replicated data; gft_mul shards a general f64 product of at least
+ * "dist_min_macs" multiply-adds (gft_set_option, default 1e10) over the leading output axis — slab k depends on
+ * x[0..=k], y[0..=k] and on no other output (mt:1001-1011), so there is no reduction: folded slab assignment
+ * (gft_plan_slabs), local kernels, then in-place ncclAllGather of the low groups and grouped ncclSend/ncclRecv of the
+ * mirrored high groups (zero-filled ncclAllReduce when the axis does not divide evenly) on the library's stream.
+ * RCCL is dlopen'ed by gft_dist_init; single-GPU users never load it. */
+int gft_dist_unique_id(void* out128);                                   /* ncclGetUniqueId (rank 0) */
+int gft_dist_init(int rank, int world, const void* unique_id128);       /* ncclCommInitRank on the gft_init device */
+int gft_dist_world(void);
+int gft_dist_rank(void);
+int gft_dist_comm_count(void);                                          /* ncclCommCount of the communicator (0: none) */
+int gft_dist_shutdown(void);
+/* ncclBroadcast of `count` doubles at `buf` (device memory) from `root`: replicating operands that originate on one rank */
+int gft_dist_broadcast(double* buf, size_t count, int root);
+/* res = x (*) y like gft_conv_raw over ALL leading slabs, sharded over the communicator; x, y replicated on every rank,
+ * every rank receives the full result.  With world == 1 (or before gft_dist_init) it is the plain product. */
+int gft_conv_raw_sharded(const double* x, const size_t* xshape, const double* y, const size_t* yshape, double* res,
+                         const size_t* rshape, size_t ndim);
 
 /* ---- constructors ------------------------------------------------------------------------- */
 gft_poly* gft_from_host(const double* coeffs, const size_t* shape, const size_t* degrees_p1,
