@@ -61,6 +61,18 @@ __device__ inline double fd_div(double n, const FastDiv& f) {
     }
     return n / f.d;
 }
+// value of lane j (wave-uniform j) in every lane
+__device__ inline double bcast_f64(double x, unsigned j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), (int)j), hi = __builtin_amdgcn_readlane(__double2hiint(x), (int)j);
+    return __hiloint2double(hi, lo);
+}
+template <class E>
+__device__ inline typename E::V bcast_lane(typename E::V v, unsigned j);
+template <>
+__device__ inline double bcast_lane<EF64>(double v, unsigned j) { return bcast_f64(v, j); }
+template <>
+__device__ inline Iv bcast_lane<EIv>(Iv v, unsigned j) { return Iv{bcast_f64(v.lo, j), bcast_f64(v.hi, j)}; }
+
 template <class E>
 struct SlabDiv {  // generic element type: the functor's own division
     typename E::V d;
@@ -133,18 +145,30 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
             }
         }
         // ---- 1-d division of the row by y[0, :], lock step over j (k_div_1d): lane j finalises res[j], then every lane
-        // k2 > j adds res[j] * y[0][k2 - j]
-        for (unsigned j = 0; j < g.n2; ++j) {
-            if (owner && k2 == j) {
-                const V r = div_y00(E::add(E::neg(cur1), t));
-                E::st(tl, g.n2p, j, r);
-                E::st(rl, rsz, (size_t)k1 * g.n2p + j, r);
-                E::st(res, rp, (size_t)k1 * g.n2 + j, r);
+        // k2 > j adds res[j] * y[0][k2 - j].  Rows of at most 64 coefficients live in ONE wave: res[j] travels by
+        // v_readlane (no LDS round trip, no barrier) and the finished row is written out once, coalesced.
+        V mine = E::zero();
+        if (g.n2 <= 64) {
+            if (wave == 0) {
+                for (unsigned j = 0; j < g.n2; ++j) {
+                    const V r = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
+                    if (k2 == j) mine = r;
+                    if (owner && k2 > j && j >= lo2) cur1 = E::add(cur1, E::mul(r, E::ld(yl, ysz, k2 - j)));
+                }
             }
-            if (g.n2 > 64) __syncthreads();
-            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"), __builtin_amdgcn_wave_barrier();
-            if (owner && k2 > j && j >= lo2) cur1 = E::add(cur1, E::mul(E::ld(tl, g.n2p, j), E::ld(yl, ysz, k2 - j)));
-            if (g.n2 <= 64) __builtin_amdgcn_wave_barrier();
+        } else {
+            for (unsigned j = 0; j < g.n2; ++j) {
+                if (owner && k2 == j) {
+                    mine = div_y00(E::add(E::neg(cur1), t));
+                    E::st(tl, g.n2p, j, mine);
+                }
+                __syncthreads();
+                if (owner && k2 > j && j >= lo2) cur1 = E::add(cur1, E::mul(E::ld(tl, g.n2p, j), E::ld(yl, ysz, k2 - j)));
+            }
+        }
+        if (owner) {
+            E::st(rl, rsz, (size_t)k1 * g.n2p + k2, mine);
+            E::st(res, rp, (size_t)k1 * g.n2 + k2, mine);
         }
         __syncthreads();  // row k1 of the quotient is in LDS for the next rows
     }
