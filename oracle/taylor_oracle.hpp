@@ -6,11 +6,16 @@
 // `genfer_amd/` may include, link or call it (only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg do).
 //
-// Parity pinning: the reference is Rust and cannot be built in this image (no
-// cargo/rustc), so the oracle is pinned by the reference's own literal unit-test vectors
-// (src/multivariate_taylor.rs:733-1513, transcribed to tests/golden/unit_vectors.json) —
-// reproduced bit-exactly by tests/test_oracle_golden.py — plus exact rational
-// known-answers generated with sympy (tests/golden/make_exact_kats.py).
+// Parity pinning: the reference is Rust and cannot be built in this image (no cargo/rustc), so the oracle is pinned by
+//   * the reference's own literal unit-test vectors (src/multivariate_taylor.rs:733-1513 and
+//     src/univariate_taylor.rs, transcribed to tests/golden/unit_vectors.json), reproduced bit-exactly by
+//     tests/test_reference_unit_vectors.py;
+//   * 109 of the reference's `.sgcl` -> `.expect` report snapshots, byte for byte, through the host interpreter
+//     (tests/test_e2e_snapshots.py);
+//   * exact rational known-answers generated with fractions.Fraction (tests/golden/make_exact_kats.py ->
+//     tests/test_exact_kats.py), independent of the reference's code;
+//   * for Interval<F64> (no reference vector exists for `--bounds`): exact-rational ENCLOSURE known-answers and a
+//     bit-for-bit cross-check against the interpreter's separately written Interval (tests/test_interval_pins.py).
 //
 // Faithfulness rules followed here:
 //   * same loop nests and the same floating-point summation order as the reference;

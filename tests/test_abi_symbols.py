@@ -80,3 +80,14 @@ def test_plan_slabs_partitions_and_balances():
         assert owned == [1] * n0, (n0, world, owned)
         if n0 % (2 * world) == 0:
             assert max(works) == min(works), (n0, world, works)  # folded assignment is exactly balanced
+
+
+def test_integration_md_extern_block_is_generated_from_the_header():
+    """INTEGRATION.md's Rust `extern "C"` block lists every declared entry point (it is generated from the header)."""
+    import subprocess
+    import sys
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_extern.py"), "--check"])
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for sym in declared_symbols():
+        assert f"pub fn {sym}(" in doc, sym
