@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -130,6 +131,8 @@ struct Runtime {
     hipEvent_t events[64] = {};
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
+    double tiled_min_override = -1;  // >= 0 while a div / log recurrence issues its accumulation products (recur_tiled_min_macs)
+    double recur_tiled_min_macs = 5.0e7;  // div / log: accumulation steps below this keep the reference's summation order
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
@@ -1077,7 +1080,8 @@ struct Ops {
                     if (i == 0 && ash.slab_hi - ash.slab_lo < ash.zs[0]) f = (double)(ash.slab_hi - ash.slab_lo) * std::min(ash.xs[0], ash.ys[0]);
                     macs *= f;
                 }
-                if (macs < R.tiled_min_macs * (split ? 10.0 : 1.0)) ok = false;
+                const double tmin = R.tiled_min_override >= 0 ? R.tiled_min_override : R.tiled_min_macs;
+                if (macs < tmin * (split ? 10.0 : 1.0)) ok = false;
             }
             if (ok) ok = conv_tiled_f64(R.stream, tx, ty, tz, at, nullptr, 0, &need, nullptr, 0);
             if (ok) {
@@ -1247,6 +1251,11 @@ struct Ops {
             if (x != 1) n++;
         return n;
     }
+    struct TiledMin {  // tiled-kernel crossover for the products issued inside this scope
+        double prev;
+        explicit TiledMin(double v) : prev(R.tiled_min_override) { R.tiled_min_override = v; }
+        ~TiledMin() { R.tiled_min_override = prev; }
+    };
     // tier-dispatched launches used by the recurrences (views carry their side)
     static void x_map_inplace(const HV& v, int op, unsigned u) {
         if (v.host) HK<E>::map_inplace(v.p, v.plane, v.numel(), op, u, Scalar2{0, 0});
@@ -1288,9 +1297,40 @@ struct Ops {
             return;  // the last two axes in one launch (gft_div2d.hip), same bits
         size_t n0 = res.shape[0];
         HV y0 = ys.index0(0);
+        // Device tier: RIGHT-LOOKING accumulation.  The reference forms cur = sum_{j<k} res[j] (*) ys[k-j] when it reaches
+        // slab k (one product per (k, j): 64 small dependent launches a slab).  Here the quotient's own memory holds the
+        // running sums: as soon as slab k is final, ONE product adds res[k] (*) ys[1..m] into the m slabs that follow.
+        // Every slab still receives its terms in ascending j, each term's row products formed from zero (mt:971-982), so
+        // the bits are the reference's; what changes is that a step is a product of m slabs wide — hundreds of
+        // workgroups instead of four.  Steps of at least recur_tiled_min_macs multiply-adds may take the tiled kernel
+        // (different summation order: 1e-10 contract), smaller ones keep the reference order.
+        const bool right = !host && R.div2d;
+        Dims rest(res.shape.begin() + 1, res.shape.end()), yrest(ys.shape.begin() + 1, ys.shape.end());
+        if (right) {
+            zero_elems(false, res.p, res.numel());
+            if (W == 2) zero_elems(false, res.p + res.plane, res.numel());
+        }
         for (size_t k = 0; k < n0; ++k) {
             HV cur = res.index0(k);
-            conv(res, ys, res, k, k + 1, false, true, 0, 1, 0);  // cur = sum_{j<k} res[j] (*) ys[k-j]
+            if (!right) conv(res, ys, res, k, k + 1, false, true, 0, 1, 0);  // cur = sum_{j<k} res[j] (*) ys[k-j]
+            struct Scatter {  // runs when slab k is final, whichever branch below finalised it
+                const HV &res, &ys, &cur;
+                const Dims &rest, &yrest;
+                size_t k, n0;
+                bool on;
+                ~Scatter() noexcept(false) {
+                    if (!on || k + 1 >= n0 || ys.shape[0] < 2 || std::uncaught_exceptions()) return;
+                    const size_t m = std::min(n0 - 1 - k, ys.shape[0] - 1);
+                    Dims xs1{1}, ysm{m}, zsm{m};
+                    xs1.insert(xs1.end(), rest.begin(), rest.end());
+                    ysm.insert(ysm.end(), yrest.begin(), yrest.end());
+                    zsm.insert(zsm.end(), rest.begin(), rest.end());
+                    HV xk{cur.p, res.plane, xs1, false}, ym{ys.p + prod(yrest), ys.plane, ysm, false},
+                        zm{res.p + (k + 1) * prod(rest), res.plane, zsm, false};
+                    TiledMin guard(R.recur_tiled_min_macs);
+                    conv(xk, ym, zm, 0, m, true, false, 0, 0, 0);
+                }
+            } scatter{res, ys, cur, rest, yrest, k, n0, right};
             if (!host && R.div2d && cur.shape.size() == 2) {
                 // neg, += xs[k], copy and the whole 2-d division of the slab fused into one launch
                 const bool have_x = k < xs.shape[0];
@@ -1425,9 +1465,18 @@ struct Ops {
         zero_elems(host, rs.p, res.numel() * W);
         Dims sub(res.shape.begin() + 1, res.shape.end());
         HV x0 = xs.index0(0);
+        // device tier: right-looking accumulation like div_rec — once rs[k] = res[k] * k is known, one product adds
+        // xs[1..m] (*) rs[k] into the m slabs that follow (terms arrive in ascending j, as in the reference)
+        const bool right = !host && R.div2d;
+        Dims xrest(xs.shape.begin() + 1, xs.shape.end());
+        if (right) {
+            HV tail{res.p + prod(sub), res.plane, res.shape, false};
+            zero_elems(false, tail.p, res.numel() - prod(sub));
+            if (W == 2) zero_elems(false, tail.p + res.plane, res.numel() - prod(sub));
+        }
         for (size_t k = 1; k < n0; ++k) {
             HV cur = res.index0(k);
-            conv(xs, rs, res, k, k + 1, false, true, 1, 1, 1);  // sum_{j} xs[k-j] (*) (res[j]*j), j ascending
+            if (!right) conv(xs, rs, res, k, k + 1, false, true, 1, 1, 1);  // sum_{j} xs[k-j] (*) (res[j]*j), j ascending
             x_map_inplace(cur, MAP_NEG, 0);
             if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD_U32_TIMES, (unsigned)k);
             // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
@@ -1441,6 +1490,17 @@ struct Ops {
             HV rk = rs.index0(k);
             copy_planes(host, rk.p, rk.plane, cur.p, cur.plane, cur.numel());
             x_map_inplace(rk, MAP_MUL_U32, (unsigned)k);
+            if (right && k + 1 < n0 && xs.shape[0] >= 2) {
+                const size_t m = std::min(n0 - 1 - k, xs.shape[0] - 1);
+                Dims xsm{m}, ys1{1}, zsm{m};
+                xsm.insert(xsm.end(), xrest.begin(), xrest.end());
+                ys1.insert(ys1.end(), sub.begin(), sub.end());
+                zsm.insert(zsm.end(), sub.begin(), sub.end());
+                HV xm{xs.p + prod(xrest), xs.plane, xsm, false}, yk{rk.p, rs.plane, ys1, false},
+                    zm{res.p + (k + 1) * prod(sub), res.plane, zsm, false};
+                TiledMin guard(R.recur_tiled_min_macs);
+                conv(xm, yk, zm, 0, m, true, false, 0, 0, 0);
+            }
         }
     }
     // Div's dispatcher (mt:1194-1231) for the slab division inside log.  tp<E>() serves a device caller whatever side
@@ -2264,6 +2324,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "div2d") R.div2d = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
+    else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
     else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;
     else if (n == "dist_min_macs") dist_set_min_macs(value);

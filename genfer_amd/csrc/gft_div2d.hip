@@ -174,6 +174,113 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
     }
 }
 
+// ---- rows of at most 64 coefficients: right-looking, operands in registers ---------------------------------------------
+// The kernel above keeps every operand of a row product in LDS (two 8-byte reads per multiply-add: LDS-bound, and a
+// 64 x 64 slab took 1.6 ms).  Here a row lives in ONE wave, one coefficient per lane:
+//   * x operand (a finished quotient row): lane j's value reaches all lanes as an SGPR pair (v_readlane);
+//   * y operand (a divisor row): the lanes hold y[c], and one DPP wave shift per step turns that into y[c - j2]
+//     (zeros enter at lane 0, which is exactly the truncation);
+// so a row product  inner[c] = sum_{j2 <= c} r[j2] * y[c - j2]  is 64 steps of {2 readlane, mul, add, 2 dpp-mov} with no
+// memory traffic at all.  The accumulation is RIGHT-LOOKING: when row k1 is final, every wave adds the term
+// res[k1] (*) y[k1' - k1] to the accumulator rows k1' it owns (k1' = wave mod NW); a row is owned by one wave, which
+// applies its terms in ascending k1 — the reference's order (mt:971-982), each term's product formed from zero — and
+// then divides the row in lock step (mt:1162-1185) with the same shift trick for y[0, :].  The owner of row k1 + 1
+// applies the last missing term first, so the division (the critical path) overlaps the other waves' updates.
+__device__ inline double wave_shr1_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1, zeros shifted in
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <class E>
+__device__ inline typename E::V wave_shr1(typename E::V v);
+template <>
+__device__ inline double wave_shr1<EF64>(double v) { return wave_shr1_f64(v); }
+template <>
+__device__ inline Iv wave_shr1<EIv>(Iv v) { return Iv{wave_shr1_f64(v.lo), wave_shr1_f64(v.hi)}; }
+
+template <class E>
+__global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+                                                        double* res, size_t rp, Div2dArgs g) {
+    typedef typename E::V V;
+    extern __shared__ double d2_lds[];
+    // layout: [y: W x ny1 x ny2p][acc: W x n1 x n2p][final rows: W x 2 x 64]
+    const size_t ysz = (size_t)g.ny1 * g.ny2p, asz = (size_t)g.n1 * g.n2p;
+    double* yl = d2_lds;
+    double* al = yl + E::W * ysz;
+    double* fl = al + E::W * asz;
+    const unsigned tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, c = tid & 63, nw = nthr >> 6;
+    for (size_t i = tid; i < (size_t)g.ny1 * g.ny2; i += nthr) {
+        const unsigned a = (unsigned)(i / g.ny2), b = (unsigned)(i - (size_t)a * g.ny2);
+        E::st(yl, ysz, (size_t)a * g.ny2p + b, E::ld(y, yp, i));
+    }
+    for (size_t i = tid; i < asz; i += nthr) E::st(al, asz, i, E::zero());
+    __syncthreads();
+    const bool col = c < g.n2;
+    const V y0v = (c < g.ny2) ? E::ld(yl, ysz, c) : E::zero();  // y[0, c]
+    const SlabDiv<E> div_y00(E::ld(yl, ysz, 0));
+    // dividend of the row this wave finalises next (prefetched: the global load is off the critical path)
+    auto dividend = [&](unsigned k1) -> V {
+        V d = E::zero();
+        if (!col || k1 >= g.n1) return d;
+        if (g.fused) {
+            d = E::neg(E::ld(res, rp, (size_t)k1 * g.n2 + c));
+            if (k1 < g.nx1 && c < g.nx2) d = E::add(d, E::ld(x, xp, (size_t)k1 * g.x_rstride + c));
+        } else if (k1 < g.nx1 && c < g.nx2) {
+            d = E::ld(x, xp, (size_t)k1 * g.x_rstride + c);
+        }
+        return d;
+    };
+    V next_dividend = dividend(wave);
+    // term res[j1] (*) y[r - j1] into accumulator row r (owned by this wave); xr = the final row j1, one coefficient per lane
+    auto apply_term = [&](unsigned r, unsigned j1, V xr) {
+        const unsigned d = r - j1;
+        if (d >= g.ny1) return;  // y has no such row: the reference's lower bound lo1 excludes the term
+        V ys = (c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
+        V inner = E::zero();
+        for (unsigned j2 = 0; j2 < g.n2; ++j2) {
+            const V xs = bcast_lane<E>(xr, j2);
+            if (col && c >= j2 && c - j2 < g.ny2) inner = E::add(inner, E::mul(xs, ys));
+            ys = wave_shr1<E>(ys);
+        }
+        if (col) {
+            const size_t at = (size_t)r * g.n2p + c;
+            E::st(al, asz, at, E::add(E::ld(al, asz, at), inner));
+        }
+    };
+    for (unsigned k1 = 0; k1 < g.n1; ++k1) {
+        const unsigned owner = k1 % nw;
+        V xr = E::zero();  // the row finished in the previous step
+        if (k1 > 0 && col) xr = E::ld(fl, 128, (size_t)((k1 - 1) & 1) * 64 + c);
+        unsigned r = k1 + ((wave + nw - owner) % nw);  // first row >= k1 this wave owns
+        if (wave == owner) {
+            if (k1 > 0) apply_term(k1, k1 - 1, xr);
+            // dividend row: cur = -acc; cur += x[k1]  (mt:1186-1188 at this level)
+            V t = E::zero();
+            if (col) t = E::neg(E::ld(al, asz, (size_t)k1 * g.n2p + c));
+            const bool has_div = g.fused || (k1 < g.nx1);
+            if (col && has_div && (g.fused || c < g.nx2)) t = E::add(t, next_dividend);
+            // 1-d division by y[0, :], lock step over j
+            V cur1 = E::zero(), ys = y0v, mine = E::zero();
+            for (unsigned j = 0; j < g.n2; ++j) {
+                const V q = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
+                if (c == j) mine = q;
+                if (col && c > j && c - j < g.ny2) cur1 = E::add(cur1, E::mul(q, ys));  // ys = y[0, c - j] after j shifts
+                ys = wave_shr1<E>(ys);
+            }
+            if (col) {
+                E::st(fl, 128, (size_t)(k1 & 1) * 64 + c, mine);
+                E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
+            }
+            next_dividend = dividend(k1 + nw);
+            r += nw;
+        }
+        if (k1 > 0)
+            for (; r < g.n1; r += nw) apply_term(r, k1 - 1, xr);
+        __syncthreads();  // row k1 is final (fl), every accumulator row holds the terms up to k1 - 1
+    }
+}
+
 template <class E>
 bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
                   size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused) {
@@ -184,6 +291,22 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
     g.fused = fused;
     g.n2p = n2 | 1;   // odd pitches: rows of one column do not share a bank
     g.ny2p = ny2 | 1;
+    if (n2 <= 64) {
+        const size_t lds = sizeof(double) * E::W * ((size_t)ny1 * g.ny2p + (size_t)n1 * g.n2p + 128);
+        if (lds <= 150 * 1024) {
+            static bool attr_set64 = false;
+            if (!attr_set64) {
+                if (hipFuncSetAttribute((const void*)k_div_2d_rows64<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return false;
+                }
+                attr_set64 = true;
+            }
+            const unsigned waves = std::max(1u, std::min<unsigned>(D2_NW, n1));
+            hipLaunchKernelGGL(k_div_2d_rows64<E>, dim3(1), dim3(64 * waves), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
+            return true;
+        }
+    }
     const size_t lds = sizeof(double) * E::W * ((size_t)ny1 * g.ny2p + (size_t)n1 * g.n2p + (size_t)D2_NW * g.n2p + g.n2p);
     if (lds > 150 * 1024) return false;
     static bool attr_set = false;
