@@ -132,7 +132,11 @@ struct Runtime {
     int conv_mode = 0;
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     double tiled_min_override = -1;  // >= 0 while a div / log recurrence issues its accumulation products (recur_tiled_min_macs)
-    double recur_tiled_min_macs = 5.0e7;  // div / log: accumulation steps below this keep the reference's summation order
+    // div / log: accumulation steps of at least this many multiply-adds may take the tiled kernel.  Off by default: the
+    // quotient of a division cancels, and the tiled kernel's summation order showed up as 4e-10 relative on single
+    // coefficients of a 64^3 quotient (profiles/r02/recurrences.txt) — inside the normwise bound of SURVEY 8d, outside
+    // the 1e-10-per-coefficient contract.  gft_set_option("recur_tiled_min_macs", 5e7) trades that for ~20 % at 64^3.
+    double recur_tiled_min_macs = 1.0e300;
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)

@@ -9,15 +9,16 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT/summary"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_kt -o kt -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/kt.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_kt -o kt -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > "$OUT/kt.log" 2>&1
 cp "$(find /tmp/gft_kt -name '*kernel_stats.csv' | head -1)" "$OUT/summary/kernel_stats.csv"
+grep -o '{"metric".*' "$OUT/kt.log" | tail -1 > "$OUT/summary/bench_c2_n1_under_rocprof.json"
 n=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
            "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD"; do
   n=$((n+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/gft_pmc_$n -o pmc -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$n.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/gft_pmc_$n -o pmc -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/pmc_$n.log" 2>&1
   f=$(find /tmp/gft_pmc_$n -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/pmc_$n.csv"
 done
@@ -35,16 +36,22 @@ for f in sorted(glob.glob(out + "/pmc_*.csv")):
     for c, d in per.items():
         v = list(d.values())
         agg[c] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
-agg["_note"] = ("rocprofv3 --pmc passes (separate runs) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` on MI355X; "
+agg["workload"] = "c2"
+agg["_note"] = ("rocprofv3 --pmc passes (separate runs) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e` on MI355X; "
                 "per-launch sums over all XCDs/SEs for the k_conv_tiled dispatches (128^3 product). FETCH_SIZE/WRITE_SIZE are in KB; "
                 "FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section): bench.py reports traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes. "
                 "TCC_EA0_RDREQ_DRAM_sum counts the read requests that went to DRAM (the rest of TCC_EA0_RDREQ_sum was served by the Infinity Cache).")
-json.dump(agg, open(out + "/summary/pmc_k_conv_tiled.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in agg.items() if k != "_note"}, indent=0)[:1500])
+json.dump(agg, open(out + "/summary/pmc_k_conv_tiled_c2.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in agg.items() if k not in ("_note", "workload")}, indent=0)[:1500])
 PY
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/summary/bench_c2_n1.json" 2> "$OUT/bench_c2.err"
-python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench_fp64.hip -o /tmp/microbench_fp64 2> "$OUT/mb.err" && /tmp/microbench_fp64 > "$OUT/summary/microbench_fp64.txt" 2>&1
+python3 tools/bench_recurrence.py > "$OUT/summary/recurrences.txt" 2> "$OUT/rec.err"
+python3 tools/bench_interval.py > "$OUT/summary/interval_product.txt" 2> "$OUT/iv.err"
+python3 tools/xover_host.py > "$OUT/summary/xover_host.txt" 2> "$OUT/xover.err"
+python3 tools/bench_e2e.py --limit 100 --runs 2 --bounds --only approx > "$OUT/e2e_bounds.log" 2>&1; tail -1 "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.json"
 python3 tools/bench_streaming.py 384 > "$OUT/summary/streaming_384.json" 2> "$OUT/streaming.err"
 python3 tools/bench_staged.py > "$OUT/staged.log" 2>&1; cp gpurun_out/staged_vs_naive.json "$OUT/summary/" 2>/dev/null
 python3 tools/sweep_tiled.py > "$OUT/summary/tiled_size_sweep.txt" 2> "$OUT/sweep.err"
