@@ -141,6 +141,7 @@ struct Runtime {
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
+    bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
@@ -1417,7 +1418,34 @@ struct Ops {
         if (res.shape[0] <= 1) return;
         HV xsc;
         std::shared_ptr<Buf> hold = scaled_by_index(xs, &xsc);
-        for (size_t k = 1; k < res.shape[0]; ++k) {
+        // Large f64 exponentials (their slab steps would take the tiled kernel anyway, i.e. the 1e-10 contract, not the
+        // reference's summation order): RIGHT-LOOKING.  As soon as res[i] is final one wide product adds
+        // (j xs[j]) (*) res[i] for j = 1..m into the m slabs that follow — 64 wide launches at full tile efficiency
+        // instead of 64 single-slab launches that are all launch / reduce overhead (64^3: 15.6 -> see recurrences.txt).
+        double total = 1.0;
+        for (size_t i = 0; i < res.shape.size(); ++i) total *= 0.5 * (double)res.shape[i] * (double)std::min(xs.shape[i], res.shape[i]) + 0.5;
+        const size_t n0 = res.shape[0];
+        if (!res.host && W == 1 && R.conv_mode == 0 && R.exp_right && total >= 64.0 * R.tiled_min_macs) {
+            Dims rest(res.shape.begin() + 1, res.shape.end()), xrest(xs.shape.begin() + 1, xs.shape.end());
+            HV tail = res.index0(1);
+            zero_elems(false, tail.p, res.numel() - prod(rest));
+            for (size_t i = 0; i + 1 < n0; ++i) {
+                HV cur = res.index0(i);
+                if (i >= 1) x_map_inplace(cur, MAP_DIV_U32, (unsigned)i);  // res[i] = acc / i: final
+                if (xs.shape[0] < 2) continue;
+                const size_t m = std::min(n0 - 1 - i, xs.shape[0] - 1);
+                Dims xsm{m}, ys1{1}, zsm{m};
+                xsm.insert(xsm.end(), xrest.begin(), xrest.end());
+                ys1.insert(ys1.end(), rest.begin(), rest.end());
+                zsm.insert(zsm.end(), rest.begin(), rest.end());
+                HV xm{xsc.p + prod(xrest), xsc.plane, xsm, false}, yi{cur.p, res.plane, ys1, false},
+                    zm{res.p + (i + 1) * prod(rest), res.plane, zsm, false};
+                conv(xm, yi, zm, 0, m, true, false, 0, 0, 0);
+            }
+            x_map_inplace(res.index0(n0 - 1), MAP_DIV_U32, (unsigned)(n0 - 1));
+            return;
+        }
+        for (size_t k = 1; k < n0; ++k) {
             HV cur = res.index0(k);
             conv(xsc, res, res, k, k + 1, false, true, 1, 0, 0);
             x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
@@ -2242,6 +2270,7 @@ int gft_init(int device) {
         }
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
         if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
+        if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
@@ -2327,6 +2356,7 @@ int gft_set_option(const char* name, double value) {
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "div2d") R.div2d = value != 0;
+    else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default

@@ -473,30 +473,49 @@ k_conv_tiled(TiledArgs A) {
     }
 }
 
-// Fixed-order sum of the partial slabs of split tiles.
+// Fixed-order sum of the partial slabs of split tiles.  One workgroup per (tile, 8-wide output block); its four waves
+// each sum a contiguous quarter of the tile's partial slabs and the quarters are added in order through LDS — the order
+// depends on the plan only, so results are deterministic.  (A slab step of a recurrence has few tiles and many partial
+// slabs: one workgroup per tile walking all of them serially took 140 us at 64^3, 2x the product itself.)
 __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red) {
-    const unsigned ti = blockIdx.x;
+    const unsigned ti = blockIdx.x, c = blockIdx.y;
     if (ti >= n_red) return;
     if (A.guard && *A.guard == A.guard_epoch) return;
+    __shared__ double part[3][64][8];
     const RedTile rt = A.red[ti];
-    for (unsigned idx = threadIdx.x; idx < A.nb * 64; idx += blockDim.x) {
-        const unsigned c = idx >> 6, lane = idx & 63u;
-        const unsigned k0 = 8 * rt.a + (lane >> 3), k1 = 8 * rt.b + (lane & 7u);
-        bool lane_in = k0 < A.z0 && k1 < A.z1;
-        if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
-        if (!lane_in) continue;
-        double v[8];
-        double* zrow = A.z + (((size_t)rt.u * A.z0 + k0) * A.z1 + k1) * A.zI;
+    const unsigned lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const unsigned k0 = 8 * rt.a + (lane >> 3), k1 = 8 * rt.b + (lane & 7u);
+    bool lane_in = k0 < A.z0 && k1 < A.z1;
+    if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+    double v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            unsigned k2 = 8 * c + r;
-            v[r] = (A.accumulate && k2 < A.zI) ? zrow[k2] : 0.0;
+    for (int r = 0; r < 8; ++r) v[r] = 0.0;
+    double* zrow = A.z + (((size_t)rt.u * A.z0 + k0) * A.z1 + k1) * A.zI;
+    if (lane_in) {
+        if (q == 0 && A.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                unsigned k2 = 8 * c + r;
+                if (k2 < A.zI) v[r] = zrow[k2];
+            }
         }
-        for (unsigned p = 0; p < rt.count; ++p) {
+        const unsigned lo = (unsigned)((unsigned long long)rt.count * q / 4), hi = (unsigned)((unsigned long long)rt.count * (q + 1) / 4);
+        for (unsigned p = lo; p < hi; ++p) {
             const double* w = A.ws + (size_t)A.red_slots[rt.first + p] * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += w[r];
         }
+        if (q > 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part[q - 1][lane][r] = v[r];
+        }
+    }
+    __syncthreads();
+    if (q == 0 && lane_in) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += part[g][lane][r];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             unsigned k2 = 8 * c + r;
@@ -990,7 +1009,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     }
     if (e != hipSuccess) return false;
     if (P.n_red) {
-        hipLaunchKernelGGL(k_conv_reduce, dim3(P.n_red), dim3(256), 0, st, T, P.n_red);
+        hipLaunchKernelGGL(k_conv_reduce, dim3(P.n_red, T.nb), dim3(256), 0, st, T, P.n_red);
         if (hipGetLastError() != hipSuccess) return false;
     }
     return true;

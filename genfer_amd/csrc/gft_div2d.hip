@@ -193,6 +193,12 @@ __device__ inline double wave_shr1_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 template <class E>
+__device__ inline bool elem_finite(typename E::V v);
+template <>
+__device__ inline bool elem_finite<EF64>(double v) { return finite_d(v); }
+template <>
+__device__ inline bool elem_finite<EIv>(Iv v) { return EIv::is_finite(v); }
+template <class E>
 __device__ inline typename E::V wave_shr1(typename E::V v);
 template <>
 __device__ inline double wave_shr1<EF64>(double v) { return wave_shr1_f64(v); }
@@ -238,10 +244,22 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         if (d >= g.ny1) return;  // y has no such row: the reference's lower bound lo1 excludes the term
         V ys = (c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
         V inner = E::zero();
-        for (unsigned j2 = 0; j2 < g.n2; ++j2) {
-            const V xs = bcast_lane<E>(xr, j2);
-            if (col && c >= j2 && c - j2 < g.ny2) inner = E::add(inner, E::mul(xs, ys));
-            ys = wave_shr1<E>(ys);
+        if (!any_lane(!elem_finite<E>(xr))) {
+            // Finite row: the positions the reference's bounds exclude (c < j2, c - j2 >= ny2) hold an exact zero in
+            // `ys` (shifted in at lane 0 / beyond the row), and  inner + x * 0 == inner  for finite x — a sum that started
+            // from +0 is never -0, and [0,0] short-circuits the interval operations — so the masks can go: same bits,
+            // half the instructions, no select in the dependency chain.
+#pragma unroll 4
+            for (unsigned j2 = 0; j2 < g.n2; ++j2) {
+                inner = E::add(inner, E::mul(bcast_lane<E>(xr, j2), ys));
+                ys = wave_shr1<E>(ys);
+            }
+        } else {
+            for (unsigned j2 = 0; j2 < g.n2; ++j2) {
+                const V xs = bcast_lane<E>(xr, j2);
+                if (col && c >= j2 && c - j2 < g.ny2) inner = E::add(inner, E::mul(xs, ys));
+                ys = wave_shr1<E>(ys);
+            }
         }
         if (col) {
             const size_t at = (size_t)r * g.n2p + c;
@@ -254,6 +272,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         if (k1 > 0 && col) xr = E::ld(fl, 128, (size_t)((k1 - 1) & 1) * 64 + c);
         unsigned r = k1 + ((wave + nw - owner) % nw);  // first row >= k1 this wave owns
         if (wave == owner) {
+            __builtin_amdgcn_s_setprio(3);  // the critical path of the slab: this wave's row must not wait for the updates of the other 15
             if (k1 > 0) apply_term(k1, k1 - 1, xr);
             // dividend row: cur = -acc; cur += x[k1]  (mt:1186-1188 at this level)
             V t = E::zero();
@@ -265,9 +284,14 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             for (unsigned j = 0; j < g.n2; ++j) {
                 const V q = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
                 if (c == j) mine = q;
-                if (col && c > j && c - j < g.ny2) cur1 = E::add(cur1, E::mul(q, ys));  // ys = y[0, c - j] after j shifts
+                // ys = y[0, c - j] after j shifts.  Lanes c <= j are past their own step (their sum no longer matters), so
+                // the lower bound needs no mask; the upper one (c - j >= ny2) multiplies by a shifted-in zero, which only a
+                // non-finite quotient coefficient could turn into something (then the select keeps the reference's bounds).
+                const V upd = E::add(cur1, E::mul(q, ys));
+                if (elem_finite<E>(q) || (col && c > j && c - j < g.ny2)) cur1 = upd;
                 ys = wave_shr1<E>(ys);
             }
+            __builtin_amdgcn_s_setprio(0);
             if (col) {
                 E::st(fl, 128, (size_t)(k1 & 1) * 64 + c, mine);
                 E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
