@@ -1703,6 +1703,87 @@ struct Ops {
         return out;
     }
 
+    // ---- a whole observation chain ----------------------------------------------------------------------------
+    // n observation steps, innermost first: a <- observe_step(a, v, x, cs[i], d + (n - 1 - i)) — what the evaluator
+    // computes for `observe k ~ Poisson(lambda * X)` (gf.rs:678-700: the loop builds n nested derive * var * const
+    // nodes, each evaluated one degree lower than the one inside it).  One launch for the chain when every step is an
+    // ordinary one (k_observe_chain); otherwise, and on the host tier, the steps one by one.
+    static P observe_chain(const P& a, size_t v, const double* x, const double* cs, size_t n, size_t d) {
+        auto stepwise = [&]() {
+            P r = a;
+            for (size_t i = 0; i < n; ++i) r = observe_step(r, v, x, cs + i * W, v_deg(d, n, i));
+            return r;
+        };
+        if (n == 0) return a;
+        if (n == 1 || tier_host(a.numel, a) || n > 4096) return stepwise();
+        if (n > (size_t)OC_MAX) {  // long chains: OC_MAX steps per launch
+            P r = a;
+            for (size_t i = 0; i < n; i += OC_MAX) {
+                const size_t m = std::min<size_t>(OC_MAX, n - i);
+                r = observe_chain(r, v, x, cs + i * W, m, v_deg(d, n, i + m - 1));
+            }
+            return r;
+        }
+        for (int i = 0; i < W; ++i)
+            if (!(x[i] - x[i] == 0.0)) return stepwise();
+        // walk the steps on the host: shapes, degrees and the conditions under which observe_step fuses
+        Dims S = a.shape, G = a.deg;
+        ObserveChainArgs g;
+        std::memset(&g, 0, sizeof(g));
+        unsigned longest = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t di = v_deg(d, n, i);
+            const double* c = cs + i * W;
+            const size_t len_of = v < G.size() ? G[v] : UMAX;
+            if (!(v < G.size() && 1 < len_of) || v >= S.size() || S[v] < 2 || di < 2 || val_is_zero(c)) return stepwise();
+            for (int k = 0; k < W; ++k)
+                if (!(c[k] - c[k] == 0.0)) return stepwise();
+            Dims dshape = S, ddeg = G;
+            dshape[v] -= 1;
+            ddeg[v] -= 1;
+            for (size_t ax = 0; ax < ddeg.size(); ++ax) {
+                ddeg[ax] = std::min(ddeg[ax], di);
+                dshape[ax] = std::min(dshape[ax], di);
+            }
+            if (prod(dshape) < 2) return stepwise();
+            if (i == 0) g.len0 = (unsigned)S[v];
+            longest = std::max<unsigned>(longest, (unsigned)std::min<size_t>(S[v], 0xffffffffu));
+            S = dshape;
+            S[v] = std::min(ddeg[v], dshape[v] + 1);
+            G = ddeg;
+            g.dl[i] = (unsigned)dshape[v];
+            g.lo[i] = (unsigned)S[v];
+            g.c[i] = Scalar2{c[0], W == 2 ? c[1] : 0.0};
+            if (val_is_one(c)) g.c_one |= 1ull << i;
+        }
+        if (longest > K<E>::OBSERVE_LINE_MAX || prod(S) / S[v] > 0x7fffffffu) return stepwise();
+        P out = make(S, G);
+        std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, 1, a.shape[v] - 1);
+        Dims ast = c_strides(a.shape), ost = c_strides(S);
+        int nd = 0;
+        g.axis = -1;
+        for (size_t ax = 0; ax < S.size(); ++ax) {
+            if (S[ax] == 1 && ax != v) continue;  // collapsed: index 0 on this axis
+            if (nd >= MAXD) return stepwise();
+            g.fs[nd] = (unsigned)S[ax];
+            g.a_stride[nd] = ast[ax];
+            g.o_stride[nd] = ost[ax];
+            if (ax == v) g.axis = nd;
+            nd++;
+        }
+        g.nd = nd;
+        g.nsteps = (unsigned)n;
+        g.x = Scalar2{x[0], W == 2 ? x[1] : 0.0};
+        g.x_is_zero = val_is_zero(x);
+        g.x_is_one = val_is_one(x);
+        g.tab = tab->p;
+        g.tab_plane = a.shape[v] - 1;
+        g.lw_pad = (longest + 8) / 8 * 8;
+        K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, (unsigned)(prod(S) / S[v]), longest);
+        return out;
+    }
+    static size_t v_deg(size_t d, size_t n, size_t i) { return d + (n - 1 - i); }  // truncation degree of step i of n
+
     // ---- shift_down (mt:514-536) -------------------------------------------------------------------------------------
     static void sum_axis_into(const P& a, size_t v, size_t upto, double* out, size_t out_plane, bool host) {
         size_t outer = 1, inner = 1;
@@ -2758,6 +2839,9 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
         return guard([&] { return Ops<E>::observe_step(*a, v, x, c, d); });                                   \
+    }                                                                                                         \
+    gft_poly* PFX##observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
+        return guard([&] { return Ops<E>::observe_chain(*a, v, x, cs, n, d); });                              \
     }                                                                                                         \
     gft_poly* PFX##derive_scale(const gft_poly* a, size_t v, const double* c, size_t d) {                     \
         return guard([&] { return Ops<E>::derive_scale(*a, v, c, d); });                                      \

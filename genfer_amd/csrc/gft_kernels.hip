@@ -362,6 +362,65 @@ void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double*
 }
 
 template <class E>
+__global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
+                                                        ObserveChainArgs g) {
+    typedef typename E::V V;
+    extern __shared__ double oc_lds[];  // [buffer][plane][lw_pad]
+    size_t aoff = 0, ooff = 0;
+    {
+        size_t r = blockIdx.x;
+#pragma unroll
+        for (int ax = MAXD - 1; ax >= 0; --ax) {
+            if (ax < g.nd && ax != g.axis) {
+                const unsigned d = g.fs[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                aoff += (size_t)k * g.a_stride[ax];
+                ooff += (size_t)k * g.o_stride[ax];
+            }
+        }
+    }
+    const size_t sva = g.a_stride[g.axis], svo = g.o_stride[g.axis];
+    const V xv = E::from(g.x);
+    for (unsigned t = 0; t < g.nsteps; ++t) {
+        const unsigned dlt = g.dl[t], lout = g.lo[t];
+        const bool first = t == 0, last = t + 1 == g.nsteps;
+        const double* src_l = oc_lds + (size_t)((t + 1) & 1u) * E::W * g.lw_pad;  // written by step t - 1
+        double* dst_l = oc_lds + (size_t)(t & 1u) * E::W * g.lw_pad;
+        const V cv = E::from(g.c[t]);
+        const bool c_one = (g.c_one >> t) & 1ull;
+        for (unsigned kv = threadIdx.x; kv < lout; kv += blockDim.x) {
+            auto src = [&](unsigned j) -> V { return first ? E::ld(a, ap, aoff + (size_t)j * sva) : E::ld(src_l, g.lw_pad, j); };
+            // D'_j = src[j + 1] * ff_j  (derivative, mt:471-479), then exactly k_observe_step's sequence
+            V res = E::zero();
+            if (g.x_is_zero) {
+                if (kv >= 1 && kv - 1 < dlt) res = E::mul(E::mul(src(kv), E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
+            } else {
+                V A = E::zero();
+                if (kv >= 1 && kv - 1 < dlt) A = E::mul(E::mul(src(kv), E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
+                res = E::add(res, A);
+                if (kv < dlt) {
+                    const V di = E::mul(src(kv + 1), E::ld(g.tab, g.tab_plane, kv));
+                    res = E::add(res, g.x_is_one ? di : E::mul(xv, di));
+                }
+            }
+            if (!c_one) res = E::mul(cv, res);
+            if (last) E::st(out, op, ooff + (size_t)kv * svo, res);
+            else E::st(dst_l, g.lw_pad, kv, res);
+        }
+        __syncthreads();
+    }
+}
+template <class E>
+void K<E>::observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                         const ObserveChainArgs& args, unsigned lines, unsigned longest) {
+    if (lines == 0 || args.nsteps == 0) return;
+    const unsigned threads = std::min<unsigned>(1024, (longest + 63) / 64 * 64);
+    const size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
+    hipLaunchKernelGGL(k_observe_chain<E>, dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args);
+}
+
+template <class E>
 __global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b, size_t bp, double* out,
                             size_t op_plane) {
     (void)op;  // SC_DIV

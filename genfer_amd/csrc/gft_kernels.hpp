@@ -65,6 +65,29 @@ struct ObserveArgs {
     size_t tab_plane;
 };
 
+// A whole chain of observation steps (the loop of generating_function.rs:684-689: `order` times derivative -> truncate ->
+// * (x + eps_v) -> * c_k) in ONE launch: the steps couple positions along v only, so every line along v runs all of them
+// on its own (one workgroup per line, intermediates in LDS), and only the lines inside the FINAL truncated box are
+// computed at all.  Per step and element exactly ObserveArgs' operations.
+constexpr int OC_MAX = 48;  // steps per launch (longer chains are cut by the host)
+struct ObserveChainArgs {
+    int nd;                    // collapsed rank of the final shape
+    unsigned fs[MAXD];         // final shape
+    size_t a_stride[MAXD];     // strides of the input tensor
+    size_t o_stride[MAXD];     // strides of the output tensor
+    int axis;                  // collapsed index of v
+    unsigned nsteps, len0;     // steps; input length along v
+    unsigned dl[OC_MAX];       // per step: length of the truncated derivative along v
+    unsigned lo[OC_MAX];       // per step: length of the step's result along v
+    Scalar2 x;
+    Scalar2 c[OC_MAX];
+    unsigned long long c_one;  // bit t: c[t] is exactly one
+    int x_is_zero, x_is_one;
+    const double* tab;         // derivative factors ff_j (mt:472-478), tab_plane apart for intervals
+    size_t tab_plane;
+    unsigned lw_pad;           // LDS line pitch (>= the longest line)
+};
+
 // One Horner step of subst_var with a LINEAR substitution s = c + m*eps_w (mt:566-579, 589-623, 873-880):
 //   out = res * s + coeff_i,   coeff_i = a[.., i, ..] along the substituted axis,
 // computed per element in exactly the order of the reference's op sequence
@@ -173,6 +196,9 @@ struct K {
     static void witness(hipStream_t st, const DView& t, unsigned* flag);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
+    static constexpr unsigned OBSERVE_LINE_MAX = 2048;  // longest line along v of observe_chain
+    static void observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                              const ObserveChainArgs& args, unsigned lines, unsigned longest);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
     // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])

@@ -58,6 +58,7 @@ struct Api {
     void* (*subst_var)(const void*, size_t, const void*);
     void* (*observe_step)(const void*, size_t, const double*, const double*, size_t);
     void* (*derive_scale)(const void*, size_t, const double*, size_t);
+    void* (*observe_chain)(const void*, size_t, const double*, const double*, size_t, size_t);
     void* (*derivative_truncated)(const void*, size_t, size_t, size_t);
     void* (*coefficients_of_term)(const void*, size_t, size_t);
     void* (*taylor_polynomial_terms)(const void*, size_t, const size_t*, size_t);
@@ -83,7 +84,7 @@ struct Api {
         GFH_BIND(shape); GFH_BIND(degrees_p1); GFH_BIND(to_host); GFH_BIND(is_zero); GFH_BIND(is_one);
         GFH_BIND(constant_term); GFH_BIND(extract_constant); GFH_BIND(coefficient); GFH_BIND(add); GFH_BIND(sub);
         GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
-        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derive_scale); GFH_BIND(derivative_truncated);
+        GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derive_scale); GFH_BIND(observe_chain); GFH_BIND(derivative_truncated);
         GFH_BIND(coefficients_of_term); GFH_BIND(taylor_polynomial_terms); GFH_BIND(truncate_to_degree_p1);
         GFH_BIND(remove_last_variable); GFH_BIND(extend_to_dim);
 #undef GFH_BIND
@@ -210,6 +211,13 @@ class Poly {
         x.store(xb);
         c.store(cb);
         return wrap(api().observe_step(h(), v, xb, cb, d));
+    }
+    Poly observe_chain(size_t v, const T& x, const std::vector<T>& cs, size_t d) const {
+        double xb[2];
+        x.store(xb);
+        std::vector<double> cb(cs.size() * T::WIDTH + 2);
+        for (size_t i = 0; i < cs.size(); ++i) cs[i].store(cb.data() + i * T::WIDTH);
+        return traced("observe_chain", nel(*this), wrap(api().observe_chain(h(), v, xb, cb.data(), cs.size(), d)));
     }
     Poly derive_scale(size_t v, const T& c, size_t d) const {
         double cb[2];

@@ -258,12 +258,30 @@ struct GenFun {
                 // (d/dv G) * v * const — one level of the compound-Poisson observation chain built by
                 // eval_taylor_coeff_at_zero (gf.rs:684-689): evaluated by the backend's fused observe_step, which
                 // performs exactly the three reference operations derivative/truncate, * var, * const.
-                if (x.b.p->kind == Const && x.a.p->kind == Mul) {
-                    const Node& m = *x.a.p;
-                    if (m.a.p->kind == Derivative && m.a.p->order == 1 && m.b.p->kind == Var && m.b.p->var == m.a.p->var) {
-                        size_t v = m.b.p->var;
-                        TP t = m.a.p->a.eval_with(inputs, degree_p1 + 1, cache);
-                        return t.observe_step(v, inputs.at(v), x.b.p->c, degree_p1);
+                {
+                    // the whole chain at once: walk down while the operand has the same shape for the same variable
+                    auto step_of = [](const Node& n, size_t* v, const GenFun** inner) {
+                        if (n.kind != Mul || n.b.p->kind != Const || n.a.p->kind != Mul) return false;
+                        const Node& m = *n.a.p;
+                        if (!(m.a.p->kind == Derivative && m.a.p->order == 1 && m.b.p->kind == Var && m.b.p->var == m.a.p->var)) return false;
+                        *v = m.b.p->var;
+                        *inner = &m.a.p->a;
+                        return true;
+                    };
+                    size_t v = 0;
+                    const GenFun* inner = nullptr;
+                    if (step_of(x, &v, &inner)) {
+                        std::vector<T> cs{x.b.p->c};  // outermost first
+                        size_t v2 = 0;
+                        const GenFun* in2 = nullptr;
+                        while (step_of(*inner->p, &v2, &in2) && v2 == v) {
+                            cs.push_back(inner->p->b.p->c);
+                            inner = in2;
+                        }
+                        std::reverse(cs.begin(), cs.end());  // innermost first
+                        TP t = inner->eval_with(inputs, degree_p1 + cs.size(), cache);
+                        if (cs.size() == 1) return t.observe_step(v, inputs.at(v), cs[0], degree_p1);
+                        return t.observe_chain(v, inputs.at(v), cs, degree_p1);
                     }
                 }
                 // (d/dv G) * const — one level of the continuous-rate Poisson observation chain (gf.rs:703-706): the

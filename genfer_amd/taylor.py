@@ -78,6 +78,7 @@ HANDLE_API = {
     "subst_var": (_VP, [_VP, C.c_size_t, _VP]),
     "observe_step": (_VP, [_VP, C.c_size_t, _DP, _DP, C.c_size_t]),
     "derive_scale": (_VP, [_VP, C.c_size_t, _DP, C.c_size_t]),
+    "observe_chain": (_VP, [_VP, C.c_size_t, _DP, _DP, C.c_size_t, C.c_size_t]),
     "derivative_truncated": (_VP, [_VP, C.c_size_t, C.c_size_t, C.c_size_t]),
     "coefficients_of_term": (_VP, [_VP, C.c_size_t, C.c_size_t]),
     "taylor_polynomial_terms": (_VP, [_VP, C.c_size_t, _SP, C.c_size_t]),
@@ -296,6 +297,14 @@ def bind(lib: C.CDLL, prefix: str):
         def observe_step(self, v: int, x, c, degree_p1: int):
             """Fused (derivative(v,1).truncate(d) * var(v,x,d)) * c  (gf.rs:684-689)."""
             return type(self)(fn.observe_step(self._h, v, scal(x), scal(c), degree_p1))
+
+        def observe_chain(self, v: int, x, cs, degree_p1: int):
+            """n fused observation steps, innermost first (gf.rs:684-689 as the evaluator unfolds it)."""
+            flat = []
+            for c in cs:
+                flat += list(scal(c))
+            buf = (C.c_double * max(len(flat), 1))(*flat)
+            return type(self)(fn.observe_chain(self._h, v, scal(x), buf, len(cs), degree_p1))
 
         def derive_scale(self, v: int, c, degree_p1: int):
             """Fused derivative(v,1).truncate(d) * c  (continuous-Poisson observation step, gf.rs:703-706)."""

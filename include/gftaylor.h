@@ -176,6 +176,10 @@ gft_poly* gft_shift_down(const gft_poly* a, size_t v, size_t n);        /* shift
  * * from(c) — one step of the compound-Poisson observation loop, generating_function.rs:684-689 — same
  * per-element operation order, one kernel launch, no dispatch read-backs. */
 gft_poly* gft_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
+/* n such steps in one call, innermost first: a <- gft_observe_step(a, v, x, cs + i*WIDTH, degree_p1 + (n - 1 - i)) for
+ * i = 0..n-1 — the whole loop of generating_function.rs:684-689 as the evaluator unfolds it (each level one degree
+ * lower than the one inside it).  One launch for the chain: every line along v runs all steps on its own. */
+gft_poly* gft_observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t degree_p1);
 /* The same for observations from a Poisson with a CONTINUOUS rate (generating_function.rs:703-706):
  * derivative(a, v, 1).truncate_to_degree_p1(d) * from(c), i.e. c * (x * ff) per element, in one launch. */
 gft_poly* gft_derive_scale(const gft_poly* a, size_t v, const double* c, size_t degree_p1);
@@ -237,6 +241,7 @@ gft_poly* gfti_derivative(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_taylor_expansion_of_coeff(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_shift_down(const gft_poly* a, size_t v, size_t n);
 gft_poly* gfti_observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t degree_p1);
+gft_poly* gfti_observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t degree_p1);
 gft_poly* gfti_derive_scale(const gft_poly* a, size_t v, const double* c, size_t degree_p1);
 gft_poly* gfti_derivative_truncated(const gft_poly* a, size_t v, size_t n, size_t degree_p1);
 gft_poly* gfti_subst_var(const gft_poly* a, size_t v, const gft_poly* subst);

@@ -210,6 +210,20 @@ static std::string format_poly(const P<S>& p, bool debug) {
                                                    P<S>::var(v, Tr<S>::load(x), d)),                            \
                                         P<S>::from_scalar(Tr<S>::load(c)))))                                  \
     }                                                                                                      \
+    void* PFX##observe_chain(const void* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
+        /* n times the unfused reference sequence, innermost first, each level one degree lower */           \
+        try {                                                                                              \
+            P<S> r = *(const P<S>*)a;                                                                      \
+            for (size_t i = 0; i < n; ++i)                                                                 \
+                r = P<S>::mul(P<S>::mul(r.derivative(v, 1).truncate_to_degree_p1(d + (n - 1 - i)),           \
+                                        P<S>::var(v, Tr<S>::load(x), d + (n - 1 - i))),                     \
+                              P<S>::from_scalar(Tr<S>::load(cs + i * Tr<S>::W)));                         \
+            return (void*)new P<S>(r);                                                                     \
+        } catch (const std::exception& e) {                                                                \
+            g_err = e.what();                                                                              \
+            return (void*)0;                                                                               \
+        }                                                                                                  \
+    }                                                                                                      \
     void* PFX##derive_scale(const void* a, size_t v, const double* c, size_t d) {                          \
         /* the unfused reference sequence (generating_function.rs:703-706 evaluated by :628-632 and Mul) */   \
         ORC_TRY((void*)new P<S>(P<S>::mul(((const P<S>*)a)->derivative(v, 1).truncate_to_degree_p1(d),       \

@@ -745,3 +745,29 @@ def test_derive_scale_fused_equals_reference_sequence(interval, OTP, GTP, OTPI, 
     assert rc == 0, want
     got, _ = genfer_amd.run_sgcl(src, flags)
     assert got == want
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_observe_chain_fused_equals_stepwise_reference(interval, OTP, GTP, OTPI, GTPI):
+    """gft_observe_chain = n observation steps (derivative -> truncate -> * (x + eps_v) -> * c_k, generating_function.rs:
+    684-689), each one degree lower than the one inside it, in ONE launch: bit-identical to the oracle's unfused loop —
+    ordinary chains, chains longer than one launch takes (48 steps), x = 0 / 1, constants 0 / 1 / non-finite, 1-element
+    intermediates (all of which make the library fall back to single steps)."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + np.abs(a) * 1e-12])) if interval else (lambda a: a)
+    sc = (lambda c: (c, c + abs(c) * 1e-12)) if interval else (lambda c: c)
+    rng = np.random.default_rng(11)
+    cases = [((30,), [40], 0, 7), ((12, 25), [14, 30], 1, 9), ((12, 25), [14, 30], 0, 5), ((5, 6, 20), [6, 6, 24], 2, 12),
+             ((3, 70), [4, 90], 1, 55), ((90, 40), [100, 48], 0, 20), ((2, 9), [2, 9], 1, 6)]
+    for shape, deg, v, n in cases:
+        a = rand(shape, 5 + n, 0.1, 1.0)
+        o, g = O.new(mk(a), deg), G.new(mk(a), deg)
+        for x in (0.7, 0.0, 1.0):
+            cs = [sc(float(c)) for c in rng.uniform(0.2, 1.5, size=n)]
+            for d in (1, 3, max(deg)):
+                check(o.observe_chain(v, sc(x), cs, d), g.observe_chain(v, sc(x), cs, d))
+        cs = [sc(0.5)] * (n - 1) + [sc(1.0)]
+        check(o.observe_chain(v, sc(0.3), cs, 4), g.observe_chain(v, sc(0.3), cs, 4))
+        for bad in (0.0, float("inf"), float("nan")):
+            cs = [sc(0.5), sc(bad), sc(0.25)]
+            check(o.observe_chain(v, sc(0.3), cs, 5), g.observe_chain(v, sc(0.3), cs, 5))
