@@ -238,32 +238,52 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         return d;
     };
     V next_dividend = dividend(wave);
-    // term res[j1] (*) y[r - j1] into accumulator row r (owned by this wave); xr = the final row j1, one coefficient per lane
-    auto apply_term = [&](unsigned r, unsigned j1, V xr) {
-        const unsigned d = r - j1;
-        if (d >= g.ny1) return;  // y has no such row: the reference's lower bound lo1 excludes the term
-        V ys = (c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
-        V inner = E::zero();
+    // Term res[j1] (*) y[r - j1] into the accumulator rows r = r0, r0 + nw, .. (up to G of them, all owned by this wave);
+    // xr = the final row j1, one coefficient per lane.  A row product is one dependent chain per lane (readlane ->
+    // mul -> add, and the DPP shift of y): ~85 cycles a step whatever the occupancy (tools/microbench_rowconv.hip).  The
+    // rows a wave owns share the x broadcast and are independent chains, so they are advanced TOGETHER: G products for
+    // little more than the latency of one.
+    constexpr int G = 4;
+    auto apply_terms = [&](unsigned r0, unsigned cnt, unsigned j1, V xr) {
+        V ys[G], inner[G];
+        bool act[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const unsigned d = r0 + (unsigned)q * nw - j1;
+            act[q] = (unsigned)q < cnt && d < g.ny1;  // no such y row: the reference's lower bound lo1 excludes the term
+            ys[q] = (act[q] && c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
+            inner[q] = E::zero();
+        }
         if (!any_lane(!elem_finite<E>(xr))) {
             // Finite row: the positions the reference's bounds exclude (c < j2, c - j2 >= ny2) hold an exact zero in
             // `ys` (shifted in at lane 0 / beyond the row), and  inner + x * 0 == inner  for finite x — a sum that started
-            // from +0 is never -0, and [0,0] short-circuits the interval operations — so the masks can go: same bits,
-            // half the instructions, no select in the dependency chain.
-#pragma unroll 4
+            // from +0 is never -0, and [0,0] short-circuits the interval operations — so the masks can go: same bits.
+#pragma unroll 2
             for (unsigned j2 = 0; j2 < g.n2; ++j2) {
-                inner = E::add(inner, E::mul(bcast_lane<E>(xr, j2), ys));
-                ys = wave_shr1<E>(ys);
+                const V xs = bcast_lane<E>(xr, j2);
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    inner[q] = E::add(inner[q], E::mul(xs, ys[q]));
+                    ys[q] = wave_shr1<E>(ys[q]);
+                }
             }
         } else {
             for (unsigned j2 = 0; j2 < g.n2; ++j2) {
                 const V xs = bcast_lane<E>(xr, j2);
-                if (col && c >= j2 && c - j2 < g.ny2) inner = E::add(inner, E::mul(xs, ys));
-                ys = wave_shr1<E>(ys);
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    if (col && c >= j2 && c - j2 < g.ny2) inner[q] = E::add(inner[q], E::mul(xs, ys[q]));
+                    ys[q] = wave_shr1<E>(ys[q]);
+                }
             }
         }
         if (col) {
-            const size_t at = (size_t)r * g.n2p + c;
-            E::st(al, asz, at, E::add(E::ld(al, asz, at), inner));
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                if (!act[q]) continue;
+                const size_t at = (size_t)(r0 + (unsigned)q * nw) * g.n2p + c;
+                E::st(al, asz, at, E::add(E::ld(al, asz, at), inner[q]));
+            }
         }
     };
     for (unsigned k1 = 0; k1 < g.n1; ++k1) {
@@ -273,7 +293,12 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         unsigned r = k1 + ((wave + nw - owner) % nw);  // first row >= k1 this wave owns
         if (wave == owner) {
             __builtin_amdgcn_s_setprio(3);  // the critical path of the slab: this wave's row must not wait for the updates of the other 15
-            if (k1 > 0) apply_term(k1, k1 - 1, xr);
+            unsigned own_group = 1;
+            if (k1 > 0) {  // the row about to be divided together with the next rows this wave owns: same latency as one
+                const unsigned left = (g.n1 - 1 - k1) / nw + 1;
+                own_group = left < (unsigned)G ? left : (unsigned)G;
+                apply_terms(k1, own_group, k1 - 1, xr);
+            }
             // dividend row: cur = -acc; cur += x[k1]  (mt:1186-1188 at this level)
             V t = E::zero();
             if (col) t = E::neg(E::ld(al, asz, (size_t)k1 * g.n2p + c));
@@ -297,10 +322,13 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
                 E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
             }
             next_dividend = dividend(k1 + nw);
-            r += nw;
+            r += own_group * nw;
         }
         if (k1 > 0)
-            for (; r < g.n1; r += nw) apply_term(r, k1 - 1, xr);
+            for (; r < g.n1; r += G * nw) {
+                const unsigned left = (g.n1 - 1 - r) / nw + 1;  // rows r, r + nw, .. below n1
+                apply_terms(r, left < (unsigned)G ? left : (unsigned)G, k1 - 1, xr);
+            }
         __syncthreads();  // row k1 is final (fl), every accumulator row holds the terms up to k1 - 1
     }
 }
