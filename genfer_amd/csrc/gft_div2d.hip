@@ -237,19 +237,18 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         }
         return d;
     };
-    V next_dividend = dividend(wave);
-    // Term res[j1] (*) y[r - j1] into the accumulator rows r = r0, r0 + nw, .. (up to G of them, all owned by this wave);
-    // xr = the final row j1, one coefficient per lane.  A row product is one dependent chain per lane (readlane ->
-    // mul -> add, and the DPP shift of y): ~85 cycles a step whatever the occupancy (tools/microbench_rowconv.hip).  The
-    // rows a wave owns share the x broadcast and are independent chains, so they are advanced TOGETHER: G products for
-    // little more than the latency of one.
-    constexpr int G = 4;
-    auto apply_terms = [&](unsigned r0, unsigned cnt, unsigned j1, V xr) {
+    // Term res[j1] (*) y[r - j1] into the accumulator rows r = r0, r0 + stride, .. (up to G of them, all owned by this
+    // wave); xr = the final row j1, one coefficient per lane.  A row product is one dependent chain per lane (readlane
+    // -> mul -> add, and the DPP shift of y): ~85 cycles a step whatever the occupancy (tools/microbench_rowconv.hip).
+    // The rows a wave owns share the x broadcast and are independent chains, so they are advanced TOGETHER: G products
+    // for little more than the latency of one.
+    constexpr int G = 5;
+    auto apply_terms = [&](unsigned r0, unsigned stride, unsigned cnt, unsigned j1, V xr) {
         V ys[G], inner[G];
         bool act[G];
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-            const unsigned d = r0 + (unsigned)q * nw - j1;
+            const unsigned d = r0 + (unsigned)q * stride - j1;
             act[q] = (unsigned)q < cnt && d < g.ny1;  // no such y row: the reference's lower bound lo1 excludes the term
             ys[q] = (act[q] && c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
             inner[q] = E::zero();
@@ -281,55 +280,73 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
 #pragma unroll
             for (int q = 0; q < G; ++q) {
                 if (!act[q]) continue;
-                const size_t at = (size_t)(r0 + (unsigned)q * nw) * g.n2p + c;
+                const size_t at = (size_t)(r0 + (unsigned)q * stride) * g.n2p + c;
                 E::st(al, asz, at, E::add(E::ld(al, asz, at), inner[q]));
             }
         }
     };
+    // Wave 0 is the DIVIDER: it owns the critical path — the lock-step division of every row — and, while it divides row
+    // k1, it already forms the term res[k1] (*) y[1] of row k1 + 1 from the quotient coefficients as they appear (the same
+    // broadcast serves both), so row k1 + 1's dividend is complete the moment row k1 is.  The other waves are UPDATERS:
+    // during step k1 they add the term res[k1 - 1] (*) y[r - k1 + 1] to the rows r >= k1 + 1 they own.  Every row
+    // receives its terms in ascending order (the updaters' by construction, the divider's last), each term's product
+    // formed from zero: the reference's operations in the reference's order.
+    const unsigned nup = nw > 1 ? nw - 1 : 1;
+    const bool divider = wave == 0, updater = nw == 1 || wave >= 1;
+    const unsigned uidx = nw > 1 ? wave - 1 : 0;  // index among the updaters
+    const bool next_term = g.ny1 >= 2;
+    const V y1v = (next_term && c < g.ny2) ? E::ld(yl, ysz, (size_t)g.ny2p + c) : E::zero();  // y[1, c]
+    V next_dividend = divider ? dividend(0) : E::zero();
+    V inner_next = E::zero();  // divider: res[k1 - 1] (*) y[1], the last term of row k1
     for (unsigned k1 = 0; k1 < g.n1; ++k1) {
-        const unsigned owner = k1 % nw;
-        V xr = E::zero();  // the row finished in the previous step
-        if (k1 > 0 && col) xr = E::ld(fl, 128, (size_t)((k1 - 1) & 1) * 64 + c);
-        unsigned r = k1 + ((wave + nw - owner) % nw);  // first row >= k1 this wave owns
-        if (wave == owner) {
-            __builtin_amdgcn_s_setprio(3);  // the critical path of the slab: this wave's row must not wait for the updates of the other 15
-            unsigned own_group = 1;
-            if (k1 > 0) {  // the row about to be divided together with the next rows this wave owns: same latency as one
-                const unsigned left = (g.n1 - 1 - k1) / nw + 1;
-                own_group = left < (unsigned)G ? left : (unsigned)G;
-                apply_terms(k1, own_group, k1 - 1, xr);
-            }
-            // dividend row: cur = -acc; cur += x[k1]  (mt:1186-1188 at this level)
+        if (divider) {
+            // dividend row: acc += last term; cur = -acc; cur += x[k1]  (mt:1186-1188 at this level)
             V t = E::zero();
-            if (col) t = E::neg(E::ld(al, asz, (size_t)k1 * g.n2p + c));
+            if (col) {
+                V a0 = E::ld(al, asz, (size_t)k1 * g.n2p + c);
+                if (k1 > 0 && next_term) a0 = E::add(a0, inner_next);
+                t = E::neg(a0);
+            }
             const bool has_div = g.fused || (k1 < g.nx1);
             if (col && has_div && (g.fused || c < g.nx2)) t = E::add(t, next_dividend);
-            // 1-d division by y[0, :], lock step over j
-            V cur1 = E::zero(), ys = y0v, mine = E::zero();
+            next_dividend = dividend(k1 + 1);  // in flight during the division below
+            // 1-d division by y[0, :], lock step over j, and the next row's last term on the same broadcast
+            V cur1 = E::zero(), ys = y0v, y1s = y1v, mine = E::zero();
+            inner_next = E::zero();
+            const bool want_next = next_term && k1 + 1 < g.n1;
             for (unsigned j = 0; j < g.n2; ++j) {
                 const V q = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
                 if (c == j) mine = q;
-                // ys = y[0, c - j] after j shifts.  Lanes c <= j are past their own step (their sum no longer matters), so
-                // the lower bound needs no mask; the upper one (c - j >= ny2) multiplies by a shifted-in zero, which only a
-                // non-finite quotient coefficient could turn into something (then the select keeps the reference's bounds).
+                // ys = y[0, c - j], y1s = y[1, c - j] after j shifts.  Lanes c <= j are past their own step (their sum no
+                // longer matters), so cur1's lower bound needs no mask; the other excluded positions multiply by a
+                // shifted-in zero, which only a non-finite quotient coefficient could turn into something (then the
+                // selects keep the reference's bounds).
+                const bool fin = elem_finite<E>(q);
                 const V upd = E::add(cur1, E::mul(q, ys));
-                if (elem_finite<E>(q) || (col && c > j && c - j < g.ny2)) cur1 = upd;
+                if (fin || (col && c > j && c - j < g.ny2)) cur1 = upd;
+                if (want_next) {
+                    const V nxt = E::add(inner_next, E::mul(q, y1s));
+                    if (fin || (col && c >= j && c - j < g.ny2)) inner_next = nxt;
+                    y1s = wave_shr1<E>(y1s);
+                }
                 ys = wave_shr1<E>(ys);
             }
-            __builtin_amdgcn_s_setprio(0);
             if (col) {
                 E::st(fl, 128, (size_t)(k1 & 1) * 64 + c, mine);
                 E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
             }
-            next_dividend = dividend(k1 + nw);
-            r += own_group * nw;
         }
-        if (k1 > 0)
-            for (; r < g.n1; r += G * nw) {
-                const unsigned left = (g.n1 - 1 - r) / nw + 1;  // rows r, r + nw, .. below n1
-                apply_terms(r, left < (unsigned)G ? left : (unsigned)G, k1 - 1, xr);
+        if (updater && k1 > 0) {
+            // term j1 = k1 - 1 into the rows r >= k1 + 1 of this updater (r = uidx mod nup)
+            V xr = E::zero();
+            if (col) xr = E::ld(fl, 128, (size_t)((k1 - 1) & 1) * 64 + c);
+            unsigned r = k1 + 1 + ((uidx + nup - (k1 + 1) % nup) % nup);
+            for (; r < g.n1; r += G * nup) {
+                const unsigned left = (g.n1 - 1 - r) / nup + 1;
+                apply_terms(r, nup, left < (unsigned)G ? left : (unsigned)G, k1 - 1, xr);
             }
-        __syncthreads();  // row k1 is final (fl), every accumulator row holds the terms up to k1 - 1
+        }
+        __syncthreads();  // row k1 is final (fl); every accumulator row >= k1 + 1 holds the terms up to k1 - 1
     }
 }
 
