@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
         if (g.n2 <= 64) {
             if (wave == 0) {
                 for (unsigned j = 0; j < g.n2; ++j) {
-                    const V r = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
+                    const V r = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
                     if (k2 == j) mine = r;
                     if (owner && k2 > j && j >= lo2) cur1 = E::add(cur1, E::mul(r, E::ld(yl, ysz, k2 - j)));
                 }
@@ -315,7 +315,10 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             inner_next = E::zero();
             const bool want_next = next_term && k1 + 1 < g.n1;
             for (unsigned j = 0; j < g.n2; ++j) {
-                const V q = bcast_lane<E>(div_y00(E::add(E::neg(cur1), t)), j);
+                // lane j's numerator first, THEN the division on the (now wave-uniform) value: the exponent-window test of
+                // the fast division is then a uniform branch — dividing per lane and broadcasting the quotient made the
+                // idle lanes (zeros: outside the window) drag every step through the full division as well
+                const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
                 if (c == j) mine = q;
                 // ys = y[0, c - j], y1s = y[1, c - j] after j shifts.  Lanes c <= j are past their own step (their sum no
                 // longer matters), so cur1's lower bound needs no mask; the other excluded positions multiply by a
