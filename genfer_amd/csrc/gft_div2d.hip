@@ -313,26 +313,34 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             // 1-d division by y[0, :], lock step over j, and the next row's last term on the same broadcast
             V cur1 = E::zero(), ys = y0v, y1s = y1v, mine = E::zero();
             inner_next = E::zero();
-            const bool want_next = next_term && k1 + 1 < g.n1;
+            // ys = y[0, c - j], y1s = y[1, c - j] after j shifts.  Branch-free body (every branch in this loop is paid 4096
+            // times a slab on the critical path): lanes c <= j are past their own step (their sum no longer matters), so
+            // cur1's lower bound needs no mask; the other positions the reference's bounds exclude multiply by a shifted-in
+            // zero, which only a NON-FINITE quotient coefficient could turn into something — the loop notes whether one
+            // appeared and the row is then redone with the bounds as selects.
+            bool all_finite = true;
             for (unsigned j = 0; j < g.n2; ++j) {
                 // lane j's numerator first, THEN the division on the (now wave-uniform) value: the exponent-window test of
-                // the fast division is then a uniform branch — dividing per lane and broadcasting the quotient made the
-                // idle lanes (zeros: outside the window) drag every step through the full division as well
+                // the fast division is a uniform branch
                 const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
+                all_finite = all_finite && elem_finite<E>(q);
                 if (c == j) mine = q;
-                // ys = y[0, c - j], y1s = y[1, c - j] after j shifts.  Lanes c <= j are past their own step (their sum no
-                // longer matters), so cur1's lower bound needs no mask; the other excluded positions multiply by a
-                // shifted-in zero, which only a non-finite quotient coefficient could turn into something (then the
-                // selects keep the reference's bounds).
-                const bool fin = elem_finite<E>(q);
-                const V upd = E::add(cur1, E::mul(q, ys));
-                if (fin || (col && c > j && c - j < g.ny2)) cur1 = upd;
-                if (want_next) {
-                    const V nxt = E::add(inner_next, E::mul(q, y1s));
-                    if (fin || (col && c >= j && c - j < g.ny2)) inner_next = nxt;
+                cur1 = E::add(cur1, E::mul(q, ys));
+                inner_next = E::add(inner_next, E::mul(q, y1s));
+                ys = wave_shr1<E>(ys);
+                y1s = wave_shr1<E>(y1s);
+            }
+            if (!all_finite) {
+                cur1 = E::zero(), ys = y0v, y1s = y1v, mine = E::zero();
+                inner_next = E::zero();
+                for (unsigned j = 0; j < g.n2; ++j) {
+                    const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
+                    if (c == j) mine = q;
+                    if (col && c > j && c - j < g.ny2) cur1 = E::add(cur1, E::mul(q, ys));
+                    if (col && c >= j && c - j < g.ny2) inner_next = E::add(inner_next, E::mul(q, y1s));
+                    ys = wave_shr1<E>(ys);
                     y1s = wave_shr1<E>(y1s);
                 }
-                ys = wave_shr1<E>(ys);
             }
             if (col) {
                 E::st(fl, 128, (size_t)(k1 & 1) * 64 + c, mine);
