@@ -880,6 +880,35 @@ struct Ops {
     }
     static P neg(const P& a) { return map_copy(a, OP_NEG, nullptr); }
 
+    // a + b * from(c) — the accumulation step of the reference's negative-binomial observation (gf.rs:743-746:
+    // `sum += term * TaylorPoly::from(lah)`) — in one pass, no intermediate tensor: per element (0 + a) + (c * b), the
+    // operations of Mul's constant path (mt:1041-1047) and of Add (mt:873-880) in their order.  Everything that is not
+    // the general case (scalar operands, c = 0 / 1 / non-finite) takes the two reference calls.
+    static P add_scaled(const P& a, const P& b, const double* c) {
+        auto unfused = [&]() { return addsub(a, mul(b, scalar(c)), false); };
+        if (a.numel == 1 || b.numel == 1 || val_is_zero(c) || val_is_one(c)) return unfused();
+        for (int i = 0; i < W; ++i)
+            if (!(c[i] - c[i] == 0.0)) return unfused();
+        P self = a, other = b;  // other = b * c has b's shape and degrees
+        Dims rd = min_degrees(self, other);
+        broadcast(self, other);
+        self = truncate_degrees(self, rd);
+        other = truncate_degrees(other, rd);
+        if (self.numel == 1 || other.numel == 1) return unfused();
+        Dims shape = max_shape(self, other);
+        const bool host = tier_host(prod(shape), self, other);
+        P out = make(shape, rd, host);
+        Dims keep = collapse_mask({&shape}, false);
+        HV vo = view(out, host), va = view(self, host), vb = view(other, host);
+        const Scalar2 cs{c[0], W == 2 ? c[1] : 0.0};
+        if (host) {
+            HK<E>::add_scaled_padded(dview(vo, &keep), dview(va, &keep), dview(vb, &keep), cs);
+            return seal(out);
+        }
+        K<E>::add_scaled_padded(R.stream, dview(vo, &keep), dview(va, &keep), dview(vb, &keep), cs);
+        return out;
+    }
+
     // ---- extract_linear (mt:275-294) --------------------------------------------------------------------
     static bool extract_linear(const P& p, double c[2], double m[2], size_t* var) {
         unsigned mask = 0;
@@ -2822,6 +2851,9 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
     gft_poly* PFX##add(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::addsub(*a, *b, false); }); } \
     gft_poly* PFX##sub(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::addsub(*a, *b, true); }); } \
     gft_poly* PFX##neg(const gft_poly* a) { return guard([&] { return Ops<E>::neg(*a); }); }                  \
+    gft_poly* PFX##add_scaled(const gft_poly* a, const gft_poly* b, const double* c) {                        \
+        return guard([&] { return Ops<E>::add_scaled(*a, *b, c); });                                          \
+    }                                                                                                         \
     gft_poly* PFX##mul(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::mul(*a, *b); }); } \
     gft_poly* PFX##div(const gft_poly* a, const gft_poly* b) { return guard([&] { return Ops<E>::div(*a, *b); }); } \
     gft_poly* PFX##exp(const gft_poly* a) { return guard([&] { return Ops<E>::exp(*a); }); }                  \

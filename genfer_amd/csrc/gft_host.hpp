@@ -94,6 +94,30 @@ struct HK {
         }
     }
 
+    static void add_scaled_padded(const DView& out, const DView& a, const DView& b, Scalar2 c) {
+        const size_t total = numel(out.sh);
+        const V cv = E::from(c);
+        for (size_t lin = 0; lin < total; ++lin) {
+            size_t r = lin, aoff = 0, boff = 0, astr = 1, bstr = 1;
+            bool ina = true, inb = true;
+            for (int ax = out.sh.nd - 1; ax >= 0; --ax) {
+                const unsigned d = out.sh.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                if (k >= a.sh.d[ax]) ina = false;
+                if (k >= b.sh.d[ax]) inb = false;
+                aoff += k * astr;
+                boff += k * bstr;
+                astr *= a.sh.d[ax];
+                bstr *= b.sh.d[ax];
+            }
+            V v = E::zero();
+            if (ina) v = E::add(v, E::ld(a.p, a.plane, aoff));
+            if (inb) v = E::add(v, E::mul(cv, E::ld(b.p, b.plane, boff)));
+            E::st(out.p, out.plane, lin, v);
+        }
+    }
+
     // k_copy_first
     static void copy_first(const double* src, size_t sp, double* dst, size_t dp, size_t n, int op, Scalar2 sv) {
         for (size_t i = 0; i < n; ++i) {

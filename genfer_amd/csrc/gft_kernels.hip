@@ -168,6 +168,40 @@ __global__ void __launch_bounds__(256) k_addsub_padded(DView out, DView a, DView
     }
 }
 
+template <class E>
+__global__ void __launch_bounds__(256) k_add_scaled_padded(DView out, DView a, DView b, Scalar2 c, size_t total) {
+    typedef typename E::V V;
+    const V cv = E::from(c);
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, aoff = 0, boff = 0, astr = 1, bstr = 1;
+        bool ina = true, inb = true;
+#pragma unroll 1
+        for (int ax = out.sh.nd - 1; ax >= 0; --ax) {
+            unsigned d = out.sh.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            if (k >= a.sh.d[ax]) ina = false;
+            if (k >= b.sh.d[ax]) inb = false;
+            aoff += k * astr;
+            boff += k * bstr;
+            astr *= a.sh.d[ax];
+            bstr *= b.sh.d[ax];
+        }
+        V v = E::zero();
+        if (ina) v = E::add(v, E::ld(a.p, a.plane, aoff));
+        if (inb) v = E::add(v, E::mul(cv, E::ld(b.p, b.plane, boff)));
+        E::st(out.p, out.plane, lin, v);
+    }
+}
+template <class E>
+void K<E>::add_scaled_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, Scalar2 c) {
+    size_t total = 1;
+    for (int i = 0; i < out.sh.nd; ++i) total *= out.sh.d[i];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_add_scaled_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, c, total);
+}
+
 // Equal shapes (the common case): 1-D, two f64 per thread.  Same per-element order: (0 + a) (+|-) b.
 __global__ void __launch_bounds__(256) k_addsub_f64x2(const double* __restrict__ a, const double* __restrict__ b,
                                                       double* __restrict__ out, size_t pairs, int subtract) {

@@ -172,6 +172,8 @@ struct K {
                        const GatherArgs& a);
     // out[k] = ((0 + a[k]?) +/- b[k]?) with a, b leading blocks of out's shape  (mt:873-880, 927-934)
     static void addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract);
+    // out[k] = (0 + a[k]?) + (c * b[k])?   — Add of a and the constant multiple c * b in one pass (mt:873-880 after mt:1041-1047)
+    static void add_scaled_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, Scalar2 c);
     // dst = copy of src (n contiguous elements) with element 0 replaced by src[0] (+|-) s; FIRST_SUB_NEG_ALL:
     // dst[0] = -(src[0] - s), dst[i>0] = -src[i]  (mt:862-868, 919-925 in one launch)
     static void copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n,

@@ -49,6 +49,7 @@ struct Api {
     void* (*mul)(const void*, const void*);
     void* (*div)(const void*, const void*);
     void* (*neg)(const void*);
+    void* (*add_scaled)(const void*, const void*, const double*);
     void* (*exp)(const void*);
     void* (*log)(const void*);
     void* (*pow)(const void*, uint32_t);
@@ -83,7 +84,7 @@ struct Api {
         GFH_BIND(var_with_degrees_p1); GFH_BIND(clone); GFH_BIND(free); GFH_BIND(num_vars); GFH_BIND(numel);
         GFH_BIND(shape); GFH_BIND(degrees_p1); GFH_BIND(to_host); GFH_BIND(is_zero); GFH_BIND(is_one);
         GFH_BIND(constant_term); GFH_BIND(extract_constant); GFH_BIND(coefficient); GFH_BIND(add); GFH_BIND(sub);
-        GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
+        GFH_BIND(mul); GFH_BIND(div); GFH_BIND(neg); GFH_BIND(add_scaled); GFH_BIND(exp); GFH_BIND(log); GFH_BIND(pow);
         GFH_BIND(derivative); GFH_BIND(taylor_expansion_of_coeff); GFH_BIND(shift_down); GFH_BIND(subst_var); GFH_BIND(observe_step); GFH_BIND(derive_scale); GFH_BIND(observe_chain); GFH_BIND(derivative_truncated);
         GFH_BIND(coefficients_of_term); GFH_BIND(taylor_polynomial_terms); GFH_BIND(truncate_to_degree_p1);
         GFH_BIND(remove_last_variable); GFH_BIND(extend_to_dim);
@@ -218,6 +219,11 @@ class Poly {
         std::vector<double> cb(cs.size() * T::WIDTH + 2);
         for (size_t i = 0; i < cs.size(); ++i) cs[i].store(cb.data() + i * T::WIDTH);
         return traced("observe_chain", nel(*this), wrap(api().observe_chain(h(), v, xb, cb.data(), cs.size(), d)));
+    }
+    Poly add_scaled(const Poly& o, const T& c) const {  // *this + o * from(c)
+        double cb[2];
+        c.store(cb);
+        return traced("add_scaled", std::max(nel(*this), nel(o)), wrap(api().add_scaled(h(), o.h(), cb)));
     }
     Poly derive_scale(size_t v, const T& c, size_t d) const {
         double cb[2];

@@ -455,7 +455,7 @@ struct GenFun {
             TP p_pv = TP::from(pr) * pv_tp;
             for (const T& lah : lahs_cur) {
                 TP subst = TP::from(pr) * TP::var_at_zero(pv, degree_p1);
-                sum = sum + inner_result.subst_var(pv, subst) * p_pow * TP::from(lah);
+                sum = sum.add_scaled(inner_result.subst_var(pv, subst) * p_pow, lah);  // sum + (term * from(lah)), one pass
                 p_pow = p_pow * p_pv;
                 inner_result = inner_result.derivative(pv, 1);
             }

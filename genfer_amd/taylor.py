@@ -69,6 +69,7 @@ HANDLE_API = {
     "mul": (_VP, [_VP, _VP]),
     "div": (_VP, [_VP, _VP]),
     "neg": (_VP, [_VP]),
+    "add_scaled": (_VP, [_VP, _VP, _DP]),
     "exp": (_VP, [_VP]),
     "log": (_VP, [_VP]),
     "pow": (_VP, [_VP, C.c_uint32]),
@@ -305,6 +306,10 @@ def bind(lib: C.CDLL, prefix: str):
                 flat += list(scal(c))
             buf = (C.c_double * max(len(flat), 1))(*flat)
             return type(self)(fn.observe_chain(self._h, v, scal(x), buf, len(cs), degree_p1))
+
+        def add_scaled(self, other: "TaylorPoly", c):
+            """Fused self + other * from(c)  (gf.rs:743-746)."""
+            return type(self)(fn.add_scaled(self._h, other._h, scal(c)))
 
         def derive_scale(self, v: int, c, degree_p1: int):
             """Fused derivative(v,1).truncate(d) * c  (continuous-Poisson observation step, gf.rs:703-706)."""

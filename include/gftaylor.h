@@ -161,6 +161,9 @@ int gft_coefficient(const gft_poly* p, const size_t* index, size_t n, double* ou
 /* ---- algebra ------------------------------------------------------------------------------ */
 gft_poly* gft_add(const gft_poly* a, const gft_poly* b);                /* Add                    mt:854-882 */
 gft_poly* gft_sub(const gft_poly* a, const gft_poly* b);                /* Sub                    mt:911-937 */
+/* a + b * from(c) in one pass (the accumulation `sum += term * TaylorPoly::from(lah)` of the negative-binomial
+ * observation, generating_function.rs:743-746): per element (0 + a) + (c * b), same operations and order as the two calls. */
+gft_poly* gft_add_scaled(const gft_poly* a, const gft_poly* b, const double* c);
 gft_poly* gft_neg(const gft_poly* a);                                   /* Neg                    mt:902-909 */
 gft_poly* gft_mul(const gft_poly* a, const gft_poly* b);                /* Mul + mul/mul_1d       mt:971-1072 */
 gft_poly* gft_div(const gft_poly* a, const gft_poly* b);                /* Div + div              mt:1162-1231 */
@@ -231,6 +234,7 @@ int gfti_extract_linear(const gft_poly* p, double* c, double* m, size_t* v);
 int gfti_coefficient(const gft_poly* p, const size_t* index, size_t n, double* out);
 gft_poly* gfti_add(const gft_poly* a, const gft_poly* b);
 gft_poly* gfti_sub(const gft_poly* a, const gft_poly* b);
+gft_poly* gfti_add_scaled(const gft_poly* a, const gft_poly* b, const double* c);
 gft_poly* gfti_neg(const gft_poly* a);
 gft_poly* gfti_mul(const gft_poly* a, const gft_poly* b);
 gft_poly* gfti_div(const gft_poly* a, const gft_poly* b);

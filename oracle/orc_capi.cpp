@@ -210,6 +210,9 @@ static std::string format_poly(const P<S>& p, bool debug) {
                                                    P<S>::var(v, Tr<S>::load(x), d)),                            \
                                         P<S>::from_scalar(Tr<S>::load(c)))))                                  \
     }                                                                                                      \
+    void* PFX##add_scaled(const void* a, const void* b, const double* c) {                                 \
+        ORC_TRY((void*)new P<S>(P<S>::add(*(const P<S>*)a, P<S>::mul(*(const P<S>*)b, P<S>::from_scalar(Tr<S>::load(c)))))) \
+    }                                                                                                      \
     void* PFX##observe_chain(const void* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
         /* n times the unfused reference sequence, innermost first, each level one degree lower */           \
         try {                                                                                              \

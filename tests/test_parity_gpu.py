@@ -771,3 +771,31 @@ def test_observe_chain_fused_equals_stepwise_reference(interval, OTP, GTP, OTPI,
         for bad in (0.0, float("inf"), float("nan")):
             cs = [sc(0.5), sc(bad), sc(0.25)]
             check(o.observe_chain(v, sc(0.3), cs, 5), g.observe_chain(v, sc(0.3), cs, 5))
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_add_scaled_fused_equals_reference_sequence(interval, OTP, GTP, OTPI, GTPI):
+    """gft_add_scaled(a, b, c) = a + b * from(c) in one pass (the Lah-number accumulation of the negative-binomial
+    observation, generating_function.rs:743-746): bit-identical to the two reference calls, ragged shapes, different
+    degrees, scalar operands and c in {0, 1, -1, inf, nan} included."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + np.abs(a) * 1e-12])) if interval else (lambda a: a)
+    sc = (lambda c: (c, c + abs(c) * 1e-12)) if interval else (lambda c: c)
+    cases = [((5,), [7], (3,), [6]), ((3, 4), [5, 5], (4, 2), [4, 6]), ((2, 3, 4), [4, 4, 4], (3, 1, 2), [3, 4, 5]),
+             ((60, 70), [64, 80], (64, 50), [64, 64]), ((1,), [4], (3,), [4]), ((3,), [4], (1,), [4])]
+    for sa, da, sb, db in cases:
+        a, b = rand(sa, 31, -1, 1), rand(sb, 32, -1, 1)
+        oa, ga, ob, gb = O.new(mk(a), da), G.new(mk(a), da), O.new(mk(b), db), G.new(mk(b), db)
+        for c in (0.375, -2.0, 1.0, 0.0, -1.0, float("inf"), float("nan")):
+            check(oa.add_scaled(ob, sc(c)), ga.add_scaled(gb, sc(c)))
+    # the whole negative-binomial observation path
+    src = "X ~ Poisson(4.5);\nobserve 7 ~ NegBinomial(X, 0.25);\nreturn X;\n"
+    import os
+    import genfer_amd
+    from conftest import ROOT
+
+    flags = "--no-timing --limit 12" + (" --bounds" if interval else "")
+    rc, want, _ = genfer_amd.run_sgcl_with_backend(src, flags, os.path.join(ROOT, "oracle", "liborc.so"), "orci_" if interval else "orc_")
+    assert rc == 0, want
+    got, _ = genfer_amd.run_sgcl(src, flags)
+    assert got == want

@@ -14,6 +14,54 @@ __device__ inline double wave_shr1_f64(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ inline double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// G independent chains sharing one readlane broadcast (the shape of k_div_2d_rows64's update loop); CTRL = DPP control:
+// 0x138 wave_shr:1 (crosses the 16-lane rows), 0x111 row_shr:1 (stays inside them)
+template <int G, int CTRL>
+__global__ void kg(double* out, long long* cycles, int reps, int n2) {
+    const unsigned c = threadIdx.x & 63;
+    double xr = 1.0 + c * 1e-3, acc = 0.0;
+    long long t0 = wall_clock64();
+    for (int r = 0; r < reps; ++r) {
+        double ys[G], inner[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) ys[q] = 0.5 + c * 1e-3 + r + q, inner[q] = 0.0;
+#pragma unroll 2
+        for (int j2 = 0; j2 < n2; ++j2) {
+            const double xs = bcast_f64(xr, j2);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                inner[q] = inner[q] + xs * ys[q];
+                ys[q] = dpp_f64<CTRL>(ys[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) acc += inner[q];
+        xr += 1e-9;
+    }
+    long long t1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+template <int G, int CTRL>
+void rung(const char* name, double* out, long long* cyc) {
+    for (int waves : {1, 4, 8, 16}) {
+        const int reps = 200, n2 = 64;
+        hipLaunchKernelGGL((kg<G, CTRL>), dim3(1), dim3(64 * waves), 0, 0, out, cyc, reps, n2);
+        hipDeviceSynchronize();
+        long long c;
+        hipMemcpy(&c, cyc, sizeof c, hipMemcpyDeviceToHost);
+        printf("%-34s waves/CU %2d: %8.1f ns per 64-step group of %d row products, %6.2f ns per step (cycles @2.4 GHz: %6.1f, per chain %5.1f)\n", name,
+               waves, c * 10.0 / reps, G, c * 10.0 / reps / n2, c * 10.0 / reps / n2 * 2.4, c * 10.0 / reps / n2 * 2.4 / G);
+    }
+}
+
 // mode bit 0: readlane broadcast (else a per-lane constant); bit 1: DPP shift (else none); bit 2: LDS operands instead
 template <int MODE>
 __global__ void k(double* out, long long* cycles, int reps, int n2) {
@@ -69,5 +117,9 @@ int main() {
     run<2>("dpp shift + mul+add", out, cyc);
     run<3>("readlane + dpp + mul+add (kernel)", out, cyc);
     run<4>("two LDS reads + mul+add", out, cyc);
+    rung<5, 0x138>("5 chains, wave_shr:1", out, cyc);
+    rung<5, 0x111>("5 chains, row_shr:1", out, cyc);
+    rung<2, 0x138>("2 chains, wave_shr:1", out, cyc);
+    rung<8, 0x111>("8 chains, row_shr:1", out, cyc);
     return 0;
 }
