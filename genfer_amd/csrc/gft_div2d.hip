@@ -198,6 +198,18 @@ template <>
 __device__ inline bool elem_finite<EF64>(double v) { return finite_d(v); }
 template <>
 __device__ inline bool elem_finite<EIv>(Iv v) { return EIv::is_finite(v); }
+__device__ inline double row_shr1_f64(double x) {  // lane l of every 16-lane row takes lane l-1's value, lane 0 takes 0
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);  // row_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <class E>
+__device__ inline typename E::V row_shr1(typename E::V v);
+template <>
+__device__ inline double row_shr1<EF64>(double v) { return row_shr1_f64(v); }
+template <>
+__device__ inline Iv row_shr1<EIv>(Iv v) { return Iv{row_shr1_f64(v.lo), row_shr1_f64(v.hi)}; }
 template <class E>
 __device__ inline typename E::V wave_shr1(typename E::V v);
 template <>
@@ -237,51 +249,82 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         }
         return d;
     };
-    // Term res[j1] (*) y[r - j1] into the accumulator rows r = r0, r0 + stride, .. (up to G of them, all owned by this
-    // wave); xr = the final row j1, one coefficient per lane.  A row product is one dependent chain per lane (readlane
-    // -> mul -> add, and the DPP shift of y): ~85 cycles a step whatever the occupancy (tools/microbench_rowconv.hip).
-    // The rows a wave owns share the x broadcast and are independent chains, so they are advanced TOGETHER: G products
-    // for little more than the latency of one.
-    constexpr int G = 5;
-    auto apply_terms = [&](unsigned r0, unsigned stride, unsigned cnt, unsigned j1, V xr) {
-        V ys[G], inner[G];
-        bool act[G];
+    // UPDATER layout: a wave is four 16-lane DPP rows, each row of lanes serves ONE accumulator row r, and lane l of it
+    // owns the four coefficients c = 4l .. 4l+3 — a register-tiled sliding window: at step j2 the lane needs
+    // y[d, c - j2] for its four c; stepping j2 shifts that window by one, three of the four values stay in the lane (a
+    // register rotation, free under 4x unrolling) and one arrives from the left neighbour by a DPP row_shr:1 — the
+    // cheap intra-row kind (a wave-wide shift costs ~25 cycles of issue per 64-bit value, tools/microbench_rowconv.hip).
+    // The x coefficient of the step is one v_readlane shared by all 256 multiply-adds of the wave.  Per output still
+    // ascending j2 from zero, so still the reference's bits; four accumulator rows per wave and step, 60 per pass of
+    // the 15 updaters.
+    const unsigned nup = nw > 1 ? nw - 1 : 1;
+    const unsigned uidx = nw > 1 ? wave - 1 : 0;  // index among the updaters
+    const unsigned drow = c >> 4, dl = c & 15u;
+    auto apply_terms4 = [&](unsigned r_first, unsigned n_rows, unsigned j1) {
+        // this DPP row's accumulator row (rows r_first + 4 * uidx + drow, then + 4 * nup per pass)
+        for (unsigned base = r_first + 4 * uidx; base < r_first + n_rows; base += 4 * nup) {
+            const unsigned r = base + drow;
+            const unsigned d = r - j1;
+            const bool act = r < r_first + n_rows && d < g.ny1;  // no such y row: the reference's bound lo1 excludes the term
+            V xl[4], w[4], inner[4];
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            const unsigned d = r0 + (unsigned)q * stride - j1;
-            act[q] = (unsigned)q < cnt && d < g.ny1;  // no such y row: the reference's lower bound lo1 excludes the term
-            ys[q] = (act[q] && c < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + c) : E::zero();
-            inner[q] = E::zero();
-        }
-        if (!any_lane(!elem_finite<E>(xr))) {
-            // Finite row: the positions the reference's bounds exclude (c < j2, c - j2 >= ny2) hold an exact zero in
-            // `ys` (shifted in at lane 0 / beyond the row), and  inner + x * 0 == inner  for finite x — a sum that started
-            // from +0 is never -0, and [0,0] short-circuits the interval operations — so the masks can go: same bits.
-#pragma unroll 2
-            for (unsigned j2 = 0; j2 < g.n2; ++j2) {
-                const V xs = bcast_lane<E>(xr, j2);
+            for (int e = 0; e < 4; ++e) {
+                const unsigned cc = 4 * dl + e;
+                xl[e] = cc < g.n2 ? E::ld(fl, 128, (size_t)(j1 & 1) * 64 + cc) : E::zero();
+                w[e] = (act && cc < g.ny2) ? E::ld(yl, ysz, (size_t)d * g.ny2p + cc) : E::zero();
+                inner[e] = E::zero();
+            }
+            bool fin = true;
 #pragma unroll
-                for (int q = 0; q < G; ++q) {
-                    inner[q] = E::add(inner[q], E::mul(xs, ys[q]));
-                    ys[q] = wave_shr1<E>(ys[q]);
+            for (int e = 0; e < 4; ++e) fin = fin && elem_finite<E>(xl[e]);
+            const unsigned steps = (g.n2 + 3) / 4;  // groups of four j2
+            if (!any_lane(!fin)) {
+                // finite x row: excluded positions multiply an exact zero (shifted in at lane 0 of the row / beyond y's
+                // row), inner + x * 0 == inner — no masks (see the divider's loop)
+                for (unsigned jg = 0; jg < steps; ++jg) {
+                    const V x0 = bcast_lane<E>(xl[0], jg), x1 = bcast_lane<E>(xl[1], jg), x2 = bcast_lane<E>(xl[2], jg), x3 = bcast_lane<E>(xl[3], jg);
+                    const V t1 = row_shr1<E>(w[3]), t2 = row_shr1<E>(w[2]), t3 = row_shr1<E>(w[1]), t4 = row_shr1<E>(w[0]);
+                    // j2 = 4 jg: window (w0, w1, w2, w3)
+                    inner[0] = E::add(inner[0], E::mul(x0, w[0])); inner[1] = E::add(inner[1], E::mul(x0, w[1]));
+                    inner[2] = E::add(inner[2], E::mul(x0, w[2])); inner[3] = E::add(inner[3], E::mul(x0, w[3]));
+                    // j2 + 1: (t1, w0, w1, w2)
+                    inner[0] = E::add(inner[0], E::mul(x1, t1)); inner[1] = E::add(inner[1], E::mul(x1, w[0]));
+                    inner[2] = E::add(inner[2], E::mul(x1, w[1])); inner[3] = E::add(inner[3], E::mul(x1, w[2]));
+                    // j2 + 2: (t2, t1, w0, w1)
+                    inner[0] = E::add(inner[0], E::mul(x2, t2)); inner[1] = E::add(inner[1], E::mul(x2, t1));
+                    inner[2] = E::add(inner[2], E::mul(x2, w[0])); inner[3] = E::add(inner[3], E::mul(x2, w[1]));
+                    // j2 + 3: (t3, t2, t1, w0)
+                    inner[0] = E::add(inner[0], E::mul(x3, t3)); inner[1] = E::add(inner[1], E::mul(x3, t2));
+                    inner[2] = E::add(inner[2], E::mul(x3, t1)); inner[3] = E::add(inner[3], E::mul(x3, w[0]));
+                    w[0] = t4; w[1] = t3; w[2] = t2; w[3] = t1;
+                }
+            } else {
+                // a non-finite coefficient in the x row: the reference's bounds as selects (c >= j2, c - j2 < ny2)
+                for (unsigned jg = 0; jg < steps; ++jg) {
+                    const V xq[4] = {bcast_lane<E>(xl[0], jg), bcast_lane<E>(xl[1], jg), bcast_lane<E>(xl[2], jg), bcast_lane<E>(xl[3], jg)};
+                    const V t1 = row_shr1<E>(w[3]), t2 = row_shr1<E>(w[2]), t3 = row_shr1<E>(w[1]), t4 = row_shr1<E>(w[0]);
+                    const V win[4][4] = {{w[0], w[1], w[2], w[3]}, {t1, w[0], w[1], w[2]}, {t2, t1, w[0], w[1]}, {t3, t2, t1, w[0]}};
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm) {
+                        const unsigned j2 = 4 * jg + sgm;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned cc = 4 * dl + e;
+                            if (j2 < g.n2 && cc < g.n2 && cc >= j2 && cc - j2 < g.ny2) inner[e] = E::add(inner[e], E::mul(xq[sgm], win[sgm][e]));
+                        }
+                    }
+                    w[0] = t4; w[1] = t3; w[2] = t2; w[3] = t1;
                 }
             }
-        } else {
-            for (unsigned j2 = 0; j2 < g.n2; ++j2) {
-                const V xs = bcast_lane<E>(xr, j2);
+            if (act) {
 #pragma unroll
-                for (int q = 0; q < G; ++q) {
-                    if (col && c >= j2 && c - j2 < g.ny2) inner[q] = E::add(inner[q], E::mul(xs, ys[q]));
-                    ys[q] = wave_shr1<E>(ys[q]);
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned cc = 4 * dl + e;
+                    if (cc < g.n2) {
+                        const size_t at = (size_t)r * g.n2p + cc;
+                        E::st(al, asz, at, E::add(E::ld(al, asz, at), inner[e]));
+                    }
                 }
-            }
-        }
-        if (col) {
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                if (!act[q]) continue;
-                const size_t at = (size_t)(r0 + (unsigned)q * stride) * g.n2p + c;
-                E::st(al, asz, at, E::add(E::ld(al, asz, at), inner[q]));
             }
         }
     };
@@ -291,9 +334,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
     // during step k1 they add the term res[k1 - 1] (*) y[r - k1 + 1] to the rows r >= k1 + 1 they own.  Every row
     // receives its terms in ascending order (the updaters' by construction, the divider's last), each term's product
     // formed from zero: the reference's operations in the reference's order.
-    const unsigned nup = nw > 1 ? nw - 1 : 1;
     const bool divider = wave == 0, updater = nw == 1 || wave >= 1;
-    const unsigned uidx = nw > 1 ? wave - 1 : 0;  // index among the updaters
     const bool next_term = g.ny1 >= 2;
     const V y1v = (next_term && c < g.ny2) ? E::ld(yl, ysz, (size_t)g.ny2p + c) : E::zero();  // y[1, c]
     V next_dividend = divider ? dividend(0) : E::zero();
@@ -347,16 +388,8 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
                 E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
             }
         }
-        if (updater && k1 > 0) {
-            // term j1 = k1 - 1 into the rows r >= k1 + 1 of this updater (r = uidx mod nup)
-            V xr = E::zero();
-            if (col) xr = E::ld(fl, 128, (size_t)((k1 - 1) & 1) * 64 + c);
-            unsigned r = k1 + 1 + ((uidx + nup - (k1 + 1) % nup) % nup);
-            for (; r < g.n1; r += G * nup) {
-                const unsigned left = (g.n1 - 1 - r) / nup + 1;
-                apply_terms(r, nup, left < (unsigned)G ? left : (unsigned)G, k1 - 1, xr);
-            }
-        }
+        if (updater && k1 > 0 && k1 + 1 < g.n1)
+            apply_terms4(k1 + 1, g.n1 - (k1 + 1), k1 - 1);  // term j1 = k1 - 1 into the rows r >= k1 + 1
         __syncthreads();  // row k1 is final (fl); every accumulator row >= k1 + 1 holds the terms up to k1 - 1
     }
 }

@@ -51,7 +51,7 @@ python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e >
 python3 tools/bench_recurrence.py > "$OUT/summary/recurrences.txt" 2> "$OUT/rec.err"
 python3 tools/bench_interval.py > "$OUT/summary/interval_product.txt" 2> "$OUT/iv.err"
 python3 tools/xover_host.py > "$OUT/summary/xover_host.txt" 2> "$OUT/xover.err"
-python3 tools/bench_e2e.py --limit 100 --runs 2 --bounds --only approx > "$OUT/e2e_bounds.log" 2>&1; tail -1 "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.json"
+python3 tools/bench_e2e.py --limit 100 --runs 2 --bounds --only approx --gpu-only > "$OUT/e2e_bounds.log" 2>&1; tail -1 "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.json"
 python3 tools/bench_streaming.py 384 > "$OUT/summary/streaming_384.json" 2> "$OUT/streaming.err"
 python3 tools/bench_staged.py > "$OUT/staged.log" 2>&1; cp gpurun_out/staged_vs_naive.json "$OUT/summary/" 2>/dev/null
 python3 tools/sweep_tiled.py > "$OUT/summary/tiled_size_sweep.txt" 2> "$OUT/sweep.err"
