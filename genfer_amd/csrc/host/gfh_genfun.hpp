@@ -29,6 +29,10 @@ struct GenFun {
         GenFun a, b;             // children (b: second operand / substitution)
         std::vector<T> coeffs;   // Polynomial
         Dims shape;
+        // used_vars() of this (immutable) node, memoised: the translation of `observe` asks for it on the whole growing
+        // DAG at every statement (semantics/gf.rs), which the reference answers with a fresh traversal each time
+        mutable bool uv_known = false;
+        mutable VarRange uv;
     };
     std::shared_ptr<const Node> p;
 
@@ -157,8 +161,7 @@ struct GenFun {
         return used_vars_with(cache);
     }
     VarRange used_vars_with(std::unordered_map<const Node*, VarRange>& cache) const {
-        auto it = cache.find(p.get());
-        if (it != cache.end()) return it->second;
+        if (p->uv_known) return p->uv;
         const Node& x = *p;
         VarRange r;
         switch (x.kind) {
@@ -171,7 +174,8 @@ struct GenFun {
             case TaylorCoeffAtZero: r = x.a.used_vars_with(cache).remove(x.var); break;
             case Derivative: case TaylorPolynomial: case TaylorCoeff: case ShiftTaylorAtZero: r = x.a.used_vars_with(cache); break;
         }
-        cache[p.get()] = r;
+        x.uv_known = true;
+        x.uv = r;
         return r;
     }
 
