@@ -1971,6 +1971,18 @@ struct Ops {
                 speculate = res_nonlinear_seen;
             }
             if (!speculate) {  // reference step; on the host tier the accumulator's scan is free
+                // Host-resident accumulator that is not linear, linear substitution: the step as ONE pass of the host tier
+                // (gft_host.hpp horner_linear: the element order of mul -> mul_linear -> add -> add, no intermediate
+                // tensors) — `--bounds` programs live on this path because subst - constant_term(subst) keeps a widened
+                // constant.  Linearity is re-checked on every step (a host scan), so the stored shapes are the reference's.
+                if (lin_known && on_host(res) && on_host(ca) && res.numel > 1 && res.shape.size() == deg.size()) {
+                    double c_[2], m_[2];
+                    size_t u_;
+                    if (!extract_linear(res, c_, m_, &u_)) {
+                        res = horner_linear_step(res, ca, v, i, c, m, w, deg);
+                        continue;
+                    }
+                }
                 res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
                 continue;
             }
@@ -2095,7 +2107,8 @@ struct Ops {
         Dims os = sh;
         if (!coeff_scalar)
             for (size_t ax = 0; ax < nd; ++ax) os[ax] = std::min(std::max(sh[ax], oc[ax]), deg[ax]);
-        P out = make(os, deg);
+        const bool host = tier_host(prod(os), res, ca);
+        P out = make(os, deg, host);
         Dims keep = collapse_mask({&os}, false);
         if (keep.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
         HornerArgs g;
@@ -2120,6 +2133,10 @@ struct Ops {
         g.c_zero = val_is_zero(c) ? 1 : 0;
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
+        if (host) {
+            HK<E>::horner_linear(hp<E>(res), res.numel, hp<E>(ca), ca.numel, hp<E>(out), out.numel, g);
+            return seal(out);
+        }
         K<E>::horner_linear(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), out.numel, g);
         return out;
     }

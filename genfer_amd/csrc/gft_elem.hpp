@@ -108,6 +108,12 @@ struct EIv {
     // add / mul are written as "compute the general result, then select" (no control flow): the hot
     // convolution loops run them once per MAC and divergent early returns cost more than the selects.
     GFT_HD static V add(V a, V b) {                                           // :126-139
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host pass: the reference's own if-chain (a CPU predicts these branches; the select form below is for lanes)
+        if (is_zero(a)) return b;
+        if (is_zero(b)) return a;
+        return widen(a.lo + b.lo, a.hi + b.hi);
+#endif
         V g = widen(a.lo + b.lo, a.hi + b.hi);
         const bool za = is_zero(a), zb = is_zero(b);
         g.lo = zb ? a.lo : g.lo;
@@ -118,6 +124,17 @@ struct EIv {
     }
     GFT_HD static V sub(V a, V b) { return add(a, neg(b)); }                  // :148-155
     GFT_HD static V mul(V a, V b) {                                           // :164-190
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if ((is_zero(a) && is_finite(b)) || (is_finite(a) && is_zero(b))) return zero();
+        if (is_one(a)) return b;
+        if (is_one(b)) return a;
+        if (a.lo == -1.0 && a.hi == -1.0) return neg(b);
+        if (b.lo == -1.0 && b.hi == -1.0) return neg(a);
+        {
+            const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
+            return widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
+        }
+#endif
         const double p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
         V g = widen(fmin_ref(fmin_ref(fmin_ref(p, q), r), s), fmax_ref(fmax_ref(fmax_ref(p, q), r), s));
         // the reference's short-circuits, lowest priority first so that the first match of its if-chain wins

@@ -317,6 +317,49 @@ struct HK {
         }
     }
 
+    // k_horner_linear: one Horner step res * (c + m eps_w) + coeff_i, the reference's element order (HornerArgs)
+    static void horner_linear(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g) {
+        const size_t total = numel(g.out);
+        const V cv = E::from(g.c), mv = E::from(g.m);
+        for (size_t lin = 0; lin < total; ++lin) {
+            size_t r = lin, roff = 0, aoff = g.a_base;
+            unsigned kw = 0;
+            bool in_p = true, in_r = true, in_c = true;
+            for (int ax = g.out.nd - 1; ax >= 0; --ax) {
+                const unsigned d = g.out.d[ax];
+                const unsigned k = (unsigned)(r % d);
+                r /= d;
+                if (k >= g.sh[ax]) in_p = false;
+                if (k >= g.rs[ax]) in_r = false;
+                if (k >= g.oc[ax]) in_c = false;
+                if (ax == g.w) kw = k;
+                roff += (size_t)k * g.rstr[ax];
+                aoff += (size_t)k * g.astr[ax];
+            }
+            V p = E::zero();
+            if (in_p) {
+                if (kw >= 1 && kw - 1 < g.upper) p = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);
+                if (!g.c_zero) {
+                    p = E::add0(p);
+                    if (in_r) {
+                        const V x = E::ld(res, rp, roff);
+                        p = E::add(p, g.c_one ? x : E::mul(cv, x));
+                    }
+                }
+            }
+            V v;
+            if (g.coeff_scalar) {
+                v = p;
+                if (lin == 0) v = E::add(p, E::ld(a, ap, g.a_base));
+            } else {
+                v = E::zero();
+                if (in_p) v = E::add0(p);
+                if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+            }
+            E::st(out, op, lin, v);
+        }
+    }
+
     static size_t count_neq(const double* a, size_t ap, const double* b, size_t bp, size_t n) {
         size_t c = 0;
         for (size_t i = 0; i < n; ++i)
