@@ -13,6 +13,7 @@
 // partial sums the leading-axis step just wrote into the quotient's own memory (the reference's neg + add + copy,
 // mt:1186-1189) — the quotient row overwrites it in place.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gft_kernels.hpp"
 
@@ -24,6 +25,8 @@ struct Div2dArgs {
     unsigned nx1, nx2;      // box of the dividend tensor x (0, 0: none)
     size_t x_rstride;       // row stride of x
     int fused;              // 1: dividend row = (-res_in_place[k1][k2]) (+ x[k1][k2] inside x's box)
+    int diag;               // timing diagnostics (GFT_DIV2D_DIAG, wrong results): 1 = no updater work, 2 = no division loop,
+                            // 4 = no dividend prefetch
     unsigned n2p, ny2p;     // LDS row pitches
 };
 
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             }
             const bool has_div = g.fused || (k1 < g.nx1);
             if (col && has_div && (g.fused || c < g.nx2)) t = E::add(t, next_dividend);
-            next_dividend = dividend(k1 + 1);  // in flight during the division below
+            next_dividend = (g.diag & 4) ? E::zero() : dividend(k1 + 1);  // in flight during the division below
             // 1-d division by y[0, :], lock step over j, and the next row's last term on the same broadcast
             V cur1 = E::zero(), ys = y0v, y1s = y1v, mine = E::zero();
             inner_next = E::zero();
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             // zero, which only a NON-FINITE quotient coefficient could turn into something — the loop notes whether one
             // appeared and the row is then redone with the bounds as selects.
             bool all_finite = true;
-            for (unsigned j = 0; j < g.n2; ++j) {
+            for (unsigned j = 0; j < ((g.diag & 2) ? 1u : g.n2); ++j) {
                 // lane j's numerator first, THEN the division on the (now wave-uniform) value: the exponent-window test of
                 // the fast division is a uniform branch
                 const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
                 E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
             }
         }
-        if (updater && k1 > 0 && k1 + 1 < g.n1)
+        if (updater && k1 > 0 && k1 + 1 < g.n1 && !(g.diag & 1))
             apply_terms4(k1 + 1, g.n1 - (k1 + 1), k1 - 1);  // term j1 = k1 - 1 into the rows r >= k1 + 1
         __syncthreads();  // row k1 is final (fl); every accumulator row >= k1 + 1 holds the terms up to k1 - 1
     }
@@ -402,6 +405,11 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
     g.n1 = n1; g.n2 = n2; g.ny1 = ny1; g.ny2 = ny2; g.nx1 = nx1; g.nx2 = nx2;
     g.x_rstride = x_rstride;
     g.fused = fused;
+    static const int diag = [] {
+        const char* e = getenv("GFT_DIV2D_DIAG");
+        return e ? atoi(e) : 0;
+    }();
+    g.diag = diag;
     g.n2p = n2 | 1;   // odd pitches: rows of one column do not share a bank
     g.ny2p = ny2 | 1;
     if (n2 <= 64) {
