@@ -79,14 +79,26 @@ __device__ inline Iv bcast_lane<EIv>(Iv v, unsigned j) { return Iv{bcast_f64(v.l
 template <class E>
 struct SlabDiv {  // generic element type: the functor's own division
     typename E::V d;
+    static constexpr bool SPECULATIVE = false;
     __device__ explicit SlabDiv(typename E::V y) : d(y) {}
     __device__ typename E::V operator()(typename E::V n) const { return E::div(n, d); }
+    __device__ typename E::V fast(typename E::V n) const { return E::div(n, d); }
+    __device__ bool fast_ok(typename E::V) const { return true; }
 };
 template <>
 struct SlabDiv<EF64> {
     FastDiv f;
+    static constexpr bool SPECULATIVE = true;
     __device__ explicit SlabDiv(double y) : f(fd_make(y)) {}
     __device__ double operator()(double n) const { return fd_div(n, f); }
+    // the three-instruction quotient WITHOUT the window test (the caller checks fast_ok(n) off the critical path and
+    // redoes the row with operator() if some numerator was outside); an exact zero is fine: 0 * r = 0, both residual
+    // steps keep it, and the sign is IEEE's
+    __device__ double fast(double n) const {
+        const double q = n * f.r;
+        return __builtin_fma(__builtin_fma(-f.d, q, n), f.r, q);
+    }
+    __device__ bool fast_ok(double n) const { return f.ok && (n == 0.0 || fd_mid(n)); }
 };
 
 template <class E>
@@ -362,18 +374,28 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             // cur1's lower bound needs no mask; the other positions the reference's bounds exclude multiply by a shifted-in
             // zero, which only a NON-FINITE quotient coefficient could turn into something — the loop notes whether one
             // appeared and the row is then redone with the bounds as selects.
-            bool all_finite = true;
+            // The quotient of the step: speculatively the 3-instruction form for every step — whether lane j's numerator
+            // was inside the exponent window is noted per lane (vector code beside the chain, not in it) and settled by
+            // one ballot after the row; a numerator in the window and a divisor in the window give a finite quotient,
+            // so the same verdict covers the masks dropped above.
+            bool lane_bad = false;
             for (unsigned j = 0; j < ((g.diag & 2) ? 1u : g.n2); ++j) {
-                // lane j's numerator first, THEN the division on the (now wave-uniform) value: the exponent-window test of
-                // the fast division is a uniform branch
-                const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), t), j));
-                all_finite = all_finite && elem_finite<E>(q);
+                const V num = E::add(E::neg(cur1), t);
+                if (SlabDiv<E>::SPECULATIVE) {
+                    if (c == j && !div_y00.fast_ok(num)) lane_bad = true;
+                } else if (c == j && !elem_finite<E>(num)) {
+                    lane_bad = true;
+                }
+                // lane j's numerator first, THEN the division on the (now wave-uniform) value
+                const V q = div_y00.fast(bcast_lane<E>(num, j));
                 if (c == j) mine = q;
                 cur1 = E::add(cur1, E::mul(q, ys));
                 inner_next = E::add(inner_next, E::mul(q, y1s));
                 ys = wave_shr1<E>(ys);
                 y1s = wave_shr1<E>(y1s);
             }
+            bool all_finite = !any_lane(lane_bad);
+            if (!SlabDiv<E>::SPECULATIVE && all_finite) all_finite = !any_lane(col && !elem_finite<E>(mine));
             if (!all_finite) {
                 cur1 = E::zero(), ys = y0v, y1s = y1v, mine = E::zero();
                 inner_next = E::zero();
