@@ -379,20 +379,34 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             // one ballot after the row; a numerator in the window and a divisor in the window give a finite quotient,
             // so the same verdict covers the masks dropped above.
             bool lane_bad = false;
-            for (unsigned j = 0; j < ((g.diag & 2) ? 1u : g.n2); ++j) {
-                const V num = E::add(E::neg(cur1), t);
-                if (SlabDiv<E>::SPECULATIVE) {
-                    if (c == j && !div_y00.fast_ok(num)) lane_bad = true;
-                } else if (c == j && !elem_finite<E>(num)) {
-                    lane_bad = true;
+            if constexpr (SlabDiv<E>::SPECULATIVE) {
+                // as few instructions as the step allows (one wave issues roughly one instruction per 8 cycles on this
+                // chain, so the instruction COUNT is the row's latency): numerator, its copy for the check after the
+                // row (same compare as `mine`), broadcast, 3-instruction quotient, two multiply-adds, two shifts
+                V mynum = E::zero();
+                for (unsigned j = 0; j < ((g.diag & 2) ? 1u : g.n2); ++j) {
+                    const V num = E::add(E::neg(cur1), t);
+                    const bool is_j = c == j;
+                    mynum = is_j ? num : mynum;
+                    const V q = div_y00.fast(bcast_lane<E>(num, j));
+                    mine = is_j ? q : mine;
+                    cur1 = E::add(cur1, E::mul(q, ys));
+                    inner_next = E::add(inner_next, E::mul(q, y1s));
+                    ys = wave_shr1<E>(ys);
+                    y1s = wave_shr1<E>(y1s);
                 }
-                // lane j's numerator first, THEN the division on the (now wave-uniform) value
-                const V q = div_y00.fast(bcast_lane<E>(num, j));
-                if (c == j) mine = q;
-                cur1 = E::add(cur1, E::mul(q, ys));
-                inner_next = E::add(inner_next, E::mul(q, y1s));
-                ys = wave_shr1<E>(ys);
-                y1s = wave_shr1<E>(y1s);
+                lane_bad = col && !div_y00.fast_ok(mynum);
+            } else {
+                for (unsigned j = 0; j < ((g.diag & 2) ? 1u : g.n2); ++j) {
+                    const V num = E::add(E::neg(cur1), t);
+                    if (c == j && !elem_finite<E>(num)) lane_bad = true;
+                    const V q = div_y00.fast(bcast_lane<E>(num, j));
+                    if (c == j) mine = q;
+                    cur1 = E::add(cur1, E::mul(q, ys));
+                    inner_next = E::add(inner_next, E::mul(q, y1s));
+                    ys = wave_shr1<E>(ys);
+                    y1s = wave_shr1<E>(y1s);
+                }
             }
             bool all_finite = !any_lane(lane_bad);
             if (!SlabDiv<E>::SPECULATIVE && all_finite) all_finite = !any_lane(col && !elem_finite<E>(mine));
