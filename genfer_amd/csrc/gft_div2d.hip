@@ -273,7 +273,11 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
     // ascending j2 from zero, so still the reference's bits; four accumulator rows per wave and step, 60 per pass of
     // the 15 updaters.
     const unsigned nup = nw > 1 ? nw - 1 : 1;
-    const unsigned uidx = nw > 1 ? wave - 1 : 0;  // index among the updaters
+    // index among the updaters: the waves of SIMDs 1..3 first, round-robin over the SIMDs (wave w runs on SIMD w % 4), the
+    // three that share SIMD 0 with the divider last — when a step has fewer rows than slots, the waves left idle are the
+    // divider's neighbours first, and the busy ones are spread evenly over the other SIMDs
+    const unsigned n_other = (nw - 1) - (nw - 1) / 4;
+    const unsigned uidx = nw <= 1 ? 0 : (wave & 3u) ? (wave >> 2) * 3 + (wave & 3u) - 1 : n_other + (wave >> 2) - 1;
     const unsigned drow = c >> 4, dl = c & 15u;
     auto apply_terms4 = [&](unsigned r_first, unsigned n_rows, unsigned j1) {
         // this DPP row's accumulator row (rows r_first + 4 * uidx + drow, then + 4 * nup per pass)
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
                     mine = is_j ? q : mine;
                     cur1 = E::add(cur1, E::mul(q, ys));
                     inner_next = E::add(inner_next, E::mul(q, y1s));
-                    ys = wave_shr1<E>(ys);
+                    ys = wave_shr1<E>(ys);  // (reading the shifted rows from LDS instead costs the same: measured)
                     y1s = wave_shr1<E>(y1s);
                 }
                 lane_bad = col && !div_y00.fast_ok(mynum);
