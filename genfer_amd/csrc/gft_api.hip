@@ -965,22 +965,22 @@ struct Ops {
         return true;
     }
 
-    // Inner-axis split for the tiled kernel (gft_conv_tiled.hip, k_pad_rows / k_fold_rows): rank 2 with a long last
-    // axis, or rank 2/3 whose last axis exceeds 128.  Fills the rank-(d+1) problem into `t` and the piece length.
+    // Inner-axis split for the tiled kernel (gft_conv_tiled.hip, k_pad_rows / k_fold_rows): rank 2/3 whose last axis
+    // exceeds the kernel's 128.  Fills the rank-4 problem (pieces, rows.., piece length) into `t` — the piece axis
+    // LEADS, which makes it the kernel's wave-uniform axis — and the piece length.
     static bool plan_inner_split(const ConvArgs& a, ConvArgs& t, unsigned* B_out) {
         const int nd = a.nd;
         if (nd != 2 && nd != 3) return false;
         if (a.j0_min || a.j0_excl || a.j0_desc) return false;
         const unsigned zI = a.zs[nd - 1];
-        if (!(zI > 128 || (nd == 2 && zI >= 96))) return false;
-        // piece length: multiple of 8, <= 64 (2B - 1 <= 127); prefer full 8-lane groups along the piece axis and
-        // long pieces (the kernel's efficiency grows with the number of 8-wide output blocks)
+        if (zI <= 128) return false;
+        // piece length: multiple of 8, <= 64 (2B - 1 <= 127).  P pieces cost P (P + 1) / 2 untruncated B x B piece
+        // products for zI^2 / 2 useful ones, and the kernel's efficiency grows with the number of 8-wide output blocks.
         unsigned best = 0;
         double best_score = -1.0;
         for (unsigned B = 64; B >= 32; B -= 8) {
-            unsigned P = (zI + B - 1) / B;
-            double util = (double)P / (8.0 * ((P + 7) / 8));
-            double score = util * (0.45 + 0.55 * B / 64.0) * ((double)zI / (P * B));
+            const double P = (double)((zI + B - 1) / B);
+            const double score = (double)zI * zI / (P * (P + 1) * B * B) * (0.45 + 0.55 * B / 64.0);
             if (score > best_score) {
                 best_score = score;
                 best = B;
@@ -988,18 +988,22 @@ struct Ops {
         }
         const unsigned B = best;
         t = a;
-        t.nd = nd + 1;
-        for (int i = 0; i + 1 < nd; ++i) {
-            t.xs[i] = a.xs[i];
-            t.ys[i] = a.ys[i];
-            t.zs[i] = a.zs[i];
+        t.nd = 4;
+        t.xs[0] = (a.xs[nd - 1] + B - 1) / B;
+        t.ys[0] = (a.ys[nd - 1] + B - 1) / B;
+        t.zs[0] = (zI + B - 1) / B;
+        if (nd == 2) {
+            t.xs[1] = t.ys[1] = t.zs[1] = 1;
+            t.xs[2] = a.xs[0]; t.ys[2] = a.ys[0]; t.zs[2] = a.zs[0];
+            t.slab_axis = 2;
+        } else {
+            t.xs[1] = a.xs[0]; t.ys[1] = a.ys[0]; t.zs[1] = a.zs[0];
+            t.xs[2] = a.xs[1]; t.ys[2] = a.ys[1]; t.zs[2] = a.zs[1];
+            t.slab_axis = 1;
         }
-        t.xs[nd - 1] = (a.xs[nd - 1] + B - 1) / B;
-        t.ys[nd - 1] = (a.ys[nd - 1] + B - 1) / B;
-        t.zs[nd - 1] = (zI + B - 1) / B;
-        t.xs[nd] = B;
-        t.ys[nd] = B;
-        t.zs[nd] = 2 * B - 1;
+        t.xs[3] = B;
+        t.ys[3] = B;
+        t.zs[3] = 2 * B - 1;
         t.accumulate = 0;  // the fold applies it
         *B_out = B;
         return true;
@@ -1157,16 +1161,16 @@ struct Ops {
                         zrows *= a.zs[i];
                         if (i > 0) zrows_per0 *= a.zs[i];
                     }
-                    const unsigned Px = at.xs[nd - 1], Py = at.ys[nd - 1], Pz = at.zs[nd - 1], RI = 2 * B - 1;
+                    const unsigned Px = at.xs[0], Py = at.ys[0], Pz = at.zs[0], RI = 2 * B - 1;
                     std::shared_ptr<Buf> xt = alloc_doubles(xrows * Px * B), yt = alloc_doubles(yrows * Py * B);
                     std::shared_ptr<Buf> zt = alloc_doubles(zrows * Pz * RI);
-                    tiled_pad_rows_f64(R.stream, xsrc, xt->p, xrows, a.xs[nd - 1], Px * B);
-                    tiled_pad_rows_f64(R.stream, ysrc, yt->p, yrows, a.ys[nd - 1], Py * B);
+                    tiled_pad_rows_f64(R.stream, xsrc, xt->p, xrows, a.xs[nd - 1], Px, B);
+                    tiled_pad_rows_f64(R.stream, ysrc, yt->p, yrows, a.ys[nd - 1], Py, B);
                     if (!conv_tiled_f64(R.stream, xt->p, yt->p, zt->p, at, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch))
                         throw Error("tiled convolution launch failed");
                     // rank 2: the slab range is a row range; rank 3: slabs of z.shape[1] rows
                     size_t per0 = nd == 2 ? 1 : zrows_per0;
-                    tiled_fold_rows_f64(R.stream, zt->p, zdst, a.slab_lo * per0, a.slab_hi * per0, Pz, B, a.zs[nd - 1],
+                    tiled_fold_rows_f64(R.stream, zt->p, zdst, zrows, a.slab_lo * per0, a.slab_hi * per0, B, a.zs[nd - 1],
                                         a.accumulate, flag, R.nf_epoch);
                 }
                 R.stats[3]++;
@@ -2486,6 +2490,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
+    else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
     else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;
     else if (n == "dist_min_macs") dist_set_min_macs(value);

@@ -58,8 +58,9 @@ struct TiledArgs {
     unsigned zU, z0, z1, zI;
     unsigned nx8, ny8;               // padded inner lengths of the packed operands
     unsigned nxc, nyc, nb;           // chunk counts (nx8/8, ny8/8) and number of 8-wide output blocks
-    unsigned P0, P1;                 // LDS pitches in doubles
-    unsigned lead_is_u;              // 1: slab range applies to u, 0: to k0
+    unsigned P1;                     // LDS row pitch in doubles
+    unsigned tsh;                    // lane tile: T1 = 1 << tsh lanes along k1, T0 = 64 >> tsh along k0 (8x8 ... 1x64)
+    unsigned slab_axis;              // the slab range applies to: 0 = u, 1 = k0, 2 = k1
     unsigned slab_lo, slab_hi;
     int accumulate;
     unsigned xcd_remap;              // 1: remap blockIdx so that each XCD owns a contiguous chunk of ranges
@@ -181,14 +182,16 @@ __device__ inline void block_mac(double (&acc)[8], unsigned c, cptr_t xr, const 
     }
 }
 
-// Fast path (x and y span every chunk the block touches: q_lo = 0, q_hi = c).  Three-way rotation of the
-// window buffers (A,B,C) and of the x buffers (X0,X1,X2): chunk i uses (X_i; cur, prev) and, right after
-// its first FMA row — i.e. after the s_waitcnt that the first use of its own operands triggers — requests
-// x[q+i+1] and W[q+i+2] for the following chunks.  Every LDS / scalar-load result is therefore >= 56 FMAs
-// (~250 cycles) old when first used, and the window slides without register moves.  The scheduling
-// barriers pin this order (hipcc otherwise sinks the loads next to their uses and stalls on them).
-// W[t] = yrow[8(c-t) ..+7]; t = c+1 reads the row's 8-double front padding, x[q] for q = nxc reads the
-// slack after the packed row — both are loaded but never used.
+// Fast path (x and y span every chunk the block touches: q_lo = 0, q_hi = c).  The window buffers rotate three ways
+// (A, B, C: current, previous, in flight), the x buffers two ways (X0, X1 — 32 SGPRs; a third set pushed the kernel's
+// scalar state out of the register file, and every per-step scalar then cost a v_readlane from a spill lane): chunk i
+// uses (X_i; cur, prev) and, right after its first FMA row — i.e. after the s_waitcnt that the first use of its own
+// operands triggers — requests x[q+i+1] and W[q+i+2] for the following chunks.  Every LDS / scalar-load result is
+// therefore >= 56 FMAs (~250 cycles) old when first used, and the window slides without register moves.  The
+// scheduling barriers pin this order (hipcc otherwise sinks the loads next to their uses and stalls on them).
+// The diagonal triangle (x chunk c against y chunk 0) goes FIRST, on the buffers the pipeline fills last (X1, C), so
+// the chunk loop needs no per-remainder epilogues: six phases (the rotation's period), then up to five of them again.
+// W[t] = yrow[8(c-t) ..+7]; t = c+1 reads the row's 8-double front padding — loaded but never used.
 #define GFT_STEP(XU, CUR, PREV, XN, TX, WN, TW)                 \
     do {                                                        \
         fma_rows(acc, XU, CUR, PREV, 0, 1);                     \
@@ -198,6 +201,33 @@ __device__ inline void block_mac(double (&acc)[8], unsigned c, cptr_t xr, const 
         __builtin_amdgcn_sched_barrier(0);                      \
         fma_rows(acc, XU, CUR, PREV, 1, 8);                     \
     } while (0)
+#define GFT_PH0 GFT_STEP(X0, A, B, X1, q + 1, C, q + 2)
+#define GFT_PH1 GFT_STEP(X1, B, C, X0, q + 2, A, q + 3)
+#define GFT_PH2 GFT_STEP(X0, C, A, X1, q + 3, B, q + 4)
+#define GFT_PH3 GFT_STEP(X1, A, B, X0, q + 4, C, q + 5)
+#define GFT_PH4 GFT_STEP(X0, B, C, X1, q + 5, A, q + 6)
+#define GFT_PH5 GFT_STEP(X1, C, A, X0, q + 6, B, q + 7)
+// chunks q .. q_hi-1 with (X0; A, B) holding chunk q's operands
+#define GFT_CHUNK_LOOP(Q_HI)                                    \
+    do {                                                        \
+        for (; q + 6 <= (Q_HI); q += 6) {                       \
+            GFT_PH0; GFT_PH1; GFT_PH2; GFT_PH3; GFT_PH4; GFT_PH5; \
+        }                                                       \
+        const unsigned rem = (Q_HI) - q;                        \
+        if (rem >= 1) {                                         \
+            GFT_PH0;                                            \
+            if (rem >= 2) {                                     \
+                GFT_PH1;                                        \
+                if (rem >= 3) {                                 \
+                    GFT_PH2;                                    \
+                    if (rem >= 4) {                             \
+                        GFT_PH3;                                \
+                        if (rem >= 5) GFT_PH4;                  \
+                    }                                           \
+                }                                               \
+            }                                                   \
+        }                                                       \
+    } while (0)
 
 template <int VAR>
 __device__ inline void block_fast(double (&acc)[8], unsigned c, cptr_t xr, const double* yrow) {
@@ -205,31 +235,19 @@ __device__ inline void block_fast(double (&acc)[8], unsigned c, cptr_t xr, const
     constexpr bool NO_X = (VAR & 32) != 0;
     constexpr bool B128 = (VAR & 2) != 0;
     const double* w0 = yrow + 8 * c;  // W[t] = w0 - 8t
-    double A[8], B[8], C[8], X0[8], X1[8], X2[8];
-    if (B128) { load8_b128(A, w0); load8_b128(B, w0 - 8); } else { load8(A, w0); load8(B, w0 - 8); }
+    double A[8], B[8], C[8], X0[8], X1[8];
+    // everything the first two chunks need is requested up front (for c = 0 the pipeline's operands are loaded and never
+    // used: x chunk 0, W[0] = the triangle's own window, W[1] = the front padding)
+    loadx(X1, xr + 8 * c);
     loadx(X0, xr);
-    if (NO_LDS) load8(C, w0);
-    if (NO_X) loadx(X1, xr), loadx(X2, xr);
+    if (B128) { load8_b128(C, yrow); load8_b128(A, w0); load8_b128(B, w0 - 8); } else { load8(C, yrow); load8(A, w0); load8(B, w0 - 8); }
+    __builtin_amdgcn_sched_barrier(0);
+    fma_tri(acc, X1, C);
     unsigned q = 0;
-    for (; q + 3 <= c; q += 3) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
-        GFT_STEP(X2, C, A, X0, q + 3, B, q + 4);
-    }
-    const unsigned rem = c - q;
-    if (rem == 2) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
-        fma_tri(acc, X2, C);
-    } else if (rem == 1) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        fma_tri(acc, X1, B);
-    } else {
-        fma_tri(acc, X0, A);
-    }
+    GFT_CHUNK_LOOP(c);
 }
 
-// The same pipeline for COMPACT operands (fewer x / y chunks than output blocks: the inner-split products, Horner
+// The same pipeline for COMPACT operands (fewer x / y chunks than output blocks: the piece-split products, Horner
 // steps with a small substitution): x chunks q in [q_lo, q_hi) with q_lo = max(0, c - nyc), q_hi = min(c, nxc), the
 // diagonal triangle only if c < nxc, and the first window is zero when it would lie beyond y's last chunk.
 // A separate function (and instantiation, VAR bit 8) so that the full-extent kernel's code is untouched.
@@ -243,7 +261,12 @@ __device__ inline void block_fast_gen(double (&acc)[8], unsigned c, cptr_t xr, c
     const bool tri = c < nxc;
     if (q_hi <= q_lo && !tri) return;
     const double* w0 = yrow + 8 * c;  // W[t] = w0 - 8t = y chunk c - t
-    double A[8], B[8], C[8], X0[8], X1[8], X2[8];
+    double A[8], B[8], C[8], X0[8], X1[8];
+    // the scalar (x) loads are unconditional, on clamped chunk indices: a conditionally loaded SGPR array becomes a phi
+    // that hipcc parks in VGPRs (16 of them, and the kernel has none to spare)
+    loadx(X1, xr + 8 * (tri ? c : 0u));
+    loadx(X0, xr + 8 * (q_hi > q_lo ? q_lo : 0u));
+    if (B128) load8_b128(C, yrow); else load8(C, yrow);
     if (c - q_lo < nyc) {
         if (B128) load8_b128(A, w0 - 8 * (int)q_lo); else load8(A, w0 - 8 * (int)q_lo);
     } else {
@@ -251,43 +274,30 @@ __device__ inline void block_fast_gen(double (&acc)[8], unsigned c, cptr_t xr, c
         for (int i = 0; i < 8; ++i) A[i] = 0.0;
     }
     if (B128) load8_b128(B, w0 - 8 * (int)(q_lo + 1)); else load8(B, w0 - 8 * (int)(q_lo + 1));
-    loadx(X0, xr + 8 * q_lo);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tri) fma_tri(acc, X1, C);
     unsigned q = q_lo;
-    for (; q + 3 <= q_hi; q += 3) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
-        GFT_STEP(X2, C, A, X0, q + 3, B, q + 4);
-    }
-    const unsigned rem = q_hi - q;
-    if (rem == 2) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        GFT_STEP(X1, B, C, X2, q + 2, A, q + 3);
-        if (tri) fma_tri(acc, X2, C);
-    } else if (rem == 1) {
-        GFT_STEP(X0, A, B, X1, q + 1, C, q + 2);
-        if (tri) fma_tri(acc, X1, B);
-    } else if (tri) {
-        fma_tri(acc, X0, A);
-    }
+    GFT_CHUNK_LOOP(q_hi);
 }
 
 struct TileGeom {
     unsigned julo, n_ju, j0lo, n_j0, j1lo, n_j1;
 };
 
-__host__ __device__ inline TileGeom tile_geom(const TiledArgs& A, unsigned u, unsigned a, unsigned b) {
+__host__ __device__ inline TileGeom tile_geom(const TiledArgs& A, unsigned tsh, unsigned u, unsigned a, unsigned b) {
     TileGeom g;
+    const unsigned T0 = 64u >> tsh, T1 = 1u << tsh;
     // uniform axis: ju in [max(0,u+1-yU), min(u+1,xU))
     g.julo = (u + 1 > A.yU) ? (u + 1 - A.yU) : 0;
     unsigned juhi = (u + 1 < A.xU) ? (u + 1) : A.xU;
     g.n_ju = juhi > g.julo ? juhi - g.julo : 0;
-    // lane axes: any lane of the tile valid.  k in [8a, min(8a+7, z-1)]
-    unsigned k0max = (8 * a + 7 < A.z0 - 1) ? 8 * a + 7 : A.z0 - 1;
-    g.j0lo = (8 * a + 1 > A.y0) ? (8 * a + 1 - A.y0) : 0;
+    // lane axes: any lane of the tile valid.  k in [T a, min(T a + T - 1, z - 1)]
+    unsigned k0max = (T0 * a + T0 - 1 < A.z0 - 1) ? T0 * a + T0 - 1 : A.z0 - 1;
+    g.j0lo = (T0 * a + 1 > A.y0) ? (T0 * a + 1 - A.y0) : 0;
     unsigned j0hi = (k0max + 1 < A.x0) ? (k0max + 1) : A.x0;
     g.n_j0 = j0hi > g.j0lo ? j0hi - g.j0lo : 0;
-    unsigned k1max = (8 * b + 7 < A.z1 - 1) ? 8 * b + 7 : A.z1 - 1;
-    g.j1lo = (8 * b + 1 > A.y1) ? (8 * b + 1 - A.y1) : 0;
+    unsigned k1max = (T1 * b + T1 - 1 < A.z1 - 1) ? T1 * b + T1 - 1 : A.z1 - 1;
+    g.j1lo = (T1 * b + 1 > A.y1) ? (T1 * b + 1 - A.y1) : 0;
     unsigned j1hi = (k1max + 1 < A.x1) ? (k1max + 1) : A.x1;
     g.n_j1 = j1hi > g.j1lo ? j1hi - g.j1lo : 0;
     return g;
@@ -297,7 +307,7 @@ constexpr int MAX_PF = 1;  // prefetch pieces (16 B each) per thread for one rin
                            // because yI <= zI (operands never exceed the result shape) and NW >= nb/2
 constexpr unsigned YPAD = 8;  // front padding of every LDS row (doubles)
 
-template <int NW, int VAR>
+template <int NW, int VAR, int TSH>
 __global__ void __launch_bounds__(NW * 64, 4)  // 4 waves per SIMD = 16 waves per CU => <= 128 VGPRs
 k_conv_tiled(TiledArgs A) {
     constexpr bool FAST = (VAR & 1) != 0;
@@ -308,7 +318,11 @@ k_conv_tiled(TiledArgs A) {
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned l0 = lane >> 3, l1 = lane & 7u;
+    // lane tile T0 x T1 over the (k0, k1) output rows: 8x8 by default (TSH = 3, compile-time); 1x64, 2x32 or 4x16 (TSH = 0:
+    // A.tsh at run time) when axis k0 is short or absent — the rank-2 products and the piece-split ones, whose lanes
+    // would otherwise sit masked
+    const unsigned tsh = TSH ? (unsigned)TSH : A.tsh, T1m = (1u << tsh) - 1u, T0 = 64u >> tsh;
+    const unsigned l0 = lane >> tsh, l1 = lane & T1m;
     constexpr unsigned NT = NW * 64;
 
     const unsigned c1 = A.blk1[wave];
@@ -316,9 +330,15 @@ k_conv_tiled(TiledArgs A) {
     const bool has1 = c1 != 0xffu;
     const bool has2 = c2 != 0xffu;
 
-    const unsigned half_row = A.ny8 >> 1;            // 16-byte pieces per row
-    const unsigned pf_pieces = 8 * half_row;         // one ring slot refill = 8 rows
+    const unsigned half_row = A.ny8 >> 1;                  // 16-byte pieces per row
+    const unsigned hr_magic = (1u << 24) / half_row + 1u;  // p / half_row == (p * magic) >> 24 for the p < 4096 used here
     const size_t y_row_stride = A.ny8;
+    // this thread's piece of a ring-slot refill (one refill = T0 rows of half_row 16-byte pieces; at most one per thread:
+    // T0 * ny8 / 2 <= 64 NW because yI <= zI and NW >= nb / 2)
+    const unsigned pf_s0 = (tid * hr_magic) >> 24, pf_col = tid - pf_s0 * half_row;
+    const bool pf_mine = pf_s0 < T0;
+    double* const lds_lane = lds + (size_t)(l0 << tsh) * A.P1 + YPAD;
+    double* const lds_pf = lds + (size_t)(pf_s0 << tsh) * A.P1 + YPAD + 2 * pf_col;
 
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a CONTIGUOUS eighth of
     // the stream-K ranges — neighbouring ranges sweep overlapping y-row windows and then share one L2.
@@ -328,71 +348,66 @@ k_conv_tiled(TiledArgs A) {
     for (unsigned si = seg_begin; si < seg_end; ++si) {
         const TileSeg seg = A.segs[si];
         const unsigned u = seg.u, a = seg.a, b = seg.b;
-        const TileGeom g = tile_geom(A, u, a, b);
-        const unsigned k0 = 8 * a + l0, k1 = 8 * b + l1;
+        const TileGeom g = tile_geom(A, tsh, u, a, b);
+        const unsigned k0 = T0 * a + l0, k1 = (b << tsh) + l1;
         bool lane_in = k0 < A.z0 && k1 < A.z1;
-        if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+        if (A.slab_axis == 1) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+        else if (A.slab_axis == 2) lane_in = lane_in && k1 >= A.slab_lo && k1 < A.slab_hi;
 
         double acc1[8], acc2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc1[i] = acc2[i] = 0.0;
 
-        unsigned s = seg.step_begin;
-        unsigned tj1 = s % g.n_j1;
-        unsigned t = s / g.n_j1;
+        unsigned tj1 = seg.step_begin % g.n_j1;
+        unsigned t = seg.step_begin / g.n_j1;
         unsigned tj0 = t % g.n_j0;
-        unsigned tju = t / g.n_j0;
-        unsigned ju = g.julo + tju, j0 = g.j0lo + tj0, j1 = g.j1lo + tj1;
+        unsigned ju = g.julo + t / g.n_j0, j0 = g.j0lo + tj0, j1 = g.j1lo + tj1;
+        unsigned steps_left = seg.step_end - seg.step_begin;
+        const unsigned j1_end = g.j1lo + g.n_j1;
 
-        bool need_full = true;
-        while (s < seg.step_end) {
-            if (need_full) {
-                // (re)load the whole 8x8 window of y rows for (ju, j0, j1)
+        // The step space is walked row by row: a ROW is a run of j1 steps under one (ju, j0) — it starts with a full
+        // window load, and inside it every per-step quantity is a running value (x row pointer, the lane's k1 - j1,
+        // the refill piece's source pointer) instead of a function of (ju, j0, j1) recomputed from the plan's scalars.
+        while (steps_left) {
+            const unsigned row_steps = steps_left < j1_end - j1 ? steps_left : j1_end - j1;
+            const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
+            if (!NO_WINDOW) {
+                // (re)load the whole T0 x T1 window of y rows for (ju, j0, j1)
                 __syncthreads();
-                const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
                 for (unsigned p = tid; p < 64 * half_row; p += NT) {
-                    unsigned row = p / half_row, col = p - row * half_row;
-                    unsigned s0 = row >> 3, s1 = row & 7u;
-                    int R0 = (int)(8 * a + s0) - (int)j0;
-                    int R1 = (int)(8 * b + s1) - (int)j1;
+                    unsigned row = (p * hr_magic) >> 24, col = p - row * half_row;
+                    unsigned s0 = row >> tsh, s1 = row & T1m;
+                    int R0 = (int)(T0 * a + s0) - (int)j0;
+                    int R1 = (int)((b << tsh) + s1) - (int)j1;
                     if (R0 >= 0 && R0 < (int)A.y0 && R1 >= 0 && R1 < (int)A.y1) {
                         const double2 v = *reinterpret_cast<const double2*>(
                             ybase + ((size_t)R0 * A.y1 + (size_t)R1) * y_row_stride + 2 * col);
-                        double* d = lds + s0 * A.P0 + ((unsigned)R1 & 7u) * A.P1 + YPAD + 2 * col;
+                        double* d = lds + ((s0 << tsh) + ((unsigned)R1 & T1m)) * A.P1 + YPAD + 2 * col;
                         d[0] = v.x;
                         d[1] = v.y;
                     }
                 }
                 __syncthreads();
-                need_full = false;
             }
-            const bool more = s + 1 < seg.step_end;
-            const bool same_row = more && (j1 + 1 < g.j1lo + g.n_j1);
-            // prefetch the ring slot that the next j1 step needs: rows R1n = 8b - j1 - 1 (+ nothing else new)
-            double2 pf[MAX_PF];
-            const int R1n = (int)(8 * b) - (int)j1 - 1;
-            const bool do_pf = !NO_WINDOW && same_row && R1n >= 0 && R1n < (int)A.y1;
-            if (do_pf) {
-                const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
-#pragma unroll
-                for (int i = 0; i < MAX_PF; ++i) {
-                    unsigned p = tid + i * NT;
-                    if (p < pf_pieces) {
-                        unsigned s0 = p / half_row, col = p - s0 * half_row;
-                        int R0 = (int)(8 * a + s0) - (int)j0;
-                        if (R0 >= 0 && R0 < (int)A.y0)
-                            pf[i] = *reinterpret_cast<const double2*>(
-                                ybase + ((size_t)R0 * A.y1 + (size_t)R1n) * y_row_stride + 2 * col);
-                    }
-                }
-            }
+            // running values of the row
+            cptr_t xr = (cptr_t)(A.xp + (((size_t)ju * A.x0 + j0) * A.x1 + j1) * A.nx8);  // wave-uniform
+            const bool valid0 = lane_in && j0 <= k0 && (k0 - j0) < A.y0;
+            int d1 = (int)k1 - (int)j1;               // this lane's y row along axis 1
+            int R1n = (int)(b << tsh) - (int)j1 - 1;  // the y row the NEXT step's window gains
+            const int pf_R0 = (int)(T0 * a + pf_s0) - (int)j0;
+            const bool pf_row = pf_mine && pf_R0 >= 0 && pf_R0 < (int)A.y0;
+            const double* pf_src = ybase + ((ptrdiff_t)pf_R0 * (ptrdiff_t)A.y1 + R1n) * (ptrdiff_t)y_row_stride + 2 * pf_col;
 
-            // ---- compute this step -------------------------------------------------------------
-            {
-                cptr_t xr = (cptr_t)(A.xp + (((size_t)ju * A.x0 + j0) * A.x1 + j1) * A.nx8);  // wave-uniform
-                const bool valid = lane_in && j0 <= k0 && (k0 - j0) < A.y0 && j1 <= k1 && (k1 - j1) < A.y1;
-                if (valid) {
-                    const double* yrow = lds + l0 * A.P0 + ((k1 - j1) & 7u) * A.P1 + YPAD;
+            for (unsigned rs = row_steps; rs > 0; --rs) {
+                const bool last = rs == 1;  // last step of the row (or of the range): no refill, no barriers
+                // prefetch the ring slot that the next j1 step needs: rows (.., R1n) — nothing else is new
+                const bool do_pf = !NO_WINDOW && !last && R1n >= 0 && R1n < (int)A.y1;
+                double2 pf;
+                if (do_pf && pf_row) pf = *reinterpret_cast<const double2*>(pf_src);
+
+                // ---- compute this step -------------------------------------------------------------
+                if (valid0 && (unsigned)d1 < A.y1) {  // j1 <= k1 and k1 - j1 < y1
+                    const double* yrow = lds_lane + (size_t)((unsigned)d1 & T1m) * A.P1;
                     if constexpr (FAST && (VAR & 8)) {  // pipelined path for compact operands
                         if (has1) block_fast_gen<VAR>(acc1, c1, xr, yrow, A.nxc, A.nyc);
                         if (has2) block_fast_gen<VAR>(acc2, c2, xr, yrow, A.nxc, A.nyc);
@@ -404,38 +419,30 @@ k_conv_tiled(TiledArgs A) {
                         if (has2) block_mac<VAR>(acc2, c2, xr, yrow, A.nxc, A.nyc);
                     }
                 }
-            }
 
-            // ---- advance ---------------------------------------------------------------------------
-            if (same_row) {
-                if (!NO_WINDOW) __syncthreads();  // everyone is done reading the slot being replaced
-                if (do_pf) {
-#pragma unroll
-                    for (int i = 0; i < MAX_PF; ++i) {
-                        unsigned p = tid + i * NT;
-                        if (p < pf_pieces) {
-                            unsigned s0 = p / half_row, col = p - s0 * half_row;
-                            int R0 = (int)(8 * a + s0) - (int)j0;
-                            if (R0 >= 0 && R0 < (int)A.y0) {
-                                double* d = lds + s0 * A.P0 + ((unsigned)R1n & 7u) * A.P1 + YPAD + 2 * col;
-                                d[0] = pf[i].x;
-                                d[1] = pf[i].y;
-                            }
-                        }
+                // ---- advance within the row ----------------------------------------------------------
+                if (!last && !NO_WINDOW) {
+                    __syncthreads();  // everyone is done reading the slot being replaced
+                    if (do_pf && pf_row) {
+                        double* d = lds_pf + (size_t)((unsigned)R1n & T1m) * A.P1;
+                        d[0] = pf.x;
+                        d[1] = pf.y;
                     }
+                    __syncthreads();
                 }
-                if (!NO_WINDOW) __syncthreads();
-                j1++;
-            } else if (more) {
-                j1 = g.j1lo;
-                if (j0 + 1 < g.j0lo + g.n_j0) j0++;
-                else {
-                    j0 = g.j0lo;
-                    ju++;
-                }
-                need_full = !NO_WINDOW;
+                xr += A.nx8;
+                d1 -= 1;
+                R1n -= 1;
+                pf_src -= y_row_stride;
             }
-            s++;
+            steps_left -= row_steps;
+            // next row
+            j1 = g.j1lo;
+            if (j0 + 1 < g.j0lo + g.n_j0) j0++;
+            else {
+                j0 = g.j0lo;
+                ju++;
+            }
         }
 
         // ---- write out ---------------------------------------------------------------------------------
@@ -484,9 +491,10 @@ __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red
     __shared__ double part[3][64][8];
     const RedTile rt = A.red[ti];
     const unsigned lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
-    const unsigned k0 = 8 * rt.a + (lane >> 3), k1 = 8 * rt.b + (lane & 7u);
+    const unsigned k0 = (64u >> A.tsh) * rt.a + (lane >> A.tsh), k1 = (rt.b << A.tsh) + (lane & ((1u << A.tsh) - 1u));
     bool lane_in = k0 < A.z0 && k1 < A.z1;
-    if (!A.lead_is_u) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+    if (A.slab_axis == 1) lane_in = lane_in && k0 >= A.slab_lo && k0 < A.slab_hi;
+    else if (A.slab_axis == 2) lane_in = lane_in && k1 >= A.slab_lo && k1 < A.slab_hi;
     double v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = 0.0;
@@ -559,17 +567,20 @@ __global__ void __launch_bounds__(256) k_prep_operands(const double* __restrict_
 // the (.., Px, B) and (.., Py, B) tensors with an UNtruncated last axis (2B - 1 <= 127 coefficients) contains
 // exactly the products of the original one: z[pB + r] = z~[p][r] + z~[p - 1][B + r] (overlap-add of the carries).
 // That turns a rank-d product with a long last axis into a rank-(d+1) product the tiled kernel supports.
+// Packed layouts put the PIECE axis first — x~[p][row][r], z~[p][row][0..2B-2] — so that the tiled kernel sees it as
+// its wave-uniform axis u and the lanes tile real rows (pieces are few: as a lane axis they left most lanes masked).
 __global__ void __launch_bounds__(256) k_pad_rows(const double* __restrict__ in, double* __restrict__ out, size_t rows,
-                                                  unsigned len, unsigned plen) {
-    size_t total = rows * plen;
+                                                  unsigned len, unsigned P, unsigned B) {
+    const size_t per_p = rows * B, total = per_p * P;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t row = i / plen;
-        unsigned col = (unsigned)(i - row * plen);
+        const unsigned p = (unsigned)(i / per_p);
+        const size_t rem = i - (size_t)p * per_p, row = rem / B;
+        const unsigned col = p * B + (unsigned)(rem - row * B);
         out[i] = col < len ? in[row * len + col] : 0.0;
     }
 }
-__global__ void __launch_bounds__(256) k_fold_rows(const double* __restrict__ zt, double* __restrict__ z, size_t row_lo,
-                                                   size_t row_hi, unsigned Pz, unsigned B, unsigned zI, int accumulate,
+__global__ void __launch_bounds__(256) k_fold_rows(const double* __restrict__ zt, double* __restrict__ z, size_t rows,
+                                                   size_t row_lo, size_t row_hi, unsigned B, unsigned zI, int accumulate,
                                                    const unsigned* guard, unsigned epoch) {
     if (guard && *guard == epoch) return;
     const unsigned RI = 2 * B - 1;
@@ -577,9 +588,8 @@ __global__ void __launch_bounds__(256) k_fold_rows(const double* __restrict__ zt
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t row = row_lo + i / zI;
         unsigned k = (unsigned)(i % zI), p = k / B, r = k - p * B;
-        const double* zr = zt + row * Pz * RI;
-        double v = zr[(size_t)p * RI + r];
-        if (p > 0 && r + 1 < B) v += zr[(size_t)(p - 1) * RI + B + r];
+        double v = zt[((size_t)p * rows + row) * RI + r];
+        if (p > 0 && r + 1 < B) v += zt[((size_t)(p - 1) * rows + row) * RI + B + r];
         double* dst = z + row * zI + k;
         *dst = accumulate ? *dst + v : v;
     }
@@ -644,23 +654,42 @@ int num_cus() {
 
 static void assign_blocks(TiledArgs& T, unsigned NW);
 
+int& tiled_force_tsh() {  // A/B and test knob (GFT_TILED_TSH / "tiled_tile"): 3..6 forces the lane tile 8x8 .. 1x64
+    static int v = [] {
+        const char* e = getenv("GFT_TILED_TSH");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     TiledArgs& T = P.base;
     std::memset(&T, 0, sizeof(T));
-    if (a.nd == 3) {
+    // canonical form z[u][k0][k1][k2]: u is wave-uniform, (k0, k1) are the lane axes, k2 the register axis
+    unsigned slab_axis;  // canonical axis the caller's slab range applies to
+    if (a.slab_axis < 0 || a.slab_axis >= a.nd - 1) return false;
+    if (a.nd == 2) {  // rows x inner: no k0 axis — the lane tile becomes 1 x 64 rows
+        T.xU = T.yU = T.zU = 1;
+        T.x0 = T.y0 = T.z0 = 1;
+        T.x1 = a.xs[0]; T.xI = a.xs[1];
+        T.y1 = a.ys[0]; T.yI = a.ys[1];
+        T.z1 = a.zs[0]; T.zI = a.zs[1];
+        slab_axis = 2;
+    } else if (a.nd == 3) {
         T.xU = T.yU = T.zU = 1;
         T.x0 = a.xs[0]; T.x1 = a.xs[1]; T.xI = a.xs[2];
         T.y0 = a.ys[0]; T.y1 = a.ys[1]; T.yI = a.ys[2];
         T.z0 = a.zs[0]; T.z1 = a.zs[1]; T.zI = a.zs[2];
-        T.lead_is_u = 0;
+        slab_axis = 1 + (unsigned)a.slab_axis;
     } else if (a.nd == 4) {
         T.xU = a.xs[0]; T.x0 = a.xs[1]; T.x1 = a.xs[2]; T.xI = a.xs[3];
         T.yU = a.ys[0]; T.y0 = a.ys[1]; T.y1 = a.ys[2]; T.yI = a.ys[3];
         T.zU = a.zs[0]; T.z0 = a.zs[1]; T.z1 = a.zs[2]; T.zI = a.zs[3];
-        T.lead_is_u = 1;
+        slab_axis = (unsigned)a.slab_axis;
     } else {
         return false;
     }
+    T.slab_axis = slab_axis;
     if (T.zI > 128 || T.xI > T.zI || T.yI > T.zI) return false;
     if (a.j0_min != 0 || a.j0_excl != 0 || a.j0_desc != 0) return false;  // recurrence steps: reference-order kernel
     T.nx8 = (T.xI + 7) / 8 * 8;
@@ -671,32 +700,63 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     // front padding + pitch: odd (8-byte slots, bijective mod 16/32 for ds_read_b64/read2_b64) or, for the
     // ds_read_b128 variant, even with P1/2 odd (16-byte slots bijective mod 16 for the b128 lane groups)
     T.P1 = (a.variant & 2) ? T.ny8 + YPAD + 2 : T.ny8 + YPAD + 1;
-    T.P0 = 8 * T.P1;
+    // Lane tile: the shape whose lanes are busiest.  A lane (k0, k1) works in step (j0, j1) iff j <= k and k - j < y's
+    // extent on both axes; the steps a tile runs are the union over its lanes, so a tile straddling the diagonal (or a
+    // short axis) carries masked lanes.  Useful / issued lane-steps factorises over the two axes.
+    {
+        auto axis_eff = [](unsigned T, unsigned nx, unsigned ny, unsigned nz) {
+            double useful = 0, issued = 0;
+            for (unsigned t = 0; t * T < nz; ++t) {
+                const unsigned kmax = std::min(T * t + T - 1, nz - 1);
+                const unsigned jlo = T * t + 1 > ny ? T * t + 1 - ny : 0, jhi = std::min(kmax + 1, nx);
+                if (jhi > jlo) issued += (double)(jhi - jlo) * T;
+                for (unsigned k = T * t; k <= kmax; ++k) {
+                    const unsigned lo = k + 1 > ny ? k + 1 - ny : 0, hi = std::min(k + 1, nx);
+                    if (hi > lo) useful += hi - lo;
+                }
+            }
+            return issued > 0 ? useful / issued : 0.0;
+        };
+        const int force = tiled_force_tsh();
+        double best = -1.0;
+        unsigned best_tsh = 3;
+        for (unsigned tsh = 3; tsh <= 6; ++tsh) {
+            const double e = axis_eff(64u >> tsh, T.x0, T.y0, T.z0) * axis_eff(1u << tsh, T.x1, T.y1, T.z1);
+            if (e > best * 1.02) {  // ties (and near ties) go to the squarer tile: fewer window reloads per step
+                best = e;
+                best_tsh = tsh;
+            }
+        }
+        T.tsh = (force >= 3 && force <= 6) ? (unsigned)force : best_tsh;
+    }
+    const unsigned TT0 = 64u >> T.tsh, TT1 = 1u << T.tsh;
     T.slab_lo = a.slab_lo;
     T.slab_hi = a.slab_hi;
     T.accumulate = a.accumulate;
     unsigned npairs = (T.nb + 1) / 2;
     P.NW = npairs <= 1 ? 1 : (npairs <= 2 ? 2 : (npairs <= 4 ? 4 : 8));
-    P.lds_bytes = (size_t)8 * T.P0 * sizeof(double);
+    P.lds_bytes = (size_t)64 * T.P1 * sizeof(double);
     assign_blocks(T, P.NW);
 
     // tiles in (u, a, b) order
     struct TileInfo { unsigned u, a, b; unsigned long long steps; };
     std::vector<TileInfo> tiles;
-    unsigned u_lo = 0, u_hi = T.zU, a_lo = 0, a_hi = (T.z0 + 7) / 8;
-    if (T.lead_is_u) {
+    unsigned u_lo = 0, u_hi = T.zU, a_lo = 0, a_hi = (T.z0 + TT0 - 1) / TT0, b_lo = 0, b_hi = (T.z1 + TT1 - 1) / TT1;
+    if (slab_axis == 0) {
         u_lo = a.slab_lo;
         u_hi = a.slab_hi;
+    } else if (slab_axis == 1) {
+        a_lo = a.slab_lo / TT0;
+        a_hi = (a.slab_hi + TT0 - 1) / TT0;
     } else {
-        a_lo = a.slab_lo / 8;
-        a_hi = (a.slab_hi + 7) / 8;
+        b_lo = a.slab_lo / TT1;
+        b_hi = (a.slab_hi + TT1 - 1) / TT1;
     }
-    unsigned b_hi = (T.z1 + 7) / 8;
     unsigned long long S = 0;
     for (unsigned u = u_lo; u < u_hi; ++u)
         for (unsigned aa = a_lo; aa < a_hi; ++aa)
-            for (unsigned bb = 0; bb < b_hi; ++bb) {
-                TileGeom g = tile_geom(T, u, aa, bb);
+            for (unsigned bb = b_lo; bb < b_hi; ++bb) {
+                TileGeom g = tile_geom(T, T.tsh, u, aa, bb);
                 unsigned long long st = (unsigned long long)g.n_ju * g.n_j0 * g.n_j1;
                 if (st == 0 || st > 0xffffffffull) return false;
                 tiles.push_back({u, aa, bb, st});
@@ -828,7 +888,10 @@ static void assign_blocks(TiledArgs& T, unsigned NW) {
         return e ? atoi(e) : 1;
     }();
     for (int w = 0; w < 8; ++w) T.blk1[w] = T.blk2[w] = 0xff;
-    if (mode == 0 || 2 * NW == T.nb || NW < 4) {
+    // (classic pairs are only balanced when every block c costs c + 1: compact operands — the piece-split products'
+    // untruncated inner axis costs min(c + 1, nxc, nyc, nb - c) — always take the LPT assignment)
+    const bool full = T.nxc >= T.nb && T.nyc >= T.nb;
+    if (mode == 0 || (full && (2 * NW == T.nb || NW < 4))) {
         for (unsigned w = 0; w < NW; ++w) {
             unsigned c1 = w, c2 = T.nb - 1 - w;
             if (c1 < T.nb && c1 <= c2) T.blk1[w] = (unsigned char)c1;
@@ -861,40 +924,46 @@ static void assign_blocks(TiledArgs& T, unsigned NW) {
     }
 }
 
-template <int NW, int VAR>
-hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
+template <int NW, int VAR, int TSH>
+hipError_t launch_main_t(hipStream_t st, const Plan& P, const TiledArgs& T) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tiled<NW, VAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tiled<NW, VAR, TSH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_tiled<NW, VAR>), dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
+    hipLaunchKernelGGL((k_conv_tiled<NW, VAR, TSH>), dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
     return hipGetLastError();
+}
+template <int NW, int VAR>
+hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
+    return T.tsh == 3 ? launch_main_t<NW, VAR, 3>(st, P, T) : launch_main_t<NW, VAR, 0>(st, P, T);
 }
 
 }  // namespace
 
-void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned plen) {
-    size_t tot = rows * plen;
+void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned P, unsigned B) {
+    size_t tot = rows * P * B;
     if (!tot) return;
     hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, in, out, rows,
-                       len, plen);
+                       len, P, B);
 }
-void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t row_lo, size_t row_hi, unsigned Pz, unsigned B,
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned B,
                          unsigned zI, int accumulate, const unsigned* guard, unsigned epoch) {
     size_t tot = (row_hi - row_lo) * zI;
     if (!tot) return;
-    hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, row_lo,
-                       row_hi, Pz, B, zI, accumulate, guard, epoch);
+    hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, rows,
+                       row_lo, row_hi, B, zI, accumulate, guard, epoch);
 }
 
+
+void tiled_set_lane_tile(int tsh) { tiled_force_tsh() = tsh; }
 
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a_in, void* ws,
                     size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch) {
     ConvArgs a = a_in;
     if (a.variant < 0) a.variant = GFT_TILED_DEFAULT_VARIANT;
-    if (a.nd == 3 || a.nd == 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
+    if (a.nd >= 2 && a.nd <= 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
         unsigned nb = (a.zs[a.nd - 1] + 7) / 8;
         if ((a.xs[a.nd - 1] + 7) / 8 < nb || (a.ys[a.nd - 1] + 7) / 8 < nb) {
             static const bool compact_fast = [] {
@@ -907,8 +976,8 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     }
     PlanKey key;
     std::memset(&key, 0, sizeof(key));
-    if (a.nd != 3 && a.nd != 4) return false;
-    key.v[0] = (unsigned)a.nd;
+    if (a.nd < 2 || a.nd > 4) return false;
+    key.v[0] = (unsigned)a.nd | ((unsigned)a.slab_axis << 8) | ((unsigned)tiled_force_tsh() << 16);
     for (int i = 0; i < a.nd; ++i) {
         key.v[1 + i] = a.xs[i];
         key.v[5 + i] = a.ys[i];

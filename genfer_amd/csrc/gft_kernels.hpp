@@ -155,6 +155,7 @@ struct ConvArgs {
     unsigned xs[MAXD], ys[MAXD], zs[MAXD];
     size_t xstr[MAXD], ystr[MAXD], zstr[MAXD];
     unsigned slab_lo, slab_hi;  // output range on axis 0
+    int slab_axis;              // tiled kernel only: the axis the range applies to instead of 0 (piece-split problems)
     int accumulate;             // 0: start from zero, 1: start from the stored value
     int j0_min;                 // exp/log recurrences start at j = 1
     int j0_excl;                // 1: exclude j0 == k0 (div/log: res[k] is not known yet)
@@ -253,8 +254,9 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 
 // Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
-void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned plen);
-void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t row_lo, size_t row_hi, unsigned Pz, unsigned B,
+void tiled_set_lane_tile(int tsh);  // 0 = planner's choice, 3..6 = force T1 = 1 << tsh lanes along k1 (tests, A/B)
+void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned P, unsigned B);
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned B,
                          unsigned zI, int accumulate, const unsigned* guard, unsigned epoch);
 
 // LDS-staged reference-order convolution (gft_conv_staged.hip): bit-identical to K<E>::conv_naive, operands

@@ -223,7 +223,8 @@ def test_random_trees_mid_size_positive(seed, OTP, GTP):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("GFT_FUZZ_SHAPES", "60"))))
 def test_conv_tiled_random_shapes(seed):
-    """The tiled kernel (forced, incl. the inner split for rank 2 / long last axes and compact operands) against the
+    """The tiled kernel (forced, incl. the inner split for long last axes, compact operands, and every lane tile
+    8x8 / 4x16 / 2x32 / 1x64 besides the planner's own choice) against the
     reference-order kernel on random ragged shapes of rank 2-4, mixed-sign data, slab range + accumulate:
     |err| <= 1e-10 * (|x| (*) |y|) coefficient-wise (SURVEY 8d normwise bound)."""
     import torch
@@ -238,7 +239,7 @@ def test_conv_tiled_random_shapes(seed):
     hi = {2: 160, 3: 36, 4: 14}[nd]
     zs = [int(rng.integers(2, hi + 1)) for _ in range(nd)]
     if nd == 2:
-        zs[1] = int(rng.integers(96, 260))  # rank 2 needs a last axis the split accepts
+        zs[1] = int(rng.integers(2, 260))  # rank 2: directly (lane tile 1 x 64 rows) up to 128, through the split beyond
     if nd == 3 and seed % 5 == 0:
         zs = [int(rng.integers(2, 10)), int(rng.integers(2, 12)), int(rng.integers(129, 200))]  # rank-3 inner split
     if nd == 4 and seed % 4 == 0:
@@ -256,14 +257,18 @@ def test_conv_tiled_random_shapes(seed):
     hi_s = int(rng.integers(lo + 1, zs[0] + 1))
     z0 = torch.from_numpy(_rand(zs, 300 + seed)).cuda()
 
+    tile = [0, 3, 4, 5, 6][seed % 5]
+
     def run(mode, a, b, acc):
         out = z0.clone() if acc else torch.full(zs, float("nan"), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()  # torch fills on ITS stream; the library runs on its own non-blocking stream
         L.gft_set_conv_mode(mode)
+        L.gft_set_option(b"tiled_tile", float(tile))
         try:
             genfer_amd.conv_raw(a.data_ptr(), xs, b.data_ptr(), ys, out.data_ptr(), zs, lo if acc else 0, hi_s if acc else zs[0], acc)
         finally:
             L.gft_set_conv_mode(0)
+            L.gft_set_option(b"tiled_tile", 0.0)
         L.gft_synchronize()
         return out
 
@@ -281,8 +286,6 @@ def test_conv_tiled_random_shapes(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("xs,ys,zs", [
     ((300,), (250,), (400,)),                                    # rank 1
-    ((40, 60), (50, 70), (64, 90)),                              # rank 2, last axis below the split's 96
-    ((1, 33, 1, 80), (1, 40, 1, 64), (1, 48, 1, 95)),            # collapses to rank 2, short last axis
     ((3, 4, 5, 6, 7), (4, 4, 4, 4, 4), (5, 6, 7, 8, 9)),         # rank 5
     ((2, 3, 2, 3, 2, 3), (3, 2, 3, 2, 3, 2), (4, 4, 4, 4, 4, 4)),  # rank 6
 ])
