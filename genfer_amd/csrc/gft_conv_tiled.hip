@@ -303,8 +303,6 @@ __host__ __device__ inline TileGeom tile_geom(const TiledArgs& A, unsigned tsh, 
     return g;
 }
 
-constexpr int MAX_PF = 1;  // prefetch pieces (16 B each) per thread for one ring slot refill: 8*ny8/2 <= 64*NW
-                           // because yI <= zI (operands never exceed the result shape) and NW >= nb/2
 constexpr unsigned YPAD = 8;  // front padding of every LDS row (doubles)
 
 template <int NW, int VAR, int TSH>

@@ -19,6 +19,16 @@
 
 namespace gft {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it also waits for every
+// outstanding GLOBAL load and store (s_waitcnt vmcnt(0)), which drains software prefetches on each step of a latency
+// chain.  Use where the threads of the block communicate through LDS alone across the barrier.
+__device__ inline void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+
 GFT_HD inline long long f64_bits(double x) { return __builtin_bit_cast(long long, x); }
 GFT_HD inline double bits_f64(long long b) { return __builtin_bit_cast(double, b); }
 // true iff some lane of the wave (device) / this element (host) raises `p`
@@ -201,6 +211,7 @@ struct EIv {
     GFT_HD static double dec_pos(double x) { return bits_f64(f64_bits(x) - 1); }  // next_down for x > 0
     GFT_HD static double inc_pos(double x) { return bits_f64(f64_bits(x) + 1); }  // next_up for 0 <= x < inf
     GFT_HD static V mul_pos(V a, V b) { return Iv{dec_pos(a.lo * b.lo), inc_pos(a.hi * b.hi)}; }
+    GFT_HD static V add_pos(V a, V b) { return Iv{dec_pos(a.lo + b.lo), inc_pos(a.hi + b.hi)}; }  // both operands pos_ok: no short-circuit, positive sums
     GFT_HD static V mac_pos(V acc, V a, V b, bool& bad) {
         const double p = a.lo * b.lo;
         const double mlo = dec_pos(p);

@@ -980,8 +980,9 @@ void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, co
 // no synchronisation between workgroups, intermediates ping-pong in LDS, the next step's coefficient is prefetched
 // while the current one is computed, the last step writes to global memory.  A step only changes which positions
 // along w are inside the current boxes (off the axis the boxes are rs0 at step 0 and the final extents afterwards).
-constexpr int HL_EPT = 2;  // positions along w per thread: lines up to 2048 long
-template <class E>
+constexpr int HL_EPT_MAX = 2;  // positions along w per thread: lines up to 2048 long
+// HL_EPT positions along w per thread; coefficient prefetch depth HL_PF steps (registers: HL_PF * HL_EPT elements)
+template <class E, int HL_EPT, int HL_PF>
 __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __restrict__ res0, size_t rp0,
                                                              const double* __restrict__ a, size_t ap,
                                                              double* __restrict__ out, size_t plane, HornerLoopArgs g,
@@ -1024,69 +1025,131 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
     const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
     unsigned kw[HL_EPT];
     bool have[HL_EPT], takes_c[HL_EPT];
-    V coef[HL_EPT];
+    // Coefficient slabs are read HL_PF steps ahead into a register ring: a step is a few hundred cycles of arithmetic,
+    // a global load ~2000 under this kernel's occupancy (one workgroup per line) — one step of lead left every step
+    // waiting for its coefficient (1.4 us per step on mixture --bounds, 2.5 of its 3.6 s).
+    V ring[HL_PF][HL_EPT];
 #pragma unroll
     for (int e = 0; e < HL_EPT; ++e) {
         kw[e] = threadIdx.x + e * blockDim.x;
         have[e] = kw[e] < lw;
         takes_c[e] = have[e] && (g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : (in_c_b && kw[e] < g.oc[g.w]));
-        coef[e] = takes_c[e] ? E::ld(a, ap, (size_t)g.first_i * g.a_vstride + aoff_b + (size_t)kw[e] * wstr_a) : E::zero();
     }
+    // The ring's loads are UNCONDITIONAL, on clamped addresses (a position outside the coefficient box reads the
+    // slab's first element, a step beyond the last reads the last step's slab), and the box is applied when the value is
+    // used: a conditional load is a phi of {zero, loaded}, which hipcc materialises in a temporary and copies into the
+    // ring's register at the end of the step — after waiting for the load it issued a moment ago.
+    size_t c_off[HL_EPT];
+#pragma unroll
+    for (int e = 0; e < HL_EPT; ++e) c_off[e] = takes_c[e] ? aoff_b + (size_t)kw[e] * wstr_a : 0;
+    const unsigned last_step = g.nsteps - 1;
+#pragma unroll
+    for (int d = 0; d < HL_PF; ++d)
+#pragma unroll
+        for (int e = 0; e < HL_EPT; ++e)
+            ring[d][e] = E::ld(a, ap, (size_t)(g.first_i - ((unsigned)d < last_step ? (unsigned)d : last_step)) * g.a_vstride + c_off[e]);
+    bool pos_consts = false;
+    if constexpr (E::HAS_POS) pos_consts = E::pos_ok(mv) && (g.c_zero || g.c_one || E::pos_ok(cv));
     unsigned rsw = g.rs0[g.w];
-    for (unsigned t = 0; t < g.nsteps; ++t) {
-        const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
-        const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
-        const unsigned osw = ocw > shw ? ocw : shw;
-        V next[HL_EPT];
-        const bool more = t + 1 < g.nsteps;
-        {
-            const size_t a_base = (size_t)(g.first_i - (more ? t + 1 : t)) * g.a_vstride + aoff_b;
+    for (unsigned t0 = 0; t0 < g.nsteps; t0 += HL_PF) {
 #pragma unroll
-            for (int e = 0; e < HL_EPT; ++e)
-                next[e] = (more && takes_c[e]) ? E::ld(a, ap, a_base + (size_t)kw[e] * wstr_a) : E::zero();
-        }
-        const double* src_l = hl_lds + (size_t)((t + 1) & 1u) * E::W * lw_pad;  // written by step t-1
-        double* dst_l = hl_lds + (size_t)(t & 1u) * E::W * lw_pad;
-        const bool last = t + 1 == g.nsteps, first = t == 0;
-        int witness = 0;
+        for (int d = 0; d < HL_PF; ++d) {
+            const unsigned t = t0 + (unsigned)d;
+            // ring slot d: hand over step t's coefficient and request step t + HL_PF's — outside the `t < nsteps` test, so
+            // that the slot's registers have ONE definition per unrolled copy (no phi, no end-of-step copy that would wait
+            // for the load just issued); the clamped address makes the surplus loads harmless
+            V coef[HL_EPT];
+            {
+                const unsigned tn = t + HL_PF;
+                const size_t a_base = (size_t)(g.first_i - (tn < last_step ? tn : last_step)) * g.a_vstride;
 #pragma unroll
-        for (int e = 0; e < HL_EPT; ++e) {
-            if (!have[e]) continue;
-            const bool in_o = (first ? off_o0 : true) && kw[e] < osw;
-            if (!in_o) continue;
-            const bool in_p = (first ? off_p0 : true) && kw[e] < shw;
-            const bool in_r = (first ? off_p0 : true) && kw[e] < rsw;
-            V p = E::zero();
-            if (in_p) {
-                if (kw[e] >= 1 && kw[e] - 1 < upper)
-                    p = E::mulw(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
-                if (!g.c_zero) {
-                    p = E::add0(p);
-                    if (in_r) {
-                        V x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
-                        p = E::addw(p, g.c_one ? x : E::mulw(cv, x));
-                    }
+                for (int e = 0; e < HL_EPT; ++e) {
+                    coef[e] = takes_c[e] ? ring[d][e] : E::zero();
+                    ring[d][e] = E::ld(a, ap, a_base + c_off[e]);
                 }
             }
-            V v;
-            if (g.coeff_scalar) {
-                v = p;
-                if (blockIdx.x == 0 && kw[e] == 0) v = E::add(p, coef[e]);
-            } else {
-                v = E::zero();
-                if (in_p) v = E::add0(p);
-                if (takes_c[e]) v = E::addw(v, coef[e]);
-            }
-            if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
-            else E::st(dst_l, lw_pad, kw[e], v);
-            if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
-        }
+            if (t >= g.nsteps) continue;
+            const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
+            const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
+            const unsigned osw = ocw > shw ? ocw : shw;
+            const double* src_l = hl_lds + (size_t)((t + 1) & 1u) * E::W * lw_pad;  // written by step t-1
+            double* dst_l = hl_lds + (size_t)(t & 1u) * E::W * lw_pad;
+            const bool last = t + 1 == g.nsteps, first = t == 0;
+            int witness = 0;
 #pragma unroll
-        for (int e = 0; e < HL_EPT; ++e) coef[e] = next[e];
-        rsw = osw;
-        const int any = __syncthreads_or(witness);
-        if (wit && !last && any && threadIdx.x == 0 && __hip_atomic_load(&wit[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; e < HL_EPT; ++e) {
+                if (!have[e]) continue;
+                const bool in_o = (first ? off_o0 : true) && kw[e] < osw;
+                if (!in_o) continue;
+                const bool in_p = (first ? off_p0 : true) && kw[e] < shw;
+                const bool in_r = (first ? off_p0 : true) && kw[e] < rsw;
+                if constexpr (E::HAS_POS) {
+                    // Positive regime (gft_elem.hpp): probability-like accumulators, coefficients and substitution — every
+                    // operand of this step a proper positive interval.  The step is then ~20 instructions instead of ~130
+                    // (no sign cases, no short-circuit selects, next_down / next_up as integer steps), the same operations
+                    // on the same values; whether the regime held is settled per wave, before (operands) and after
+                    // (no underflow to zero, no overflow) — otherwise the general code below computes the step.
+                    if (pos_consts) {
+                        const bool t1 = in_p && kw[e] >= 1 && kw[e] - 1 < upper;  // res[k - 1] * m
+                        const bool t2 = in_p && !g.c_zero && in_r;               // c * res[k]
+                        const bool t3 = g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : takes_c[e];
+                        V xm1 = E::one(), x = E::one();
+                        if (t1) xm1 = first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1);
+                        if (t2) x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
+                        const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef[e]));
+                        if (!any_lane(!ok)) {
+                            const V p1 = E::mul_pos(xm1, mv);
+                            const V p2 = g.c_one ? x : E::mul_pos(cv, x);
+                            bool bad = (t1 && !E::pos_first_ok(p1)) || (t2 && !g.c_one && !E::pos_first_ok(p2));
+                            const V p12 = E::add_pos(p1, p2);
+                            V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
+                            const bool has_p = t1 || t2;
+                            const V pc = E::add_pos(p, coef[e]);
+                            V v = t3 ? (has_p ? pc : coef[e]) : p;
+                            if (!g.coeff_scalar && !in_p) v = t3 ? coef[e] : E::zero();
+                            bad = bad || ((has_p || t3) && !E::pos_result_ok(v));
+                            if (!any_lane(bad)) {
+                                if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
+                                else E::st(dst_l, lw_pad, kw[e], v);
+                                if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
+                                continue;
+                            }
+                        }
+                    }
+                }
+                V p = E::zero();
+                if (in_p) {
+                    if (kw[e] >= 1 && kw[e] - 1 < upper)
+                        p = E::mulw(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
+                    if (!g.c_zero) {
+                        p = E::add0(p);
+                        if (in_r) {
+                            V x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
+                            p = E::addw(p, g.c_one ? x : E::mulw(cv, x));
+                        }
+                    }
+                }
+                V v;
+                if (g.coeff_scalar) {
+                    v = p;
+                    if (blockIdx.x == 0 && kw[e] == 0) v = E::add(p, coef[e]);
+                } else {
+                    v = E::zero();
+                    if (in_p) v = E::add0(p);
+                    if (takes_c[e]) v = E::addw(v, coef[e]);
+                }
+                if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
+                else E::st(dst_l, lw_pad, kw[e], v);
+                if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
+            }
+            rsw = osw;
+            // the witness word is raised per WAVE (ballot + one lane), not through a block-wide OR: __syncthreads_or is a
+            // shared-memory reduction with several barriers of its own, paid on every step of this latency chain
+            // (a plain store, no load-and-test first: a load would have to be waited for, and with it the whole prefetch ring)
+            if (wit && !last && any_lane(witness != 0) && (threadIdx.x & 63u) == 0)
+                __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_barrier();  // the line passes from step to step through LDS; global loads (the ring) stay in flight
+        }
     }
 }
 template <class E>
@@ -1102,7 +1165,10 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
     }();
     unsigned threads = std::min<unsigned>(1024, ((lw + per_thread - 1) / per_thread + 63) / 64 * 64);
     size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
-    hipLaunchKernelGGL(k_horner_linear_loop<E>, dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+    if (lw <= threads)
+        hipLaunchKernelGGL((k_horner_linear_loop<E, 1, 8>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+    else
+        hipLaunchKernelGGL((k_horner_linear_loop<E, HL_EPT_MAX, 4>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
 }
 
 template <class E>
