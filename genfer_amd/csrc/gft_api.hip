@@ -117,6 +117,13 @@ struct Runtime {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // Side stream of the blocked recurrences (div / log): the bulk of a right-looking update runs here while the main
+    // stream already divides the next slab.  Joined before the recurrence returns, so the pool's "one stream" rule holds
+    // for every buffer that outlives it.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_bulk = nullptr;
+    bool side_pending = false;     // a bulk update is (possibly) still running on `side`
+    bool recur_overlap = true;     // GFT_RECUR_OVERLAP=0 / "recur_overlap": everything on the main stream (A/B, bisecting)
     // size-class pool: freed blocks are reused immediately — legal because every kernel, memset and
     // copy of this library is ordered on the one stream.
     std::map<size_t, std::vector<void*>> free_blocks;  // size class -> free device blocks (vectors: no node churn)
@@ -1312,6 +1319,39 @@ struct Ops {
         copy_elems(host, dst, src, n);
         if (W == 2) copy_elems(host, dst + dplane, src + splane, n);
     }
+    // z[0..m) += a (*) b for the m slabs that follow a slab the recurrence has just finalised (right-looking update, see
+    // div_rec).  Only z[0] is needed by the next step of the recurrence: it is updated on the main stream, the other m - 1
+    // slabs on the side stream, overlapping the next slab's division (a single-workgroup latency chain that leaves the
+    // GPU empty).  Order per slab is unchanged — slab s receives term j from bulk(j) for j < s - 1 (side stream, in
+    // order), then from the critical update of step s - 1, which waits for the latest bulk first.
+    static void right_update(const HV& a, const HV& b, const HV& z, size_t m) {
+        TiledMin guard(R.recur_tiled_min_macs);
+        if (!R.recur_overlap || !R.side || m < 2) {
+            join_side();
+            conv(a, b, z, 0, m, true, false, 0, 0, 0);
+            return;
+        }
+        join_side();  // the previous bulk added its term to z[0] (and beyond)
+        conv(a, b, z, 0, 1, true, false, 0, 0, 0);
+        HIP_OK(hipEventRecord(R.ev_main, R.stream));      // slab final (+ critical update): the bulk may read it
+        HIP_OK(hipStreamWaitEvent(R.side, R.ev_main, 0));
+        std::swap(R.stream, R.side);
+        try {
+            conv(a, b, z, 1, m, true, false, 0, 0, 0);
+        } catch (...) {
+            std::swap(R.stream, R.side);
+            throw;
+        }
+        std::swap(R.stream, R.side);
+        HIP_OK(hipEventRecord(R.ev_bulk, R.side));
+        R.side_pending = true;
+    }
+    // the main stream waits for everything issued on the side stream so far
+    static void join_side() {
+        if (!R.side_pending) return;
+        HIP_OK(hipStreamWaitEvent(R.stream, R.ev_bulk, 0));
+        R.side_pending = false;
+    }
     static void div_rec(const HV& xs, const HV& ys, const HV& res) {
         if (xs.numel() == 0) return;
         const bool host = res.host;
@@ -1365,8 +1405,7 @@ struct Ops {
                     zsm.insert(zsm.end(), rest.begin(), rest.end());
                     HV xk{cur.p, res.plane, xs1, false}, ym{ys.p + prod(yrest), ys.plane, ysm, false},
                         zm{res.p + (k + 1) * prod(rest), res.plane, zsm, false};
-                    TiledMin guard(R.recur_tiled_min_macs);
-                    conv(xk, ym, zm, 0, m, true, false, 0, 0, 0);
+                    right_update(xk, ym, zm, m);
                 }
             } scatter{res, ys, cur, rest, yrest, k, n0, right};
             if (!host && R.div2d && cur.shape.size() == 2) {
@@ -1385,6 +1424,7 @@ struct Ops {
             copy_planes(host, copy.p, copy.plane, cur.p, cur.plane, cur.numel());
             div_rec(copy, y0, cur);
         }
+        if (right) join_side();
     }
     static P div(P self, P other) {
         broadcast(self, other);
@@ -1542,19 +1582,32 @@ struct Ops {
         for (size_t k = 1; k < n0; ++k) {
             HV cur = res.index0(k);
             if (!right) conv(xs, rs, res, k, k + 1, false, true, 1, 1, 1);  // sum_{j} xs[k-j] (*) (res[j]*j), j ascending
-            x_map_inplace(cur, MAP_NEG, 0);
-            if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD_U32_TIMES, (unsigned)k);
-            // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
-            P num = make(sub, sub, host), den = make(x0.shape, sub, host);
-            copy_planes(host, tp<E>(num, host), num.numel, cur.p, cur.plane, cur.numel());
-            copy_planes(host, tp<E>(den, host), den.numel, x0.p, x0.plane, x0.numel());
-            P q = div_same_tier(num, den, host);
-            if (q.shape != sub) throw Error("log: internal shape mismatch after division");
-            copy_planes(host, cur.p, cur.plane, tp<E>(q, host), q.numel, cur.numel());
-            x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
             HV rk = rs.index0(k);
-            copy_planes(host, rk.p, rk.plane, cur.p, cur.plane, cur.numel());
-            x_map_inplace(rk, MAP_MUL_U32, (unsigned)k);
+            bool step_done = false;
+            if (right && cur.shape.size() == 2 && x0.numel() > 1) {
+                // the whole slab step in one launch (gft_div2d.hip, fused == 2): neg, += k * xs[k], the 2-d division by xs[0]
+                // — what Div's dispatcher (mt:1194-1231) comes to for a divisor of more than one coefficient —, / k, and
+                // rs[k] = res[k] * k; element for element the sequence below
+                const bool have_x = k < xs.shape[0];
+                HV xk = have_x ? xs.index0(k) : HV{nullptr, 0, Dims{0, 0}, false};
+                step_done = K<E>::div_2d(R.stream, xk.p, xk.plane, have_x ? (unsigned)xk.shape[0] : 0u, have_x ? (unsigned)xk.shape[1] : 0u,
+                                         have_x ? xk.shape[1] : 0, x0.p, x0.plane, (unsigned)x0.shape[0], (unsigned)x0.shape[1], cur.p,
+                                         cur.plane, (unsigned)cur.shape[0], (unsigned)cur.shape[1], 2, (unsigned)k, rk.p, rk.plane);
+            }
+            if (!step_done) {
+                x_map_inplace(cur, MAP_NEG, 0);
+                if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD_U32_TIMES, (unsigned)k);
+                // current = current / xs[0] as full TaylorPoly division with degrees = current.shape (mt:1376-1383)
+                P num = make(sub, sub, host), den = make(x0.shape, sub, host);
+                copy_planes(host, tp<E>(num, host), num.numel, cur.p, cur.plane, cur.numel());
+                copy_planes(host, tp<E>(den, host), den.numel, x0.p, x0.plane, x0.numel());
+                P q = div_same_tier(num, den, host);
+                if (q.shape != sub) throw Error("log: internal shape mismatch after division");
+                copy_planes(host, cur.p, cur.plane, tp<E>(q, host), q.numel, cur.numel());
+                x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
+                copy_planes(host, rk.p, rk.plane, cur.p, cur.plane, cur.numel());
+                x_map_inplace(rk, MAP_MUL_U32, (unsigned)k);
+            }
             if (right && k + 1 < n0 && xs.shape[0] >= 2) {
                 const size_t m = std::min(n0 - 1 - k, xs.shape[0] - 1);
                 Dims xsm{m}, ys1{1}, zsm{m};
@@ -1563,10 +1616,10 @@ struct Ops {
                 zsm.insert(zsm.end(), sub.begin(), sub.end());
                 HV xm{xs.p + prod(xrest), xs.plane, xsm, false}, yk{rk.p, rs.plane, ys1, false},
                     zm{res.p + (k + 1) * prod(sub), res.plane, zsm, false};
-                TiledMin guard(R.recur_tiled_min_macs);
-                conv(xm, yk, zm, 0, m, true, false, 0, 0, 0);
+                right_update(xm, yk, zm, m);
             }
         }
+        if (right) join_side();
     }
     // Div's dispatcher (mt:1194-1231) for the slab division inside log.  tp<E>() serves a device caller whatever side
     // the quotient is on; a host caller needs it in host memory.
@@ -2381,6 +2434,9 @@ int gft_init(int device) {
             throw Error(std::string("device is ") + prop.gcnArchName + ", but libgftaylor is built for gfx950 only");
         HIP_OK(hipStreamCreateWithFlags(&R.own_stream, hipStreamNonBlocking));
         R.stream = R.own_stream;
+        HIP_OK(hipStreamCreateWithFlags(&R.side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&R.ev_main, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&R.ev_bulk, hipEventDisableTiming));
         HIP_OK(hipMalloc((void**)&R.d_flag, 256));
         {
             unsigned init[64] = {0};
@@ -2402,6 +2458,7 @@ int gft_init(int device) {
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
         if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
+        if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
@@ -2435,6 +2492,12 @@ void gft_shutdown(void) {
     R.h_mail = R.d_mail = nullptr;
     for (auto& ev : R.events) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(R.own_stream);
+    if (R.side) (void)hipStreamDestroy(R.side);
+    if (R.ev_main) (void)hipEventDestroy(R.ev_main);
+    if (R.ev_bulk) (void)hipEventDestroy(R.ev_bulk);
+    R.side = nullptr;
+    R.ev_main = R.ev_bulk = nullptr;
+    R.side_pending = false;
     R.ready = false;
 }
 
@@ -2488,6 +2551,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "div2d") R.div2d = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
+    else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);

@@ -25,12 +25,31 @@ struct Div2dArgs {
     unsigned nx1, nx2;      // box of the dividend tensor x (0, 0: none)
     size_t x_rstride;       // row stride of x
     int fused;              // 1: dividend row = (-res_in_place[k1][k2]) (+ x[k1][k2] inside x's box)
+                            // 2: log's slab step (mt:1366-1384): dividend = (-res_in_place) (+ from(log_k) * x inside x's box), and
+                            //    the slab stored is quotient / from(log_k), with (that) * from(log_k) stored to res2 as well
+    unsigned log_k;
+    double* res2;
+    size_t r2p;
     int diag;               // timing diagnostics (GFT_DIV2D_DIAG, wrong results): 1 = no updater work, 2 = no division loop,
                             // 4 = no dividend prefetch
     unsigned n2p, ny2p;     // LDS row pitches
 };
 
 constexpr int D2_NW = 16;  // waves per workgroup
+
+// what a finished quotient coefficient becomes in memory: itself, or — log's slab step — res[k] = q / k and rs[k] = res[k] * k
+// (mt:1384 and mt:1362-1365; the same element operations MAP_DIV_U32 / MAP_MUL_U32 perform when the step is not fused)
+template <class E>
+__device__ inline void store_quotient(const Div2dArgs& g, double* res, size_t rp, size_t at, typename E::V q) {
+    if (g.fused == 2) {
+        const typename E::V kk = E::from_u32(g.log_k);
+        const typename E::V r = E::div(q, kk);
+        E::st(res, rp, at, r);
+        E::st(g.res2, g.r2p, at, E::mul(r, kk));
+    } else {
+        E::st(res, rp, at, q);
+    }
+}
 
 // Division by a divisor that stays the same for a whole slab (y[0, 0]): the f64 quotient n / d as the compiler expands
 // it on gfx950 (v_div_scale, v_rcp, two Newton steps on the reciprocal, q = n*r, one residual step, v_div_fmas,
@@ -153,7 +172,10 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
             t = E::neg(acc);
             if (g.fused) {
                 V xv = E::neg(E::ld(res, rp, (size_t)k1 * g.n2 + k2));
-                if (k1 < g.nx1 && k2 < g.nx2) xv = E::add(xv, E::ld(x, xp, (size_t)k1 * g.x_rstride + k2));
+                if (k1 < g.nx1 && k2 < g.nx2) {
+                    const V xin = E::ld(x, xp, (size_t)k1 * g.x_rstride + k2);
+                    xv = E::add(xv, g.fused == 2 ? E::mul(E::from_u32(g.log_k), xin) : xin);
+                }
                 t = E::add(t, xv);
             } else if (k1 < g.nx1 && k2 < g.nx2) {
                 t = E::add(t, E::ld(x, xp, (size_t)k1 * g.x_rstride + k2));
@@ -183,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_div_2d(const double* __restrict__ x, s
         }
         if (owner) {
             E::st(rl, rsz, (size_t)k1 * g.n2p + k2, mine);
-            E::st(res, rp, (size_t)k1 * g.n2 + k2, mine);
+            store_quotient<E>(g, res, rp, (size_t)k1 * g.n2 + k2, mine);
         }
         __syncthreads();  // row k1 of the quotient is in LDS for the next rows
     }
@@ -258,7 +280,10 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
         if (!col || k1 >= g.n1) return d;
         if (g.fused) {
             d = E::neg(E::ld(res, rp, (size_t)k1 * g.n2 + c));
-            if (k1 < g.nx1 && c < g.nx2) d = E::add(d, E::ld(x, xp, (size_t)k1 * g.x_rstride + c));
+            if (k1 < g.nx1 && c < g.nx2) {
+                const V xin = E::ld(x, xp, (size_t)k1 * g.x_rstride + c);
+                d = E::add(d, g.fused == 2 ? E::mul(E::from_u32(g.log_k), xin) : xin);
+            }
         } else if (k1 < g.nx1 && c < g.nx2) {
             d = E::ld(x, xp, (size_t)k1 * g.x_rstride + c);
         }
@@ -428,7 +453,7 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
             }
             if (col) {
                 E::st(fl, 128, (size_t)(k1 & 1) * 64 + c, mine);
-                E::st(res, rp, (size_t)k1 * g.n2 + c, mine);
+                store_quotient<E>(g, res, rp, (size_t)k1 * g.n2 + c, mine);
             }
         }
         if (updater && k1 > 0 && k1 + 1 < g.n1 && !(g.diag & 1))
@@ -439,12 +464,17 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
 
 template <class E>
 bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
-                  size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused) {
+                  size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused, unsigned log_k, double* res2,
+                  size_t r2_plane) {
     if (n1 == 0 || n2 < 2 || n2 > 1024 || ny1 > n1 || ny2 > n2) return false;
     Div2dArgs g;
     g.n1 = n1; g.n2 = n2; g.ny1 = ny1; g.ny2 = ny2; g.nx1 = nx1; g.nx2 = nx2;
     g.x_rstride = x_rstride;
     g.fused = fused;
+    g.log_k = log_k;
+    g.res2 = res2;
+    g.r2p = r2_plane;
+    if (fused == 2 && (!res2 || log_k == 0)) return false;
     static const int diag = [] {
         const char* e = getenv("GFT_DIV2D_DIAG");
         return e ? atoi(e) : 0;
@@ -485,8 +515,8 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
 }
 
 template bool K<EF64>::div_2d(hipStream_t, const double*, size_t, unsigned, unsigned, size_t, const double*, size_t, unsigned, unsigned,
-                              double*, size_t, unsigned, unsigned, int);
+                              double*, size_t, unsigned, unsigned, int, unsigned, double*, size_t);
 template bool K<EIv>::div_2d(hipStream_t, const double*, size_t, unsigned, unsigned, size_t, const double*, size_t, unsigned, unsigned,
-                             double*, size_t, unsigned, unsigned, int);
+                             double*, size_t, unsigned, unsigned, int, unsigned, double*, size_t);
 
 }  // namespace gft

@@ -223,10 +223,12 @@ struct K {
                        size_t y_plane, unsigned ny, double* res, size_t r_plane, unsigned n);
     // The last TWO axes of the division recurrence in one launch (gft_div2d.hip): res[n1, n2] = dividend / y[ny1, ny2],
     // bit-identical to the host-driven recursion.  fused == 0: dividend = x (box nx1 x nx2, row stride x_rstride);
-    // fused == 1: dividend = (-res) (+ x inside its box), res holding the leading-axis partial sums on entry
+    // fused == 1: dividend = (-res) (+ x inside its box), res holding the leading-axis partial sums on entry;
+    // fused == 2: log's slab step — dividend = (-res) (+ log_k * x), stores res = q / log_k and res2 = res * log_k
     // (mt:1186-1189).  Returns false (nothing launched) if the slab does not fit one workgroup's LDS.
     static bool div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
-                       size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused);
+                       size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused,
+                       unsigned log_k = 0, double* res2 = nullptr, size_t r2_plane = 0);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);
