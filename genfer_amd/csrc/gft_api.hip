@@ -1126,7 +1126,9 @@ struct Ops {
                     macs *= f;
                 }
                 const double tmin = R.tiled_min_override >= 0 ? R.tiled_min_override : R.tiled_min_macs;
-                if (macs < tmin * (split ? 10.0 : 1.0)) ok = false;
+                // rank 2 runs the kernel with a 1 x 64 lane tile (half-empty below 64 rows), split products pay the pad /
+                // fold passes: their crossovers sit higher (tools/xover_host.py: 32^2 staged 34 us / tiled 48, 48^2 60 / 44)
+                if (macs < tmin * (split ? 10.0 : (ash.nd == 2 ? 4.0 : 1.0))) ok = false;
             }
             if (ok) ok = conv_tiled_f64(R.stream, tx, ty, tz, at, nullptr, 0, &need, nullptr, 0);
             if (ok) {

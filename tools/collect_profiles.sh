@@ -56,5 +56,9 @@ python3 tools/bench_streaming.py 384 > "$OUT/summary/streaming_384.json" 2> "$OU
 python3 tools/bench_staged.py > "$OUT/staged.log" 2>&1; cp gpurun_out/staged_vs_naive.json "$OUT/summary/" 2>/dev/null
 python3 tools/sweep_tiled.py > "$OUT/summary/tiled_size_sweep.txt" 2> "$OUT/sweep.err"
 python3 tools/bench_sync.py > "$OUT/summary/host_round_trip.txt" 2> "$OUT/sync.err"
+python3 tools/bench_horner.py > "$OUT/summary/horner_loop.txt" 2> "$OUT/horner.err"
+python3 tools/bench_div2d.py 32 64 > "$OUT/summary/div2d_slab.txt" 2> "$OUT/div2d.err"
+(cd /tmp && rm -rf /tmp/gft_e2e_mix && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mix -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only > "$OUT/e2e_mix_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mix -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_kernel_stats.csv")
+(cd /tmp && rm -rf /tmp/gft_e2e_mixb && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mixb -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only --bounds > "$OUT/e2e_mixb_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mixb -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_bounds_kernel_stats.csv")
 python3 tools/bench_e2e.py --limit 100 --runs 3 > "$OUT/e2e.log" 2>&1; tail -1 "$OUT/e2e.log" > "$OUT/summary/e2e_neurips_limit100.json"
 ls -la "$OUT/summary"
