@@ -1951,8 +1951,13 @@ struct Ops {
                     const double mm[2] = {m[0], m[1]};
                     return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, mm, 1, nullptr, 1);
                 }
-                if (lens[v] <= 256)  // short axis: every thread forms its own m^k (same running product), no table launch
+                if (lens[v] <= 256) {  // short axis: every thread forms its own m^k (same running product), no table launch
+                    if (m_known) {  // m travels by value: a host-resident subst needs no device mirror (one upload launch less)
+                        const double mm[2] = {m[0], m[1]};
+                        return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, mm, (int)v, nullptr, 0, nullptr, 0);
+                    }
                     return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel, nullptr, 0);
+                }
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
                 return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v], nullptr, 0);

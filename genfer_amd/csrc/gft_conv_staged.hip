@@ -56,15 +56,19 @@ __device__ inline typename E::V inner_sum(const double* xl, size_t xcap, const d
     typedef typename E::V V;
     if constexpr (E::HAS_POS) {
         if (pos) {
+            // No per-term checks: the two ways a term can leave the regime poison the running sum — a product that
+            // underflows to zero makes dec_pos produce a NaN pattern, an upper bound that reaches inf makes inc_pos
+            // produce one — and NaNs stay NaNs through the following adds and integer steps.  One test of the finished
+            // sum (lower bound still positive, upper bound finite) therefore covers every term; a sum that fails it is
+            // recomputed with the general mac below.  (The loop was issue-bound: 15 -> 10 instructions per interval MAC.)
             bool bad = false;
             V inner = E::zero();
             if (lo < hi) {
                 inner = E::mul_pos(E::ld(xl, xcap, xb + lo), E::ld(yl, ycap, yb - lo));  // [0,0] + m returns m unchanged
-                bad = !E::pos_first_ok(inner);
 #pragma unroll 4
                 for (unsigned j = lo + 1; j < hi; ++j)
-                    inner = E::mac_pos(inner, E::ld(xl, xcap, xb + j), E::ld(yl, ycap, yb - j), bad);
-                bad = bad || !E::pos_result_ok(inner);
+                    inner = E::mac_pos_unchecked(inner, E::ld(xl, xcap, xb + j), E::ld(yl, ycap, yb - j));
+                bad = !E::pos_first_ok(inner) || !E::pos_result_ok(inner);
             }
             if (!any_lane(bad)) return inner;
         }

@@ -218,6 +218,12 @@ struct EIv {
         bad = bad || !(mlo > 0.0);  // p underflowed to 0 or to the least subnormal: next_down leaves the positive half
         return Iv{dec_pos(acc.lo + mlo), inc_pos(acc.hi + inc_pos(a.hi * b.hi))};
     }
+    // mac_pos without the per-term test: a term that leaves the regime turns the sum's bound into a NaN (dec_pos(+0) and
+    // inc_pos(inf) are NaN bit patterns, and NaN survives every later add and integer step), so the caller tests the
+    // FINISHED sum with pos_first_ok && pos_result_ok instead
+    GFT_HD static V mac_pos_unchecked(V acc, V a, V b) {
+        return Iv{dec_pos(acc.lo + dec_pos(a.lo * b.lo)), inc_pos(acc.hi + inc_pos(a.hi * b.hi))};
+    }
     GFT_HD static bool pos_first_ok(V m) { return m.lo > 0.0; }  // the first product's lower bound stayed positive
     GFT_HD static bool pos_result_ok(V v) { return v.hi < bits_f64(0x7ff0000000000000LL); }  // no overflow on the way (NaN fails too)
     GFT_HD static V div(V a, V b) {                                           // :199-234

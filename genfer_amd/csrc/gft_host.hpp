@@ -54,7 +54,7 @@ struct HK {
                     case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
                     case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
                     case OP_MUL_POW: {
-                        const V mv = E::ld(a.tab, a.tab_plane, 0);
+                        const V mv = a.tab ? E::ld(a.tab, a.tab_plane, 0) : E::from(a.s);
                         V f = E::one();
                         for (unsigned i = 0; i < kaxis; ++i) f = E::mul(f, mv);
                         v = E::mul(v, f);

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, 
                 case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
                 case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
                 case OP_MUL_POW: {
-                    const V mv = E::ld(a.tab, a.tab_plane, 0);
+                    const V mv = a.tab ? E::ld(a.tab, a.tab_plane, 0) : E::from(a.s);  // m in memory, or by value
                     V f = E::one();
                     for (unsigned i = 0; i < kaxis; ++i) f = E::mul(f, mv);
                     v = E::mul(v, f);
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
                 case OP_MUL_TAB: { double f = a.tab[kaxis]; v.x = v.x * f; v.y = v.y * f; break; }
                 case OP_MUL_TAB_LMUL_S: { double f = a.tab[kaxis]; v.x = a.s.a * (v.x * f); v.y = a.s.a * (v.y * f); break; }
                 case OP_MUL_POW: {
-                    const double m = a.tab[0];
+                    const double m = a.tab ? a.tab[0] : a.s.a;
                     double f = 1.0;
                     for (unsigned i = 0; i < kaxis; ++i) f = f * m;
                     v.x = v.x * f;
