@@ -426,8 +426,18 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     chunks = (span + threads - 1) / threads;
     g.chunks = (unsigned)chunks;
     // row groups (see the kernel): as many as the batch has rows and the block has room for
+    static const unsigned rw_cap = [] {
+        const char* e = getenv("GFT_STAGED_RW");  // experiment knob: cap on the row groups of a block
+        return (unsigned)(e ? std::max(1, atoi(e)) : 1024);
+    }();
     if (S == 1 && a.inner_from_zero && g.batch > 1) {
-        unsigned rw = std::min<unsigned>(g.batch, 1024u / threads);
+        unsigned rw = std::min<unsigned>(std::min<unsigned>(g.batch, 1024u / threads), rw_cap);
+        // Row groups shorten the serial chain of ONE block (a recurrence step has a handful of blocks and nothing else to
+        // run); a product with thousands of blocks is better served by more, smaller blocks per CU — their staging,
+        // summing and adding phases interleave instead of 16 waves idling through them together (interval 128^3:
+        // 741 ms with 8 groups, 537 ms with 4).
+        const unsigned long long nblocks = n_outer * chunks;
+        if (nblocks >= 1024) rw = std::min(rw, 4u);  // (2 groups: 128^3 the same, mixed-sign 64^3 — the long general path — 28 % slower)
         if (rw > 1 && lds + (size_t)g.batch * threads * 8 * W <= 64 * 1024) {
             g.rw = rw;
             lds += (size_t)g.batch * threads * 8 * W;
