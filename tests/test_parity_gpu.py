@@ -799,3 +799,67 @@ def test_add_scaled_fused_equals_reference_sequence(interval, OTP, GTP, OTPI, GT
     assert rc == 0, want
     got, _ = genfer_amd.run_sgcl(src, flags)
     assert got == want
+
+
+@pytest.mark.parametrize("shape", [(24, 40), (6, 10, 33), (3, 4, 5, 20)])
+def test_interval_positive_regime_leaves_and_returns_bit_exact(OTPI, GTPI, shape):
+    """Strictly positive interval products whose sums LEAVE the positive regime on the way: a term whose lower bound
+    underflows to zero, an upper bound that overflows, a lower bound that reaches the least subnormal.  The staged
+    kernel's positive-regime sums carry no per-term test (a bad term poisons the running bound with a NaN pattern and the
+    finished sum is tested once); whatever it decides, the bits must be the reference's."""
+    n = int(np.prod(shape))
+    base = 0.05 + rand(shape, 1301)
+    for tag, scale_x, scale_y in (("underflow", 1e-170, 1e-170), ("overflow", 1e160, 1e155), ("subnormal", 1e-160, 1e-160), ("mixed", 1.0, 1.0)):
+        x, y = base * scale_x, (0.05 + rand(shape, 1302)) * scale_y
+        if tag == "mixed":  # a few extreme entries inside ordinary data: only some sums (some lanes) fall back
+            x, y = x.copy(), y.copy()
+            x.flat[n // 3], y.flat[n // 2], x.flat[n - 2], y.flat[1] = 1e-300, 1e-300, 1e200, 1e200
+        xi, yi = np.stack([x, x * (1 + 1e-15)]), np.stack([y, y * (1 + 1e-15)])
+        o = OTPI.new(xi, list(shape)) * OTPI.new(yi, list(shape))
+        g = GTPI.new(xi, list(shape)) * GTPI.new(yi, list(shape))
+        same_meta(o, g)
+        a, b = np.asarray(o.array()), np.asarray(g.array())
+        ok = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+        assert np.all(ok), (tag, a[~ok][:4], b[~ok][:4])
+
+
+@pytest.mark.parametrize("shape", [(20, 18, 16), (5, 6, 9, 10)])
+def test_recurrences_side_stream_overlap_is_bit_identical(GTP, GTPI, shape):
+    """div / log with the bulk of the right-looking update on the side stream (default) against the single-stream
+    order ("recur_overlap" = 0): same launches, same operands, only the stream differs — identical bits, f64 and
+    interval, including back-to-back calls that reuse pooled buffers."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    x, y = 0.5 + rand(shape, 1401), 0.5 + rand(shape, 1402)
+
+    def run(cls, xa, ya):
+        a, b = cls.new(xa, list(shape)), cls.new(ya, list(shape))
+        out = []
+        for _ in range(2):
+            q = a / b
+            l = (cls.from_scalar(1.0 if xa.ndim == len(shape) else (1.0, 1.0)) + a).log()
+            out += [np.asarray(q.array()).copy(), np.asarray(l.array()).copy()]
+        return out
+
+    for cls, xa, ya in ((GTP, x, y), (GTPI, np.stack([x, x * (1 + 1e-15)]), np.stack([y, y * (1 + 1e-15)]))):
+        L.gft_set_option(b"recur_overlap", 1.0)
+        on = run(cls, xa, ya)
+        L.gft_set_option(b"recur_overlap", 0.0)
+        try:
+            off = run(cls, xa, ya)
+        finally:
+            L.gft_set_option(b"recur_overlap", 1.0)
+        for p, q in zip(on, off):
+            assert np.array_equal(p.view(np.uint64), q.view(np.uint64))
+
+
+def test_log_fused_slab_step_equals_unfused(OTP, GTP):
+    """log of 3-d tensors: the slab step fused into the 2-d division launch (neg, += k * xs[k], divide by xs[0], / k,
+    rs[k] = res[k] * k) against the oracle, bit for bit — compact arguments (xs shorter than the result on every
+    axis) and full ones."""
+    for xs, deg in (((12, 10, 14), [12, 10, 14]), ((5, 7, 3), [9, 8, 11]), ((9, 2, 64), [9, 6, 64])):
+        x = 0.2 * rand(xs, 1501, -1, 1)
+        x[(0,) * len(xs)] = 1.25
+        o, g = both(OTP, GTP, x, deg)
+        check(o.log(), g.log())
