@@ -2156,6 +2156,11 @@ struct Ops {
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
         g.lw_pad = (unsigned)((fs[w] + 7) / 8 * 8);
+        static const int hdiag = [] {
+            const char* e = getenv("GFT_HORNER_DIAG");
+            return e ? atoi(e) : 0;
+        }();
+        g.diag = hdiag;
         K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
         *result = out;
         return true;

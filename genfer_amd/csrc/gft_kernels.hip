@@ -1148,7 +1148,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             // (a plain store, no load-and-test first: a load would have to be waited for, and with it the whole prefetch ring)
             if (wit && !last && any_lane(witness != 0) && (threadIdx.x & 63u) == 0)
                 __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lds_barrier();  // the line passes from step to step through LDS; global loads (the ring) stay in flight
+            if (!(g.diag & 2)) lds_barrier();  // the line passes from step to step through LDS; global loads (the ring) stay in flight
         }
     }
 }

@@ -128,6 +128,7 @@ struct HornerLoopArgs {
     unsigned first_i, nsteps;  // coefficient index of the first in-kernel step; steps i = first_i, first_i-1, ...
     Scalar2 c, m;
     int c_zero, c_one, coeff_scalar;
+    int diag;                  // timing diagnostics (GFT_HORNER_DIAG, wrong results): 2 = no barrier
 };
 
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
