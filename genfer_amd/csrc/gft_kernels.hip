@@ -114,6 +114,68 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
     }
 }
 
+// Row-oriented gather: one WAVE per output row (all axes but the last), lanes along the row.  The row's multi-index,
+// its validity and its source offset are wave-uniform and formed once per row; the lanes only add their position on the
+// last axis — no per-element division (the generic kernel spends ~100 instructions per axis and element on the 64-bit
+// index decomposition, which shows as soon as the 16-byte fast path does not apply: rows shifted by one element along
+// the last axis, interval tensors).  Same per-element operations as k_gather.
+template <class E>
+__global__ void __launch_bounds__(256) k_gather_rows(const double* __restrict__ src, size_t src_plane,
+                                                     double* __restrict__ out, size_t out_plane, GatherArgs a, size_t rows) {
+    typedef typename E::V V;
+    const int last = a.out.nd - 1;
+    const unsigned inner = a.out.d[last];
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    const long long shl = a.shift[last], lenl = a.src_len[last];
+    const size_t strl = a.src_stride[last];
+    const bool tab_last = a.tab_axis == last;
+    for (size_t row = wave0; row < rows; row += nwaves) {
+        size_t r = row, soff = 0;
+        bool valid_row = true;
+        unsigned kaxis_row = 0;
+#pragma unroll 1
+        for (int ax = last - 1; ax >= 0; --ax) {
+            unsigned d = a.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            long long si = (long long)k + a.shift[ax];
+            if (si < 0 || si >= (long long)a.src_len[ax]) valid_row = false;
+            soff += (size_t)(si < 0 ? 0 : si) * a.src_stride[ax];
+            if (ax == a.tab_axis) kaxis_row = k;
+        }
+        if (valid_row && a.keep && !tab_last && !a.keep[kaxis_row]) valid_row = false;
+        const size_t obase = row * inner;
+        for (unsigned k = lane; k < inner; k += 64) {
+            const long long si = (long long)k + shl;
+            const unsigned kaxis = tab_last ? k : kaxis_row;
+            bool valid = valid_row && si >= 0 && si < lenl;
+            if (valid && a.keep && tab_last && !a.keep[kaxis]) valid = false;
+            V v = E::zero();
+            if (valid) {
+                v = E::ld(src, src_plane, soff + (size_t)si * strl);
+                switch (a.op) {
+                    case OP_MUL_S: v = E::mul(v, E::from(a.s)); break;
+                    case OP_DIV_S: v = E::div(v, E::from(a.s)); break;
+                    case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
+                    case OP_NEG: v = E::neg(v); break;
+                    case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                    case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
+                    case OP_MUL_POW: {
+                        const V mv = a.tab ? E::ld(a.tab, a.tab_plane, 0) : E::from(a.s);
+                        V f = E::one();
+                        for (unsigned i = 0; i < kaxis; ++i) f = E::mul(f, mv);
+                        v = E::mul(v, f);
+                        break;
+                    }
+                    default: break;
+                }
+            }
+            E::st(out, out_plane, obase + k, v);
+        }
+    }
+}
+
 template <class E>
 void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* out, size_t out_plane,
                   const GatherArgs& a) {
@@ -131,6 +193,19 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
             hipLaunchKernelGGL(k_gather_f64x2, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, pairs);
             return;
         }
+    }
+    // rows of at least a wave's width that missed the 16-byte path: one wave per row (no per-element index arithmetic)
+    static const bool rows_on = [] {
+        const char* e = getenv("GFT_GATHER_ROWS");  // A/B knob
+        return e ? atoi(e) != 0 : true;
+    }();
+    // (only where bandwidth is the issue: on a 180 x 180 tensor one wave per row is 180 waves walking their rows serially
+    // where the per-element kernel has 32 000 threads in flight — mixture --bounds 3.0 -> 3.7 s when it was unconditional)
+    if (rows_on && a.out.nd >= 2 && a.out.d[a.out.nd - 1] >= 48 && total >= ((size_t)1 << 20)) {
+        const size_t rows = total / a.out.d[a.out.nd - 1];
+        const size_t blocks = std::min<size_t>((rows + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(k_gather_rows<E>, dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, out, out_plane, a, rows);
+        return;
     }
     hipLaunchKernelGGL(k_gather<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, a,
                        total);
