@@ -998,7 +998,7 @@ struct Ops {
         t.nd = 4;
         t.xs[0] = (a.xs[nd - 1] + B - 1) / B;
         t.ys[0] = (a.ys[nd - 1] + B - 1) / B;
-        t.zs[0] = (zI + B - 1) / B;
+        t.zs[0] = std::min((zI + B - 1) / B, t.xs[0] + t.ys[0] - 1);  // pieces that receive piece products (the fold knows)
         if (nd == 2) {
             t.xs[1] = t.ys[1] = t.zs[1] = 1;
             t.xs[2] = a.xs[0]; t.ys[2] = a.ys[0]; t.zs[2] = a.zs[0];
@@ -1179,7 +1179,7 @@ struct Ops {
                         throw Error("tiled convolution launch failed");
                     // rank 2: the slab range is a row range; rank 3: slabs of z.shape[1] rows
                     size_t per0 = nd == 2 ? 1 : zrows_per0;
-                    tiled_fold_rows_f64(R.stream, zt->p, zdst, zrows, a.slab_lo * per0, a.slab_hi * per0, B, a.zs[nd - 1],
+                    tiled_fold_rows_f64(R.stream, zt->p, zdst, zrows, a.slab_lo * per0, a.slab_hi * per0, Pz, B, a.zs[nd - 1],
                                         a.accumulate, flag, R.nf_epoch);
                 }
                 R.stats[3]++;

@@ -578,16 +578,18 @@ __global__ void __launch_bounds__(256) k_pad_rows(const double* __restrict__ in,
     }
 }
 __global__ void __launch_bounds__(256) k_fold_rows(const double* __restrict__ zt, double* __restrict__ z, size_t rows,
-                                                   size_t row_lo, size_t row_hi, unsigned B, unsigned zI, int accumulate,
-                                                   const unsigned* guard, unsigned epoch) {
+                                                   size_t row_lo, size_t row_hi, unsigned Pz, unsigned B, unsigned zI,
+                                                   int accumulate, const unsigned* guard, unsigned epoch) {
     if (guard && *guard == epoch) return;
     const unsigned RI = 2 * B - 1;
     size_t total = (row_hi - row_lo) * zI;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t row = row_lo + i / zI;
         unsigned k = (unsigned)(i % zI), p = k / B, r = k - p * B;
-        double v = zt[((size_t)p * rows + row) * RI + r];
-        if (p > 0 && r + 1 < B) v += zt[((size_t)(p - 1) * rows + row) * RI + B + r];
+        // z~ has Pz = min(pieces of z, pieces of x + pieces of y - 1) pieces: the last output piece may consist of the
+        // carry alone (a 110-long row times a 63-long one reaches k = 171 with 2 + 1 - 1 = 2 piece products)
+        double v = p < Pz ? zt[((size_t)p * rows + row) * RI + r] : 0.0;
+        if (p > 0 && p - 1 < Pz && r + 1 < B) v += zt[((size_t)(p - 1) * rows + row) * RI + B + r];
         double* dst = z + row * zI + k;
         *dst = accumulate ? *dst + v : v;
     }
@@ -946,12 +948,12 @@ void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t ro
     hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, in, out, rows,
                        len, P, B);
 }
-void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned B,
-                         unsigned zI, int accumulate, const unsigned* guard, unsigned epoch) {
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned Pz,
+                         unsigned B, unsigned zI, int accumulate, const unsigned* guard, unsigned epoch) {
     size_t tot = (row_hi - row_lo) * zI;
     if (!tot) return;
     hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, rows,
-                       row_lo, row_hi, B, zI, accumulate, guard, epoch);
+                       row_lo, row_hi, Pz, B, zI, accumulate, guard, epoch);
 }
 
 

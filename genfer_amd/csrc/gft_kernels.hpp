@@ -259,8 +259,8 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
 void tiled_set_lane_tile(int tsh);  // 0 = planner's choice, 3..6 = force T1 = 1 << tsh lanes along k1 (tests, A/B)
 void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned P, unsigned B);
-void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned B,
-                         unsigned zI, int accumulate, const unsigned* guard, unsigned epoch);
+void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned Pz,
+                         unsigned B, unsigned zI, int accumulate, const unsigned* guard, unsigned epoch);
 
 // LDS-staged reference-order convolution (gft_conv_staged.hip): bit-identical to K<E>::conv_naive, operands
 // staged through LDS once per workgroup step.  Returns false (nothing launched) if the shape does not suit

@@ -237,6 +237,8 @@ def test_conv_tiled_random_shapes(seed):
     # inner split; unit axes are collapsed by the library first, so a rank-4 shape with one unit axis is a rank-3
     # problem); what lies outside is covered by test_conv_outside_tiled_domain_falls_back_bit_exactly
     hi = {2: 160, 3: 36, 4: 14}[nd]
+    if os.environ.get("GFT_FUZZ_BIG"):  # occasional deep run: many tiles, stream-K ranges cut through tiles, reductions
+        hi = {2: 700, 3: 100, 4: 30}[nd]
     zs = [int(rng.integers(2, hi + 1)) for _ in range(nd)]
     if nd == 2:
         zs[1] = int(rng.integers(2, 260))  # rank 2: directly (lane tile 1 x 64 rows) up to 128, through the split beyond
