@@ -1419,6 +1419,15 @@ struct Ops {
                                  (unsigned)cur.shape[0], (unsigned)cur.shape[1], 1))
                     continue;
             }
+            if (!host && R.div2d && cur.shape.size() == 1) {
+                // 2-d quotient whose rows do not fit the slab kernel: row by row, each row's neg, += xs[k], copy and 1-d
+                // division in one launch
+                const bool have_x = k < xs.shape[0];
+                HV xk = have_x ? xs.index0(k) : HV{nullptr, 0, Dims{0}, false};
+                if (K<E>::div_1d(R.stream, xk.p, xk.plane, have_x ? (unsigned)xk.shape[0] : 0u, y0.p, y0.plane, (unsigned)y0.shape[0], cur.p,
+                                 cur.plane, (unsigned)cur.shape[0], 1))
+                    continue;
+            }
             x_map_inplace(cur, MAP_NEG, 0);
             if (k < xs.shape[0]) x_block_op(cur, xs.index0(k), BLK_ADD, 0);
             std::shared_ptr<Buf> tmp = alloc_tier(host, cur.numel() * W);

@@ -462,6 +462,210 @@ __global__ void __launch_bounds__(1024) k_div_2d_rows64(const double* __restrict
     }
 }
 
+// ---- 1-d division (mt:1162-1185 base case) -----------------------------------------------------------------------------
+// res[k] = (x[k] - sum_{j<k} res[j] * y[k-j]) / y[0], the sum accumulated for j ascending.  Serial in k, but lane k's
+// chain only needs res[j] at its j-th step and res[j] is final once lane j has done its steps 0..j-1 — so all lanes
+// advance in lock step over j: step j = (the owner of j finalises and publishes res[j]) then (every lane k > j adds
+// res[j] * y[k-j]).  Depth n instead of n^2/2, per-lane operation order unchanged.  A step is an LDS round trip and a
+// handful of instructions, so nothing slow may sit in it: the divisor row lives in LDS (was: a global load per step and
+// lane), every lane's dividend is loaded up front, the quotient uses the slab division's refined reciprocal (3
+// instructions inside the exponent window instead of the ~30 of a full f64 division), the barrier orders LDS only
+// (the result's global store stays in flight), and the fused form takes the dividend as (-res) (+ x) in place —
+// the three element-wise launches the row recursion of div_rec spent per row.
+constexpr int DIV1D_EPT = 4;  // outputs per thread: n <= 4096 in one workgroup
+template <class E>
+__global__ void __launch_bounds__(1024) k_div_1d(const double* __restrict__ xs, size_t xp, unsigned nx,
+                                                 const double* __restrict__ ys, size_t yp, unsigned ny, double* res, size_t rp,
+                                                 unsigned n, int fused) {
+    typedef typename E::V V;
+    extern __shared__ double d1_lds[];  // [plane][n] quotient mirror, [plane][ny] divisor row
+    double* rl = d1_lds;
+    double* yl = d1_lds + (size_t)E::W * n;
+    const unsigned nys = ny < n ? ny : n;  // y[k - j] with k - j < n
+    for (unsigned i = threadIdx.x; i < nys; i += blockDim.x) E::st(yl, nys, i, E::ld(ys, yp, i));
+    V cur[DIV1D_EPT], dvd[DIV1D_EPT];
+    unsigned kk[DIV1D_EPT], lo[DIV1D_EPT];
+#pragma unroll
+    for (int e = 0; e < DIV1D_EPT; ++e) {
+        kk[e] = threadIdx.x + e * blockDim.x;
+        lo[e] = (kk[e] + 1 > ny) ? (kk[e] + 1 - ny) : 0;
+        cur[e] = E::zero();
+        dvd[e] = E::zero();
+        if (kk[e] < n) {
+            if (fused) {  // dividend = (-acc) (+ x): mt:1186-1188 at the level above
+                dvd[e] = E::neg(E::ld(res, rp, kk[e]));
+                if (kk[e] < nx) dvd[e] = E::add(dvd[e], E::ld(xs, xp, kk[e]));
+            } else if (kk[e] < nx) {
+                dvd[e] = E::ld(xs, xp, kk[e]);
+            }
+        }
+    }
+    const SlabDiv<E> div_y0(E::ld(ys, yp, 0));
+    __syncthreads();
+    for (unsigned j = 0; j < n; ++j) {
+        // the owner of output j finalises it
+        const unsigned oe = j / blockDim.x;
+        if (threadIdx.x == j - oe * blockDim.x) {
+#pragma unroll
+            for (int e = 0; e < DIV1D_EPT; ++e) {
+                if (e == (int)oe) {
+                    V c = E::neg(cur[e]);
+                    if (fused || j < nx) c = E::add(c, dvd[e]);
+                    const V r = div_y0(c);
+                    E::st(res, rp, j, r);
+                    E::st(rl, n, j, r);
+                }
+            }
+        }
+        lds_barrier();
+        const V rj = E::ld(rl, n, j);
+#pragma unroll
+        for (int e = 0; e < DIV1D_EPT; ++e) {
+            const unsigned k = kk[e];
+            if (k < n && k > j && j >= lo[e]) cur[e] = E::add(cur[e], E::mul(rj, E::ld(yl, nys, k - j)));
+        }
+    }
+}
+// Rows of at most 1024 coefficients: ONE wave, DIV1D_WSEG = 4, 8 or 16 coefficients per lane (k = 64 e + lane).  The quotient coefficient of
+// the step reaches all lanes by v_readlane instead of an LDS round trip plus a workgroup barrier — 0.06 us a step on
+// the slab kernel's divider against 0.44 us here before (a lone workgroup runs at the idle clock; every instruction and
+// every barrier of the chain is paid in full) — and the divisor row comes from LDS at a per-lane sliding address.
+template <class E, int DIV1D_WSEG>
+__global__ void __launch_bounds__(64) k_div_1d_wave(const double* __restrict__ xs, size_t xp, unsigned nx,
+                                                    const double* __restrict__ ys, size_t yp, unsigned ny, double* res, size_t rp,
+                                                    unsigned n, int fused) {
+    typedef typename E::V V;
+    extern __shared__ double d1_lds[];  // [plane][64 zeros | 64 * DIV1D_WSEG of the divisor row, zero beyond ny]
+    constexpr unsigned CAP = 64 * (DIV1D_WSEG + 1);
+    const unsigned lane = threadIdx.x;
+    E::st(d1_lds, CAP, lane, E::zero());
+#pragma unroll
+    for (int e = 0; e < DIV1D_WSEG; ++e) {
+        const unsigned i = 64 * e + lane;
+        E::st(d1_lds, CAP, 64 + i, i < ny ? E::ld(ys, yp, i) : E::zero());
+    }
+    V cur[DIV1D_WSEG], dvd[DIV1D_WSEG], mine[DIV1D_WSEG];
+    unsigned lo[DIV1D_WSEG];
+#pragma unroll
+    for (int e = 0; e < DIV1D_WSEG; ++e) {
+        const unsigned k = 64 * e + lane;
+        lo[e] = (k + 1 > ny) ? (k + 1 - ny) : 0;
+        cur[e] = mine[e] = dvd[e] = E::zero();
+        if (k < n) {
+            if (fused) {
+                dvd[e] = E::neg(E::ld(res, rp, k));
+                if (k < nx) dvd[e] = E::add(dvd[e], E::ld(xs, xp, k));
+            } else if (k < nx) {
+                dvd[e] = E::ld(xs, xp, k);
+            }
+        }
+    }
+    const SlabDiv<E> div_y0(E::ld(ys, yp, 0));
+    __syncthreads();
+    // Fast pass: no per-lane bounds.  A lane past its own step keeps accumulating a sum nobody reads; a position beyond
+    // the divisor's length multiplies a staged zero, and cur + q * 0 == cur for every FINITE q (cur is never -0: it
+    // starts at +0 and only adds) — so the pass is exact unless a non-finite quotient coefficient appears, which is
+    // noted and settled by redoing the row with the bounds as selects (the reference's own case analysis).
+    // The divisor values of step j + 1 are requested before the quotient of step j is formed: no LDS wait in the chain.
+    bool bad = false;
+#pragma unroll
+    for (int oe = 0; oe < DIV1D_WSEG; ++oe) {
+        const unsigned j0 = 64u * oe, j1 = n < j0 + 64 ? n : j0 + 64;
+        if (j0 >= j1) break;
+        V yv[DIV1D_WSEG];
+#pragma unroll
+        for (int e = oe; e < DIV1D_WSEG; ++e) yv[e] = E::ld(d1_lds, CAP, 64 + 64 * e + lane - j0);
+        for (unsigned j = j0; j < j1; ++j) {
+            const unsigned ol = j - j0;
+            V num = E::neg(cur[oe]);
+            if (fused || j < nx) num = E::add(num, dvd[oe]);
+            V yn[DIV1D_WSEG];
+#pragma unroll
+            for (int e = oe; e < DIV1D_WSEG; ++e) yn[e] = E::ld(d1_lds, CAP, 64 + 64 * e + lane - (j + 1));
+            const V q = div_y0(bcast_lane<E>(num, ol));
+            bad = bad || !elem_finite<E>(q);
+            if (lane == ol) mine[oe] = q;
+#pragma unroll
+            for (int e = oe; e < DIV1D_WSEG; ++e) {
+                cur[e] = E::add(cur[e], E::mul(q, yv[e]));
+                yv[e] = yn[e];
+            }
+        }
+    }
+    if (bad) {  // (wave-uniform: every lane saw the same quotient coefficients)
+#pragma unroll
+        for (int e = 0; e < DIV1D_WSEG; ++e) cur[e] = E::zero();
+        for (unsigned j = 0; j < n; ++j) {
+            const unsigned oe = j >> 6, ol = j & 63u;
+            V num = E::zero();
+#pragma unroll
+            for (int e = 0; e < DIV1D_WSEG; ++e)
+                if ((unsigned)e == oe) {
+                    num = E::neg(cur[e]);
+                    if (fused || j < nx) num = E::add(num, dvd[e]);
+                }
+            const V q = div_y0(bcast_lane<E>(num, ol));
+#pragma unroll
+            for (int e = 0; e < DIV1D_WSEG; ++e) {
+                const unsigned k = 64 * e + lane;
+                if ((unsigned)e == oe && lane == ol) mine[e] = q;
+                if (k < n && k > j && j >= lo[e]) cur[e] = E::add(cur[e], E::mul(q, E::ld(d1_lds, CAP, 64 + k - j)));
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < DIV1D_WSEG; ++e) {
+        const unsigned k = 64 * e + lane;
+        if (k < n) E::st(res, rp, k, mine[e]);
+    }
+}
+// serial fallback for n > 4096
+template <class E>
+__global__ void k_div_1d_serial(const double* xs, size_t xp, unsigned nx, const double* ys, size_t yp, unsigned ny,
+                                double* res, size_t rp, unsigned n) {
+    typedef typename E::V V;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V y0 = E::ld(ys, yp, 0);
+    for (unsigned k = 0; k < n; ++k) {
+        V cur = E::zero();
+        unsigned lo = (k + 1 > ny) ? (k + 1 - ny) : 0;
+        for (unsigned j = lo; j < k; ++j) cur = E::add(cur, E::mul(E::ld(res, rp, j), E::ld(ys, yp, k - j)));
+        cur = E::neg(cur);
+        if (k < nx) cur = E::add(cur, E::ld(xs, xp, k));
+        E::st(res, rp, k, E::div(cur, y0));
+    }
+}
+template <class E>
+bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys, size_t y_plane,
+                  unsigned ny, double* res, size_t r_plane, unsigned n, int fused) {
+    if (n == 0) return true;
+    if (n > 1024 * DIV1D_EPT) {
+        if (fused) return false;  // the caller prepares the dividend itself
+        hipLaunchKernelGGL(k_div_1d_serial<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
+        return true;
+    }
+    static const bool wave_on = [] {
+        const char* e = getenv("GFT_DIV1D_WAVE");  // A/B knob
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (wave_on && n <= 1024) {
+#define GFT_D1W(SEG)                                                                                                        \
+    hipLaunchKernelGGL((k_div_1d_wave<E, SEG>), dim3(1), dim3(64), (size_t)E::W * 64 * (SEG + 1) * sizeof(double), st, xs, x_plane, \
+                       nx, ys, y_plane, ny, res, r_plane, n, fused)
+        if (n <= 256) GFT_D1W(4);
+        else if (n <= 512) GFT_D1W(8);
+        else GFT_D1W(16);
+#undef GFT_D1W
+        return true;
+    }
+    unsigned threads = std::min<unsigned>(1024, (n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_div_1d<E>, dim3(1), dim3(threads), (size_t)E::W * ((size_t)n + std::min(ny, n)) * sizeof(double), st, xs, x_plane, nx, ys,
+                       y_plane, ny, res, r_plane, n, fused);
+    return true;
+}
+template bool K<EF64>::div_1d(hipStream_t, const double*, size_t, unsigned, const double*, size_t, unsigned, double*, size_t, unsigned, int);
+template bool K<EIv>::div_1d(hipStream_t, const double*, size_t, unsigned, const double*, size_t, unsigned, double*, size_t, unsigned, int);
+
 template <class E>
 bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
                   size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused, unsigned log_k, double* res2,

@@ -655,80 +655,6 @@ void K<E>::log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
     hipLaunchKernelGGL(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
 }
 
-// 1-d division recurrence (mt:1162-1185 base case): res[k] = (xs[k] - sum_{j<k} res[j] * ys[k-j]) / ys[0], the sum
-// accumulated for j ascending.  Serial in k, but lane k's chain only needs res[j] at its j-th step and res[j] is
-// final once lane j has done its steps 0..j-1 — so all lanes advance in lockstep over j: step j = (lane j
-// finalises and publishes res[j]) then (every lane k > j adds res[j] * ys[k-j]).  Per lane the operation order is
-// exactly the serial one (bit-identical), the depth drops from n^2/2 to n.
-constexpr int DIV1D_EPT = 4;  // outputs per thread: n <= 4096 in one workgroup
-template <class E>
-__global__ void __launch_bounds__(1024) k_div_1d(const double* __restrict__ xs, size_t xp, unsigned nx,
-                                                 const double* __restrict__ ys, size_t yp, unsigned ny, double* res, size_t rp,
-                                                 unsigned n) {
-    typedef typename E::V V;
-    extern __shared__ double d1_lds[];  // res mirror: [plane][n]
-    const V y0 = E::ld(ys, yp, 0);
-    V cur[DIV1D_EPT];
-    unsigned kk[DIV1D_EPT], lo[DIV1D_EPT];
-#pragma unroll
-    for (int e = 0; e < DIV1D_EPT; ++e) {
-        kk[e] = threadIdx.x + e * blockDim.x;
-        lo[e] = (kk[e] + 1 > ny) ? (kk[e] + 1 - ny) : 0;
-        cur[e] = E::zero();
-    }
-    for (unsigned j = 0; j < n; ++j) {
-        // the owner of output j finalises it
-        const unsigned oe = j / blockDim.x;
-        if (threadIdx.x == j - oe * blockDim.x) {
-#pragma unroll
-            for (int e = 0; e < DIV1D_EPT; ++e) {
-                if (e == (int)oe) {
-                    V c = E::neg(cur[e]);
-                    if (j < nx) c = E::add(c, E::ld(xs, xp, j));
-                    V r = E::div(c, y0);
-                    E::st(res, rp, j, r);
-                    E::st(d1_lds, n, j, r);
-                }
-            }
-        }
-        __syncthreads();
-        const V rj = E::ld(d1_lds, n, j);
-#pragma unroll
-        for (int e = 0; e < DIV1D_EPT; ++e) {
-            const unsigned k = kk[e];
-            if (k < n && k > j && j >= lo[e]) cur[e] = E::add(cur[e], E::mul(rj, E::ld(ys, yp, k - j)));
-        }
-    }
-}
-// serial fallback for n > 4096
-template <class E>
-__global__ void k_div_1d_serial(const double* xs, size_t xp, unsigned nx, const double* ys, size_t yp, unsigned ny,
-                                double* res, size_t rp, unsigned n) {
-    typedef typename E::V V;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    V y0 = E::ld(ys, yp, 0);
-    for (unsigned k = 0; k < n; ++k) {
-        V cur = E::zero();
-        unsigned lo = (k + 1 > ny) ? (k + 1 - ny) : 0;
-        for (unsigned j = lo; j < k; ++j) cur = E::add(cur, E::mul(E::ld(res, rp, j), E::ld(ys, yp, k - j)));
-        cur = E::neg(cur);
-        if (k < nx) cur = E::add(cur, E::ld(xs, xp, k));
-        E::st(res, rp, k, E::div(cur, y0));
-    }
-}
-template <class E>
-void K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys, size_t y_plane,
-                  unsigned ny, double* res, size_t r_plane, unsigned n) {
-    if (n == 0) return;
-    if (n > 1024 * DIV1D_EPT) {
-        hipLaunchKernelGGL(k_div_1d_serial<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
-        return;
-    }
-    unsigned threads = std::min<unsigned>(1024, (n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_div_1d<E>, dim3(1), dim3(threads), (size_t)E::W * n * sizeof(double), st, xs, x_plane, nx, ys, y_plane, ny,
-                       res, r_plane, n);
-}
-
 template <class E>
 __global__ void k_factor_table(int op, unsigned n, unsigned len, const double* m, size_t mp, double* tab,
                                size_t tp) {

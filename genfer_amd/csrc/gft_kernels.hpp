@@ -220,8 +220,10 @@ struct K {
     static void log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
                        unsigned n, Scalar2 seed);
     // last-axis level of the division recurrence (mt:1162-1192 with 0-dim base): res = xs / ys, 1-D
-    static void div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys,
-                       size_t y_plane, unsigned ny, double* res, size_t r_plane, unsigned n);
+    // 1-d base case of the division recurrence; fused: the dividend is (-res) (+ xs inside its length) taken in place.
+    // false (fused only): shape outside the lock-step kernel — the caller prepares the dividend itself
+    static bool div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, const double* ys,
+                       size_t y_plane, unsigned ny, double* res, size_t r_plane, unsigned n, int fused = 0);
     // The last TWO axes of the division recurrence in one launch (gft_div2d.hip): res[n1, n2] = dividend / y[ny1, ny2],
     // bit-identical to the host-driven recursion.  fused == 0: dividend = x (box nx1 x nx2, row stride x_rstride);
     // fused == 1: dividend = (-res) (+ x inside its box), res holding the leading-axis partial sums on entry;

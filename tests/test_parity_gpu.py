@@ -863,3 +863,29 @@ def test_log_fused_slab_step_equals_unfused(OTP, GTP):
         x[(0,) * len(xs)] = 1.25
         o, g = both(OTP, GTP, x, deg)
         check(o.log(), g.log())
+
+
+@pytest.mark.parametrize("xs,ys", [((40,), (40,)), ((130,), (9,)), ((200,), (200,)), ((7, 90), (7, 90)), ((12, 33), (5, 20)), ((3, 4, 70), (3, 4, 70))])
+def test_division_with_non_finite_and_extreme_coefficients_bit_exact(OTP, GTP, OTPI, GTPI, xs, ys):
+    """The blocked division kernels run their rows WITHOUT per-lane bounds (excluded positions multiply a staged zero)
+    and with the 3-instruction quotient inside an exponent window; a non-finite or out-of-window coefficient must send
+    the row through the bounded / full-division form.  Dividends and divisors with inf, NaN, huge, tiny and exact-zero
+    coefficients: quotients bit-identical to the oracle (NaN payloads aside), f64 and interval."""
+    deg = [max(a, b) for a, b in zip(xs, ys)]
+    base_x, base_y = rand(xs, 1601, -1, 1), rand(ys, 1602, -1, 1)
+    base_y[(0,) * len(ys)] = 1.5
+    for tag, edit in (("inf_in_x", lambda x, y: x.__setitem__(tuple(min(2, s - 1) for s in xs), np.inf)),
+                      ("nan_in_x", lambda x, y: x.__setitem__(tuple(min(1, s - 1) for s in xs), np.nan)),
+                      ("huge", lambda x, y: x.__setitem__(tuple(min(3, s - 1) for s in xs), 1e306)),
+                      ("tiny", lambda x, y: x.__setitem__(tuple(0 for _ in xs), 1e-310)),
+                      ("inf_in_y", lambda x, y: y.__setitem__(tuple(min(1, s - 1) for s in ys), np.inf)),
+                      ("zeros", lambda x, y: (x.__setitem__(tuple(0 for _ in xs), 0.0), y.flat.__setitem__(slice(1, None, 3), 0.0)))):
+        x, y = base_x.copy(), base_y.copy()
+        edit(x, y)
+        for O, G, mk in ((OTP, GTP, lambda a: a), (OTPI, GTPI, lambda a: np.stack([a, a]))):
+            o = O.new(mk(x), deg) / O.new(mk(y), deg)
+            g = G.new(mk(x), deg) / G.new(mk(y), deg)
+            same_meta(o, g)
+            a, b = np.asarray(o.array()), np.asarray(g.array())
+            ok = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+            assert np.all(ok), (tag, O.__qualname__, np.argwhere(~ok)[:3], a[~ok][:3], b[~ok][:3])
