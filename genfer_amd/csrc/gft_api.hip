@@ -1487,6 +1487,26 @@ struct Ops {
     // The scalar seeds exp(xs[0]) / ln(xs[0]) (mt:1286-1289, 1336-1339; f64.rs:54-61 = the platform libm) are formed on
     // the host from the constant term — one value, SURVEY §8a row S — so that they are the same libm result whichever
     // side runs the recurrence; every coefficient operation after the seed is device (or host-tier) arithmetic.
+    // The 1-d base case of exp / log on DEVICE tensors.  Its order (the newest coefficient's term first, mt:1296-1310)
+    // makes it one serial chain of n^2/2 multiply-adds: a single GPU lane needs 75 ns a step (1.5 ms for a 200-long line,
+    // 30 ms for 900 — slower than the CPU from ~100 coefficients on), a host core 1 ns.  Lines of 48 coefficients or more
+    // therefore make the round trip: the argument line to pinned host memory, the host tier's own loop (the same functor,
+    // the same bits), the result line back.  ~25 us of synchronisation against milliseconds.
+    template <class F>
+    static bool line_on_host(const HV& xs, const HV& res, F&& compute) {
+        const size_t nxh = xs.numel(), nrh = res.numel();
+        if (nrh < 48 || nrh > 65536) return false;
+        std::vector<double> hx(nxh * W), hr(nrh * W);
+        for (size_t pl = 0; pl < (size_t)W; ++pl)
+            HIP_OK(hipMemcpyAsync(hx.data() + pl * nxh, xs.p + pl * xs.plane, sizeof(double) * nxh, hipMemcpyDeviceToHost, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        compute(hx.data(), nxh, hr.data(), nrh);
+        for (size_t pl = 0; pl < (size_t)W; ++pl)
+            HIP_OK(hipMemcpyAsync(res.p + pl * res.plane, hr.data() + pl * nrh, sizeof(double) * nrh, hipMemcpyHostToDevice, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));  // hr is pageable and dies here
+        R.stats[6]++;
+        return true;
+    }
     static void exp_rec(const HV& xs, const HV& res, Scalar2 seed) {
         if (xs.numel() == 0) return;
         if (res.shape.empty()) {
@@ -1495,7 +1515,10 @@ struct Ops {
         }
         if (nonunit_axes(res.shape) == 1) {
             if (res.host) HK<E>::exp_1d(xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
-            else K<E>::exp_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
+            else if (!line_on_host(xs, res, [&](const double* hx, size_t nxh, double* hr, size_t nrh) {
+                         HK<E>::exp_1d(hx, nxh, (unsigned)nxh, hr, nrh, (unsigned)nrh, seed);
+                     }))
+                K<E>::exp_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
             return;
         }
         exp_rec(xs.index0(0), res.index0(0), seed);
@@ -1569,7 +1592,10 @@ struct Ops {
         if (nonunit_axes(xs.shape) == 1) {
             if (nonunit_axes(res.shape) != 1) throw Error("log: called `Option::unwrap()` on a `None` value (mt:1346)");
             if (host) HK<E>::log_1d(xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
-            else K<E>::log_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
+            else if (!line_on_host(xs, res, [&](const double* hx, size_t nxh, double* hr, size_t nrh) {
+                         HK<E>::log_1d(hx, nxh, (unsigned)nxh, hr, nrh, (unsigned)nrh, seed);
+                     }))
+                K<E>::log_1d(R.stream, xs.p, xs.plane, (unsigned)xs.numel(), res.p, res.plane, (unsigned)res.numel(), seed);
             return;
         }
         log_rec(xs.index0(0), res.index0(0), seed);
