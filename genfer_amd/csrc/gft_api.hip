@@ -1703,7 +1703,21 @@ struct Ops {
         if (cache.size() > 4096) cache.clear();
         std::shared_ptr<Buf> tab = alloc_tier(host, len * W);
         if (host) HK<E>::factor_table(table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
-        else K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
+        else if (len * W <= 1920 && [] {
+                     static const bool on = [] {
+                         const char* e = getenv("GFT_HOST_TABLES");  // A/B knob
+                         return e ? atoi(e) != 0 : true;
+                     }();
+                     return on;
+                 }()) {
+            // a data-independent table is a serial chain (a running product): one GPU lane takes 8 us for 200 f64 factors
+            // and 90 us for 200 interval ones, a host core well under a microsecond — same functor, same bits; the values
+            // travel as kernel arguments (no pinned staging, stream-ordered)
+            std::vector<double> h(len * W);
+            HK<E>::factor_table(table_op, (unsigned)n, (unsigned)len, nullptr, 0, h.data(), len);
+            upload_small(R.stream, tab->p, h.data(), len * W);
+        } else
+            K<E>::factor_table(R.stream, table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
         cache[key] = tab;
         return tab;
     }
