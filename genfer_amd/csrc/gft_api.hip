@@ -2001,7 +2001,25 @@ struct Ops {
                     return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, mm, 1, nullptr, 1);
                 }
                 if (lens[v] <= 256) {  // short axis: every thread forms its own m^k (same running product), no table launch
-                    if (m_known) {  // m travels by value: a host-resident subst needs no device mirror (one upload launch less)
+                    if (m_known) {
+                        // m is known on the host: the powers m^k — the reference's running product ((1*m)*m)*.. (mt:557-565), the
+                        // same functor on the host, so the same bits — are formed here and travel BY VALUE; the threads
+                        // of the gather no longer walk the product themselves (up to 255 dependent multiplies each), and a
+                        // host-resident subst needs no device mirror
+                        static const bool htab_on = [] {
+                            const char* e = getenv("GFT_POW_HTAB");  // A/B knob
+                            return e ? atoi(e) != 0 : true;
+                        }();
+                        if (htab_on && lens[v] <= (W == 1 ? HTAB_CAP : HTAB_CAP / 2)) {
+                            std::vector<double> pw(lens[v] * W);
+                            typename E::V f = E::one();
+                            const typename E::V mv = E::from(Scalar2{m[0], W == 2 ? m[1] : 0.0});
+                            for (size_t k = 0; k < lens[v]; ++k) {
+                                E::st(pw.data(), lens[v], k, f);
+                                f = E::mul(f, mv);
+                            }
+                            return gather(a, lens, deg, shift, a.shape, OP_MUL_HTAB, nullptr, (int)v, pw.data(), lens[v], nullptr, 0);
+                        }
                         const double mm[2] = {m[0], m[1]};
                         return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, mm, (int)v, nullptr, 0, nullptr, 0);
                     }

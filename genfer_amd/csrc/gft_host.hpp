@@ -51,7 +51,8 @@ struct HK {
                     case OP_DIV_S: v = E::div(v, E::from(a.s)); break;
                     case OP_LMUL_S: v = E::mul(E::from(a.s), v); break;
                     case OP_NEG: v = E::neg(v); break;
-                    case OP_MUL_TAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
+                    case OP_MUL_TAB:
+                    case OP_MUL_HTAB: v = E::mul(v, E::ld(a.tab, a.tab_plane, kaxis)); break;
                     case OP_MUL_TAB_LMUL_S: v = E::mul(E::from(a.s), E::mul(v, E::ld(a.tab, a.tab_plane, kaxis))); break;
                     case OP_MUL_POW: {
                         const V mv = a.tab ? E::ld(a.tab, a.tab_plane, 0) : E::from(a.s);

@@ -67,8 +67,10 @@ __global__ void __launch_bounds__(256) k_gather(const double* __restrict__ src, 
 
 // f64 fast path: the innermost (collapsed) axis is unit-stride, unshifted, fully valid and even, all outer
 // strides are even and both bases 16-byte aligned => every thread moves one double2 (global_load_dwordx4).
+struct NoTab {};
+template <class TAB>
 __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__ src, double* __restrict__ out,
-                                                      GatherArgs a, size_t total_pairs) {
+                                                      GatherArgs a, TAB t, size_t total_pairs) {
     const int last = a.out.nd - 1;
     const unsigned half = a.out.d[last] >> 1;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total_pairs;
@@ -98,6 +100,9 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
                 case OP_LMUL_S: v.x = a.s.a * v.x; v.y = a.s.a * v.y; break;
                 case OP_NEG: v.x = -v.x; v.y = -v.y; break;
                 case OP_MUL_TAB: { double f = a.tab[kaxis]; v.x = v.x * f; v.y = v.y * f; break; }
+                case OP_MUL_HTAB:
+                    if constexpr (sizeof(TAB) > 1) { double f = t.v[kaxis]; v.x = v.x * f; v.y = v.y * f; }
+                    break;
                 case OP_MUL_TAB_LMUL_S: { double f = a.tab[kaxis]; v.x = a.s.a * (v.x * f); v.y = a.s.a * (v.y * f); break; }
                 case OP_MUL_POW: {
                     const double m = a.tab ? a.tab[0] : a.s.a;
@@ -111,6 +116,35 @@ __global__ void __launch_bounds__(256) k_gather_f64x2(const double* __restrict__
             }
         }
         *reinterpret_cast<double2*>(out + 2 * lin) = v;
+    }
+}
+
+// k_gather with the per-slab factors passed BY VALUE (OP_MUL_HTAB): x * t[k_axis]
+template <class E>
+__global__ void __launch_bounds__(256) k_gather_htab(const double* __restrict__ src, size_t src_plane,
+                                                     double* __restrict__ out, size_t out_plane, GatherArgs a, HostTab t,
+                                                     size_t total) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
+         lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin;
+        size_t soff = 0;
+        bool valid = true;
+        unsigned kaxis = 0;
+#pragma unroll 1
+        for (int ax = a.out.nd - 1; ax >= 0; --ax) {
+            unsigned d = a.out.d[ax];
+            unsigned k = (unsigned)(r % d);
+            r /= d;
+            long long si = (long long)k + a.shift[ax];
+            if (si < 0 || si >= (long long)a.src_len[ax]) valid = false;
+            soff += (size_t)(si < 0 ? 0 : si) * a.src_stride[ax];
+            if (ax == a.tab_axis) kaxis = k;
+        }
+        V v = E::zero();
+        if (valid && a.keep && !a.keep[kaxis]) valid = false;
+        if (valid) v = E::mul(E::ld(src, src_plane, soff), E::ld(t.v, HTAB_CAP / 2, kaxis));
+        E::st(out, out_plane, lin, v);
     }
 }
 
@@ -182,6 +216,15 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
     size_t total = 1;
     for (int i = 0; i < a.out.nd; ++i) total *= a.out.d[i];
     if (total == 0) return;
+    HostTab t;
+    GatherArgs b = a;
+    if (a.op == OP_MUL_HTAB) {  // a.tab is a HOST array here: [plane][tab_plane] -> by-value kernel argument
+        std::memset(&t, 0, sizeof(t));
+        const unsigned len = a.tab_axis >= 0 ? a.out.d[a.tab_axis] : 0;
+        for (unsigned pl = 0; pl < (unsigned)E::W; ++pl)
+            std::memcpy(t.v + pl * (HTAB_CAP / 2), a.tab + pl * a.tab_plane, sizeof(double) * len);
+        b.tab = nullptr;
+    }
     if (E::W == 1 && a.out.nd >= 1) {
         const int last = a.out.nd - 1;
         bool ok = a.src_stride[last] == 1 && a.shift[last] == 0 && a.out.d[last] <= a.src_len[last] &&
@@ -190,9 +233,16 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
             if (a.src_stride[i] & 1) ok = false;
         if (ok) {
             size_t pairs = total / 2;
-            hipLaunchKernelGGL(k_gather_f64x2, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, pairs);
+            if (a.op == OP_MUL_HTAB)
+                hipLaunchKernelGGL(k_gather_f64x2<HostTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, b, t, pairs);
+            else
+                hipLaunchKernelGGL(k_gather_f64x2<NoTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, NoTab{}, pairs);
             return;
         }
+    }
+    if (a.op == OP_MUL_HTAB) {
+        hipLaunchKernelGGL(k_gather_htab<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, b, t, total);
+        return;
     }
     // rows of at least a wave's width that missed the 16-byte path: one wave per row (no per-element index arithmetic)
     static const bool rows_on = [] {

@@ -28,7 +28,13 @@ struct DView {
 };
 
 enum GatherOp { OP_COPY = 0, OP_MUL_S = 1, OP_DIV_S = 2, OP_NEG = 3, OP_MUL_TAB = 4, OP_LMUL_S = 5, OP_MUL_POW = 6,
-                OP_MUL_TAB_LMUL_S = 7 /* s * (x * tab[k]): derivative scaling, then a constant factor on the left */ };
+                OP_MUL_TAB_LMUL_S = 7 /* s * (x * tab[k]): derivative scaling, then a constant factor on the left */,
+                OP_MUL_HTAB = 8 /* x * tab[k] with tab a HOST array of at most HTAB_CAP / W entries per plane: it travels to the
+                                   device kernel as a kernel argument (no table launch, no per-thread running product) */ };
+constexpr unsigned HTAB_CAP = 384;  // doubles in the by-value table (intervals: two planes of HTAB_CAP / 2)
+struct HostTab {
+    double v[HTAB_CAP];
+};
 enum MapOp { MAP_NEG = 0, MAP_DIV_U32 = 1, MAP_MUL_U32 = 2, MAP_MUL_S = 3, MAP_DIV_S = 4, MAP_LMUL_S = 5 };
 enum FirstOp { FIRST_ADD = 0, FIRST_SUB = 1, FIRST_SUB_NEG_ALL = 2 };
 enum BlockOp { BLK_ADD = 0, BLK_ADD_U32_TIMES = 1, BLK_ASSIGN = 2 };
