@@ -2000,31 +2000,36 @@ struct Ops {
                     const double mm[2] = {m[0], m[1]};
                     return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, mm, 1, nullptr, 1);
                 }
-                if (lens[v] <= 256) {  // short axis: every thread forms its own m^k (same running product), no table launch
-                    if (m_known) {
-                        // m is known on the host: the powers m^k — the reference's running product ((1*m)*m)*.. (mt:557-565), the
-                        // same functor on the host, so the same bits — are formed here and travel BY VALUE; the threads
-                        // of the gather no longer walk the product themselves (up to 255 dependent multiplies each), and a
-                        // host-resident subst needs no device mirror
-                        static const bool htab_on = [] {
-                            const char* e = getenv("GFT_POW_HTAB");  // A/B knob
-                            return e ? atoi(e) != 0 : true;
-                        }();
-                        if (htab_on && lens[v] <= (W == 1 ? HTAB_CAP : HTAB_CAP / 2)) {
-                            std::vector<double> pw(lens[v] * W);
-                            typename E::V f = E::one();
-                            const typename E::V mv = E::from(Scalar2{m[0], W == 2 ? m[1] : 0.0});
-                            for (size_t k = 0; k < lens[v]; ++k) {
-                                E::st(pw.data(), lens[v], k, f);
-                                f = E::mul(f, mv);
-                            }
-                            return gather(a, lens, deg, shift, a.shape, OP_MUL_HTAB, nullptr, (int)v, pw.data(), lens[v], nullptr, 0);
+                if (m_known) {
+                    // m is known on the host: the powers m^k — the reference's running product ((1*m)*m)*.. (mt:557-565), the
+                    // same functor on the host, so the same bits — are formed here.  Up to HTAB_CAP of them travel BY VALUE
+                    // with the gather (no table launch, no per-thread running product, no device mirror of a host-resident
+                    // subst); longer tables are uploaded.
+                    static const bool htab_on = [] {
+                        const char* e = getenv("GFT_POW_HTAB");  // A/B knob
+                        return e ? atoi(e) != 0 : true;
+                    }();
+                    if (htab_on) {
+                        std::vector<double> pw(lens[v] * W);
+                        typename E::V f = E::one();
+                        const typename E::V mv = E::from(Scalar2{m[0], W == 2 ? m[1] : 0.0});
+                        for (size_t k = 0; k < lens[v]; ++k) {
+                            E::st(pw.data(), lens[v], k, f);
+                            f = E::mul(f, mv);
                         }
+                        if (lens[v] <= (W == 1 ? HTAB_CAP : HTAB_CAP / 2))
+                            return gather(a, lens, deg, shift, a.shape, OP_MUL_HTAB, nullptr, (int)v, pw.data(), lens[v], nullptr, 0);
+                        std::shared_ptr<Buf> tabh = alloc_doubles(lens[v] * W);
+                        upload_small(R.stream, tabh->p, pw.data(), lens[v] * W);
+                        return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tabh->p, lens[v], nullptr, 0);
+                    }
+                    if (lens[v] <= 256) {
                         const double mm[2] = {m[0], m[1]};
                         return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, mm, (int)v, nullptr, 0, nullptr, 0);
                     }
-                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel, nullptr, 0);
                 }
+                if (lens[v] <= 256)  // short axis: every thread forms its own m^k (same running product), no table launch
+                    return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, dp<E>(subst) + sst[w], subst.numel, nullptr, 0);
                 std::shared_ptr<Buf> tab = alloc_doubles(lens[v] * W);
                 K<E>::factor_table(R.stream, TAB_POW, 0, (unsigned)lens[v], dp<E>(subst) + sst[w], subst.numel, tab->p, lens[v]);
                 return gather(a, lens, deg, shift, a.shape, OP_MUL_TAB, nullptr, (int)v, tab->p, lens[v], nullptr, 0);
