@@ -889,3 +889,26 @@ def test_division_with_non_finite_and_extreme_coefficients_bit_exact(OTP, GTP, O
             a, b = np.asarray(o.array()), np.asarray(g.array())
             ok = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
             assert np.all(ok), (tag, O.__qualname__, np.argwhere(~ok)[:3], a[~ok][:3], b[~ok][:3])
+
+
+def test_row_oriented_gather_large_tensors_bit_exact(OTP, GTP, OTPI, GTPI):
+    """Tensors of >= 2^20 elements whose gathers miss the 16-byte path (a shift along the last axis, odd row lengths,
+    interval planes) take the row-oriented kernel (one wave per row): derivative / coefficient expansion / mul_var /
+    truncation / linear substitution along every axis against the oracle, bit for bit."""
+    shape = (96, 101, 111)  # 1.08e6 elements, odd rows
+    x = rand(shape, 1701, -1, 1)
+    o, g = both(OTP, GTP, x, list(shape))
+    for v in range(3):
+        check(o.derivative(v, 2), g.derivative(v, 2))
+        check(o.taylor_expansion_of_coeff(v, 1), g.taylor_expansion_of_coeff(v, 1))
+        check(o * OTP.var(v, 0.0, shape[v]), g * GTP.var(v, 0.0, shape[v]))
+        lin = np.zeros([2 if ax == v else 1 for ax in range(3)])
+        lin.flat[1] = 0.75
+        check(o.subst_var(v, OTP.new(lin, list(shape))), g.subst_var(v, GTP.new(lin, list(shape))))
+    check(o.truncate_to_degree_p1(57), g.truncate_to_degree_p1(57))
+    xi = np.stack([x, x + 1e-9])
+    oi, gi = OTPI.new(xi, list(shape)), GTPI.new(xi, list(shape))
+    for v in (0, 2):
+        a, b = oi.derivative(v, 1), gi.derivative(v, 1)
+        same_meta(a, b)
+        assert np.array_equal(np.asarray(a.array()), np.asarray(b.array()))
