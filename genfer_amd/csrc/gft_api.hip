@@ -2458,12 +2458,17 @@ static Dims dims(const size_t* p, size_t n) { return Dims(p, p + n); }
 struct ApiTrace {
     bool on = getenv("GFT_TRACE_API") != nullptr;
     std::map<std::string, size_t> counts;
+    std::map<std::string, size_t> tiny;  // results of at most 2 elements that live in DEVICE memory, by entry point
     void hit(const char* fn) {
         if (on) counts[fn]++;
+    }
+    void result(const char* fn, const gft_poly& r) {
+        if (on && r.numel <= 2 && r.buf && !r.buf->host) tiny[fn]++;
     }
     ~ApiTrace() {
         if (!on) return;
         for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %zu\n", kv.first.c_str(), kv.second);
+        for (auto& kv : tiny) fprintf(stderr, "[gft api] tiny device result from %-22s %zu\n", kv.first.c_str(), kv.second);
     }
 };
 static ApiTrace g_api_trace;
@@ -2476,7 +2481,9 @@ static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
         require_ready();
         g_api_trace.hit(fn);
-        return new gft_poly(f());
+        gft_poly* r = new gft_poly(f());
+        g_api_trace.result(fn, *r);
+        return r;
     } catch (const std::exception& e) {
         g_err = e.what();
         return nullptr;
