@@ -541,6 +541,12 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
     }
     const size_t sva = g.a_stride[g.axis], svo = g.o_stride[g.axis];
     const V xv = E::from(g.x);
+    // the derivative factors of this thread's (first) position are the same in every step: read them ONCE — a global load
+    // inside the step loop is a full memory latency on a chain of a handful of steps (the whole kernel), as is the
+    // full fence of __syncthreads(); indices are < dl[t] <= len0 - 1
+    const unsigned k0 = threadIdx.x, ntab = g.len0 ? g.len0 - 1 : 0;
+    const V tab_lo = (k0 >= 1 && k0 - 1 < ntab) ? E::ld(g.tab, g.tab_plane, k0 - 1) : E::zero();
+    const V tab_hi = k0 < ntab ? E::ld(g.tab, g.tab_plane, k0) : E::zero();
     for (unsigned t = 0; t < g.nsteps; ++t) {
         const unsigned dlt = g.dl[t], lout = g.lo[t];
         const bool first = t == 0, last = t + 1 == g.nsteps;
@@ -552,14 +558,15 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
             auto src = [&](unsigned j) -> V { return first ? E::ld(a, ap, aoff + (size_t)j * sva) : E::ld(src_l, g.lw_pad, j); };
             // D'_j = src[j + 1] * ff_j  (derivative, mt:471-479), then exactly k_observe_step's sequence
             V res = E::zero();
+            const bool mine = kv == k0;
             if (g.x_is_zero) {
-                if (kv >= 1 && kv - 1 < dlt) res = E::mul(E::mul(src(kv), E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
+                if (kv >= 1 && kv - 1 < dlt) res = E::mul(E::mul(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
             } else {
                 V A = E::zero();
-                if (kv >= 1 && kv - 1 < dlt) A = E::mul(E::mul(src(kv), E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
+                if (kv >= 1 && kv - 1 < dlt) A = E::mul(E::mul(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
                 res = E::add(res, A);
                 if (kv < dlt) {
-                    const V di = E::mul(src(kv + 1), E::ld(g.tab, g.tab_plane, kv));
+                    const V di = E::mul(src(kv + 1), mine ? tab_hi : E::ld(g.tab, g.tab_plane, kv));
                     res = E::add(res, g.x_is_one ? di : E::mul(xv, di));
                 }
             }
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
             if (last) E::st(out, op, ooff + (size_t)kv * svo, res);
             else E::st(dst_l, g.lw_pad, kv, res);
         }
-        __syncthreads();
+        lds_barrier();  // the line passes through LDS only
     }
 }
 template <class E>
