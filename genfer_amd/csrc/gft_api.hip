@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed by gft_dist_init (single-GPU users never load it)
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -2115,6 +2116,10 @@ struct Ops {
                     double c_[2], m_[2];
                     size_t u_;
                     if (!extract_linear(res, c_, m_, &u_)) {
+                        // proven (interval, non-zero finite constant): the accumulator stays non-linear for the rest of the
+                        // loop, so every remaining step runs in one host loop — two ping-pong buffers, no per-step scan,
+                        // handle or shape vectors (they cost as much as the arithmetic on ~100-element tensors)
+                        if (proven && horner_linear_rest_host(res, ca, v, i, c, m, w, deg, &res)) break;
                         res = horner_linear_step(res, ca, v, i, c, m, w, deg);
                         continue;
                     }
@@ -2235,6 +2240,72 @@ struct Ops {
         g.diag = hdiag;
         K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
         *result = out;
+        return true;
+    }
+    // Steps i0, i0-1, .., 0 of the linear Horner loop on HOST-resident operands, one pass of HK::horner_linear per step
+    // (exactly horner_linear_step's arguments, unit axes kept instead of collapsed), without the per-step handles.
+    static bool horner_linear_rest_host(const P& res0, const P& ca, size_t v, size_t i0, const double c[2], const double m[2],
+                                        size_t w, const Dims& deg, P* result) {
+        const size_t nd = deg.size();
+        if (nd == 0 || nd > (size_t)MAXD || res0.shape.size() != nd || ca.shape.size() != nd) return false;
+        Dims oc = ca.shape;
+        oc[v] = 1;
+        for (size_t ax = 0; ax < nd; ++ax) oc[ax] = std::min(oc[ax], deg[ax]);
+        const bool coeff_scalar = prod(oc) == 1;
+        auto step_shapes = [&](const Dims& rs, Dims& sh, Dims& os) {
+            sh = rs;
+            sh[w] = std::min(deg[w], sh[w] + 1);
+            os = sh;
+            if (!coeff_scalar)
+                for (size_t ax = 0; ax < nd; ++ax) os[ax] = std::min(std::max(sh[ax], oc[ax]), deg[ax]);
+        };
+        Dims rs = res0.shape, sh, os, fs = res0.shape;
+        size_t cap = 0;
+        for (size_t t = 0; t <= i0; ++t) {  // largest intermediate (shapes only grow)
+            step_shapes(fs, sh, os);
+            fs = os;
+            cap = std::max(cap, prod(os));
+        }
+        if (!tier_host(cap, res0, ca)) return false;
+        P out = make(fs, deg, true);
+        std::shared_ptr<Buf> ping = alloc_host_doubles(cap * W), pong = alloc_host_doubles(cap * W);
+        const double* src = hp<E>(res0);
+        size_t src_plane = res0.numel;
+        const Dims ast = c_strides(ca.shape);
+        HornerArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.c = Scalar2{c[0], W == 2 ? c[1] : 0.0};
+        g.m = Scalar2{m[0], W == 2 ? m[1] : 0.0};
+        g.c_zero = val_is_zero(c) ? 1 : 0;
+        g.c_one = val_is_one(c) ? 1 : 0;
+        g.coeff_scalar = coeff_scalar ? 1 : 0;
+        g.w = (int)w;
+        g.out.nd = (int)nd;
+        for (size_t ax = 0; ax < nd; ++ax) {
+            g.oc[ax] = (unsigned)oc[ax];
+            g.astr[ax] = ax == v ? 0 : ast[ax];
+        }
+        for (size_t i = i0, t = 0;; --i, ++t) {
+            step_shapes(rs, sh, os);
+            size_t stride = 1;
+            for (size_t ax = nd; ax-- > 0;) {
+                g.out.d[ax] = (unsigned)os[ax];
+                g.rs[ax] = (unsigned)rs[ax];
+                g.sh[ax] = (unsigned)sh[ax];
+                g.rstr[ax] = stride;
+                stride *= rs[ax];
+            }
+            g.a_base = i * ast[v];
+            g.upper = (unsigned)std::min(sh[w] - 1, rs[w]);
+            const size_t n_out = prod(os);
+            double* dst = i == 0 ? hp<E>(out) : ((t & 1) ? pong->p : ping->p);
+            HK<E>::horner_linear(src, src_plane, hp<E>(ca), ca.numel, dst, n_out, g);
+            rs = os;
+            src = dst;
+            src_plane = n_out;
+            if (i == 0) break;
+        }
+        *result = seal(out);
         return true;
     }
     static P horner_linear_step(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
@@ -2459,15 +2530,27 @@ struct ApiTrace {
     bool on = getenv("GFT_TRACE_API") != nullptr;
     std::map<std::string, size_t> counts;
     std::map<std::string, size_t> tiny;  // results of at most 2 elements that live in DEVICE memory, by entry point
+    std::map<std::string, double> secs;  // host wall time inside the entry point (host-tier ops: their compute time)
     void hit(const char* fn) {
         if (on) counts[fn]++;
     }
+    struct Timer {
+        ApiTrace& t;
+        const char* fn;
+        std::chrono::steady_clock::time_point t0;
+        Timer(ApiTrace& tr, const char* f) : t(tr), fn(f) {
+            if (t.on) t0 = std::chrono::steady_clock::now();
+        }
+        ~Timer() {
+            if (t.on) t.secs[fn] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    };
     void result(const char* fn, const gft_poly& r) {
         if (on && r.numel <= 2 && r.buf && !r.buf->host) tiny[fn]++;
     }
     ~ApiTrace() {
         if (!on) return;
-        for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %zu\n", kv.first.c_str(), kv.second);
+        for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %10zu calls %10.4f s\n", kv.first.c_str(), kv.second, secs[kv.first]);
         for (auto& kv : tiny) fprintf(stderr, "[gft api] tiny device result from %-22s %zu\n", kv.first.c_str(), kv.second);
     }
 };
@@ -2481,6 +2564,7 @@ static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
         require_ready();
         g_api_trace.hit(fn);
+        ApiTrace::Timer timer(g_api_trace, fn);
         gft_poly* r = new gft_poly(f());
         g_api_trace.result(fn, *r);
         return r;
@@ -2494,6 +2578,7 @@ static int guard_int(F&& f, const char* fn = __builtin_FUNCTION()) {
     try {
         require_ready();
         g_api_trace.hit(fn);
+        ApiTrace::Timer timer(g_api_trace, fn);
         return f();
     } catch (const std::exception& e) {
         g_err = e.what();

@@ -318,47 +318,97 @@ struct HK {
         }
     }
 
-    // k_horner_linear: one Horner step res * (c + m eps_w) + coeff_i, the reference's element order (HornerArgs)
+    // k_horner_linear: one Horner step res * (c + m eps_w) + coeff_i, the reference's element order (HornerArgs).
+    // `--bounds` programs whose tensors stay small (switchpoint: 73 000 substitutions of ~100 steps each) live in this
+    // loop, so it avoids what does not belong to the arithmetic: the multi-index is an odometer over the outer axes with
+    // a plain loop along the last one (no division per element), and interval operands in the positive regime
+    // (gft_elem.hpp: probability-like values) take mul_pos / add_pos — the same operations on the same values as the
+    // general forms, hence the same bits — with the general form as the fallback per element.
     static void horner_linear(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g) {
-        const size_t total = numel(g.out);
+        const int nd = g.out.nd;
+        if (nd == 0) {
+            horner_linear_elem(res, rp, a, ap, out, op, g, 0, 0, g.a_base, 0, true, true, true, false);
+            return;
+        }
         const V cv = E::from(g.c), mv = E::from(g.m);
-        for (size_t lin = 0; lin < total; ++lin) {
-            size_t r = lin, roff = 0, aoff = g.a_base;
-            unsigned kw = 0;
-            bool in_p = true, in_r = true, in_c = true;
-            for (int ax = g.out.nd - 1; ax >= 0; --ax) {
-                const unsigned d = g.out.d[ax];
-                const unsigned k = (unsigned)(r % d);
-                r /= d;
-                if (k >= g.sh[ax]) in_p = false;
-                if (k >= g.rs[ax]) in_r = false;
-                if (k >= g.oc[ax]) in_c = false;
-                if (ax == g.w) kw = k;
-                roff += (size_t)k * g.rstr[ax];
-                aoff += (size_t)k * g.astr[ax];
+        bool pos_consts = false;
+        if constexpr (E::HAS_POS) pos_consts = E::pos_ok(mv) && (g.c_zero || g.c_one || E::pos_ok(cv));
+        const int last = nd - 1;
+        const unsigned nlast = g.out.d[last];
+        size_t outer = 1;
+        for (int ax = 0; ax < last; ++ax) outer *= g.out.d[ax];
+        unsigned idx[MAXD] = {0};
+        size_t lin = 0;
+        for (size_t o = 0; o < outer; ++o) {
+            bool in_p0 = true, in_r0 = true, in_c0 = true;
+            size_t roff0 = 0, aoff0 = g.a_base;
+            unsigned kw0 = 0;
+            for (int ax = 0; ax < last; ++ax) {
+                const unsigned k = idx[ax];
+                if (k >= g.sh[ax]) in_p0 = false;
+                if (k >= g.rs[ax]) in_r0 = false;
+                if (k >= g.oc[ax]) in_c0 = false;
+                if (ax == g.w) kw0 = k;
+                roff0 += (size_t)k * g.rstr[ax];
+                aoff0 += (size_t)k * g.astr[ax];
             }
-            V p = E::zero();
-            if (in_p) {
-                if (kw >= 1 && kw - 1 < g.upper) p = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);
-                if (!g.c_zero) {
-                    p = E::add0(p);
-                    if (in_r) {
-                        const V x = E::ld(res, rp, roff);
-                        p = E::add(p, g.c_one ? x : E::mul(cv, x));
+            for (unsigned k = 0; k < nlast; ++k, ++lin) {
+                const bool in_p = in_p0 && k < g.sh[last], in_r = in_r0 && k < g.rs[last], in_c = in_c0 && k < g.oc[last];
+                const unsigned kw = g.w == last ? k : kw0;
+                const size_t roff = roff0 + (size_t)k * g.rstr[last], aoff = aoff0 + (size_t)k * g.astr[last];
+                horner_linear_elem(res, rp, a, ap, out, op, g, lin, roff, aoff, kw, in_p, in_r, in_c, pos_consts);
+            }
+            for (int ax = last - 1; ax >= 0; --ax) {
+                if (++idx[ax] < g.out.d[ax]) break;
+                idx[ax] = 0;
+            }
+        }
+    }
+    static inline void horner_linear_elem(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g,
+                                          size_t lin, size_t roff, size_t aoff, unsigned kw, bool in_p, bool in_r, bool in_c, bool pos_consts) {
+        const V cv = E::from(g.c), mv = E::from(g.m);
+        const bool t1 = in_p && kw >= 1 && kw - 1 < g.upper;  // res[k - 1] * m exists
+        const bool t2 = in_p && !g.c_zero && in_r;            // c * res[k] exists
+        const bool t3 = g.coeff_scalar ? lin == 0 : in_c;     // the coefficient slab reaches this position
+        if constexpr (E::HAS_POS) {
+            if (pos_consts) {
+                const V xm1 = t1 ? E::ld(res, rp, roff - g.rstr[g.w]) : E::one(), x = t2 ? E::ld(res, rp, roff) : E::one();
+                const V cf = t3 ? E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff) : E::one();
+                if ((!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(cf))) {
+                    const V p1 = E::mul_pos(xm1, mv), p2 = g.c_one ? x : E::mul_pos(cv, x);
+                    bool bad = (t1 && !E::pos_first_ok(p1)) || (t2 && !g.c_one && !E::pos_first_ok(p2));
+                    const V p = t1 ? (t2 ? E::add_pos(p1, p2) : p1) : (t2 ? p2 : E::zero());
+                    const bool has_p = t1 || t2;
+                    V v = t3 ? (has_p ? E::add_pos(p, cf) : cf) : p;
+                    bad = bad || ((has_p || t3) && !E::pos_result_ok(v));
+                    if (!bad) {
+                        E::st(out, op, lin, v);
+                        return;
                     }
                 }
             }
-            V v;
-            if (g.coeff_scalar) {
-                v = p;
-                if (lin == 0) v = E::add(p, E::ld(a, ap, g.a_base));
-            } else {
-                v = E::zero();
-                if (in_p) v = E::add0(p);
-                if (in_c) v = E::add(v, E::ld(a, ap, aoff));
-            }
-            E::st(out, op, lin, v);
         }
+        V p = E::zero();
+        if (in_p) {
+            if (t1) p = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);
+            if (!g.c_zero) {
+                p = E::add0(p);
+                if (in_r) {
+                    const V x = E::ld(res, rp, roff);
+                    p = E::add(p, g.c_one ? x : E::mul(cv, x));
+                }
+            }
+        }
+        V v;
+        if (g.coeff_scalar) {
+            v = p;
+            if (lin == 0) v = E::add(p, E::ld(a, ap, g.a_base));
+        } else {
+            v = E::zero();
+            if (in_p) v = E::add0(p);
+            if (in_c) v = E::add(v, E::ld(a, ap, aoff));
+        }
+        E::st(out, op, lin, v);
     }
 
     static size_t count_neq(const double* a, size_t ap, const double* b, size_t bp, size_t n) {
