@@ -1108,6 +1108,9 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             ring[d][e] = E::ld(a, ap, (size_t)(g.first_i - ((unsigned)d < last_step ? (unsigned)d : last_step)) * g.a_vstride + c_off[e]);
     bool pos_consts = false;
     if constexpr (E::HAS_POS) pos_consts = E::pos_ok(mv) && (g.c_zero || g.c_one || E::pos_ok(cv));
+    bool semi_consts = false;
+    if constexpr (E::HAS_POS)
+        semi_consts = !(g.diag & 32) && !pos_consts && E::pos_ok(mv) && (g.c_zero || g.c_one || (E::is_finite(cv) && cv.lo <= cv.hi && !E::maybe_special(cv)));
     unsigned rsw = g.rs0[g.w];
     for (unsigned t0 = 0; t0 < g.nsteps; t0 += HL_PF) {
 #pragma unroll
@@ -1172,6 +1175,40 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                                 if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
                                 continue;
                             }
+                        }
+                    }
+                }
+                if constexpr (E::HAS_POS) {
+                    // SEMI-positive regime: accumulator and coefficients positive, m positive, the constant c any finite
+                    // interval that is not one of the points 0 / +-1 — what the `--bounds` programs bring (their
+                    // c = subst - constant_term(subst) is a few ulps around zero).  With x > 0 the reference's min / max
+                    // of the four products of c * x (iv:164-190) are known from the signs of c's bounds, and for
+                    // positive operands they are lo * lo and hi * hi; the outward steps stay the general next_down /
+                    // next_up, so every intermediate is exactly the reference's whatever under- or overflows, and no
+                    // operation can short-circuit (no operand or partial result is [0,0] or a +-1 point: widened
+                    // intervals are never points).  ~60 instead of ~120 instructions per element, no fallback needed.
+                    if (semi_consts) {
+                        const bool t1 = in_p && kw[e] >= 1 && kw[e] - 1 < upper;
+                        const bool t2 = in_p && !g.c_zero && in_r;
+                        const bool t3 = g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : takes_c[e];
+                        V xm1 = E::one(), x = E::one();
+                        if (t1) xm1 = first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1);
+                        if (t2) x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
+                        const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef[e]));
+                        if (!any_lane(!ok)) {
+                            const V p1 = E::widen(xm1.lo * mv.lo, xm1.hi * mv.hi);
+                            V p2 = x;
+                            if (!g.c_one) p2 = E::widen(cv.lo * (cv.lo >= 0.0 ? x.lo : x.hi), cv.hi * (cv.hi >= 0.0 ? x.hi : x.lo));
+                            const V p12 = E::widen(p1.lo + p2.lo, p1.hi + p2.hi);
+                            const V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
+                            const bool has_p = t1 || t2;
+                            const V pc = E::widen(p.lo + coef[e].lo, p.hi + coef[e].hi);
+                            V v = t3 ? (has_p ? pc : coef[e]) : p;
+                            if (!g.coeff_scalar && !in_p) v = t3 ? coef[e] : E::zero();
+                            if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
+                            else E::st(dst_l, lw_pad, kw[e], v);
+                            if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
+                            continue;
                         }
                     }
                 }
