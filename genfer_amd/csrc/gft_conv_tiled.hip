@@ -4,20 +4,19 @@
 //
 //   canonical problem   z[u][k0][k1][k2] = sum_j x[ju][j0][j1][j2] * y[u-ju][k0-j0][k1-j1][k2-j2]
 //                       (rank 3: U = 1; rank 4: U = leading axis)
-//   lanes               the 64 lanes of a wave own an 8x8 tile of (k0,k1) output ROWS; each lane keeps
-//                       R = 8 consecutive k2 outputs of its row in registers (two such blocks per wave,
-//                       c and nb-1-c, so every wave of the workgroup has the same trip count although
-//                       the index space is triangular)
+//   lanes               the 64 lanes of a wave own a T0 x T1 tile of (k0,k1) output ROWS (8x8 by default; 4x16, 2x32 or
+//                       1x64 when k0 is short or absent: rank 2, piece-split products); each lane keeps R = 8
+//                       consecutive k2 outputs of its row in registers (two such blocks per wave, c and nb-1-c, so
+//                       every wave of the workgroup has the same trip count although the index space is triangular)
 //   x operand           wave-uniform: x[J][j2..j2+7] comes from scalar loads (constant address space =>
 //                       s_load_dwordx16) into SGPRs and is the SGPR source of v_fma_f64 — zero VGPR/LDS
 //                       traffic for one of the two operands
-//   y operand           an 8x8 window of y rows lives in LDS, row r = 8*slot0 + slot1 at offset r*P1 doubles
-//                       with P1 = ny8+1 (odd) => the rows read by any aligned group of 16 or 32 lanes
-//                       start in distinct 8-byte bank slots (conflict-free ds_read_b64 / ds_read2_b64);
-//                       each lane slides an 8-wide register window along its row: 8 new doubles from
-//                       LDS per 64 FMAs
-//   window motion       stepping j1 replaces one of the 8 ring slots (8 rows, prefetched global->VGPR
-//                       during the step, written to LDS after it); stepping j0/ju reloads the window
+//   y operand           a T0 x T1 window of y rows lives in LDS, row slot r at offset r*P1 doubles with P1/2 odd
+//                       (conflict-free ds_read_b128 per 16-lane group); each lane slides an 8-wide register window
+//                       along its row: 8 new doubles from LDS per 64 FMAs
+//   window motion       the step space is walked row by row (a run of j1 steps under one (ju, j0)): stepping j1
+//                       replaces one of the T1 ring slots (T0 rows, prefetched global->VGPR during the step, written
+//                       to LDS after it); a new row starts with a full window load
 //   triangular waste    none along k2 (the diagonal 8x8 chunk is a 36-FMA triangle); (n+8)/(n+1) per
 //                       lane axis from masked lanes in diagonal tiles
 //   load balance        stream-K: the linearised (tile, ju, j0, j1) step space is cut into equal
