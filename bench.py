@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before anything initialises HIP (see genfer_amd/__init__.py)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

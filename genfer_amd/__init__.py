@@ -15,6 +15,11 @@ from __future__ import annotations
 import ctypes
 import os
 
+# Launch-bound programs (10^5 small dependent kernels) run measurably faster with kernel arguments in device memory; the
+# HIP runtime reads the flag when it initialises, so it is set as early as this package can (a user's own value wins).
+# libgftaylor sets it too when it is loaded (gft_api.hip, prefer_device_kernargs).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 from .taylor import USIZE_MAX, TaylorError, bind  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
