@@ -140,7 +140,7 @@ def cpu_baseline_all_cores(shape, x, y, max_threads=64):
     }
 
 
-PROFILE_ROUNDS = ("r02", "r01")  # newest first
+PROFILE_ROUNDS = ("r03", "r02", "r01")  # newest first
 
 
 def pmc_traffic(world, workload):
@@ -149,7 +149,7 @@ def pmc_traffic(world, workload):
     doubled per MI355X_MICROARCH.md §HBM — gfx950 reports half of wide coalesced reads).  PMC counters cannot be
     read from inside this process; null when no profile of this workload is committed (and for N > 1)."""
     if world != 1:
-        return None
+        return None, "not collected for N > 1"
     for rnd in PROFILE_ROUNDS:
         names = [f"pmc_k_conv_tiled_{workload}.json"] + (["pmc_k_conv_tiled.json"] if workload == "c2" else [])
         for name in names:
@@ -160,10 +160,12 @@ def pmc_traffic(world, workload):
             if d.get("workload", "c2") != workload:
                 continue
             try:
-                return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+                return ((2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0,
+                        f"committed rocprofv3 --pmc passes of this command, profiles/{rnd}/{name} (2 x FETCH_SIZE + WRITE_SIZE per "
+                        "launch); NOT measured by this run — PMC counters cannot be read from inside the process")
             except KeyError:
                 continue
-    return None
+    return None, "no committed PMC profile of this workload"
 
 
 E2E_PROGRAMS = ("approx/hmm/hmm", "approx/mixture/mixture", "approx/two_populations/two_populations", "approx/switchpoint/switchpoint")
@@ -256,16 +258,28 @@ def main():
     exchange = "none" if world == 1 else os.environ.get("GFT_BENCH_EXCHANGE", "abi")
     exchange_note = None
     if exchange == "abi":
-        try:
-            ids = [genfer_amd.dist_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            genfer_amd.dist_init(rank, world, ids[0])
-        except Exception as e:  # noqa: BLE001 - any failure here means "use the other exchange", loudly noted
-            exchange, exchange_note = "torch", f"C-ABI RCCL communicator failed ({e}); torch.distributed exchange used"
-        ok = torch.tensor([1 if exchange == "abi" else 0], device="cuda")
+        # Every rank executes the same collectives whatever fails where: the id travels in a broadcast that always
+        # happens (None on failure), and the ranks agree on the outcome of each phase with an all-reduce BEFORE any of
+        # them enters ncclCommInitRank (which would hang if a peer never calls it).
+        ids, err = [None], None
+        if rank == 0:
+            try:
+                ids = [genfer_amd.dist_unique_id()]
+            except Exception as e:  # noqa: BLE001
+                err = f"gft_dist_unique_id failed ({e})"
+        dist.broadcast_object_list(ids, src=0)
+        ok = torch.tensor([0 if ids[0] is None else 1], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and exchange == "abi":
-            exchange, exchange_note = "torch", "another rank could not create the C-ABI communicator; torch.distributed exchange used"
+        if int(ok.item()) == 1:
+            try:
+                genfer_amd.dist_init(rank, world, ids[0])
+            except Exception as e:  # noqa: BLE001 - a rank that fails here fails on every rank or aborts the job (RCCL)
+                err = f"gft_dist_init failed ({e})"
+            ok = torch.tensor([0 if err else 1], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            exchange = "torch"
+            exchange_note = (err or "another rank could not create the C-ABI communicator") + "; torch.distributed exchange used"
 
     g0, g1, even, launches = local_ranges(shape[0], world, rank)
     local_macs = sum(genfer_amd.conv_macs(shape, shape, shape, a, b) for a, b in (g0, g1) if b > a)
@@ -311,6 +325,7 @@ def main():
     value = total_macs * args.steps / elapsed / 1e9
     k_ms = float(np.mean(kern_ms))
     achieved_tflops = 2.0 * local_macs / (k_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(world, args.workload)
     out = {
         "metric": "TaylorPoly mul f64 GMAC/s",
         "value": value,
@@ -323,6 +338,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
+        "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),  # process-wide launch setting this run had
         "data": "synthetic (splitmix64 uniform [0,1), seeds 1/2, row-major; SURVEY §8d)",
         "config": {
             "workload": f"{args.workload}: {desc}; z = x (*) y truncated at degrees_p1 = shape",
@@ -333,14 +349,16 @@ def main():
                            f"({'inside libgftaylor (gft_conv_raw_sharded)' if exchange == 'abi' else 'torch.distributed'})",
         },
         "roofline": {
-            "bound": "mfma",
+            "bound": "valu_fma_f64",
+            "bound_contract_class": "mfma",  # the contract's two classes are "hbm" | "mfma": this is the compute one
             "bound_detail": "FP64 FMA issue rate of the vector pipe (v_fma_f64); no MFMA instruction is issued — on gfx950 "
                             "the FP64 matrix peak is the same 78.6 TFLOP/s and measured lower (profiles/r02/microbench_fp64.txt)",
             "achieved": achieved_tflops,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / FP64_PEAK_TFLOPS,
-            "traffic": pmc_traffic(world, args.workload),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "note": "FP64 FMA roof (vector == matrix FP64 peak on gfx950, 78.6 TFLOP/s); flops = 2*MACs of the "
                     "slabs this rank computes / mean HIP-event duration of the product launch(es) on its stream",
             "kernel_ms": k_ms,

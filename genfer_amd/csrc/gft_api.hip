@@ -1329,7 +1329,13 @@ struct Ops {
     // order), then from the critical update of step s - 1, which waits for the latest bulk first.
     static void right_update(const HV& a, const HV& b, const HV& z, size_t m) {
         TiledMin guard(R.recur_tiled_min_macs);
-        if (!R.recur_overlap || !R.side || m < 2) {
+        // The overlap is only legal for launches that own nothing but their arguments: the reference-order kernels.  A
+        // tiled product takes pooled temporaries (freed for reuse by the MAIN stream as soon as conv() returns), the
+        // one conv workspace and the non-finite epoch word — shared state that two streams must not touch at once.  So
+        // whenever a product of this recurrence could take the tiled kernel ("recur_tiled_min_macs" lowered, or
+        // conv_mode 2) everything stays on the main stream.
+        const bool may_tile = W == 1 && (R.conv_mode == 2 || (R.conv_mode == 0 && R.recur_tiled_min_macs < 1.0e299));
+        if (!R.recur_overlap || !R.side || m < 2 || may_tile) {
             join_side();
             conv(a, b, z, 0, m, true, false, 0, 0, 0);
             return;
@@ -1349,6 +1355,16 @@ struct Ops {
         HIP_OK(hipEventRecord(R.ev_bulk, R.side));
         R.side_pending = true;
     }
+    // Unwinding out of a recurrence with a bulk update in flight: its operands (rsbuf / tmp / the quotient itself) are
+    // about to be released, so the side stream is drained first.
+    struct SideDrain {
+        ~SideDrain() {
+            if (R.side_pending && std::uncaught_exceptions()) {
+                (void)hipStreamSynchronize(R.side);
+                R.side_pending = false;
+            }
+        }
+    };
     // the main stream waits for everything issued on the side stream so far
     static void join_side() {
         if (!R.side_pending) return;
@@ -1357,6 +1373,7 @@ struct Ops {
     }
     static void div_rec(const HV& xs, const HV& ys, const HV& res) {
         if (xs.numel() == 0) return;
+        SideDrain drain_on_unwind;
         const bool host = res.host;
         if (res.shape.empty()) {
             if (host) E::st(res.p, res.plane, 0, E::div(E::ld(xs.p, xs.plane, 0), E::ld(ys.p, ys.plane, 0)));
@@ -1585,6 +1602,7 @@ struct Ops {
 
     static void log_rec(const HV& xs, const HV& res, Scalar2 seed) {
         if (xs.numel() == 0) return;
+        SideDrain drain_on_unwind;
         const bool host = res.host;
         if (res.shape.empty()) {
             x_set_scalar(res, seed);
@@ -2091,11 +2109,13 @@ struct Ops {
             else if (on_host(subst) || subst.c0_known || (subst.numel == 1 && subst.cached)) { first_value(subst, c0); have = true; }
             proven = have && !val_is_zero(c0) && (c0[0] - c0[0] == 0.0) && (c0[1] - c0[1] == 0.0);
         }
+#ifdef GFT_DIAG  // measurement-only builds (make EXTRA=-DGFT_DIAG): skipping the verdict makes the speculation unsound
         static const bool verify = [] {
-            const char* e = getenv("GFT_HORNER_VERIFY");  // A/B knob (0 = skip the verdict; measurement only)
+            const char* e = getenv("GFT_HORNER_VERIFY");
             return e ? atoi(e) != 0 : true;
         }();
         if (!verify) proven = true;
+#endif
         for (size_t i = ca.shape[v]; i-- > 0;) {
             bool speculate = false;
             if (!on_host(res) && res.numel > 1) {
@@ -2471,8 +2491,9 @@ struct Ops {
 
     // `impl Display for TaylorPoly` = fmt_polynomial (mt:694-730): non-zero coefficients in row-major order, each
     // followed by its variables ("a".."z", then x_<i>; "^e" above 1), joined by " + "; "0" if there is none.
-    // `debug`: `impl Debug` (mt:632-636), "TaylorPoly([degrees_p1], <polynomial>)" with the coefficients in the same
-    // polynomial form (the reference prints ndarray's nested-list Display there; the information is the same).
+    // `debug`: `impl Debug` (mt:632-636) = "TaylorPoly({:?}, {})" of degrees_p1 (a Vec<usize>: "[4, 5]", usize::MAX in
+    // full) and of the coefficient ARRAY through ndarray's Display: nested brackets with every stored element, zeros
+    // included (gft_fmt.hpp fmt_ndarray).
     static std::string format(const P& a, bool debug) {
         std::vector<double> h(a.numel * W);
         if (on_host(a)) std::memcpy(h.data(), hp<E>(a), sizeof(double) * h.size());
@@ -2484,6 +2505,11 @@ struct Ops {
             if (W == 1) return gftfmt::fmt_f64(h[i]);
             return "[" + gftfmt::fmt_f64(h[i]) + ", " + gftfmt::fmt_f64(h[a.numel + i]) + "]";  // interval.rs:243-247
         };
+        if (debug) {
+            std::string d = "TaylorPoly([";
+            for (size_t i = 0; i < a.deg.size(); ++i) d += (i ? ", " : "") + std::to_string(a.deg[i]);
+            return d + "], " + gftfmt::fmt_ndarray(a.shape.begin(), a.shape.size(), num) + ")";
+        }
         std::string out;
         bool first = true;
         Dims idx(a.shape.size(), 0);
@@ -2505,10 +2531,7 @@ struct Ops {
             }
         }
         if (first) out = "0";
-        if (!debug) return out;
-        std::string d = "TaylorPoly([";
-        for (size_t i = 0; i < a.deg.size(); ++i) d += (i ? ", " : "") + std::to_string(a.deg[i]);
-        return d + "], " + out + ")";
+        return out;
     }
 
     static bool equal(const P& a, const P& b) {
@@ -2558,14 +2581,10 @@ static ApiTrace g_api_trace;
 
 // Genfer-style programs are launch-bound (10^5 dependent kernels of 2-6 us): the HIP runtime places kernel arguments in
 // device memory when HIP_FORCE_DEV_KERNARG=1, which shortens every launch (hmm -25 %, mixture -9 % on the same box).  The
-// flag is read when the runtime initialises, so it is set when this library is loaded — never overriding a value the
-// user chose — and again in gft_init for hosts that load the library late (no effect once HIP is up).
-static void prefer_device_kernargs() { (void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
-namespace {
-struct EnvTune {
-    EnvTune() { prefer_device_kernargs(); }
-} g_env_tune;
-}  // namespace
+// flag is read when the HIP runtime initialises and it is process-wide, so it is the HOST's to set: this library never
+// touches the environment (round 2 called setenv from a static constructor).  The entry points of this repo that own
+// their process set it before HIP comes up (the `genfer` executable, bench.py, the genfer_amd Python package);
+// INTEGRATION.md tells a Rust host to do the same; bench.py records the value its process ran with.
 
 void dist_set_min_macs(double v);  // multi-GPU section below
 void dist_set_event_slot(double v);
@@ -2606,7 +2625,6 @@ extern "C" {
 
 int gft_init(int device) {
     if (R.ready) return 0;
-    prefer_device_kernargs();
     try {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
@@ -2665,6 +2683,11 @@ int gft_init(int device) {
 void gft_shutdown(void) {
     if (!R.ready) return;
     (void)hipStreamSynchronize(R.stream);
+    if (R.side) (void)hipStreamSynchronize(R.side);
+    (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
+    for (auto& kv : R.host_blocks)
+        for (void* q : kv.second) std::free(q);
+    R.host_blocks.clear();
     for (auto& kv : R.free_blocks)
         for (void* q : kv.second) (void)hipFree(q);
     R.free_blocks.clear();

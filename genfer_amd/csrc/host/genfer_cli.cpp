@@ -22,6 +22,10 @@ void gfh_free(void* p);
 }
 
 int main(int argc, char** argv) {
+    // This executable owns its process: kernel arguments in device memory shorten every launch of a launch-bound
+    // program (libgftaylor documents the flag; the library itself never touches the environment).  A value the user
+    // exported wins.  Must happen before the backend library brings up HIP.
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
     std::string file, flags;
     bool bounds = false;
     for (int i = 1; i < argc; ++i) {

@@ -83,6 +83,55 @@ static std::string fmt_num(double x) {
 }
 static std::string fmt_scalar(const F64& s) { return fmt_num(s.v); }
 static std::string fmt_scalar(const Interval& s) { return "[" + fmt_num(s.lo) + ", " + fmt_num(s.hi) + "]"; }
+// ndarray 0.15.6 `Display for ArrayBase` (arrayformat.rs format_array_inner / format_with_overflow): 0-d = the element;
+// 1-d = "[a, b, c]"; n-d = sub-arrays separated by ",\n", (n-2) blank lines and (depth+1) spaces; from 500 elements on
+// every axis is abbreviated to limit/2 items from each end around "..." (limits: last axis 11, next-to-last 11, others 6);
+// any zero-length axis = "[[..]]" with nothing inside.
+template <class S>
+static void ndarray_walk(const P<S>& p, usize depth, usize offset, bool many, std::string& o) {
+    const std::vector<usize>& shape = p.coeffs.shape;
+    const usize nd = shape.size();
+    if (depth == nd) {
+        o += fmt_scalar(p.coeffs.data[offset]);
+        return;
+    }
+    usize stride = 1;
+    for (usize i = depth + 1; i < nd; ++i) stride *= shape[i];
+    const usize from_last = nd - 1 - depth;
+    const usize limit = !many ? (usize)-1 : (from_last <= 1 ? 11 : 6);
+    std::string sep;
+    if (from_last == 0) sep = ", ";
+    else {
+        sep = ",\n";
+        for (usize i = 1; i < from_last; ++i) sep += "\n";
+        for (usize i = 0; i <= depth; ++i) sep += " ";
+    }
+    std::vector<long> items;  // -1 = ellipsis
+    if (shape[depth] <= limit) {
+        for (usize i = 0; i < shape[depth]; ++i) items.push_back((long)i);
+    } else {
+        const usize edge = limit / 2;
+        items.push_back(0);
+        for (usize i = 1; i < edge; ++i) items.push_back((long)i);
+        items.push_back(-1);
+        for (usize i = shape[depth] - edge; i < shape[depth]; ++i) items.push_back((long)i);
+    }
+    o += "[";
+    for (usize k = 0; k < items.size(); ++k) {
+        if (k) o += sep;
+        if (items[k] < 0) o += "...";
+        else ndarray_walk(p, depth + 1, offset + (usize)items[k] * stride, many, o);
+    }
+    o += "]";
+}
+template <class S>
+static std::string ndarray_display(const P<S>& p) {
+    const usize nd = p.coeffs.shape.size();
+    if (p.coeffs.data.empty()) return std::string(nd, '[') + std::string(nd, ']');
+    std::string o;
+    ndarray_walk(p, 0, 0, p.coeffs.data.size() >= 500, o);
+    return o;
+}
 template <class S>
 static std::string format_poly(const P<S>& p, bool debug) {
     std::string out;
@@ -107,9 +156,10 @@ static std::string format_poly(const P<S>& p, bool debug) {
     }
     if (first) out = "0";
     if (!debug) return out;
+    // `impl Debug` (multivariate_taylor.rs:632-636): "TaylorPoly({:?}, {})" of degrees_p1 and of the ndarray itself.
     std::string d = "TaylorPoly([";
     for (usize i = 0; i < p.degrees_p1.size(); ++i) d += (i ? ", " : "") + std::to_string(p.degrees_p1[i]);
-    return d + "], " + out + ")";
+    return d + "], " + ndarray_display(p) + ")";
 }
 
 #define DEFINE_API(PFX, S)                                                                                 \

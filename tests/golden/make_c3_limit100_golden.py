@@ -1,0 +1,40 @@
+"""Generates tests/golden/c3_limit100/*.oracle.txt: the report of a NeurIPS'23 program at `--limit 100` as the host
+interpreter prints it over the CPU ORACLE backend (oracle/liborc.so) — the checker of BASELINE configs[2] / [4] at the
+benchmarked size.  Only programs whose oracle run is too long to repeat inside the GPU test run are stored
+(mixture `--bounds`: ~12 minutes of one host core); the others are recomputed by the test itself.
+
+    python tests/golden/make_c3_limit100_golden.py            # all entries of STORED
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+STORED = [("approx/mixture/mixture", True)]
+OUT = os.path.join(ROOT, "tests", "golden", "c3_limit100")
+
+
+def stored_path(prog, bounds):
+    return os.path.join(OUT, prog.split("/")[-1] + ("-bounds" if bounds else "") + ".oracle.txt")
+
+
+def main():
+    import genfer_amd
+
+    os.makedirs(OUT, exist_ok=True)
+    oracle = os.path.join(ROOT, "oracle", "liborc.so")
+    for prog, bounds in STORED:
+        src = open(os.path.join(ROOT, "tests", "golden", "sgcl", "neurips2023", prog + ".sgcl")).read()
+        flags = "--no-timing --limit 100" + (" --bounds" if bounds else "")
+        t0 = time.time()
+        rc, text, _ = genfer_amd.run_sgcl_with_backend(src, flags, oracle, "orci_" if bounds else "orc_")
+        assert rc == 0, text
+        with open(stored_path(prog, bounds), "w") as f:
+            f.write(text)
+        print(f"{prog} bounds={bounds}: {time.time() - t0:.1f} s, {len(text)} bytes")
+
+
+if __name__ == "__main__":
+    main()

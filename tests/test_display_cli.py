@@ -20,12 +20,38 @@ GENFER = os.path.join(ROOT, "genfer_amd", "csrc", "host", "genfer")
 ORACLE = os.path.join(ROOT, "oracle", "liborc.so")
 SGCL = os.path.join(GOLDEN, "sgcl")
 
+# Debug = "TaylorPoly({:?}, {})" of degrees_p1 and of the coefficient ndarray (mt:632-636): ndarray 0.15.6's Display —
+# nested brackets with EVERY stored element through `Display for F64`, rows separated by ",\n" + (ndim-2) blank lines +
+# one space per depth, usize::MAX degrees in full.  Literal strings, written out from arrayformat.rs' rules.
+UMAX = 18446744073709551615
 DISPLAY_CASES = [
-    (np.array([[1.0, 2.0, 0.0], [3.0, 0.0, 4.5e-7]]), [4, 5], "1.0 + 2.0b + 3.0a + 4.5e-7ab^2", "TaylorPoly([4, 5], 1.0 + 2.0b + 3.0a + 4.5e-7ab^2)"),
-    (np.zeros((2, 2)), [2, 2], "0", "TaylorPoly([2, 2], 0)"),
-    (np.array([0.1 + 0.2, 1e22, -1e-7, 123456789012345680.0]), [4], "0.30000000000000004 + 1e22a + -1e-7a^2 + 1.2345678901234568e17a^3", None),
-    (np.array([[[0.0, 0.5], [0.0, 0.0]], [[0.0, 0.0], [0.0, -2.0]]]), [2, 2, 2], "0.5c + -2.0abc", None),
+    (np.array([[1.0, 2.0, 0.0], [3.0, 0.0, 4.5e-7]]), [4, 5], "1.0 + 2.0b + 3.0a + 4.5e-7ab^2",
+     "TaylorPoly([4, 5], [[1.0, 2.0, 0.0],\n [3.0, 0.0, 4.5e-7]])"),
+    (np.zeros((2, 2)), [2, 2], "0", "TaylorPoly([2, 2], [[0.0, 0.0],\n [0.0, 0.0]])"),
+    (np.array([0.1 + 0.2, 1e22, -1e-7, 123456789012345680.0]), [UMAX], "0.30000000000000004 + 1e22a + -1e-7a^2 + 1.2345678901234568e17a^3",
+     "TaylorPoly([18446744073709551615], [0.30000000000000004, 1e22, -1e-7, 1.2345678901234568e17])"),
+    (np.array([[[0.0, 0.5], [0.0, 0.0]], [[0.0, 0.0], [0.0, -2.0]]]), [2, 2, 2], "0.5c + -2.0abc",
+     "TaylorPoly([2, 2, 2], [[[0.0, 0.5],\n  [0.0, 0.0]],\n\n [[0.0, 0.0],\n  [0.0, -2.0]]])"),
 ]
+
+
+def _check_debug_large(T):
+    """From 500 elements on ndarray abbreviates: 11 items on the last two axes, 6 on the others, half from each end."""
+    p = T.new(np.arange(600, dtype=np.float64), [600])
+    want = "[" + ", ".join(f"{i}.0" for i in range(5)) + ", ..., " + ", ".join(f"{i}.0" for i in range(595, 600)) + "]"
+    assert repr(p) == f"TaylorPoly([600], {want})"
+    a = np.arange(8 * 12 * 13, dtype=np.float64).reshape(8, 12, 13)
+    p = T.new(a, [8, 12, 13])
+
+    def row(r):
+        return "[" + ", ".join(f"{v:.1f}" for v in r[:5]) + ", ..., " + ", ".join(f"{v:.1f}" for v in r[-5:]) + "]"
+
+    def plane(m):
+        rows = [row(r) for r in m[:5]] + ["..."] + [row(r) for r in m[-5:]]
+        return "[" + ",\n  ".join(rows) + "]"
+
+    planes = [plane(m) for m in a[:3]] + ["..."] + [plane(m) for m in a[-3:]]
+    assert repr(p) == "TaylorPoly([8, 12, 13], [" + ",\n\n ".join(planes) + "])"
 
 
 def _check_display(T):
@@ -35,18 +61,23 @@ def _check_display(T):
         if dbg:
             assert repr(p) == dbg
     assert str(T.from_scalar(0.0)) == "0" and str(T.from_scalar(2.5)) == "2.5"
+    assert repr(T.from_scalar(2.5)) == "TaylorPoly([], 2.5)"  # 0-dimensional array: the element itself
+    _check_debug_large(T)
     assert str(T.var(27, 0.0, 3)) == "1.0x_27"  # ppl.rs:113: variables beyond z
 
 
 def test_display_oracle(OTP, OTPI):
     _check_display(OTP)
-    assert str(OTPI.new(np.stack([np.array([0.0, 1.5]), np.array([0.0, 1.75])]), [3])) == "[1.5, 1.75]a"  # interval.rs:243-247
+    iv = OTPI.new(np.stack([np.array([0.0, 1.5]), np.array([0.0, 1.75])]), [3])
+    assert str(iv) == "[1.5, 1.75]a"  # interval.rs:243-247
+    assert repr(iv) == "TaylorPoly([3], [[0.0, 0.0], [1.5, 1.75]])"
 
 
 @pytest.mark.gpu
 def test_display_hip(GTP, GTPI, OTP):
     _check_display(GTP)
-    assert str(GTPI.new(np.stack([np.array([0.0, 1.5]), np.array([0.0, 1.75])]), [3])) == "[1.5, 1.75]a"
+    iv = GTPI.new(np.stack([np.array([0.0, 1.5]), np.array([0.0, 1.75])]), [3])
+    assert str(iv) == "[1.5, 1.75]a" and repr(iv) == "TaylorPoly([3], [[0.0, 0.0], [1.5, 1.75]])"
     rng = np.random.default_rng(5)
     for shape in [(7,), (3, 4), (2, 3, 2), (40, 60)]:  # the last one lives on the device under the default dispatch
         a = rng.standard_normal(shape) * 10.0 ** rng.integers(-12, 12, size=shape)

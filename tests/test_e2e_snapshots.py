@@ -51,8 +51,11 @@ def test_snapshot_oracle_byte_exact(path, oracle_path):
     assert text == open(path[:-5] + ".expect").read()
 
 
-@pytest.mark.parametrize("path", SLOW[:2], ids=rel)
+@pytest.mark.parametrize("path", SLOW, ids=rel)
 def test_snapshot_oracle_byte_exact_slow(path, oracle_path):
+    """All six `slow/` fixtures of the reference (tests/integration.rs runs them behind `--ignored`): mixture,
+    nested_infer_expensive and the multi-variable population_* / two_populations2000 programs SURVEY §8c-iii singles
+    out.  0.0-2.0 s each on the oracle."""
     rc, text = run(path, oracle_path, "orc_")
     assert rc == 0, text
     assert text == open(path[:-5] + ".expect").read()
@@ -115,6 +118,17 @@ def compare_reports(got, want):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FAST, ids=rel)
 def test_snapshot_hip_within_tolerance(path):
+    import genfer_amd
+
+    genfer_amd.lib()
+    rc, text = run(path, genfer_amd.LIB_PATH, "gft_")
+    assert rc == 0, text
+    compare_reports(text, open(path[:-5] + ".expect").read())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SLOW, ids=rel)
+def test_snapshot_hip_within_tolerance_slow(path):
     import genfer_amd
 
     genfer_amd.lib()
@@ -201,11 +215,29 @@ def test_bounds_hip_matches_oracle(prog, oracle_path):
 # The `.expect` snapshots were generated at the programs' auto-limit, so at --limit 100 the checker is the oracle
 # itself, run here on the host beside the HIP run of the same program (the shipped configuration: default
 # size-threshold dispatch, products above the crossover on the tiled kernel).
-C3_LIMIT100 = [
-    ("approx/hmm/hmm", False), ("approx/two_populations/two_populations", False), ("approx/mixture/mixture", False),
-    ("approx/switchpoint/switchpoint", False), ("approx/population/population", False),
-    ("approx/hmm/hmm", True), ("approx/two_populations/two_populations", True),
-]
+C3_F64 = ["approx/hmm/hmm", "approx/two_populations/two_populations", "approx/mixture/mixture", "approx/switchpoint/switchpoint",
+          "approx/population/population", "approx/population_modified/population_modified", "exact/alarm/alarm",
+          "exact/clickGraph/clickGraph", "exact/clinicalTrial2/clinicalTrial2", "exact/evidence1/evidence1", "exact/evidence2/evidence2",
+          "exact/grass/grass", "exact/murderMystery/murderMystery", "exact/twoCoins/twoCoins"]  # the whole suite
+C3_BOUNDS = ["approx/hmm/hmm", "approx/two_populations/two_populations", "approx/mixture/mixture", "approx/switchpoint/switchpoint",
+             "approx/population/population"]
+C3_LIMIT100 = [(p, False) for p in C3_F64] + [(p, True) for p in C3_BOUNDS]
+# oracle runs too long to repeat inside the GPU test run are committed by tests/golden/make_c3_limit100_golden.py
+# (mixture --bounds: ~12 minutes of one host core)
+C3_STORED = os.path.join(GOLDEN, "c3_limit100")
+
+
+def c3_stored(prog, bounds):
+    return os.path.join(C3_STORED, prog.split("/")[-1] + ("-bounds" if bounds else "") + ".oracle.txt")
+
+
+def test_c3_stored_oracle_reports_are_wellformed():
+    """The committed oracle reports (generated by make_c3_limit100_golden.py) have the benchmarked size."""
+    files = glob.glob(os.path.join(C3_STORED, "*.oracle.txt"))
+    assert files
+    for f in files:
+        text = open(f).read()
+        assert text.count("p(") >= 100 and "Total measure" in text
 
 
 @pytest.mark.gpu
@@ -223,7 +255,10 @@ def test_c3_limit100_hip_matches_oracle(prog, bounds, oracle_path):
         assert rc == 0, got
     finally:
         conftest._set_tier("device")
-    rc, want = run_flags(path, oracle_path, "orci_" if bounds else "orc_", flags)
-    assert rc == 0, want
-    assert want.count("p(") >= 100
+    if os.path.exists(c3_stored(prog, bounds)):
+        want = open(c3_stored(prog, bounds)).read()
+    else:
+        rc, want = run_flags(path, oracle_path, "orci_" if bounds else "orc_", flags)
+        assert rc == 0, want
+    assert "Total measure" in want and (want.count("p(") >= 100 or "clickGraph" in prog)  # clickGraph's result is continuous
     compare_reports(got, want)

@@ -503,6 +503,32 @@ def test_conv_tiled_vs_oracle_and_pgf_like_dynamic_range(oracle_lib):
     assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want))
 
 
+def test_conv_tiled_full_tensor_vs_oracle_64cubed(oracle_lib):
+    """The tiled kernel against the CPU oracle DIRECTLY on a whole 64^3 tensor (9e9 multiply-adds, ~3.5 s of oracle):
+    no transitivity through the GPU reference-order kernel.  Positive data: 1e-10 per coefficient; mixed signs:
+    normwise against |x| (*) |y|."""
+    import ctypes as C
+
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_raw.restype = C.c_int
+    oracle_lib.orc_mul_raw.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t]
+    shape = (64, 64, 64)
+    sz = (C.c_size_t * 3)(*shape)
+
+    def oracle(a, b):
+        out = np.zeros(shape)
+        oracle_lib.orc_mul_raw(a.ctypes.data_as(C.c_void_p), sz, b.ctypes.data_as(C.c_void_p), sz, out.ctypes.data_as(C.c_void_p), sz, 3)
+        return out
+
+    x, y = rand(shape, 61), rand(shape, 62)
+    want = oracle(x, y)
+    got = _conv_raw_gpu(2, x, y, shape)
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / want).max()
+    xm, ym = 2 * x - 1, 2 * y - 1
+    bound = oracle(np.abs(xm), np.abs(ym))
+    assert np.all(np.abs(_conv_raw_gpu(2, xm, ym, shape) - oracle(xm, ym)) <= 1e-10 * bound)
+
+
 SPLIT_SHAPES = [
     ((378, 378), (378, 378), (378, 378)),             # rank 2 (two_populations-like): last axis split into 6 x 64
     ((100, 130), (70, 97), (150, 200)),               # ragged rank 2, compact operands
@@ -630,6 +656,24 @@ def test_full_size_c5_interval_product_encloses_f64(GTP, GTPI):
     assert np.all(lo - slack <= mid) and np.all(mid <= hi + slack)
     assert np.all(hi - lo <= 1e-9 * np.abs(mid))
     assert lo[0, 0, 0] == hi[0, 0, 0] == x[0, 0, 0] * y[0, 0, 0] or lo[0, 0, 0] < x[0, 0, 0] * y[0, 0, 0] < hi[0, 0, 0]
+
+
+def test_full_size_c5_mixed_sign_interval_product_encloses_f64(GTP, GTPI):
+    """BASELINE configs[4] at the C2 size with MIXED-SIGN data (no sign-regime fast path applies to all of it): thin
+    intervals [x, x + 1e-12 |x|] around data in [-1, 1).  Soundness at full size: lo <= hi, and the f64 product of the
+    lower endpoints lies inside every interval up to the f64 product's own normwise error (1e-10 |x| (*) |y|)."""
+    shape = (128, 128, 128)
+    x, y = 2 * rand(shape, 1) - 1, 2 * rand(shape, 2) - 1
+    xh, yh = x + 1e-12 * np.abs(x), y + 1e-12 * np.abs(y)
+    iv = (GTPI.new(np.stack([x, xh]), list(shape)) * GTPI.new(np.stack([y, yh]), list(shape))).array()
+    lo, hi = np.asarray(iv[0]), np.asarray(iv[1])
+    assert np.all(lo <= hi)
+    mid = (GTP.new(x, list(shape)) * GTP.new(y, list(shape))).array()
+    bound = (GTP.new(np.abs(x), list(shape)) * GTP.new(np.abs(y), list(shape))).array()
+    slack = 1e-10 * bound
+    assert np.all(lo - slack <= mid) and np.all(mid <= hi + slack)
+    assert np.all(hi - lo <= 1e-8 * bound)  # widths: 1e-12 relative inputs + ~2e6 outward roundings per coefficient
+    assert lo[0, 0, 0] <= x[0, 0, 0] * y[0, 0, 0] <= hi[0, 0, 0]
 
 
 def test_interval_edge_values_bit_exact(OTPI, GTPI):
