@@ -188,12 +188,17 @@ def e2e_seconds(gpu_runs=5):
         for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs), ("cpu_oracle_s", oracle, "orc_", 1 if name == "mixture" else 2)):
             best = None
             for _ in range(runs):
+                before = genfer_amd.op_stats() if key == "gpu_s" else None
                 rc, text, t = genfer_amd.run_sgcl_with_backend(src, "--limit 100", lib, prefix)
                 if rc != 0:
                     row[key + "_error"] = text[-200:]
                     best = None
                     break
                 best = t["time_infer"] if best is None else min(best, t["time_infer"])
+                if before is not None:  # what one run of the program costs (the same every run)
+                    after = genfer_amd.op_stats()
+                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged"):
+                        row[k] = after[k] - before[k]
             row[key] = best
             row[key.replace("_s", "_runs")] = runs
         rows[name] = row

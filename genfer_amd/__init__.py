@@ -65,6 +65,7 @@ def _declare_runtime(L):
     L.gft_last_error.restype, L.gft_last_error.argtypes = c.c_char_p, []
     L.gft_pool_stats.restype, L.gft_pool_stats.argtypes = None, [sz]
     L.gft_op_stats.restype, L.gft_op_stats.argtypes = None, [sz]
+    L.gft_op_stats_ex.restype, L.gft_op_stats_ex.argtypes = c.c_size_t, [sz, c.c_size_t]
     L.gft_event_record.restype, L.gft_event_record.argtypes = c.c_int, [c.c_int]
     L.gft_event_elapsed_ms.restype, L.gft_event_elapsed_ms.argtypes = c.c_float, [c.c_int, c.c_int]
     L.gft_set_conv_mode.restype, L.gft_set_conv_mode.argtypes = c.c_int, [c.c_int]
@@ -150,6 +151,22 @@ def run_sgcl(source: str, flags: str = ""):
     if rc != 0:
         raise TaylorError(text)
     return text, timings
+
+
+OP_STATS = ("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops",
+            "host_to_device_mirrors")
+OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_launches")
+
+
+def op_stats() -> dict:
+    """Cumulative counters of the library since gft_init (gft_op_stats + gft_op_stats_ex) by name."""
+    L = lib()
+    a, b = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)()
+    L.gft_op_stats(a)
+    n = L.gft_op_stats_ex(b, 8)
+    out = dict(zip(OP_STATS, (int(v) for v in a)))
+    out.update(dict(zip(OP_STATS_EX, (int(v) for v in b[:n]))))
+    return out
 
 
 def _sz(seq):

@@ -146,6 +146,8 @@ struct Runtime {
     // the 1e-10-per-coefficient contract.  gft_set_option("recur_tiled_min_macs", 5e7) trades that for ~20 % at 64^3.
     double recur_tiled_min_macs = 1.0e300;
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
+    size_t stats_ex[4] = {0, 0, 0, 0};  // {operations deferred into a chain, chains materialised, fused chain add/sub launches, -}
+    bool defer = true;             // GFT_DEFER=0 / "defer": one launch per elementwise operation (A/B, bisecting)
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
@@ -329,6 +331,29 @@ static void peek(double* out, const double* dev_src, size_t stride, unsigned n) 
     wait_mail(mb, out, n);
 }
 
+// ---- deferred elementwise chains (gft_kernels.hpp ChainSrc) -------------------------------------------------------------
+// A device table of factors shared by chain stages: the powers m^k of a scaling substitution (the reference's running
+// product, mt:557-565), computed once per m on the host tier's functor and reused by every later substitution by the
+// same m (Genfer programs substitute the same few constants thousands of times).
+struct TabEntry {
+    std::shared_ptr<Buf> dev;   // W planes of `len` doubles
+    std::vector<double> host;   // the same values (element 0 of a chain is host-computable)
+    size_t len = 0;
+};
+struct PendStage {
+    int kind = 0, axis = 0;
+    double s[2] = {0, 0};
+    std::shared_ptr<TabEntry> tab;
+};
+struct Pend {
+    Dims base_shape;            // shape of the base tensor in `buf` (its axes align with the handle's leading axes)
+    size_t base_numel = 1;      // = plane stride of the base
+    int n = 0;
+    PendStage st[gft::CHAIN_MAX];
+    std::shared_ptr<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
+    Dims mat_shape;
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -354,6 +379,10 @@ struct gft_poly {
     // Subst node, and subst_var then needs no device scan to learn that a 2-element substitution has no constant
     mutable bool c0_known = false;
     mutable double c0[2] = {0, 0};
+    // deferred elementwise chain: the value is chain(buf restricted to the leading box `shape`); buf holds the BASE
+    // tensor (device).  Consumers that understand chains read it directly, everyone else goes through dp(), which
+    // materialises it once (settle).
+    mutable std::shared_ptr<Pend> pend;
 };
 
 namespace {
@@ -361,8 +390,87 @@ namespace {
 // Device pointer of a polynomial's coefficients.  1-element polynomials built from host scalars are lazy:
 // their value travels as a kernel argument wherever possible (constant scaling, scalar add, division by a
 // constant) and a device buffer is only created when some kernel really needs to read it from memory.
+static bool same_dims_mod_trailing_ones(const Dims& a, const Dims& b) {
+    const size_t n = std::max(a.size(), b.size());
+    for (size_t i = 0; i < n; ++i)
+        if ((i < a.size() ? a[i] : 1) != (i < b.size() ? b[i] : 1)) return false;
+    return true;
+}
+// The chain of `p` (or the plain tensor, as a chain without stages) as a kernel operand over the output axes `keep`.
+template <class E>
+static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
+    gft::ChainSrc c;
+    std::memset(&c, 0, sizeof(c));
+    const Dims& bs = p.pend ? p.pend->base_shape : p.shape;
+    Dims st(bs.size(), 1);
+    for (size_t i = bs.size(); i-- > 1;) st[i - 1] = st[i] * bs[i];
+    c.p = p.buf->p;
+    c.plane = p.pend ? p.pend->base_numel : p.numel;
+    for (size_t j = 0; j < keep.size(); ++j) {
+        const size_t ax = keep[j];
+        c.box[j] = (unsigned)(ax < p.shape.size() ? p.shape[ax] : 1);
+        c.stride[j] = ax < bs.size() ? st[ax] : 0;
+    }
+    if (p.pend) {
+        c.nstages = p.pend->n;
+        for (int i = 0; i < p.pend->n; ++i) {
+            const PendStage& g = p.pend->st[i];
+            gft::ChainStage& o = c.st[i];
+            o.kind = g.kind;
+            o.s = gft::Scalar2{g.s[0], g.s[1]};
+            o.axis = 0;
+            if (g.kind == gft::CH_MUL_TAB) {
+                bool found = false;
+                for (size_t j = 0; j < keep.size(); ++j)
+                    if (keep[j] == (size_t)g.axis) {
+                        o.axis = (int)j;
+                        found = true;
+                    }
+                if (!found) throw Error("internal: table axis of a deferred chain was collapsed");
+                o.tab = g.tab->dev->p;
+                o.tab_plane = g.tab->len;
+            }
+        }
+    }
+    return c;
+}
+// output axes of a chain kernel: the non-unit axes of `shape` plus every table axis of the operands
+static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*> ops) {
+    Dims keep;
+    for (size_t a = 0; a < shape.size(); ++a) {
+        bool k = shape[a] != 1;
+        for (const gft_poly* p : ops)
+            if (p->pend)
+                for (int i = 0; i < p->pend->n; ++i)
+                    if (p->pend->st[i].kind == gft::CH_MUL_TAB && (size_t)p->pend->st[i].axis == a) k = true;
+        if (k) keep.push_back(a);
+    }
+    return keep;
+}
+// Materialise a deferred chain (one launch; every copy of the handle shares the result).
+template <class E>
+static void settle(const gft_poly& p) {
+    if (!p.pend) return;
+    Pend& q = *p.pend;
+    if (!(q.mat && same_dims_mod_trailing_ones(q.mat_shape, p.shape))) {
+        std::shared_ptr<Buf> out = alloc_doubles(p.numel * E::W);
+        Dims keep = chain_keep(p.shape, {&p});
+        if (keep.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
+        Shape sh;
+        sh.nd = (int)keep.size();
+        for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)p.shape[keep[j]];
+        K<E>::chain_copy(R.stream, out->p, p.numel, sh, chain_src<E>(p, keep));
+        q.mat = out;
+        q.mat_shape = p.shape;
+        R.stats_ex[1]++;
+    }
+    p.buf = q.mat;
+    p.pend = nullptr;
+}
+
 template <class E>
 static double* dp(const gft_poly& p) {
+    if (p.pend) settle<E>(p);
     if (!p.buf) {
         p.buf = alloc_doubles(p.numel * E::W);
         Scalar2 v{p.cv[0], p.cv[1]};
@@ -565,6 +673,107 @@ struct Ops {
         return r;
     }
 
+    // ---- deferred elementwise chains (gft_kernels.hpp ChainSrc; struct Pend above) ---------------------------------------
+    // An elementwise operation on a device tensor is not launched: the result handle shares the operand's buffer and
+    // records the operation; the kernel that eventually consumes it applies the recorded stages, in order, to every
+    // element it loads (same functors => the bits of one launch per operation).  Tensors of fewer than 4 elements and
+    // everything host-resident keep the direct paths.
+    static ChainSrc chain_src_dev(const P& p, const Dims& keep) {
+        ChainSrc c = chain_src<E>(p, keep);
+        if (!p.pend) c.p = dp<E>(p);  // a host-tier tensor is read through its device mirror
+        return c;
+    }
+    static bool can_defer(const P& src, size_t out_numel) {
+        return R.defer && src.buf && !src.buf->host && out_numel >= 4;
+    }
+    // element 0 after one more stage, from element 0 before it (host side of a chain: same functors, same bits)
+    static void stage_apply_first(const PendStage& g, double v[2]) {
+        typename E::V x = E::from(hv(v));
+        const typename E::V sv = E::from(hv(g.s));
+        switch (g.kind) {
+            case CH_LMUL_S: x = E::mul(sv, x); break;
+            case CH_MUL_S: x = E::mul(x, sv); break;
+            case CH_DIV_S: x = E::div(x, sv); break;
+            case CH_NEG: x = E::neg(x); break;
+            case CH_FIRST_ADD: x = E::add(x, sv); break;
+            case CH_FIRST_SUB: x = E::sub(x, sv); break;
+            case CH_FIRST_SUB_NEG_ALL: x = E::neg(E::sub(x, sv)); break;
+            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab->host.data(), g.tab->len, 0)); break;
+            default: break;
+        }
+        double o[2] = {0.0, 0.0};
+        E::st(o, 1, 0, x);
+        v[0] = o[0];
+        v[1] = W == 2 ? o[1] : 0.0;
+    }
+    // `src` restricted to its leading box `out_shape`, with room for `extra` more stages: a handle that shares src's
+    // base buffer and copies its chain.  (A chain that is full, or that somebody has already materialised, restarts
+    // from the materialised tensor.)
+    static P deferred(const P& src, const Dims& out_shape, const Dims& out_deg, int extra) {
+        check_invariants(out_shape, out_deg);
+        if (src.pend && (src.pend->n + extra > CHAIN_MAX || src.pend->mat)) settle<E>(src);
+        P r;
+        r.width = W;
+        r.shape = out_shape;
+        r.deg = out_deg;
+        r.numel = prod(out_shape);
+        r.buf = src.buf;
+        r.c0_known = src.c0_known;
+        r.c0[0] = src.c0[0];
+        r.c0[1] = src.c0[1];
+        r.pend = std::make_shared<Pend>();
+        if (src.pend) {
+            r.pend->base_shape = src.pend->base_shape;
+            r.pend->base_numel = src.pend->base_numel;
+            r.pend->n = src.pend->n;
+            for (int i = 0; i < src.pend->n; ++i) r.pend->st[i] = src.pend->st[i];
+        } else {
+            r.pend->base_shape = src.shape;
+            r.pend->base_numel = src.numel;
+        }
+        return r;
+    }
+    static void push_stage(P& r, int kind, const double* sv, int axis = 0, std::shared_ptr<TabEntry> tab = nullptr) {
+        Pend& q = *r.pend;
+        if (q.n >= CHAIN_MAX) throw Error("internal: deferred chain overflow");
+        PendStage& g = q.st[q.n++];
+        g.kind = kind;
+        g.axis = axis;
+        g.s[0] = sv ? sv[0] : 0.0;
+        g.s[1] = (sv && W == 2) ? sv[1] : 0.0;
+        g.tab = tab;
+        if (r.c0_known) stage_apply_first(g, r.c0);
+        R.stats_ex[0]++;
+    }
+    // powers m^k, k < len, of a scaling substitution: the reference's running product ((1*m)*m)*.. (mt:557-565) on the
+    // host tier's functor, kept on the device per value of m (a longer request re-forms the table: the running product
+    // makes every table a prefix of the longer one)
+    static std::shared_ptr<TabEntry> pow_table(const double m[2], size_t len) {
+        static std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<TabEntry>> cache;
+        unsigned long long k0, k1 = 0;
+        std::memcpy(&k0, &m[0], 8);
+        if (W == 2) std::memcpy(&k1, &m[1], 8);
+        auto key = std::make_tuple(k0, k1);
+        auto it = cache.find(key);
+        if (it != cache.end() && it->second->len >= len) return it->second;
+        if (cache.size() > 256) cache.clear();
+        size_t want = std::max<size_t>(len, 64);
+        if (it != cache.end()) want = std::max(want, 2 * it->second->len);
+        auto t = std::make_shared<TabEntry>();
+        t->len = want;
+        t->host.resize(want * W);
+        typename E::V f = E::one();
+        const typename E::V mv = E::from(Scalar2{m[0], W == 2 ? m[1] : 0.0});
+        for (size_t k = 0; k < want; ++k) {
+            E::st(t->host.data(), want, k, f);
+            f = E::mul(f, mv);
+        }
+        t->dev = alloc_doubles(want * W);
+        upload_small(R.stream, t->dev->p, t->host.data(), want * W);
+        cache[key] = t;
+        return t;
+    }
+
     // ---- value inspection (the only host syncs) ---------------------------------------------
     static void first_value(const P& p, double out[2]) {
         if ((p.numel == 1 && p.cached) || (!p.buf && p.lazy_lin)) {  // host-known element 0
@@ -575,6 +784,18 @@ struct Ops {
         if (p.c0_known) {
             out[0] = p.c0[0];
             out[1] = p.c0[1];
+            return;
+        }
+        if (p.pend) {  // element 0 of the base, then the chain's stages on the host (same functors)
+            double v[2] = {0, 0};
+            R.stats[1]++;
+            peek(v, p.buf->p, p.pend->base_numel, W);
+            for (int i = 0; i < p.pend->n; ++i) stage_apply_first(p.pend->st[i], v);
+            out[0] = v[0];
+            out[1] = v[1];
+            p.c0_known = true;
+            p.c0[0] = v[0];
+            p.c0[1] = v[1];
             return;
         }
         if (p.buf && p.buf->host) {
@@ -658,6 +879,18 @@ struct Ops {
                     const Dims& src_len, int op = OP_COPY, const double* s = nullptr, int tab_axis = -1,
                     const double* tab = nullptr, size_t tab_plane = 0, const unsigned char* keep = nullptr, int tier = -1) {
         const bool host = tier < 0 ? gather_tier(src, out_shape) : tier != 0;
+        if (!host && !tab && !keep && (op == OP_COPY || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG || op == OP_LMUL_S) &&
+            can_defer(src, prod(out_shape))) {
+            // a leading box of src, optionally mapped elementwise: deferred (no launch)
+            bool prefix = out_shape.size() <= src.shape.size();
+            for (size_t ax = 0; ax < out_shape.size() && prefix; ++ax)
+                if (shift[ax] != 0 || out_shape[ax] > src_len[ax] || out_shape[ax] > src.shape[ax]) prefix = false;
+            if (prefix) {
+                P r = deferred(src, out_shape, out_deg, op == OP_COPY ? 0 : 1);
+                if (op != OP_COPY) push_stage(r, op == OP_MUL_S ? CH_MUL_S : (op == OP_DIV_S ? CH_DIV_S : (op == OP_NEG ? CH_NEG : CH_LMUL_S)), s);
+                return r;
+            }
+        }
         P out = make(out_shape, out_deg, host);
         if (out.numel == 0) return out;
         Dims sst = c_strides(src.shape);
@@ -849,6 +1082,11 @@ struct Ops {
                                   Scalar2{other.cv[0], other.cv[1]});
                 return seal(out);
             }
+            if (other.cached && can_defer(self, self.numel)) {  // element 0 (+|-) a host-known scalar: one more stage
+                P r = deferred(self, self.shape, rd, 1);
+                push_stage(r, subtract ? CH_FIRST_SUB : CH_FIRST_ADD, other.cv);
+                return r;
+            }
             P out = make(self.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(self), self.numel, dp<E>(out), out.numel, self.numel,
                              subtract ? FIRST_SUB : FIRST_ADD, sptr(other), other.numel, Scalar2{other.cv[0], other.cv[1]});
@@ -869,6 +1107,11 @@ struct Ops {
                                   subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, Scalar2{self.cv[0], self.cv[1]});
                 return seal(out);
             }
+            if (self.cached && can_defer(other, other.numel)) {
+                P r = deferred(other, other.shape, rd, 1);
+                push_stage(r, subtract ? CH_FIRST_SUB_NEG_ALL : CH_FIRST_ADD, self.cv);
+                return r;
+            }
             P out = make(other.shape, rd);
             K<E>::copy_first(R.stream, dp<E>(other), other.numel, dp<E>(out), out.numel, other.numel,
                              subtract ? FIRST_SUB_NEG_ALL : FIRST_ADD, sptr(self), self.numel, Scalar2{self.cv[0], self.cv[1]});
@@ -876,6 +1119,22 @@ struct Ops {
         }
         Dims shape = max_shape(self, other);
         const bool host = tier_host(prod(shape), self, other);
+        if (!host && (self.pend || other.pend)) {
+            // deferred operands: their chains are evaluated inside the add itself (one launch for the whole run of
+            // operations that led here)
+            Dims ckeep = chain_keep(shape, {&self, &other});
+            if (ckeep.size() <= (size_t)MAXD) {
+                P out = make(shape, rd);
+                if (!self.pend) (void)dp<E>(self);   // plain operands: lazy handles / host-tier tensors get their device buffer
+                if (!other.pend) (void)dp<E>(other);
+                Shape sh;
+                sh.nd = (int)ckeep.size();
+                for (size_t j = 0; j < ckeep.size(); ++j) sh.d[j] = (unsigned)shape[ckeep[j]];
+                K<E>::chain_addsub(R.stream, dp<E>(out), out.numel, sh, chain_src_dev(self, ckeep), chain_src_dev(other, ckeep), subtract ? 1 : 0);
+                R.stats_ex[2]++;
+                return out;
+            }
+        }
         P out = make(shape, rd, host);
         Dims keep = collapse_mask({&shape}, false);
         HV vo = view(out, host), va = view(self, host), vb = view(other, host);
@@ -929,6 +1188,7 @@ struct Ops {
             *var = p.lazy_var;
             return true;
         }
+        settle<E>(p);  // the verdict is memoised per buffer: a deferred chain is materialised first
         if (p.buf && p.buf->lin_state) {
             if (p.buf->lin_state == 1) return false;
             c[0] = p.buf->lin_c[0]; c[1] = p.buf->lin_c[1];
@@ -2019,6 +2279,12 @@ struct Ops {
                     const double mm[2] = {m[0], m[1]};
                     return gather(a, lens, deg, shift, a.shape, OP_MUL_POW, nullptr, (int)v, mm, 1, nullptr, 1);
                 }
+                if (m_known && can_defer(a, prod(lens)) && lens.size() <= a.shape.size()) {
+                    // deferred: x * m^k along v as a chain stage reading the per-m device table (no launch here)
+                    P r = deferred(a, lens, deg, 1);
+                    push_stage(r, CH_MUL_TAB, nullptr, (int)v, pow_table(m, lens[v]));
+                    return r;
+                }
                 if (m_known) {
                     // m is known on the host: the powers m^k — the reference's running product ((1*m)*m)*.. (mt:557-565), the
                     // same functor on the host, so the same bits — are formed here.  Up to HTAB_CAP of them travel BY VALUE
@@ -2665,6 +2931,7 @@ int gft_init(int device) {
         if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
         if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
+        if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
@@ -2731,6 +2998,11 @@ const char* gfti_last_error(void) { return g_err.c_str(); }
 void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
+size_t gft_op_stats_ex(size_t* out, size_t cap) {
+    const size_t v[4] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2]};
+    for (size_t i = 0; i < 4 && i < cap; ++i) out[i] = v[i];
+    return 4;
+}
 void gft_pool_stats(size_t out[3]) {
     out[0] = R.in_use;
     out[1] = R.cached;
@@ -2763,6 +3035,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "div2d") R.div2d = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
+    else if (n == "defer") R.defer = value != 0;
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);

@@ -345,7 +345,7 @@ bool launch(hipStream_t st, const double* x, size_t xp, const double* y, size_t 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_staged<E, INNER0, S>), dim3(blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
+    GFT_LAUNCH((k_conv_staged<E, INNER0, S>), dim3(blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
     return true;
 }
 

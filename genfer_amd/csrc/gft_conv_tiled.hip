@@ -931,7 +931,7 @@ hipError_t launch_main_t(hipStream_t st, const Plan& P, const TiledArgs& T) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_tiled<NW, VAR, TSH>), dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
+    GFT_LAUNCH((k_conv_tiled<NW, VAR, TSH>), dim3(P.n_wg), dim3(NW * 64), P.lds_bytes, st, T);
     return hipGetLastError();
 }
 template <int NW, int VAR>
@@ -944,14 +944,14 @@ hipError_t launch_main(hipStream_t st, const Plan& P, const TiledArgs& T) {
 void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned P, unsigned B) {
     size_t tot = rows * P * B;
     if (!tot) return;
-    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, in, out, rows,
+    GFT_LAUNCH(k_pad_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, in, out, rows,
                        len, P, B);
 }
 void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned Pz,
                          unsigned B, unsigned zI, int accumulate, const unsigned* guard, unsigned epoch) {
     size_t tot = (row_hi - row_lo) * zI;
     if (!tot) return;
-    hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, rows,
+    GFT_LAUNCH(k_fold_rows, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, zt, z, rows,
                        row_lo, row_hi, Pz, B, zI, accumulate, guard, epoch);
 }
 
@@ -1025,7 +1025,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     double* yp = (double*)(wb + al(b_slots) + al(b_xp));
     {
         size_t tot = x_rows * B.nx8 + (pack_y ? y_rows * B.ny8 : y_rows * B.yI);
-        hipLaunchKernelGGL(k_prep_operands, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, x,
+        GFT_LAUNCH(k_prep_operands, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, x,
                            xp, x_rows, B.xI, B.nx8, y, pack_y ? yp : nullptr, y_rows, B.yI, B.ny8, nf_flag, nf_epoch);
         T.xp = xp;
         T.yp = pack_y ? yp : y;
@@ -1077,7 +1077,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     }
     if (e != hipSuccess) return false;
     if (P.n_red) {
-        hipLaunchKernelGGL(k_conv_reduce, dim3(P.n_red, T.nb), dim3(256), 0, st, T, P.n_red);
+        GFT_LAUNCH(k_conv_reduce, dim3(P.n_red, T.nb), dim3(256), 0, st, T, P.n_red);
         if (hipGetLastError() != hipSuccess) return false;
     }
     return true;

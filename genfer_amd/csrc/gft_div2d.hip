@@ -641,7 +641,7 @@ bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
     if (n == 0) return true;
     if (n > 1024 * DIV1D_EPT) {
         if (fused) return false;  // the caller prepares the dividend itself
-        hipLaunchKernelGGL(k_div_1d_serial<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
+        GFT_LAUNCH(k_div_1d_serial<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
         return true;
     }
     static const bool wave_on = [] {
@@ -650,7 +650,7 @@ bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
     }();
     if (wave_on && n <= 1024) {
 #define GFT_D1W(SEG)                                                                                                        \
-    hipLaunchKernelGGL((k_div_1d_wave<E, SEG>), dim3(1), dim3(64), (size_t)E::W * 64 * (SEG + 1) * sizeof(double), st, xs, x_plane, \
+    GFT_LAUNCH((k_div_1d_wave<E, SEG>), dim3(1), dim3(64), (size_t)E::W * 64 * (SEG + 1) * sizeof(double), st, xs, x_plane, \
                        nx, ys, y_plane, ny, res, r_plane, n, fused)
         if (n <= 256) GFT_D1W(4);
         else if (n <= 512) GFT_D1W(8);
@@ -659,7 +659,7 @@ bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
         return true;
     }
     unsigned threads = std::min<unsigned>(1024, (n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_div_1d<E>, dim3(1), dim3(threads), (size_t)E::W * ((size_t)n + std::min(ny, n)) * sizeof(double), st, xs, x_plane, nx, ys,
+    GFT_LAUNCH(k_div_1d<E>, dim3(1), dim3(threads), (size_t)E::W * ((size_t)n + std::min(ny, n)) * sizeof(double), st, xs, x_plane, nx, ys,
                        y_plane, ny, res, r_plane, n, fused);
     return true;
 }
@@ -698,7 +698,7 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
                 attr_set64 = true;
             }
             const unsigned waves = std::max(1u, std::min<unsigned>(D2_NW, n1));
-            hipLaunchKernelGGL(k_div_2d_rows64<E>, dim3(1), dim3(64 * waves), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
+            GFT_LAUNCH(k_div_2d_rows64<E>, dim3(1), dim3(64 * waves), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
             return true;
         }
     }
@@ -714,7 +714,7 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
     }
     // threads: one per row element, at least enough waves to form the row products in parallel
     unsigned threads = std::max<unsigned>((n2 + 63) / 64 * 64, std::min<unsigned>(1024, 64 * (unsigned)std::min<unsigned>(D2_NW, std::max(1u, n1))));
-    hipLaunchKernelGGL(k_div_2d<E>, dim3(1), dim3(threads), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
+    GFT_LAUNCH(k_div_2d<E>, dim3(1), dim3(threads), lds, st, x, x_plane, y, y_plane, res, r_plane, g);
     return true;
 }
 

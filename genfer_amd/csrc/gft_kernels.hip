@@ -9,6 +9,8 @@
 
 namespace gft {
 
+unsigned long long g_launches = 0;
+
 static inline unsigned grid_for(size_t n, unsigned block = 256) {
     size_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -234,14 +236,14 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
         if (ok) {
             size_t pairs = total / 2;
             if (a.op == OP_MUL_HTAB)
-                hipLaunchKernelGGL(k_gather_f64x2<HostTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, b, t, pairs);
+                GFT_LAUNCH(k_gather_f64x2<HostTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, b, t, pairs);
             else
-                hipLaunchKernelGGL(k_gather_f64x2<NoTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, NoTab{}, pairs);
+                GFT_LAUNCH(k_gather_f64x2<NoTab>, dim3(grid_for(pairs)), dim3(256), 0, st, src, out, a, NoTab{}, pairs);
             return;
         }
     }
     if (a.op == OP_MUL_HTAB) {
-        hipLaunchKernelGGL(k_gather_htab<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, b, t, total);
+        GFT_LAUNCH(k_gather_htab<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, b, t, total);
         return;
     }
     // rows of at least a wave's width that missed the 16-byte path: one wave per row (no per-element index arithmetic)
@@ -254,10 +256,10 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
     if (rows_on && a.out.nd >= 2 && a.out.d[a.out.nd - 1] >= 48 && total >= ((size_t)1 << 20)) {
         const size_t rows = total / a.out.d[a.out.nd - 1];
         const size_t blocks = std::min<size_t>((rows + 3) / 4, 256 * 16);
-        hipLaunchKernelGGL(k_gather_rows<E>, dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, out, out_plane, a, rows);
+        GFT_LAUNCH(k_gather_rows<E>, dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, out, out_plane, a, rows);
         return;
     }
-    hipLaunchKernelGGL(k_gather<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, a,
+    GFT_LAUNCH(k_gather<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, out, out_plane, a,
                        total);
 }
 
@@ -324,7 +326,7 @@ void K<E>::add_scaled_padded(hipStream_t st, const DView& out, const DView& a, c
     size_t total = 1;
     for (int i = 0; i < out.sh.nd; ++i) total *= out.sh.d[i];
     if (total == 0) return;
-    hipLaunchKernelGGL(k_add_scaled_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, c, total);
+    GFT_LAUNCH(k_add_scaled_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, c, total);
 }
 
 // Equal shapes (the common case): 1-D, two f64 per thread.  Same per-element order: (0 + a) (+|-) b.
@@ -349,10 +351,90 @@ void K<E>::addsub_padded(hipStream_t st, const DView& out, const DView& a, const
     for (int i = 0; i < out.sh.nd && same; ++i)
         if (a.sh.d[i] != out.sh.d[i] || b.sh.d[i] != out.sh.d[i]) same = false;
     if (same) {
-        hipLaunchKernelGGL(k_addsub_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, a.p, b.p, out.p, total / 2, subtract);
+        GFT_LAUNCH(k_addsub_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, a.p, b.p, out.p, total / 2, subtract);
         return;
     }
-    hipLaunchKernelGGL(k_addsub_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, subtract, total);
+    GFT_LAUNCH(k_addsub_padded<E>, dim3(grid_for(total)), dim3(256), 0, st, out, a, b, subtract, total);
+}
+
+// ------------------------------------------------------------------------------------------
+// deferred elementwise chains (gft_kernels.hpp ChainSrc): materialise one, or add / subtract two on the fly
+// ------------------------------------------------------------------------------------------
+template <class E>
+__device__ __forceinline__ typename E::V chain_eval(const ChainSrc& c, size_t off, const unsigned* k, bool first) {
+    typedef typename E::V V;
+    V x = E::ld(c.p, c.plane, off);
+#pragma unroll 1
+    for (int i = 0; i < c.nstages; ++i) {
+        const ChainStage& g = c.st[i];
+        switch (g.kind) {
+            case CH_LMUL_S: x = E::mul(E::from(g.s), x); break;
+            case CH_MUL_S: x = E::mul(x, E::from(g.s)); break;
+            case CH_DIV_S: x = E::div(x, E::from(g.s)); break;
+            case CH_NEG: x = E::neg(x); break;
+            case CH_FIRST_ADD: if (first) x = E::add(x, E::from(g.s)); break;
+            case CH_FIRST_SUB: if (first) x = E::sub(x, E::from(g.s)); break;
+            case CH_FIRST_SUB_NEG_ALL:
+                if (first) x = E::sub(x, E::from(g.s));
+                x = E::neg(x);
+                break;
+            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab, g.tab_plane, k[g.axis])); break;
+            default: break;
+        }
+    }
+    return x;
+}
+
+template <class E, bool TWO>
+__global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, ChainSrc b,
+                                               int subtract, size_t total) {
+    typedef typename E::V V;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, aoff = 0, boff = 0;
+        bool ina = true, inb = true;
+        unsigned k[MAXD];
+#pragma unroll 1
+        for (int ax = sh.nd - 1; ax >= 0; --ax) {
+            const unsigned d = sh.d[ax];
+            const unsigned kk = (unsigned)(r % d);
+            r /= d;
+            k[ax] = kk;
+            if (kk >= a.box[ax]) ina = false;
+            aoff += (size_t)kk * a.stride[ax];
+            if (TWO) {
+                if (kk >= b.box[ax]) inb = false;
+                boff += (size_t)kk * b.stride[ax];
+            }
+        }
+        const bool first = lin == 0;
+        V v;
+        if (!TWO) {
+            v = ina ? chain_eval<E>(a, aoff, k, first) : E::zero();
+        } else {
+            v = E::zero();
+            if (ina) v = E::add(v, chain_eval<E>(a, aoff, k, first));
+            if (inb) {
+                V w = chain_eval<E>(b, boff, k, first);
+                v = subtract ? E::sub(v, w) : E::add(v, w);
+            }
+        }
+        E::st(out, out_plane, lin, v);
+    }
+}
+template <class E>
+void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a) {
+    size_t total = 1;
+    for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
+    if (total == 0) return;
+    GFT_LAUNCH((k_chain<E, false>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
+}
+template <class E>
+void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b,
+                        int subtract) {
+    size_t total = 1;
+    for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
+    if (total == 0) return;
+    GFT_LAUNCH((k_chain<E, true>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -377,7 +459,7 @@ template <class E>
 void K<E>::copy_first(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t n, int op,
                       const double* s, size_t s_plane, Scalar2 sv) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_copy_first<E>, dim3(grid_for(n)), dim3(256), 0, st, src, src_plane, dst, dst_plane, n, op, s,
+    GFT_LAUNCH(k_copy_first<E>, dim3(grid_for(n)), dim3(256), 0, st, src, src_plane, dst, dst_plane, n, op, s,
                        s_plane, sv);
 }
 
@@ -388,7 +470,7 @@ __global__ void k_set_small(double* p, size_t plane, unsigned n, Scalar2 v0, Sca
 }
 template <class E>
 void K<E>::set_small(hipStream_t st, double* p, size_t plane, unsigned n, Scalar2 v0, Scalar2 v1) {
-    hipLaunchKernelGGL(k_set_small<E>, dim3(1), dim3(1), 0, st, p, plane, n, v0, v1);
+    GFT_LAUNCH(k_set_small<E>, dim3(1), dim3(1), 0, st, p, plane, n, v0, v1);
 }
 
 template <class E>
@@ -458,7 +540,7 @@ void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsig
     for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
     if (total == 0) return;
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 128);  // few tickets; dense tensors exit at once
-    hipLaunchKernelGGL(k_linear_scan<E>, dim3(blocks), dim3(256), 0, st, t, axes_mask, state, mb, total);
+    GFT_LAUNCH(k_linear_scan<E>, dim3(blocks), dim3(256), 0, st, t, axes_mask, state, mb, total);
 }
 
 template <class E>
@@ -516,7 +598,7 @@ void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double*
     size_t total = 1;
     for (int i = 0; i < args.out.nd; ++i) total *= args.out.d[i];
     if (total == 0) return;
-    hipLaunchKernelGGL(k_observe_step<E>, dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args,
+    GFT_LAUNCH(k_observe_step<E>, dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args,
                        total);
 }
 
@@ -583,7 +665,7 @@ void K<E>::observe_chain(hipStream_t st, const double* a, size_t a_plane, double
     if (lines == 0 || args.nsteps == 0) return;
     const unsigned threads = std::min<unsigned>(1024, (longest + 63) / 64 * 64);
     const size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
-    hipLaunchKernelGGL(k_observe_chain<E>, dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args);
+    GFT_LAUNCH(k_observe_chain<E>, dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args);
 }
 
 template <class E>
@@ -595,7 +677,7 @@ __global__ void k_scalar_op(int op, const double* a, size_t ap, const double* b,
 template <class E>
 void K<E>::scalar_op(hipStream_t st, int op, const double* a, size_t a_plane, const double* b, size_t b_plane,
                      double* out, size_t out_plane) {
-    hipLaunchKernelGGL(k_scalar_op<E>, dim3(1), dim3(1), 0, st, op, a, a_plane, b, b_plane, out, out_plane);
+    GFT_LAUNCH(k_scalar_op<E>, dim3(1), dim3(1), 0, st, op, a, a_plane, b, b_plane, out, out_plane);
 }
 
 template <class E>
@@ -621,14 +703,14 @@ __global__ void __launch_bounds__(256) k_map_inplace(double* p, size_t plane, si
 template <class E>
 void K<E>::map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, u, s,
+    GFT_LAUNCH(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, u, s,
                        (const double*)nullptr, (size_t)0);
 }
 template <class E>
 void K<E>::map_inplace_dev(hipStream_t st, double* p, size_t plane, size_t n, int op, const double* s_ptr,
                            size_t s_plane) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, 0u, Scalar2{0, 0},
+    GFT_LAUNCH(k_map_inplace<E>, dim3(grid_for(n)), dim3(256), 0, st, p, plane, n, op, 0u, Scalar2{0, 0},
                        s_ptr, s_plane);
 }
 
@@ -664,7 +746,7 @@ void K<E>::block_op(hipStream_t st, const DView& dst, const DView& src, int op, 
     size_t total = 1;
     for (int i = 0; i < src.sh.nd; ++i) total *= src.sh.d[i];
     if (total == 0) return;
-    hipLaunchKernelGGL(k_block_op<E>, dim3(grid_for(total)), dim3(256), 0, st, dst, src, op, u, total);
+    GFT_LAUNCH(k_block_op<E>, dim3(grid_for(total)), dim3(256), 0, st, dst, src, op, u, total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -686,7 +768,7 @@ __global__ void k_exp_1d(const double* xs, size_t xp, unsigned nx, double* res, 
 template <class E>
 void K<E>::exp_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
                   unsigned n, Scalar2 seed) {
-    hipLaunchKernelGGL(k_exp_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
+    GFT_LAUNCH(k_exp_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
 }
 
 template <class E>
@@ -709,7 +791,7 @@ __global__ void k_log_1d(const double* xs, size_t xp, unsigned nx, double* res, 
 template <class E>
 void K<E>::log_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx, double* res, size_t r_plane,
                   unsigned n, Scalar2 seed) {
-    hipLaunchKernelGGL(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
+    GFT_LAUNCH(k_log_1d<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, res, r_plane, n, seed);
 }
 
 template <class E>
@@ -745,7 +827,7 @@ __global__ void k_factor_table(int op, unsigned n, unsigned len, const double* m
 template <class E>
 void K<E>::factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                         double* tab, size_t tab_plane) {
-    hipLaunchKernelGGL(k_factor_table<E>, dim3(1), dim3(64), 0, st, op, n, len, m, m_plane, tab, tab_plane);
+    GFT_LAUNCH(k_factor_table<E>, dim3(1), dim3(64), 0, st, op, n, len, m, m_plane, tab, tab_plane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -835,17 +917,17 @@ void K<E>::sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned 
     if (mode == SUM_WAVE && E::W == 1 && inner == 1) {
         size_t blocks = (outer + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_sum_last_axis_wave, dim3((unsigned)blocks), dim3(256), 0, st, in, outer, len,
+        GFT_LAUNCH(k_sum_last_axis_wave, dim3((unsigned)blocks), dim3(256), 0, st, in, outer, len,
                            axis_stride_outer, out);
         return;
     }
     if (E::W == 1 && mode != SUM_UNROLL8 && (inner & 1u) == 0 && (axis_stride_outer & 1) == 0 &&
         (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
-        hipLaunchKernelGGL(k_sum_axis_seq_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, in, outer, len, inner,
+        GFT_LAUNCH(k_sum_axis_seq_f64x2, dim3(grid_for(total / 2)), dim3(256), 0, st, in, outer, len, inner,
                            axis_stride_outer, out);
         return;
     }
-    hipLaunchKernelGGL(k_sum_axis_seq<E>, dim3(grid_for(total)), dim3(256), 0, st, in, in_plane, outer, len, inner,
+    GFT_LAUNCH(k_sum_axis_seq<E>, dim3(grid_for(total)), dim3(256), 0, st, in, in_plane, outer, len, inner,
                        axis_stride_outer, out, out_plane, mode == SUM_WAVE ? SUM_SEQ : mode);
 }
 
@@ -865,7 +947,7 @@ template <class E>
 void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const double* b, size_t b_plane, size_t n,
                      unsigned* count) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
+    GFT_LAUNCH(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -954,7 +1036,7 @@ static void launch_conv_naive(hipStream_t st, const double* x, size_t xp, const 
     dim3 g(grid_for(total)), b(256);
 #define GFT_CASE(N)                                                                                         \
     case N:                                                                                                 \
-        hipLaunchKernelGGL((k_conv_naive<E, N, INNER0>), g, b, 0, st, x, xp, y, yp, z, zp, a, total, slab); \
+        GFT_LAUNCH((k_conv_naive<E, N, INNER0>), g, b, 0, st, x, xp, y, yp, z, zp, a, total, slab); \
         break;
     switch (a.nd) {
         GFT_CASE(0) GFT_CASE(1) GFT_CASE(2) GFT_CASE(3) GFT_CASE(4) GFT_CASE(5) GFT_CASE(6) GFT_CASE(7)
@@ -1029,8 +1111,143 @@ void K<E>::horner_linear(hipStream_t st, const double* res, size_t res_plane, co
     size_t total = 1;
     for (int i = 0; i < args.out.nd; ++i) total *= args.out.d[i];
     if (total == 0) return;
-    hipLaunchKernelGGL(k_horner_linear<E>, dim3(grid_for(total)), dim3(256), 0, st, res, res_plane, a, a_plane, out, out_plane,
+    GFT_LAUNCH(k_horner_linear<E>, dim3(grid_for(total)), dim3(256), 0, st, res, res_plane, a, a_plane, out, out_plane,
                        args, total);
+}
+
+// value of lane l - 1 in lane l (lane 0: zero) — DPP wave_shr:1, no LDS
+__device__ inline double wave_shr1_d(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <class E>
+__device__ inline typename E::V wave_shr1_any(typename E::V v);
+template <>
+__device__ inline double wave_shr1_any<EF64>(double v) { return wave_shr1_d(v); }
+template <>
+__device__ inline Iv wave_shr1_any<EIv>(Iv v) { return Iv{wave_shr1_d(v.lo), wave_shr1_d(v.hi)}; }
+
+// LDS mailboxes between the waves of a workgroup (k_horner_linear_pipe).  The reads must be NON-BLOCKING — requested a
+// step ahead, consumed a step later — and ordered (counter before value; value before counter on the writing side).
+// C++ gives no such load: `volatile` makes hipcc fall back to flat accesses with a full wait after each one, an acquire
+// load waits at the point of issue.  So the four instructions are written out: DS operations of one wave enter the CU's
+// LDS queue in program order and complete in order, `asm volatile` statements keep their program order, and lds_wait()
+// ties the requested registers to the s_waitcnt so that no use can move above it.
+__device__ inline unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)p; }  // low half of the LDS aperture address
+__device__ inline void lds_request_b32(unsigned addr, unsigned& out) { asm volatile("ds_read_b32 %0, %1" : "=v"(out) : "v"(addr) : "memory"); }
+__device__ inline void lds_request_b64(unsigned addr, double& out) { asm volatile("ds_read_b64 %0, %1" : "=v"(out) : "v"(addr) : "memory"); }
+__device__ inline void lds_post_b64(unsigned addr, double v) { asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
+__device__ inline void lds_post_b32(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
+__device__ inline void lds_wait(unsigned& c, double& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(v) : : "memory"); }
+__device__ inline void lds_wait(unsigned& c, Iv& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(v.lo), "+v"(v.hi) : : "memory"); }
+__device__ inline void lds_wait(unsigned& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c) : : "memory"); }
+__device__ inline void lds_request(unsigned addr, unsigned plane_bytes, double& v) { lds_request_b64(addr, v); }
+__device__ inline void lds_request(unsigned addr, unsigned plane_bytes, Iv& v) {
+    lds_request_b64(addr, v.lo);
+    lds_request_b64(addr + plane_bytes, v.hi);
+}
+__device__ inline void lds_post(unsigned addr, unsigned plane_bytes, double v) { lds_post_b64(addr, v); }
+__device__ inline void lds_post(unsigned addr, unsigned plane_bytes, Iv v) {
+    lds_post_b64(addr, v.lo);
+    lds_post_b64(addr + plane_bytes, v.hi);
+}
+
+// One element of one Horner step with a linear substitution (HornerArgs' operation sequence), shared by the in-kernel
+// loops below so that they produce the same bits:  xm1 = res[k - e_w] (valid iff t1), x = res[k] (valid iff t2),
+// coef = the step's coefficient at k (valid iff t3); in_p: k lies inside P = res * s.  Called by every lane that is
+// inside the step's output box (the wave-level ballots inside cover exactly those lanes).
+template <class E>
+struct HornerConsts {
+    typename E::V cv, mv;
+    bool c_zero, c_one, coeff_scalar, pos_consts, semi_consts;
+};
+template <class E>
+__device__ __forceinline__ HornerConsts<E> horner_consts(const HornerLoopArgs& g) {
+    HornerConsts<E> h;
+    h.cv = E::from(g.c);
+    h.mv = E::from(g.m);
+    h.c_zero = g.c_zero != 0;
+    h.c_one = g.c_one != 0;
+    h.coeff_scalar = g.coeff_scalar != 0;
+    h.pos_consts = false;
+    h.semi_consts = false;
+    if constexpr (E::HAS_POS) {
+        h.pos_consts = E::pos_ok(h.mv) && (h.c_zero || h.c_one || E::pos_ok(h.cv));
+        h.semi_consts = !(g.diag & 32) && !h.pos_consts && E::pos_ok(h.mv) &&
+                        (h.c_zero || h.c_one || (E::is_finite(h.cv) && h.cv.lo <= h.cv.hi && !E::maybe_special(h.cv)));
+    }
+    return h;
+}
+template <class E>
+__device__ __forceinline__ typename E::V horner_elem(const HornerConsts<E>& h, bool in_p, bool t1, bool t2, bool t3,
+                                                     typename E::V xm1, typename E::V x, typename E::V coef) {
+    typedef typename E::V V;
+    if constexpr (E::HAS_POS) {
+        // Positive regime (gft_elem.hpp): probability-like accumulators, coefficients and substitution — every
+        // operand of this step a proper positive interval.  The step is then ~20 instructions instead of ~130
+        // (no sign cases, no short-circuit selects, next_down / next_up as integer steps), the same operations
+        // on the same values; whether the regime held is settled per wave, before (operands) and after
+        // (no underflow to zero, no overflow) — otherwise the general code below computes the step.
+        if (h.pos_consts) {
+            const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef));
+            if (!any_lane(!ok)) {
+                const V p1 = E::mul_pos(xm1, h.mv);
+                const V p2 = h.c_one ? x : E::mul_pos(h.cv, x);
+                bool bad = (t1 && !E::pos_first_ok(p1)) || (t2 && !h.c_one && !E::pos_first_ok(p2));
+                const V p12 = E::add_pos(p1, p2);
+                V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
+                const bool has_p = t1 || t2;
+                const V pc = E::add_pos(p, coef);
+                V v = t3 ? (has_p ? pc : coef) : p;
+                if (!h.coeff_scalar && !in_p) v = t3 ? coef : E::zero();
+                bad = bad || ((has_p || t3) && !E::pos_result_ok(v));
+                if (!any_lane(bad)) return v;
+            }
+        }
+        // SEMI-positive regime: accumulator and coefficients positive, m positive, the constant c any finite
+        // interval that is not one of the points 0 / +-1 — what the `--bounds` programs bring (their
+        // c = subst - constant_term(subst) is a few ulps around zero).  With x > 0 the reference's min / max
+        // of the four products of c * x (iv:164-190) are known from the signs of c's bounds, and for
+        // positive operands they are lo * lo and hi * hi; the outward steps stay the general next_down /
+        // next_up, so every intermediate is exactly the reference's whatever under- or overflows, and no
+        // operation can short-circuit (no operand or partial result is [0,0] or a +-1 point: widened
+        // intervals are never points).  ~60 instead of ~120 instructions per element, no fallback needed.
+        if (h.semi_consts) {
+            const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef));
+            if (!any_lane(!ok)) {
+                const V p1 = E::widen(xm1.lo * h.mv.lo, xm1.hi * h.mv.hi);
+                V p2 = x;
+                if (!h.c_one) p2 = E::widen(h.cv.lo * (h.cv.lo >= 0.0 ? x.lo : x.hi), h.cv.hi * (h.cv.hi >= 0.0 ? x.hi : x.lo));
+                const V p12 = E::widen(p1.lo + p2.lo, p1.hi + p2.hi);
+                const V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
+                const bool has_p = t1 || t2;
+                const V pc = E::widen(p.lo + coef.lo, p.hi + coef.hi);
+                V v = t3 ? (has_p ? pc : coef) : p;
+                if (!h.coeff_scalar && !in_p) v = t3 ? coef : E::zero();
+                return v;
+            }
+        }
+    }
+    V p = E::zero();
+    if (in_p) {
+        if (t1) p = E::mulw(xm1, h.mv);
+        if (!h.c_zero) {
+            p = E::add0(p);
+            if (t2) p = E::addw(p, h.c_one ? x : E::mulw(h.cv, x));
+        }
+    }
+    V v;
+    if (h.coeff_scalar) {
+        v = p;
+        if (t3) v = E::add(p, coef);
+    } else {
+        v = E::zero();
+        if (in_p) v = E::add0(p);
+        if (t3) v = E::addw(v, coef);
+    }
+    return v;
 }
 
 // The Horner recursion out[k] = f(res[k], res[k - e_w], coeff[k]) couples positions along the substitution axis w
@@ -1048,7 +1265,6 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
     typedef typename E::V V;
     extern __shared__ double hl_lds[];  // [buffer][plane][lw_pad]
     const unsigned lw = g.fs[g.w], lw_pad = g.lw_pad;
-    const V cv = E::from(g.c), mv = E::from(g.m);
     // this block's line: position on the axes other than w
     size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
     bool off_p0 = true, off_o0 = true, in_c_b = true;  // step 0 / coefficient box, axes other than w
@@ -1106,11 +1322,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
 #pragma unroll
         for (int e = 0; e < HL_EPT; ++e)
             ring[d][e] = E::ld(a, ap, (size_t)(g.first_i - ((unsigned)d < last_step ? (unsigned)d : last_step)) * g.a_vstride + c_off[e]);
-    bool pos_consts = false;
-    if constexpr (E::HAS_POS) pos_consts = E::pos_ok(mv) && (g.c_zero || g.c_one || E::pos_ok(cv));
-    bool semi_consts = false;
-    if constexpr (E::HAS_POS)
-        semi_consts = !(g.diag & 32) && !pos_consts && E::pos_ok(mv) && (g.c_zero || g.c_one || (E::is_finite(cv) && cv.lo <= cv.hi && !E::maybe_special(cv)));
+    const HornerConsts<E> hc = horner_consts<E>(g);
     unsigned rsw = g.rs0[g.w];
     for (unsigned t0 = 0; t0 < g.nsteps; t0 += HL_PF) {
 #pragma unroll
@@ -1144,95 +1356,12 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                 if (!in_o) continue;
                 const bool in_p = (first ? off_p0 : true) && kw[e] < shw;
                 const bool in_r = (first ? off_p0 : true) && kw[e] < rsw;
-                if constexpr (E::HAS_POS) {
-                    // Positive regime (gft_elem.hpp): probability-like accumulators, coefficients and substitution — every
-                    // operand of this step a proper positive interval.  The step is then ~20 instructions instead of ~130
-                    // (no sign cases, no short-circuit selects, next_down / next_up as integer steps), the same operations
-                    // on the same values; whether the regime held is settled per wave, before (operands) and after
-                    // (no underflow to zero, no overflow) — otherwise the general code below computes the step.
-                    if (pos_consts) {
-                        const bool t1 = in_p && kw[e] >= 1 && kw[e] - 1 < upper;  // res[k - 1] * m
-                        const bool t2 = in_p && !g.c_zero && in_r;               // c * res[k]
-                        const bool t3 = g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : takes_c[e];
-                        V xm1 = E::one(), x = E::one();
-                        if (t1) xm1 = first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1);
-                        if (t2) x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
-                        const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef[e]));
-                        if (!any_lane(!ok)) {
-                            const V p1 = E::mul_pos(xm1, mv);
-                            const V p2 = g.c_one ? x : E::mul_pos(cv, x);
-                            bool bad = (t1 && !E::pos_first_ok(p1)) || (t2 && !g.c_one && !E::pos_first_ok(p2));
-                            const V p12 = E::add_pos(p1, p2);
-                            V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
-                            const bool has_p = t1 || t2;
-                            const V pc = E::add_pos(p, coef[e]);
-                            V v = t3 ? (has_p ? pc : coef[e]) : p;
-                            if (!g.coeff_scalar && !in_p) v = t3 ? coef[e] : E::zero();
-                            bad = bad || ((has_p || t3) && !E::pos_result_ok(v));
-                            if (!any_lane(bad)) {
-                                if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
-                                else E::st(dst_l, lw_pad, kw[e], v);
-                                if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
-                                continue;
-                            }
-                        }
-                    }
-                }
-                if constexpr (E::HAS_POS) {
-                    // SEMI-positive regime: accumulator and coefficients positive, m positive, the constant c any finite
-                    // interval that is not one of the points 0 / +-1 — what the `--bounds` programs bring (their
-                    // c = subst - constant_term(subst) is a few ulps around zero).  With x > 0 the reference's min / max
-                    // of the four products of c * x (iv:164-190) are known from the signs of c's bounds, and for
-                    // positive operands they are lo * lo and hi * hi; the outward steps stay the general next_down /
-                    // next_up, so every intermediate is exactly the reference's whatever under- or overflows, and no
-                    // operation can short-circuit (no operand or partial result is [0,0] or a +-1 point: widened
-                    // intervals are never points).  ~60 instead of ~120 instructions per element, no fallback needed.
-                    if (semi_consts) {
-                        const bool t1 = in_p && kw[e] >= 1 && kw[e] - 1 < upper;
-                        const bool t2 = in_p && !g.c_zero && in_r;
-                        const bool t3 = g.coeff_scalar ? (blockIdx.x == 0 && kw[e] == 0) : takes_c[e];
-                        V xm1 = E::one(), x = E::one();
-                        if (t1) xm1 = first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1);
-                        if (t2) x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
-                        const bool ok = (!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(coef[e]));
-                        if (!any_lane(!ok)) {
-                            const V p1 = E::widen(xm1.lo * mv.lo, xm1.hi * mv.hi);
-                            V p2 = x;
-                            if (!g.c_one) p2 = E::widen(cv.lo * (cv.lo >= 0.0 ? x.lo : x.hi), cv.hi * (cv.hi >= 0.0 ? x.hi : x.lo));
-                            const V p12 = E::widen(p1.lo + p2.lo, p1.hi + p2.hi);
-                            const V p = t1 ? (t2 ? p12 : p1) : (t2 ? p2 : E::zero());
-                            const bool has_p = t1 || t2;
-                            const V pc = E::widen(p.lo + coef[e].lo, p.hi + coef[e].hi);
-                            V v = t3 ? (has_p ? pc : coef[e]) : p;
-                            if (!g.coeff_scalar && !in_p) v = t3 ? coef[e] : E::zero();
-                            if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
-                            else E::st(dst_l, lw_pad, kw[e], v);
-                            if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
-                            continue;
-                        }
-                    }
-                }
-                V p = E::zero();
-                if (in_p) {
-                    if (kw[e] >= 1 && kw[e] - 1 < upper)
-                        p = E::mulw(first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1), mv);
-                    if (!g.c_zero) {
-                        p = E::add0(p);
-                        if (in_r) {
-                            V x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
-                            p = E::addw(p, g.c_one ? x : E::mulw(cv, x));
-                        }
-                    }
-                }
-                V v;
-                if (g.coeff_scalar) {
-                    v = p;
-                    if (blockIdx.x == 0 && kw[e] == 0) v = E::add(p, coef[e]);
-                } else {
-                    v = E::zero();
-                    if (in_p) v = E::add0(p);
-                    if (takes_c[e]) v = E::addw(v, coef[e]);
-                }
+                const bool t1 = in_p && kw[e] >= 1 && kw[e] - 1 < upper;  // res[k - 1] * m
+                const bool t2 = in_p && !g.c_zero && in_r;               // c * res[k]
+                V xm1 = E::one(), x = E::one();
+                if (t1) xm1 = first ? E::ld(res0, rp0, roff0_b + (size_t)(kw[e] - 1) * wstr_0) : E::ld(src_l, lw_pad, kw[e] - 1);
+                if (t2) x = first ? E::ld(res0, rp0, roff0_b + (size_t)kw[e] * wstr_0) : E::ld(src_l, lw_pad, kw[e]);
+                const V v = horner_elem<E>(hc, in_p, t1, t2, takes_c[e], xm1, x, coef[e]);
                 if (last) E::st(out, plane, foff_b + (size_t)kw[e] * wstr_f, v);
                 else E::st(dst_l, lw_pad, kw[e], v);
                 if (kw[e] >= wit_from && !E::is_zero(v)) witness = 1;
@@ -1247,11 +1376,198 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
         }
     }
 }
+// The same loop as a WAVE PIPELINE (round 3).  The kernel above passes the line from step to step through LDS and a
+// workgroup barrier: ~0.7 us per interval step on a lone workgroup, all of it latency (LDS round trip, barrier, the
+// dependent arithmetic at one wave per SIMD).  But position k of step t depends on positions k - 1 and k of step t - 1
+// only — data flows UP the line and never down.  So: one position per lane, the line's values stay in REGISTERS from
+// step to step, res[k - 1] arrives by a DPP wave shift, and the only value that crosses a wave boundary — the last
+// position of wave b, needed by lane 0 of wave b + 1 one step later — is published in an LDS ring slot per step with a
+// step counter.  Nothing flows back, so wave b never waits for wave b + 1: the waves of a line run as a pipeline,
+// wave b + 1 a step or two behind wave b, with no barrier anywhere; the consumer requests its boundary value one step
+// ahead (counter and value are read in order, the producer writes them in order, both through the CU's in-order LDS
+// queue), so in steady state nothing on the step's dependent chain touches memory.  A line of 180 intervals is three
+// waves on three SIMDs; the time per step is one wave's arithmetic chain.  Same horner_elem per element => same bits.
+// POINT: the coefficient box is a single position along w (always when the substituted variable is w itself — `--bounds`
+// runs of v -> c + m*v — or when the coefficient slab is one element): only position 0 of the line takes a coefficient,
+// one per step.  All of them are fetched into LDS before the pipeline starts and wave 0 requests step t + 1's during
+// step t, so no step of the loop touches global memory (a register ring of global loads, the general case, leaves the
+// compiler's conservative vmcnt waits on the dependent chain of every few steps).
+template <class E, int HL_PF, bool POINT>
+__global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __restrict__ res0, size_t rp0,
+                                                             const double* __restrict__ a, size_t ap,
+                                                             double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                             unsigned* __restrict__ wit) {
+    typedef typename E::V V;
+    extern __shared__ double hp_lds[];  // [boundary b][plane][nsteps] ring (one slot per step), then the counters
+    const unsigned lw = g.fs[g.w];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    const unsigned nslots = g.nsteps;
+    const unsigned plane_b = nslots * 8u;                                                          // bytes between the planes of a ring
+    const unsigned ring_b = lds_offset(hp_lds) + (wave ? wave - 1 : 0) * E::W * plane_b;          // the boundary BELOW this wave
+    const unsigned ring_a = lds_offset(hp_lds) + wave * E::W * plane_b;                           // the boundary ABOVE (this wave writes)
+    double* coef_l = hp_lds + (size_t)(nw - 1) * E::W * nslots;  // POINT: [plane][nsteps] coefficients of this line
+    unsigned* cnt = reinterpret_cast<unsigned*>(coef_l + (POINT ? (size_t)E::W * nslots : 0));
+    const unsigned cnt_b = lds_offset(cnt) + (wave ? wave - 1 : 0) * 4u, cnt_a = lds_offset(cnt) + wave * 4u;
+    if (threadIdx.x < nw) cnt[threadIdx.x] = 0u;  // cnt[b] = steps whose boundary value wave b has published
+    size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
+    bool off_p0 = true, off_o0 = true, in_c_b = true;
+    unsigned wit_from = 2;
+    {
+        size_t r = blockIdx.x;
+        unsigned nz_coords = 0;
+        bool big = false;
+#pragma unroll
+        for (int ax = MAXD - 1; ax >= 0; --ax) {
+            if (ax < g.nd && ax != g.w) {
+                unsigned d = g.fs[ax];
+                unsigned k = (unsigned)(r % d);
+                r /= d;
+                foff_b += (size_t)k * g.fstr[ax];
+                aoff_b += (size_t)k * g.astr[ax];
+                roff0_b += (size_t)k * g.rstr0[ax];
+                unsigned r0 = g.rs0[ax], o0 = (!g.coeff_scalar && g.oc[ax] > r0) ? g.oc[ax] : r0;
+                if (k >= r0) off_p0 = false;
+                if (k >= o0) off_o0 = false;
+                if (k >= g.oc[ax]) in_c_b = false;
+                if (k) nz_coords++;
+                if (k >= 2) big = true;
+            }
+        }
+        if (big || nz_coords >= 2) wit_from = 0;
+        else if (nz_coords == 1) wit_from = 1;
+    }
+    const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w], wstr_a = g.astr[g.w];
+    const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
+    const unsigned kw = threadIdx.x;
+    const bool have = kw < lw;
+    const bool takes_c = have && (g.coeff_scalar ? (blockIdx.x == 0 && kw == 0) : (in_c_b && kw < g.oc[g.w]));
+    const size_t c_off = takes_c ? aoff_b + (size_t)kw * wstr_a : 0;
+    const unsigned last_step = g.nsteps - 1;
+    V ring[HL_PF];  // coefficient slabs HL_PF steps ahead, unconditional clamped loads (see k_horner_linear_loop)
+    if constexpr (POINT) {
+        const bool line_takes = g.coeff_scalar ? blockIdx.x == 0 : in_c_b;  // position 0 of this line has coefficients at all
+        for (unsigned i = threadIdx.x; i < g.nsteps; i += blockDim.x)
+            E::st(coef_l, nslots, i, line_takes ? E::ld(a, ap, (size_t)(g.first_i - i) * g.a_vstride + aoff_b) : E::zero());
+    } else {
+#pragma unroll
+        for (int d = 0; d < HL_PF; ++d) ring[d] = E::ld(a, ap, (size_t)(g.first_i - ((unsigned)d < last_step ? (unsigned)d : last_step)) * g.a_vstride + c_off);
+    }
+    __syncthreads();  // the only barrier: counters zeroed, coefficients staged — then the pipeline runs free
+    const unsigned coef_o = lds_offset(coef_l);
+    V c_cur = E::zero(), c_nxt = E::zero();
+    if (POINT && wave == 0) c_cur = E::ld(coef_l, nslots, 0);
+    const HornerConsts<E> hc = horner_consts<E>(g);
+    unsigned rsw = g.rs0[g.w];
+    // The incoming accumulator enters the registers here, so that no step has a global load on its path (inside the
+    // unrolled loop a `first ? global : register` operand makes every HL_PF-th step wait for ALL outstanding loads —
+    // the coefficient ring's included).  Step 0 reads res0[k] / res0[k - 1] only inside res0's box, which is what the
+    // guards below load; everything else is never looked at.
+    V cur = E::zero();     // this position's value after the previous step
+    V below = E::zero();   // lane 0, wave > 0: the value of position kw - 1 after the previous step (from the ring)
+    if (off_p0 && kw < rsw) cur = E::ld(res0, rp0, roff0_b + (size_t)kw * wstr_0);
+    if (lane == 0 && wave && off_p0 && kw - 1 < rsw) below = E::ld(res0, rp0, roff0_b + (size_t)(kw - 1) * wstr_0);
+    unsigned bc = 0;       // prefetched counter of the boundary below
+    V bv = E::zero();      // prefetched (speculative) ring value for the NEXT step
+    asm volatile("; loop-invariant scalars are in their registers" : : "s"(rsw), "s"(degw), "s"(ocw), "s"(nslots));
+    for (unsigned t0 = 0; t0 < g.nsteps; t0 += HL_PF) {
+#pragma unroll
+        for (int d = 0; d < HL_PF; ++d) {
+            const unsigned t = t0 + (unsigned)d;
+            V coef;
+            if constexpr (!POINT) {
+                const unsigned tn = t + HL_PF;
+                const size_t a_base = (size_t)(g.first_i - (tn < last_step ? tn : last_step)) * g.a_vstride;
+                coef = takes_c ? ring[d] : E::zero();
+                ring[d] = E::ld(a, ap, a_base + c_off);
+            }
+            if (t >= g.nsteps) continue;
+            const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
+            const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
+            const unsigned osw = ocw > shw ? ocw : shw;
+            const bool last = t + 1 == g.nsteps, first = t == 0;
+            if constexpr (POINT) {
+                coef = takes_c ? c_cur : E::zero();
+                if (wave == 0 && !last) lds_request(coef_o + (t + 1) * 8u, plane_b, c_nxt);  // consumed after this step
+            }
+            // request the boundary value of THIS step's output from the wave below (needed at step t + 1): counter, then
+            // value, in order; consumed after this step's arithmetic
+            if (wave && !last) {
+                lds_request_b32(cnt_b, bc);
+                lds_request(ring_b + t * 8u, plane_b, bv);
+            }
+            // res[k - 1] after the previous step: the neighbouring lane, or the ring for lane 0
+            V shifted = wave_shr1_any<E>(cur);
+            if (lane == 0) shifted = below;
+            int witness = 0;
+            const bool in_o = have && (first ? off_o0 : true) && kw < osw;
+            if (in_o) {
+                const bool in_p = (first ? off_p0 : true) && kw < shw;
+                const bool in_r = (first ? off_p0 : true) && kw < rsw;
+                const bool t1 = in_p && kw >= 1 && kw - 1 < upper;
+                const bool t2 = in_p && !g.c_zero && in_r;
+                V xm1 = E::one(), x = E::one();
+                if (t1) xm1 = shifted;
+                if (t2) x = cur;
+                const V v = horner_elem<E>(hc, in_p, t1, t2, takes_c, xm1, x, coef);
+                if (last) E::st(out, plane, foff_b + (size_t)kw * wstr_f, v);
+                cur = v;
+                if (kw >= wit_from && !E::is_zero(v)) witness = 1;
+            }
+            rsw = osw;
+            if (last) continue;
+            // publish this wave's last position for the wave above: value, then counter (in-order LDS queue)
+            if (lane == 63 && wave + 1 < nw) {
+                lds_post(ring_a + t * 8u, plane_b, cur);
+                lds_post_b32(cnt_a, t + 1);
+            }
+            if (wit && any_lane(witness != 0) && lane == 0) __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (POINT) {
+                if (wave == 0) {
+                    unsigned dummy = 0;
+                    lds_wait(dummy, c_nxt);
+                    c_cur = c_nxt;
+                }
+            }
+            // the value requested at the top of the step: valid if the counter had already reached t + 1 then; else wait
+            if (wave) {
+                lds_wait(bc, bv);
+                if (bc < t + 1) {  // (wave-uniform: every lane requested the same words)
+                    do {
+                        __builtin_amdgcn_s_sleep(1);
+                        lds_request_b32(cnt_b, bc);
+                        lds_wait(bc);
+                    } while (bc < t + 1);
+                    lds_request(ring_b + t * 8u, plane_b, bv);
+                    lds_wait(bc, bv);
+                }
+                below = bv;
+            }
+        }
+    }
+}
+
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
                               size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit) {
     if (args.nsteps == 0 || lines == 0) return;
     const unsigned lw = args.fs[args.w];
+    // wave pipeline (k_horner_linear_pipe): lines up to 1024 whose boundary rings fit LDS
+    static const bool pipe_on = [] {
+        const char* e = getenv("GFT_HORNER_PIPE");  // A/B knob (0 = the LDS ping-pong loop below)
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (pipe_on && lw <= 1024) {
+        const unsigned nwv = (lw + 63) / 64;
+        const bool point = args.coeff_scalar || args.oc[args.w] == 1;
+        const size_t lds = (size_t)(nwv - 1 + (point ? 1 : 0)) * E::W * args.nsteps * sizeof(double) + (size_t)nwv * sizeof(unsigned) + 16;
+        if (lds <= 60 * 1024) {
+            if (point)
+                GFT_LAUNCH((k_horner_linear_pipe<E, 8, true>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+            else
+                GFT_LAUNCH((k_horner_linear_pipe<E, 8, false>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+            return;
+        }
+    }
     // one position per thread up to 1024-long lines (measured: two per thread is 10 % slower — the element chains
     // are not interleaved by the compiler, more waves hide the latency better)
     static const unsigned per_thread = [] {
@@ -1261,9 +1577,9 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
     unsigned threads = std::min<unsigned>(1024, ((lw + per_thread - 1) / per_thread + 63) / 64 * 64);
     size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
     if (lw <= threads)
-        hipLaunchKernelGGL((k_horner_linear_loop<E, 1, 8>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+        GFT_LAUNCH((k_horner_linear_loop<E, 1, 8>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
     else
-        hipLaunchKernelGGL((k_horner_linear_loop<E, HL_EPT_MAX, 4>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+        GFT_LAUNCH((k_horner_linear_loop<E, HL_EPT_MAX, 4>), dim3(lines), dim3(threads), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
 }
 
 template <class E>
@@ -1294,7 +1610,7 @@ void K<E>::witness(hipStream_t st, const DView& t, unsigned* flag) {
     for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
     if (total == 0) return;
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 64);  // dense tensors are settled by the first elements
-    hipLaunchKernelGGL(k_witness<E>, dim3(blocks), dim3(256), 0, st, t, flag, total);
+    GFT_LAUNCH(k_witness<E>, dim3(blocks), dim3(256), 0, st, t, flag, total);
 }
 
 __global__ void __launch_bounds__(256) k_witness_verdict(const unsigned* __restrict__ flags, unsigned n, Mailbox mb) {
@@ -1308,7 +1624,7 @@ __global__ void __launch_bounds__(256) k_witness_verdict(const unsigned* __restr
     }
 }
 void witness_verdict(hipStream_t st, const unsigned* flags, unsigned n, const Mailbox& mb) {
-    hipLaunchKernelGGL(k_witness_verdict, dim3(1), dim3(256), 0, st, flags, n, mb);
+    GFT_LAUNCH(k_witness_verdict, dim3(1), dim3(256), 0, st, flags, n, mb);
 }
 
 struct UploadChunk {
@@ -1322,7 +1638,7 @@ void upload_small(hipStream_t st, double* dst, const double* host_src, size_t n)
         UploadChunk c;
         const unsigned cnt = (unsigned)std::min<size_t>(480, n - off);
         std::memcpy(c.v, host_src + off, sizeof(double) * cnt);
-        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, st, dst + off, c, cnt);
+        GFT_LAUNCH(k_upload_small, dim3(1), dim3(256), 0, st, dst + off, c, cnt);
     }
 }
 
@@ -1332,7 +1648,7 @@ __global__ void k_peek(const double* __restrict__ src, size_t stride, unsigned n
     if (threadIdx.x == 0) mailbox_publish(mb);
 }
 void peek_to_mailbox(hipStream_t st, const double* src, size_t stride, unsigned n, const Mailbox& mb) {
-    hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, st, src, stride, n, mb);
+    GFT_LAUNCH(k_peek, dim3(1), dim3(64), 0, st, src, stride, n, mb);
 }
 
 template struct K<EF64>;

@@ -12,6 +12,15 @@
 
 namespace gft {
 
+// Every kernel launch of the library goes through GFT_LAUNCH: one counter for "how many launches did this program
+// cost" (gft_op_stats_ex; bench.py's e2e rows) — the quantity a launch-bound program is made of.
+extern unsigned long long g_launches;
+#define GFT_LAUNCH(...)                    \
+    do {                                   \
+        ++::gft::g_launches;               \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 constexpr int MAXD = 12;  // max tensor rank after unit-axis collapsing (reference programs: <= 8 vars)
 
 struct Shape {
@@ -55,6 +64,39 @@ struct GatherArgs {
                                 // (the reference's running product, mt:557-565: no table launch for short axes)
     size_t tab_plane;
     const unsigned char* keep;  // optional: keep[k_axis] == 0 -> write zero
+};
+
+// ---- deferred elementwise chains (round 3) ---------------------------------------------------------------------------
+// Genfer's evaluator emits runs of cheap elementwise operations on one tensor — `subst_var` by a pure scaling m*x_v
+// (x * m^k along v, mt:557-565), `+ const` (element 0, mt:862-869), `* const` (mt:1041-1047), truncation (mt:183-204) —
+// that end in an Add of two such results (the two arms of an `if`, generating_function.rs:557-566).  One launch per
+// operation is 4 us of nothing: the host keeps such a result as a CHAIN — a leading (prefix) box of a contiguous base
+// tensor plus up to CHAIN_MAX elementwise stages — and the consuming kernel applies the stages to each element it
+// loads, in the recorded order, with the same functors: the same roundings in the same order as one launch per stage.
+constexpr int CHAIN_MAX = 6;
+enum ChainKind {
+    CH_LMUL_S = 0,             // s * x
+    CH_MUL_S = 1,              // x * s
+    CH_DIV_S = 2,              // x / s
+    CH_NEG = 3,                // -x
+    CH_FIRST_ADD = 4,          // element 0: x + s
+    CH_FIRST_SUB = 5,          // element 0: x - s
+    CH_FIRST_SUB_NEG_ALL = 6,  // element 0: -(x - s), every other element: -x
+    CH_MUL_TAB = 7,            // x * tab[k_axis]  (device table, tab_plane apart for intervals)
+};
+struct ChainStage {
+    int kind, axis;
+    Scalar2 s;
+    const double* tab;
+    size_t tab_plane;
+};
+struct ChainSrc {
+    const double* p;           // base tensor (contiguous)
+    size_t plane;
+    unsigned box[MAXD];        // extent of the operand per output axis: an output index at or beyond it reads padding (zero)
+    size_t stride[MAXD];       // base strides per output axis
+    int nstages;
+    ChainStage st[CHAIN_MAX];
 };
 
 // Fused observation step (generating_function.rs:678-700): out = c * ((D * 1)>>v + x * D) with
@@ -178,6 +220,11 @@ struct K {
     // out[k] = f(src[k + shift]) or zero outside the source box
     static void gather(hipStream_t st, const double* src, size_t src_plane, double* out, size_t out_plane,
                        const GatherArgs& a);
+    // out[k] = chain(base[k]) inside the operand's box, zero outside: materialises a deferred chain
+    static void chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a);
+    // out[k] = ((0 + A[k]?) +/- B[k]?) like addsub_padded, A / B deferred chains evaluated on the fly
+    static void chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a,
+                             const ChainSrc& b, int subtract);
     // out[k] = ((0 + a[k]?) +/- b[k]?) with a, b leading blocks of out's shape  (mt:873-880, 927-934)
     static void addsub_padded(hipStream_t st, const DView& out, const DView& a, const DView& b, int subtract);
     // out[k] = (0 + a[k]?) + (c * b[k])?   — Add of a and the constant multiple c * b in one pass (mt:873-880 after mt:1041-1047)

@@ -66,6 +66,10 @@ void gft_pool_stats(size_t out[3]);
  * reference-order kernel, on the one-thread-per-output kernel, operations computed on the host tier,
  * host-resident tensors mirrored to the device}.  Diagnostics. */
 void gft_op_stats(size_t out[8]);
+/* More counters (returns how many exist, writes min(cap, that many)): {kernel launches of the library, elementwise
+ * operations deferred into a chain instead of launched, chains materialised by a consumer that needed the tensor in
+ * memory, add/sub launches that evaluated deferred chains on the fly}.  Diagnostics; bench.py's e2e rows. */
+size_t gft_op_stats_ex(size_t* out, size_t cap);
 /* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
 float gft_event_elapsed_ms(int slot_a, int slot_b);
@@ -79,7 +83,7 @@ int gft_set_conv_mode(int mode);
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
  * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div2d" (0: host-driven division
- * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
+ * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
  * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */

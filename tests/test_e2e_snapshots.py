@@ -231,7 +231,7 @@ def c3_stored(prog, bounds):
     return os.path.join(C3_STORED, prog.split("/")[-1] + ("-bounds" if bounds else "") + ".oracle.txt")
 
 
-def test_c3_stored_oracle_reports_are_wellformed():
+def test_oracle_c3_stored_reports_are_wellformed():
     """The committed oracle reports (generated by make_c3_limit100_golden.py) have the benchmarked size."""
     files = glob.glob(os.path.join(C3_STORED, "*.oracle.txt"))
     assert files

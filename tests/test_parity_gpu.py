@@ -956,3 +956,53 @@ def test_row_oriented_gather_large_tensors_bit_exact(OTP, GTP, OTPI, GTPI):
         a, b = oi.derivative(v, 1), gi.derivative(v, 1)
         same_meta(a, b)
         assert np.array_equal(np.asarray(a.array()), np.asarray(b.array()))
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, GTPI, tier):
+    """Round 3: runs of elementwise operations on a device tensor — subst_var by a pure scaling m*x_v (mt:557-565),
+    `+ const` (mt:862-869), `* const` / `/ const` / neg (mt:1041-1047), truncation — are recorded on the handle and
+    evaluated inside the consuming Add/Sub (the two arms of an `if`, generating_function.rs:557-566).  Bit for bit the
+    oracle's sequence, whichever consumer ends the chain; and the chains really replace launches."""
+    import genfer_amd
+
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    mk = (lambda a: np.stack([a, a + 1e-9 * np.abs(a)])) if interval else (lambda a: a)
+    sc = (lambda x: (x, x)) if interval else (lambda x: x)
+    L = genfer_amd.lib()
+
+    def program(T, A, B, v, d, deg):
+        s = T.var(v, sc(0.0), deg[v]) * T.from_scalar(sc(0.9048374180359595))  # m * x_v
+        p = (A.subst_var(v, s) + T.from_scalar(sc(0.25))) * T.from_scalar(sc(0.5))
+        q = (B.subst_var(v, s).truncate_to_degree_p1(d) - T.from_scalar(sc(1.5))) / T.from_scalar(sc(3.0))
+        n = T.from_scalar(sc(2.0)) - (-q)                      # scalar - tensor: FIRST_SUB_NEG_ALL after a neg stage
+        outs = [p + q, p - q, n + p, (p + q).truncate_to_degree_p1(max(d - 1, 1))]
+        outs.append(p * q)                                     # a consumer that needs the tensors in memory
+        outs.append((p + T.from_scalar(sc(1.0))).derivative(v, 1))
+        seven = p
+        for k in range(8):                                     # longer than CHAIN_MAX: the chain restarts
+            seven = seven * T.from_scalar(sc(1.0 + 0.125 * k))
+        outs.append(seven + q)
+        return outs, [p.constant_term(), q.constant_term(), n.constant_term(), seven.constant_term()]
+
+    for shape, deg in (((24, 20), [30, 22]), ((6, 7, 9), [8, 8, 9]), ((40,), [64]), ((3, 1, 12), [5, 4, 12])):
+        a, b = rand(shape, 201, 0.1, 1.0), rand(shape, 202, -1.0, 1.0)
+        for v in range(len(shape)):
+            for d in (3, 7, 100):
+                want, wc = program(O, O.new(mk(a), deg), O.new(mk(b), deg), v, d, deg)
+                counts = {}
+                for defer in (1, 0):
+                    assert L.gft_set_option(b"defer", float(defer)) == 0
+                    try:
+                        before = genfer_amd.op_stats()
+                        got, gc = program(G, G.new(mk(a), deg), G.new(mk(b), deg), v, d, deg)
+                        for o, g in zip(want, got):
+                            check(o, g)
+                        assert gc == wc
+                        after = genfer_amd.op_stats()
+                        counts[defer] = {k: after[k] - before[k] for k in ("launches", "deferred_ops", "chain_addsub_launches")}
+                    finally:
+                        L.gft_set_option(b"defer", 1.0)
+                assert counts[0]["deferred_ops"] == 0
+                if tier == "device" and int(np.prod(shape)) >= 64:  # the tensors live in HBM
+                    assert counts[1]["deferred_ops"] > 0 and counts[1]["launches"] < counts[0]["launches"], counts

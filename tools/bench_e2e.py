@@ -48,16 +48,17 @@ for f in files:
     for name, lib, prefix in backends[: 1 if gpu_only else 2]:
         best = None
         for _ in range(runs):
+            before = genfer_amd.op_stats() if name == "gpu" else None
             rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, prefix)
             if rc != 0:
                 best = None
                 row[name + "_error"] = text[-200:]
                 break
             best = t["time_infer"] if best is None else min(best, t["time_infer"])
+            if before is not None:  # counters of ONE run of the program
+                after = genfer_amd.op_stats()
+                row["gpu_op_stats_per_run"] = {k: after[k] - before[k] for k in after}
         row[name + "_s"] = best
-    st = (ctypes.c_size_t * 8)()
-    genfer_amd.lib().gft_op_stats(st)
-    row["gpu_op_stats_cumulative"] = dict(zip(("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops", "host_to_device_mirrors"), list(st)[:8]))
     rows.append(row)
-    print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}", flush=True)
+    print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}  launches {row.get('gpu_op_stats_per_run', {}).get('launches')}", flush=True)
 print(json.dumps({"limit": limit, "runs": runs, "host_cores": os.cpu_count(), "rows": rows}))

@@ -20,7 +20,10 @@ for n in sizes:
     s[0, 0, 0], s[1, 0, 0] = 0.25, 0.25 * (1 + 1e-15)
     s[0, 0, 1], s[1, 0, 1] = 0.5, 0.5 * (1 + 1e-15)
     sub = TPI.new(s, (n, n))
-    for cls, aa, ss, tag in ((TPI, a, sub, "interval"), (TP, TP.new(lo, (n, n)), TP.new(s[0], (n, n)), "f64")):
+    s0 = np.ascontiguousarray(s.reshape(2, 2, 1))  # the same substitution for variable 0 along variable 0 itself (`--bounds`: v -> c + m*v)
+    sub0 = TPI.new(s0, (n, n))
+    for cls, aa, ss, tag in ((TPI, a, sub, "interval"), (TP, TP.new(lo, (n, n)), TP.new(s[0], (n, n)), "f64"),
+                             (TPI, a, sub0, "iv  w==v"), (TP, TP.new(lo, (n, n)), TP.new(s0[0], (n, n)), "f64 w==v")):
         r = aa.subst_var(0, ss)
         L.gft_synchronize()
         reps = 5
