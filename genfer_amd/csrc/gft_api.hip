@@ -348,6 +348,7 @@ struct PendStage {
 struct Pend {
     Dims base_shape;            // shape of the base tensor in `buf` (its axes align with the handle's leading axes)
     size_t base_numel = 1;      // = plane stride of the base
+    size_t base_off = 0;        // element offset of the handle's element 0 inside the base (a sub-box view)
     int n = 0;
     PendStage st[gft::CHAIN_MAX];
     std::shared_ptr<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
@@ -404,7 +405,7 @@ static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
     const Dims& bs = p.pend ? p.pend->base_shape : p.shape;
     Dims st(bs.size(), 1);
     for (size_t i = bs.size(); i-- > 1;) st[i - 1] = st[i] * bs[i];
-    c.p = p.buf->p;
+    c.p = p.buf->p + (p.pend ? p.pend->base_off : 0);
     c.plane = p.pend ? p.pend->base_numel : p.numel;
     for (size_t j = 0; j < keep.size(); ++j) {
         const size_t ax = keep[j];
@@ -615,13 +616,21 @@ struct Ops {
         return r;
     }
     static V2 hv(const double v[2]) { return V2{v[0], W == 2 ? v[1] : 0.0}; }
+    // device-to-device copies and memsets keep their place among the queued launches (gft_launch.hpp): they are queued
+    // too instead of making the API thread wait for the launch thread
     static void copy_elems(bool host, double* dst, const double* src, size_t n) {
         if (host) std::memcpy(dst, src, sizeof(double) * n);
-        else HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, R.stream));
+        else {
+            hipStream_t st = R.stream;
+            enqueue_task([=] { (void)(hipMemcpyAsync)(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st); });
+        }
     }
     static void zero_elems(bool host, double* dst, size_t n) {
         if (host) std::memset(dst, 0, sizeof(double) * n);
-        else HIP_OK(hipMemsetAsync(dst, 0, sizeof(double) * n, R.stream));
+        else {
+            hipStream_t st = R.stream;
+            enqueue_task([=] { (void)(hipMemsetAsync)(dst, 0, sizeof(double) * n, st); });
+        }
     }
     static DView dview(const HV& v, const Dims* keep = nullptr) {
         DView d;
@@ -725,6 +734,7 @@ struct Ops {
         if (src.pend) {
             r.pend->base_shape = src.pend->base_shape;
             r.pend->base_numel = src.pend->base_numel;
+            r.pend->base_off = src.pend->base_off;
             r.pend->n = src.pend->n;
             for (int i = 0; i < src.pend->n; ++i) r.pend->st[i] = src.pend->st[i];
         } else {
@@ -789,7 +799,7 @@ struct Ops {
         if (p.pend) {  // element 0 of the base, then the chain's stages on the host (same functors)
             double v[2] = {0, 0};
             R.stats[1]++;
-            peek(v, p.buf->p, p.pend->base_numel, W);
+            peek(v, p.buf->p + p.pend->base_off, p.pend->base_numel, W);
             for (int i = 0; i < p.pend->n; ++i) stage_apply_first(p.pend->st[i], v);
             out[0] = v[0];
             out[1] = v[1];
@@ -881,12 +891,29 @@ struct Ops {
         const bool host = tier < 0 ? gather_tier(src, out_shape) : tier != 0;
         if (!host && !tab && !keep && (op == OP_COPY || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG || op == OP_LMUL_S) &&
             can_defer(src, prod(out_shape))) {
-            // a leading box of src, optionally mapped elementwise: deferred (no launch)
-            bool prefix = out_shape.size() <= src.shape.size();
-            for (size_t ax = 0; ax < out_shape.size() && prefix; ++ax)
-                if (shift[ax] != 0 || out_shape[ax] > src_len[ax] || out_shape[ax] > src.shape[ax]) prefix = false;
-            if (prefix) {
+            // a box of src that lies wholly inside it (no zero padding), optionally mapped elementwise: deferred (no
+            // launch).  A box that does not start at element 0 moves the view's origin, which is only meaningful for stages
+            // that do not look at positions: a chain holding FIRST / table stages is materialised first.
+            bool inside = out_shape.size() <= src.shape.size(), shifted = false;
+            for (size_t ax = 0; ax < out_shape.size() && inside; ++ax) {
+                if (shift[ax] < 0 || (size_t)shift[ax] + out_shape[ax] > std::min(src_len[ax], src.shape[ax])) inside = false;
+                if (shift[ax] != 0) shifted = true;
+            }
+            if (inside && shifted && src.pend)
+                for (int i = 0; i < src.pend->n; ++i)
+                    if (src.pend->st[i].kind >= CH_FIRST_ADD) inside = false;  // FIRST_* and MUL_TAB are positional
+            if (inside) {
                 P r = deferred(src, out_shape, out_deg, op == OP_COPY ? 0 : 1);
+                if (shifted) {
+                    const Dims& bs = r.pend->base_shape;
+                    size_t stride = 1, off = 0;
+                    for (size_t ax = bs.size(); ax-- > 0;) {
+                        if (ax < out_shape.size()) off += (size_t)shift[ax] * stride;
+                        stride *= bs[ax];
+                    }
+                    r.pend->base_off += off;
+                    r.c0_known = false;  // element 0 is another element now
+                }
                 if (op != OP_COPY) push_stage(r, op == OP_MUL_S ? CH_MUL_S : (op == OP_DIV_S ? CH_DIV_S : (op == OP_NEG ? CH_NEG : CH_LMUL_S)), s);
                 return r;
             }
@@ -1602,8 +1629,14 @@ struct Ops {
         }
         join_side();  // the previous bulk added its term to z[0] (and beyond)
         conv(a, b, z, 0, 1, true, false, 0, 0, 0);
-        HIP_OK(hipEventRecord(R.ev_main, R.stream));      // slab final (+ critical update): the bulk may read it
-        HIP_OK(hipStreamWaitEvent(R.side, R.ev_main, 0));
+        {
+            hipStream_t ms = R.stream, ss = R.side;
+            hipEvent_t ev = R.ev_main;
+            enqueue_task([=] {  // slab final (+ critical update): the bulk may read it
+                (void)(hipEventRecord)(ev, ms);
+                (void)(hipStreamWaitEvent)(ss, ev, 0);
+            });
+        }
         std::swap(R.stream, R.side);
         try {
             conv(a, b, z, 1, m, true, false, 0, 0, 0);
@@ -1612,7 +1645,11 @@ struct Ops {
             throw;
         }
         std::swap(R.stream, R.side);
-        HIP_OK(hipEventRecord(R.ev_bulk, R.side));
+        {
+            hipStream_t ss = R.side;
+            hipEvent_t ev = R.ev_bulk;
+            enqueue_task([=] { (void)(hipEventRecord)(ev, ss); });
+        }
         R.side_pending = true;
     }
     // Unwinding out of a recurrence with a bulk update in flight: its operands (rsbuf / tmp / the quotient itself) are
@@ -1628,7 +1665,11 @@ struct Ops {
     // the main stream waits for everything issued on the side stream so far
     static void join_side() {
         if (!R.side_pending) return;
-        HIP_OK(hipStreamWaitEvent(R.stream, R.ev_bulk, 0));
+        {
+            hipStream_t ms = R.stream;
+            hipEvent_t ev = R.ev_bulk;
+            enqueue_task([=] { (void)(hipStreamWaitEvent)(ms, ev, 0); });
+        }
         R.side_pending = false;
     }
     static void div_rec(const HV& xs, const HV& ys, const HV& res) {
@@ -2524,6 +2565,23 @@ struct Ops {
             return e ? atoi(e) : 0;
         }();
         g.diag = hdiag;
+        g.stat = nullptr;
+        if (hdiag & 64) {
+            static unsigned long long* d_stat = nullptr;
+            if (!d_stat) {
+                HIP_OK(hipMalloc((void**)&d_stat, 16));
+                HIP_OK(hipMemsetAsync(d_stat, 0, 16, R.stream));
+                static struct Printer {
+                    unsigned long long** p;
+                    ~Printer() {
+                        unsigned long long h[2] = {0, 0};
+                        if (*p && hipMemcpy(h, *p, 16, hipMemcpyDeviceToHost) == hipSuccess)
+                            fprintf(stderr, "[gft horner] lean wave-steps %llu of %llu\n", h[0], h[1]);
+                    }
+                } printer{&d_stat};
+            }
+            g.stat = d_stat;
+        }
         K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
         *result = out;
         return true;
@@ -2932,6 +2990,10 @@ int gft_init(int device) {
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
         if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
+        {
+            const char* al = getenv("GFT_ASYNC_LAUNCH");
+            lq_configure(device, al ? atoi(al) != 0 : true);
+        }
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
@@ -2949,6 +3011,7 @@ int gft_init(int device) {
 
 void gft_shutdown(void) {
     if (!R.ready) return;
+    lq_shutdown();
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
@@ -3036,6 +3099,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
+    else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
@@ -3070,6 +3134,7 @@ int gft_conv_raw(const double* x, const size_t* xshape, const double* y, const s
         if (ndim > 0 && (slab_lo > slab_hi || slab_hi > rshape[0])) throw Error("conv_raw: bad slab range");
         // Whole-product semantics on the selected slabs: same summation structure as Mul's general path.
         O::conv(xv, yv, zv, slab_lo, slab_hi, accumulate != 0, false, 0, 0, 0);
+        launch_drain();  // raw entry point on the caller's stream: every launch is in the stream when this returns
         return 0;
     });
 }
@@ -3151,6 +3216,7 @@ static void rccl_load() {
 // zero-filled all-reduce (adding zeros is exact).  `even` and the ranges come from gft_plan_slabs.
 static void dist_exchange(double* z, size_t n0, size_t slab, bool zeroed_outside) {
     if (D.world <= 1) return;
+    launch_drain();  // the collectives go to the stream from this thread: after every queued launch
     size_t mine[4];
     const bool even = gft_plan_slabs(n0, D.world, D.rank, mine) != 0;
     if (!even) {
@@ -3263,6 +3329,7 @@ int gft_dist_shutdown(void) {
 int gft_dist_broadcast(double* buf, size_t count, int root) {
     return guard_int([&] {
         if (!D.comm) throw Error("gft_dist_broadcast: gft_dist_init has not been called");
+        launch_drain();
         NCCL_OK(D.Broadcast(buf, buf, count, ncclDouble, root, D.comm, R.stream));
         return 0;
     });
@@ -3279,6 +3346,7 @@ int gft_conv_raw_sharded(const double* x, const size_t* xshape, const double* y,
         O::HV yv{const_cast<double*>(y), 0, dims(yshape, ndim)};
         O::HV zv{res, 0, dims(rshape, ndim)};
         dist_conv<O>(xv, yv, zv);
+        launch_drain();
         return 0;
     });
 }

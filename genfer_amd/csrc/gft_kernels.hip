@@ -5,11 +5,110 @@
 #include "gft_kernels.hpp"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace gft {
 
 unsigned long long g_launches = 0;
+
+// ------------------------------------------------------------------------------------------
+// the launch thread (gft_launch.hpp): single-producer / single-consumer ring of launch closures
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t LQ_SLOTS = 1024;  // power of two; 2 MB of slots
+struct LaunchQueue {
+    std::atomic<uint64_t> head{0};   // consumer: slots [0, head) have been issued
+    std::atomic<uint64_t> tail{0};   // producer: slots [0, tail) have been written
+    LaunchSlot* slots = nullptr;
+    std::thread worker;
+    std::atomic<bool> stop{false}, sleeping{false};
+    std::mutex m;
+    std::condition_variable cv;
+    int device = -1;
+    bool enabled = true;
+    std::thread::id worker_id;
+
+    void run() {
+        if (device >= 0) (void)hipSetDevice(device);
+        uint64_t h = head.load(std::memory_order_relaxed);
+        unsigned idle = 0;
+        for (;;) {
+            if (h != tail.load(std::memory_order_acquire)) {
+                LaunchSlot& s = slots[h & (LQ_SLOTS - 1)];
+                s.run(s.payload);
+                head.store(++h, std::memory_order_release);
+                idle = 0;
+                continue;
+            }
+            if (stop.load(std::memory_order_acquire)) return;
+            if (++idle < 20000) {  // ~100 us of polling: the producer is rarely further away than that inside a program
+                __builtin_ia32_pause();
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(m);
+            sleeping.store(true, std::memory_order_seq_cst);
+            cv.wait(lk, [&] { return h != tail.load(std::memory_order_seq_cst) || stop.load(std::memory_order_seq_cst); });
+            sleeping.store(false, std::memory_order_seq_cst);
+            idle = 0;
+        }
+    }
+    void start() {
+        if (!slots) slots = new LaunchSlot[LQ_SLOTS];
+        stop.store(false);
+        worker = std::thread([this] { run(); });
+        worker_id = worker.get_id();
+    }
+    void shutdown() {
+        if (!worker.joinable()) return;
+        drain();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop.store(true, std::memory_order_seq_cst);
+        }
+        cv.notify_all();
+        worker.join();
+    }
+    void drain() {
+        if (!worker.joinable() || std::this_thread::get_id() == worker_id) return;
+        const uint64_t t = tail.load(std::memory_order_relaxed);
+        while (head.load(std::memory_order_acquire) < t) __builtin_ia32_pause();
+    }
+    ~LaunchQueue() { shutdown(); }
+};
+LaunchQueue g_lq;
+}  // namespace
+
+bool lq_enabled() { return g_lq.enabled; }
+int lq_debug() {
+    static const int d = [] {
+        const char* e = getenv("GFT_ASYNC_DEBUG");
+        return e ? atoi(e) : 0;
+    }();
+    return d;
+}
+void lq_configure(int device, bool enabled) {
+    g_lq.drain();
+    g_lq.device = device;
+    g_lq.enabled = enabled;
+}
+void lq_shutdown() { g_lq.shutdown(); }
+void launch_drain() { g_lq.drain(); }
+LaunchSlot* lq_begin() {
+    if (!g_lq.worker.joinable()) g_lq.start();
+    const uint64_t t = g_lq.tail.load(std::memory_order_relaxed);
+    while (t - g_lq.head.load(std::memory_order_acquire) >= LQ_SLOTS) __builtin_ia32_pause();  // ring full: the worker is behind
+    return &g_lq.slots[t & (LQ_SLOTS - 1)];
+}
+void lq_commit() {
+    g_lq.tail.store(g_lq.tail.load(std::memory_order_relaxed) + 1, std::memory_order_seq_cst);
+    if (g_lq.sleeping.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lk(g_lq.m);
+        g_lq.cv.notify_one();
+    }
+}
 
 static inline unsigned grid_for(size_t n, unsigned block = 256) {
     size_t g = (n + block - 1) / block;
@@ -1129,29 +1228,52 @@ __device__ inline double wave_shr1_any<EF64>(double v) { return wave_shr1_d(v); 
 template <>
 __device__ inline Iv wave_shr1_any<EIv>(Iv v) { return Iv{wave_shr1_d(v.lo), wave_shr1_d(v.hi)}; }
 
-// LDS mailboxes between the waves of a workgroup (k_horner_linear_pipe).  The reads must be NON-BLOCKING — requested a
-// step ahead, consumed a step later — and ordered (counter before value; value before counter on the writing side).
-// C++ gives no such load: `volatile` makes hipcc fall back to flat accesses with a full wait after each one, an acquire
-// load waits at the point of issue.  So the four instructions are written out: DS operations of one wave enter the CU's
-// LDS queue in program order and complete in order, `asm volatile` statements keep their program order, and lds_wait()
-// ties the requested registers to the s_waitcnt so that no use can move above it.
-__device__ inline unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)p; }  // low half of the LDS aperture address
-__device__ inline void lds_request_b32(unsigned addr, unsigned& out) { asm volatile("ds_read_b32 %0, %1" : "=v"(out) : "v"(addr) : "memory"); }
-__device__ inline void lds_request_b64(unsigned addr, double& out) { asm volatile("ds_read_b64 %0, %1" : "=v"(out) : "v"(addr) : "memory"); }
-__device__ inline void lds_post_b64(unsigned addr, double v) { asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
-__device__ inline void lds_post_b32(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
-__device__ inline void lds_wait(unsigned& c, double& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(v) : : "memory"); }
-__device__ inline void lds_wait(unsigned& c, Iv& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c), "+v"(v.lo), "+v"(v.hi) : : "memory"); }
-__device__ inline void lds_wait(unsigned& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c) : : "memory"); }
-__device__ inline void lds_request(unsigned addr, unsigned plane_bytes, double& v) { lds_request_b64(addr, v); }
-__device__ inline void lds_request(unsigned addr, unsigned plane_bytes, Iv& v) {
-    lds_request_b64(addr, v.lo);
-    lds_request_b64(addr + plane_bytes, v.hi);
+// LDS rings between the waves of a workgroup (the Horner pipelines below): one slot per step, written once by the wave
+// below, read once by the wave above.  Slots start out EMPTY (a quiet-NaN payload no arithmetic produces); the reader
+// REQUESTS a slot a step ahead — a relaxed workgroup-scope atomic load: a plain ds_read the compiler may neither hoist
+// nor merge and whose result register it tracks like any other load's (round 3 first wrote these as inline-asm ds_read
+// with a later s_waitcnt: the compiler, thinking the register defined at the asm statement, was free to copy it before
+// the data arrived — wrong bounds in a fraction of the runs) — and looks at it a step later; an EMPTY slot is polled.
+// Should a genuine value ever carry the EMPTY pattern the reader accepts it after ~1 s of polling (the writer is long
+// done by then): slow, never wrong.
+constexpr unsigned long long RING_EMPTY = 0x7ff8dead5a5a0badull;
+__device__ inline unsigned long long ring_load_bits(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ inline void lds_post(unsigned addr, unsigned plane_bytes, double v) { lds_post_b64(addr, v); }
-__device__ inline void lds_post(unsigned addr, unsigned plane_bytes, Iv v) {
-    lds_post_b64(addr, v.lo);
-    lds_post_b64(addr + plane_bytes, v.hi);
+__device__ inline void ring_store_bits(double* p, unsigned long long b) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+struct RingWord {  // a requested slot: the raw bits of its planes
+    unsigned long long lo, hi;
+};
+template <class E>
+__device__ inline RingWord ring_request(const double* slot, size_t plane) {
+    RingWord w;
+    w.lo = ring_load_bits(slot);
+    w.hi = E::W == 2 ? ring_load_bits(slot + plane) : 0ull;
+    return w;
+}
+template <class E>
+__device__ inline bool ring_ready(const RingWord& w) { return w.lo != RING_EMPTY && (E::W == 1 || w.hi != RING_EMPTY); }
+template <class E>
+__device__ inline typename E::V ring_value(const RingWord& w);
+template <>
+__device__ inline double ring_value<EF64>(const RingWord& w) { return bits_f64((long long)w.lo); }
+template <>
+__device__ inline Iv ring_value<EIv>(const RingWord& w) { return Iv{bits_f64((long long)w.lo), bits_f64((long long)w.hi)}; }
+// the value of `slot`, requested earlier as `w`: polls while it is still EMPTY
+template <class E>
+__device__ inline typename E::V ring_receive(const double* slot, size_t plane, RingWord w) {
+    for (unsigned spins = 0; !ring_ready<E>(w) && spins < (1u << 22); ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        w = ring_request<E>(slot, plane);
+    }
+    return ring_value<E>(w);
+}
+__device__ inline void ring_put(double* slot, size_t, double v) { ring_store_bits(slot, (unsigned long long)f64_bits(v)); }
+__device__ inline void ring_put(double* slot, size_t plane, Iv v) {
+    ring_store_bits(slot, (unsigned long long)f64_bits(v.lo));
+    ring_store_bits(slot + plane, (unsigned long long)f64_bits(v.hi));
 }
 
 // One element of one Horner step with a linear substitution (HornerArgs' operation sequence), shared by the in-kernel
@@ -1402,13 +1524,10 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
     const unsigned lw = g.fs[g.w];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
     const unsigned nslots = g.nsteps;
-    const unsigned plane_b = nslots * 8u;                                                          // bytes between the planes of a ring
-    const unsigned ring_b = lds_offset(hp_lds) + (wave ? wave - 1 : 0) * E::W * plane_b;          // the boundary BELOW this wave
-    const unsigned ring_a = lds_offset(hp_lds) + wave * E::W * plane_b;                           // the boundary ABOVE (this wave writes)
+    const double* ring_b = hp_lds + (size_t)(wave ? wave - 1 : 0) * E::W * nslots;  // the boundary BELOW this wave
+    double* ring_a = hp_lds + (size_t)wave * E::W * nslots;                          // the boundary ABOVE (this wave writes)
     double* coef_l = hp_lds + (size_t)(nw - 1) * E::W * nslots;  // POINT: [plane][nsteps] coefficients of this line
-    unsigned* cnt = reinterpret_cast<unsigned*>(coef_l + (POINT ? (size_t)E::W * nslots : 0));
-    const unsigned cnt_b = lds_offset(cnt) + (wave ? wave - 1 : 0) * 4u, cnt_a = lds_offset(cnt) + wave * 4u;
-    if (threadIdx.x < nw) cnt[threadIdx.x] = 0u;  // cnt[b] = steps whose boundary value wave b has published
+    for (size_t i = threadIdx.x; i < (size_t)(nw - 1) * E::W * nslots; i += blockDim.x) ring_store_bits(hp_lds + i, RING_EMPTY);
     size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
     bool off_p0 = true, off_o0 = true, in_c_b = true;
     unsigned wit_from = 2;
@@ -1453,7 +1572,6 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
         for (int d = 0; d < HL_PF; ++d) ring[d] = E::ld(a, ap, (size_t)(g.first_i - ((unsigned)d < last_step ? (unsigned)d : last_step)) * g.a_vstride + c_off);
     }
     __syncthreads();  // the only barrier: counters zeroed, coefficients staged — then the pipeline runs free
-    const unsigned coef_o = lds_offset(coef_l);
     V c_cur = E::zero(), c_nxt = E::zero();
     if (POINT && wave == 0) c_cur = E::ld(coef_l, nslots, 0);
     const HornerConsts<E> hc = horner_consts<E>(g);
@@ -1466,8 +1584,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
     V below = E::zero();   // lane 0, wave > 0: the value of position kw - 1 after the previous step (from the ring)
     if (off_p0 && kw < rsw) cur = E::ld(res0, rp0, roff0_b + (size_t)kw * wstr_0);
     if (lane == 0 && wave && off_p0 && kw - 1 < rsw) below = E::ld(res0, rp0, roff0_b + (size_t)(kw - 1) * wstr_0);
-    unsigned bc = 0;       // prefetched counter of the boundary below
-    V bv = E::zero();      // prefetched (speculative) ring value for the NEXT step
+    RingWord bw{0, 0};     // the requested ring slot: the boundary value for the NEXT step
     asm volatile("; loop-invariant scalars are in their registers" : : "s"(rsw), "s"(degw), "s"(ocw), "s"(nslots));
     for (unsigned t0 = 0; t0 < g.nsteps; t0 += HL_PF) {
 #pragma unroll
@@ -1487,14 +1604,11 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
             const bool last = t + 1 == g.nsteps, first = t == 0;
             if constexpr (POINT) {
                 coef = takes_c ? c_cur : E::zero();
-                if (wave == 0 && !last) lds_request(coef_o + (t + 1) * 8u, plane_b, c_nxt);  // consumed after this step
+                if (wave == 0 && !last) c_nxt = E::ld(coef_l, nslots, t + 1);  // consumed after this step
             }
             // request the boundary value of THIS step's output from the wave below (needed at step t + 1): counter, then
             // value, in order; consumed after this step's arithmetic
-            if (wave && !last) {
-                lds_request_b32(cnt_b, bc);
-                lds_request(ring_b + t * 8u, plane_b, bv);
-            }
+            if (wave && !last) bw = ring_request<E>(ring_b + t, nslots);
             // res[k - 1] after the previous step: the neighbouring lane, or the ring for lane 0
             V shifted = wave_shr1_any<E>(cur);
             if (lane == 0) shifted = below;
@@ -1516,33 +1630,284 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
             rsw = osw;
             if (last) continue;
             // publish this wave's last position for the wave above: value, then counter (in-order LDS queue)
-            if (lane == 63 && wave + 1 < nw) {
-                lds_post(ring_a + t * 8u, plane_b, cur);
-                lds_post_b32(cnt_a, t + 1);
-            }
+            if (lane == 63 && wave + 1 < nw) ring_put(ring_a + t, nslots, cur);
             if (wit && any_lane(witness != 0) && lane == 0) __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if constexpr (POINT) {
-                if (wave == 0) {
-                    unsigned dummy = 0;
-                    lds_wait(dummy, c_nxt);
-                    c_cur = c_nxt;
-                }
+                if (wave == 0) c_cur = c_nxt;
             }
-            // the value requested at the top of the step: valid if the counter had already reached t + 1 then; else wait
-            if (wave) {
-                lds_wait(bc, bv);
-                if (bc < t + 1) {  // (wave-uniform: every lane requested the same words)
-                    do {
-                        __builtin_amdgcn_s_sleep(1);
-                        lds_request_b32(cnt_b, bc);
-                        lds_wait(bc);
-                    } while (bc < t + 1);
-                    lds_request(ring_b + t * 8u, plane_b, bv);
-                    lds_wait(bc, bv);
-                }
-                below = bv;
+            // the slot requested at the top of the step (polled if the wave below had not published it yet)
+            if (wave) below = ring_receive<E>(ring_b + t, nslots, bw);
+        }
+    }
+}
+
+// ---- the POINT pipeline, lean ------------------------------------------------------------------------------------------
+// A lone wave issues roughly one instruction every five cycles, whatever the instruction: the time of a step IS its
+// instruction count (measured: the generic step above is ~330 instructions for intervals, ~130 for f64 — flag
+// arithmetic, exec-mask branches, three regimes — and costs 0.78 / 0.36 us a step; profiles/r03/horner_loop.txt).  This
+// kernel is the same pipeline with a step written for instruction count, for the case the `--bounds` programs live in:
+// coefficients at position 0 only (POINT), substitution constant c neither 0 nor 1, steps after the first.
+//   * the boxes of a step follow from ONE scalar: A = extent of the accumulator along w, S = min(A + 1, deg);
+//     position k multiplies res[k - 1] by m iff k - 1 < A and k < S (t1), adds c * res[k] iff k < A (t2);
+//   * straight-line code, selects instead of branches; lanes outside the box compute garbage nobody reads; the wave index
+//     is a scalar, the publishing lane writes through a per-lane address (everyone else into a dummy area), witnesses
+//     are collected in a scalar bit mask and stored once per 64 steps;
+//   * intervals: every operand of a lean step is a positive finite interval (own outputs are tested when they are
+//     produced, the boundary value when it arrives, the line's coefficients when they are staged), m positive, c a
+//     finite interval with non-zero bounds.  Then the reference's products and sums (iv:126-190) take no short-circuit
+//     and the SIGN of every bound is known before it is computed — x * m and (q + c x) positive, c.lo * x and c.hi * x
+//     with the signs of c's bounds — so each outward step next_down / next_up (f64.rs:127-171) is the integer step
+//     `bits -/+ 1` in the direction that sign dictates: 2 instructions instead of 9.  Where an assumption fails (a
+//     product underflows to zero, a sum is not positive, a bound reaches infinity) the integer step produces a NaN
+//     pattern or a non-positive bound, which survives to the step's output: ONE test of the output (lo > 0, hi < inf)
+//     validates the whole step, and a wave whose test fails recomputes that step with horner_elem from the operands it
+//     still holds.  Same operations on the same values => same bits (tests: GFT_HORNER_LEAN=0 / GFT_HORNER_PIPE=0 A/B
+//     against the oracle);
+//   * `p1 + p2` (inner positions) and `coef + p2` (position 0) are one addition with a selected first operand (IEEE
+//     addition commutes bit for bit).
+template <class E>
+struct LeanConsts;
+template <>
+struct LeanConsts<EF64> {
+    double c, m;
+    bool scalar_coef;
+    __device__ explicit LeanConsts(const HornerConsts<EF64>& h) : c(h.cv), m(h.mv), scalar_coef(h.coeff_scalar) {}
+    __device__ static bool usable(const HornerConsts<EF64>& h) { return !h.c_zero && !h.c_one; }
+    __device__ static bool operand_ok(double) { return true; }
+    __device__ static bool result_ok(double) { return true; }
+    static constexpr bool CHECKED = false;
+    // t1 / t2 / t3 as in horner_elem; unused operands may hold anything
+    __device__ __forceinline__ double step(bool t1, bool t2, bool t3, double xm1, double x, double coef) const {
+        double p = t1 ? xm1 * m : 0.0;
+        p = 0.0 + p;
+        const double p2 = p + c * x;
+        p = t2 ? p2 : p;
+        const double v = scalar_coef ? p : 0.0 + p;
+        const double vc = v + coef;
+        return t3 ? vc : v;
+    }
+};
+template <>
+struct LeanConsts<EIv> {
+    Iv c, m;
+    bool lo_uses_hi, hi_uses_lo;   // c.lo < 0: c.lo * x is smallest at x.hi; c.hi < 0: c.hi * x is largest at x.lo
+    long long dlo, dhi;            // integer steps of next_down(c.lo * x) / next_up(c.hi * x): by the sign of the product
+    __device__ explicit LeanConsts(const HornerConsts<EIv>& h) : c(h.cv), m(h.mv) {
+        lo_uses_hi = !(c.lo >= 0.0);
+        hi_uses_lo = !(c.hi >= 0.0);
+        dlo = c.lo < 0.0 ? 1 : -1;   // a negative bound moves away from zero, a positive one towards it
+        dhi = c.hi > 0.0 ? 1 : -1;
+    }
+    // m a positive interval; c finite, ordered, no 0 / +-1 point and no zero bound (the signs of c.lo * x and c.hi * x
+    // must be known): the constants of horner_elem's positive AND semi-positive regimes
+    __device__ static bool usable(const HornerConsts<EIv>& h) {
+        return !h.c_zero && !h.c_one && EIv::pos_ok(h.mv) && EIv::is_finite(h.cv) && h.cv.lo <= h.cv.hi && !EIv::maybe_special(h.cv) &&
+               h.cv.lo != 0.0 && h.cv.hi != 0.0;
+    }
+    __device__ static bool operand_ok(Iv v) { return EIv::pos_ok(v); }
+    // a lean output: widened (never a point), so positive and finite is all there is to test; NaN fails both compares
+    __device__ static bool result_ok(Iv v) { return v.lo > 0.0 && v.hi < bits_f64(0x7ff0000000000000LL); }
+    static constexpr bool CHECKED = true;
+    __device__ __forceinline__ Iv step(bool t1, bool t2, bool t3, Iv xm1, Iv x, Iv coef) const {
+        const Iv p1 = EIv::mul_pos(xm1, m);
+        Iv p2;
+        p2.lo = bits_f64(f64_bits(c.lo * (lo_uses_hi ? x.hi : x.lo)) + dlo);
+        p2.hi = bits_f64(f64_bits(c.hi * (hi_uses_lo ? x.lo : x.hi)) + dhi);
+        Iv q;
+        q.lo = t1 ? p1.lo : coef.lo;
+        q.hi = t1 ? p1.hi : coef.hi;
+        const Iv s = EIv::add_pos(q, p2);
+        const bool both = t2 && (t1 || t3);
+        Iv v;  // t2 only: p2; t1 only: p1 (= q)
+        v.lo = both ? s.lo : (t2 ? p2.lo : q.lo);
+        v.hi = both ? s.hi : (t2 ? p2.hi : q.hi);
+        return v;
+    }
+};
+
+template <class E>
+__global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __restrict__ res0, size_t rp0,
+                                                            const double* __restrict__ a, size_t ap,
+                                                            double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                            unsigned* __restrict__ wit) {
+    typedef typename E::V V;
+    typedef LeanConsts<E> LC;
+    extern __shared__ double hp_lds[];  // [boundary b][plane][nsteps] rings, [plane][nsteps] coefficients, counters, dummy area
+    const unsigned lw = g.fs[g.w];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    const unsigned nslots = g.nsteps;
+    const double* ring_b = hp_lds + (size_t)(wave ? wave - 1 : 0) * E::W * nslots;
+    double* ring_a = hp_lds + (size_t)wave * E::W * nslots;
+    double* coef_l = hp_lds + (size_t)(nw - 1) * E::W * nslots;
+    double* dummy = coef_l + (size_t)E::W * nslots;  // 64 x value planes nobody reads (where the non-publishing lanes write)
+    for (size_t i = threadIdx.x; i < (size_t)(nw - 1) * E::W * nslots; i += blockDim.x) ring_store_bits(hp_lds + i, RING_EMPTY);
+    size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
+    bool off_p0 = true, off_o0 = true, in_c_b = true;
+    unsigned wit_from = 2;
+    {
+        size_t r = blockIdx.x;
+        unsigned nz_coords = 0;
+        bool big = false;
+#pragma unroll
+        for (int ax = MAXD - 1; ax >= 0; --ax) {
+            if (ax < g.nd && ax != g.w) {
+                unsigned d = g.fs[ax];
+                unsigned k = (unsigned)(r % d);
+                r /= d;
+                foff_b += (size_t)k * g.fstr[ax];
+                aoff_b += (size_t)k * g.astr[ax];
+                roff0_b += (size_t)k * g.rstr0[ax];
+                unsigned r0 = g.rs0[ax], o0 = (!g.coeff_scalar && g.oc[ax] > r0) ? g.oc[ax] : r0;
+                if (k >= r0) off_p0 = false;
+                if (k >= o0) off_o0 = false;
+                if (k >= g.oc[ax]) in_c_b = false;
+                if (k) nz_coords++;
+                if (k >= 2) big = true;
             }
         }
+        if (big || nz_coords >= 2) wit_from = 0;
+        else if (nz_coords == 1) wit_from = 1;
+    }
+    const size_t wstr_f = g.fstr[g.w], wstr_0 = g.rstr0[g.w];
+    const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
+    const unsigned kw = threadIdx.x, kwm1 = kw - 1u;  // position 0: kwm1 = 2^32 - 1, below no extent
+    const bool have = kw < lw;
+    const bool line_takes = g.coeff_scalar ? blockIdx.x == 0 : in_c_b;
+    const bool takes_c = have && kw == 0 && line_takes;
+    // stage the line's coefficients; are they all usable as lean operands?
+    int coefs_ok = 1;
+    for (unsigned i = threadIdx.x; i < g.nsteps; i += blockDim.x) {
+        const V cf = line_takes ? E::ld(a, ap, (size_t)(g.first_i - i) * g.a_vstride + aoff_b) : E::zero();
+        E::st(coef_l, nslots, i, cf);
+        if (line_takes && !LC::operand_ok(cf)) coefs_ok = 0;
+    }
+    coefs_ok = __syncthreads_and(coefs_ok);  // the only barrier: rings emptied, coefficients staged — then the pipeline runs free
+    V c_cur = E::zero();
+    if (wave == 0) c_cur = E::ld(coef_l, nslots, 0);
+    const HornerConsts<E> hc = horner_consts<E>(g);
+    const LC lc(hc);
+    unsigned rsw = g.rs0[g.w];
+    V cur = E::zero(), below = E::zero();
+    if (off_p0 && kw < rsw) cur = E::ld(res0, rp0, roff0_b + (size_t)kw * wstr_0);
+    if (lane == 0 && wave && off_p0 && kwm1 < rsw) below = E::ld(res0, rp0, roff0_b + (size_t)kwm1 * wstr_0);
+    // where this lane publishes: lane 63 of a wave with a wave above it into the ring / counter, everyone else into the dummy area
+    const bool publisher = lane == 63 && wave + 1 < nw;
+    double* const post_v = publisher ? ring_a : dummy + lane;
+    const size_t post_vplane = publisher ? nslots : 64u;
+    const unsigned post_vstep = publisher ? 1u : 0u;
+    // What a wave requests at the top of step t and looks at after it: wave 0 the coefficient of step t + 1, the others
+    // slot t of the ring below.  ONE unconditional load site (clamped index at the last step): a request under a
+    // condition is a phi of {old, loaded}, which the compiler resolves with a copy — and a wait — right at the request.
+    const double* const req_base = wave ? ring_b : coef_l;
+    const bool lean_possible = LC::usable(hc) && (wave != 0 || coefs_ok);
+    bool lean = false;           // decided at the end of every step from the values the next step reads
+    bool in_o_last = false;
+    unsigned n_lean = 0;
+    unsigned long long wmask = 0;  // bit (t & 63): step t raised a witness in this wave
+    asm volatile("; loop-invariant scalars are in their registers" : : "s"(rsw), "s"(degw), "s"(ocw), "s"(nslots));
+    const unsigned nloop = g.nsteps - 1;  // steps [0, nloop) publish and request; the last step does neither
+    // the witness words of steps [t0, t0 + 64) that lie before the last step
+    auto flush_witnesses = [&](unsigned t0) {
+        if (((wmask >> lane) & 1ull) && t0 + lane < nloop) __hip_atomic_store(&wit[t0 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wmask = 0;
+    };
+    // STEADY STATE: lean steps [t, t_end), all before the last step, written as one tight loop per role (W0: the wave that
+    // holds position 0 reads coefficients; the others read the ring below) — no role, witness-mode or last-step decision
+    // inside.  Leaves early, BEFORE executing step t, if that step's output fails the regime test, and AFTER it if the
+    // boundary value for the next step is no lean operand; the generic step below takes over from there.
+    auto lean_run = [&](auto w0_tag, auto wit_tag, unsigned& t, unsigned t_end) {
+        constexpr bool W0 = decltype(w0_tag)::value, WIT = decltype(wit_tag)::value;
+        const double* const req = W0 ? coef_l + 1 : ring_b;
+        for (; t < t_end; ++t) {
+            const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
+            const RingWord rw = ring_request<E>(req + t, nslots);
+            V shifted = wave_shr1_any<E>(cur);
+            if (!W0 && lane == 0) shifted = below;
+            const bool act = kw < shw, t2 = kw < rsw, t1 = kwm1 < rsw && act;
+            const V v = lc.step(t1, t2, takes_c, shifted, cur, c_cur);
+            if (LC::CHECKED && any_lane(act && !LC::result_ok(v))) {
+                lean = false;
+                return;
+            }
+            cur = v;
+            rsw = shw;
+            in_o_last = act;
+            n_lean++;
+            if (WIT && any_lane(act && kw >= wit_from && !E::is_zero(v))) wmask |= 1ull << (t & 63u);
+            ring_put(post_v + (size_t)t * post_vstep, post_vplane, v);
+            if (W0) {
+                c_cur = ring_value<E>(rw);
+            } else {
+                below = ring_receive<E>(ring_b + t, nslots, rw);
+                // position 64 * wave reads `below` in the next step iff 64 * wave - 1 < rsw: only then must it be usable
+                if (LC::CHECKED && any_lane(lane == 0 && kwm1 < rsw && !LC::operand_ok(below))) {
+                    lean = false;
+                    ++t;
+                    return;
+                }
+            }
+        }
+    };
+    for (unsigned t = 0; t <= nloop;) {
+        if (lean && t < nloop && !(g.diag & 16)) {
+            const unsigned chunk_end = (t | 63u) + 1u;  // witness words are flushed per 64 steps
+            const unsigned t_end = (wit && chunk_end < nloop) ? chunk_end : nloop;
+            if (wave == 0) {
+                if (wit) lean_run(std::true_type{}, std::true_type{}, t, t_end);
+                else lean_run(std::true_type{}, std::false_type{}, t, t_end);
+            } else {
+                if (wit) lean_run(std::false_type{}, std::true_type{}, t, t_end);
+                else lean_run(std::false_type{}, std::false_type{}, t, t_end);
+            }
+            if (wit && (t & 63u) == 0u && t > 0) flush_witnesses(t - 64u);  // ran up to a chunk boundary
+            continue;
+        }
+        // ---- one generic step: step 0, the last step, lines outside the lean regime, a lean step whose output test failed
+        const bool last = t == nloop, first = t == 0;
+        const unsigned shw = rsw + 1 < degw ? rsw + 1 : degw;
+        const RingWord rw = ring_request<E>(req_base + (wave ? t : (t < nloop ? t + 1 : nloop)), nslots);
+        V shifted = wave_shr1_any<E>(cur);
+        if (lane == 0) shifted = below;
+        bool witness = false, val_ok = true;
+        {
+            const unsigned upper = shw - 1 < rsw ? shw - 1 : rsw;
+            const unsigned osw = ocw > shw ? ocw : shw;
+            const bool in_o = have && (first ? off_o0 : true) && kw < osw;
+            if (in_o) {
+                const bool in_p = (first ? off_p0 : true) && kw < shw;
+                const bool in_r = (first ? off_p0 : true) && kw < rsw;
+                const bool t1 = in_p && kw >= 1 && kwm1 < upper;
+                const bool t2 = in_p && !g.c_zero && in_r;
+                V xm1 = E::one(), x = E::one();
+                if (t1) xm1 = shifted;
+                if (t2) x = cur;
+                const V coef = takes_c ? c_cur : E::zero();
+                const V v = horner_elem<E>(hc, in_p, t1, t2, takes_c, xm1, x, coef);
+                cur = v;
+                witness = kw >= wit_from && !E::is_zero(v);
+                val_ok = LC::operand_ok(v);
+            }
+            in_o_last = in_o;
+            rsw = osw;
+        }
+        if (wit && any_lane(witness)) wmask |= 1ull << (t & 63u);
+        if (wit && ((t & 63u) == 63u || last)) flush_witnesses(t & ~63u);
+        if (last) break;
+        ring_put(post_v + (size_t)t * post_vstep, post_vplane, cur);
+        if (wave == 0) {
+            c_cur = ring_value<E>(rw);
+        } else {
+            below = ring_receive<E>(ring_b + t, nslots, rw);
+            if (LC::CHECKED && lane == 0 && kwm1 < rsw) val_ok = val_ok && LC::operand_ok(below);
+        }
+        // the next step is lean iff every value it will read is a lean operand
+        lean = lean_possible && (!LC::CHECKED || !any_lane(!val_ok));
+        ++t;
+    }
+    if (have && in_o_last) E::st(out, plane, foff_b + (size_t)kw * wstr_f, cur);
+    if (g.stat && lane == 0) {  // GFT_HORNER_DIAG & 64: how many of the steps ran lean (per wave)
+        atomicAdd(&g.stat[0], (unsigned long long)n_lean);
+        atomicAdd(&g.stat[1], (unsigned long long)g.nsteps);
     }
 }
 
@@ -1559,9 +1924,15 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
     if (pipe_on && lw <= 1024) {
         const unsigned nwv = (lw + 63) / 64;
         const bool point = args.coeff_scalar || args.oc[args.w] == 1;
-        const size_t lds = (size_t)(nwv - 1 + (point ? 1 : 0)) * E::W * args.nsteps * sizeof(double) + (size_t)nwv * sizeof(unsigned) + 16;
+        const size_t lds = (size_t)(nwv - 1 + (point ? 1 : 0)) * E::W * args.nsteps * sizeof(double) + (point ? (size_t)128 * 8 : 0) + 16;
         if (lds <= 60 * 1024) {
-            if (point)
+            static const bool lean_on = [] {
+                const char* e = getenv("GFT_HORNER_LEAN");  // A/B knob (0 = the generic pipeline step for POINT lines too)
+                return e ? atoi(e) != 0 : true;
+            }();
+            if (point && lean_on)
+                GFT_LAUNCH((k_horner_pipe_point<E>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+            else if (point)
                 GFT_LAUNCH((k_horner_linear_pipe<E, 8, true>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
             else
                 GFT_LAUNCH((k_horner_linear_pipe<E, 8, false>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);

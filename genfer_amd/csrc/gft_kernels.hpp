@@ -9,17 +9,9 @@
 #include <vector>
 
 #include "gft_elem.hpp"
+#include "gft_launch.hpp"  // GFT_LAUNCH: every kernel launch of the library (counted, issued by the launch thread)
 
 namespace gft {
-
-// Every kernel launch of the library goes through GFT_LAUNCH: one counter for "how many launches did this program
-// cost" (gft_op_stats_ex; bench.py's e2e rows) — the quantity a launch-bound program is made of.
-extern unsigned long long g_launches;
-#define GFT_LAUNCH(...)                    \
-    do {                                   \
-        ++::gft::g_launches;               \
-        hipLaunchKernelGGL(__VA_ARGS__);   \
-    } while (0)
 
 constexpr int MAXD = 12;  // max tensor rank after unit-axis collapsing (reference programs: <= 8 vars)
 
@@ -177,6 +169,7 @@ struct HornerLoopArgs {
     Scalar2 c, m;
     int c_zero, c_one, coeff_scalar;
     int diag;                  // timing diagnostics (GFT_HORNER_DIAG, wrong results): 2 = no barrier
+    unsigned long long* stat;  // GFT_HORNER_DIAG & 64: {lean wave-steps, wave-steps} of the POINT pipeline are added here
 };
 
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the

@@ -23,6 +23,11 @@
  *   - The ABI is NON-consuming: `out = op(a, b)` never frees or mutates its inputs (the Rust
  *     operators consume by value, mt:857,914,1017,1197; a shim maps that to "call, then drop").
  *     Handles are immutable values; gft_clone is O(1) (shared device buffer).
+ *   - Kernel launches are issued by a LAUNCH THREAD of the library, in program order (a launch-bound program spends ~3 us
+ *     of host time inside every hipLaunchKernel; the calling thread only records the launch).  Every value inspection,
+ *     gft_synchronize, gft_event_record and the raw entry points gft_conv_raw* / gft_dist_* return with all launches in
+ *     the stream; a caller that shares the stream with the HANDLE API (gft_set_stream) and records its own events or
+ *     launches its own kernels there calls gft_synchronize() or gft_event_record() first.
  *   - Single calling thread per process; one HIP stream (gft_set_stream to adopt the caller's).
  *     The host only synchronises when a VALUE is inspected (to_host, coefficient, constant_term,
  *     is_zero/is_one/extract_*, equal) — and data-dependent dispatch inside mul/div/subst_var
@@ -83,7 +88,8 @@ int gft_set_conv_mode(int mode);
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
  * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div2d" (0: host-driven division
- * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
+ * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "async_launch" (0: kernels are launched by the
+ * calling thread instead of the library's launch thread), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
  * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */

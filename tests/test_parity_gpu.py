@@ -983,6 +983,9 @@ def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, 
         for k in range(8):                                     # longer than CHAIN_MAX: the chain restarts
             seven = seven * T.from_scalar(sc(1.0 + 0.125 * k))
         outs.append(seven + q)
+        # sub-box views that do not start at element 0 (slab extraction): deferred on position-independent chains only
+        outs.append((A * T.from_scalar(sc(2.0))).coefficients_of_term(v, 1) + q.coefficients_of_term(v, 0))
+        outs.append(((-B).coefficients_of_term(v, min(2, deg[v] - 1)) * T.from_scalar(sc(0.75))) - p.coefficients_of_term(v, 1))
         return outs, [p.constant_term(), q.constant_term(), n.constant_term(), seven.constant_term()]
 
     for shape, deg in (((24, 20), [30, 22]), ((6, 7, 9), [8, 8, 9]), ((40,), [64]), ((3, 1, 12), [5, 4, 12])):
