@@ -82,6 +82,7 @@ def _declare_runtime(L):
     L.gft_dist_rank.restype, L.gft_dist_rank.argtypes = c.c_int, []
     L.gft_dist_comm_count.restype, L.gft_dist_comm_count.argtypes = c.c_int, []
     L.gft_dist_shutdown.restype, L.gft_dist_shutdown.argtypes = c.c_int, []
+    L.gft_dist_selftest.restype, L.gft_dist_selftest.argtypes = c.c_int, []
     L.gft_dist_broadcast.restype, L.gft_dist_broadcast.argtypes = c.c_int, [c.c_void_p, c.c_size_t, c.c_int]
     L.gft_conv_raw_sharded.restype = c.c_int
     L.gft_conv_raw_sharded.argtypes = [c.c_void_p, sz, c.c_void_p, sz, c.c_void_p, sz, c.c_size_t]

@@ -1395,6 +1395,7 @@ struct Ops {
             HIP_OK(hipMemsetAsync(cur.p, 0, sizeof(double) * cur.numel(), R.stream));
             return;
         }
+        if (want_tiled && ash.nd > 4 && !ash.accumulate && ash.zs[ash.nd - 1] <= 128 && conv_tiled_high_rank(x, y, z, a, ash, tx, ty, tz)) return;
         if (want_tiled) {
             // rank 2, or a last axis longer than the tiled kernel's 128: split the last axis into (P, B) pieces
             ConvArgs at = ash;
@@ -1487,6 +1488,106 @@ struct Ops {
         }
         R.stats[5]++;
         K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a);
+    }
+
+    // Rank >= 5 on the tiled kernel (the reference's product is rank-generic, mt:984-1012; the kernel takes the last four
+    // axes): the leading axes are walked on the host — for every leading output index u and every admissible j <= u one
+    // accumulate-mode rank-4 launch  z[u] += x[j] (*) y[u - j]  on the trailing blocks, which are contiguous in the
+    // operands' own layout.  Same multiply-adds as the rank-4 kernel performs, summed per u in ascending j: the tiled
+    // contract (1e-10), not the reference's order.  false: not worth it / not supported — the caller takes the
+    // reference-order kernels.
+    static bool conv_tiled_high_rank(const HV& x, const HV& y, const HV& z, const ConvArgs& a, const ConvArgs& ash, const double* tx,
+                                     const double* ty, double* tz) {
+        const int extra = ash.nd - 4;
+        ConvArgs sub;
+        std::memset(&sub, 0, sizeof(sub));
+        sub.nd = 4;
+        double macs = 1.0, lead_pairs = 1.0;
+        for (int i = 0; i < ash.nd; ++i) macs *= 0.5 * (double)ash.zs[i] * (double)std::min(ash.xs[i], ash.ys[i]);
+        for (int i = 0; i < 4; ++i) {
+            sub.xs[i] = ash.xs[extra + i];
+            sub.ys[i] = ash.ys[extra + i];
+            sub.zs[i] = ash.zs[extra + i];
+            sub.xstr[i] = ash.xstr[extra + i];
+            sub.ystr[i] = ash.ystr[extra + i];
+            sub.zstr[i] = ash.zstr[extra + i];
+        }
+        sub.slab_lo = 0;
+        sub.slab_hi = sub.zs[0];
+        sub.variant = ash.variant;
+        for (int i = 0; i < extra; ++i) lead_pairs *= 0.5 * (double)ash.zs[i] * (double)std::min(ash.xs[i], ash.ys[i]) + 0.5;
+        // every launch must be worth a launch: the trailing rank-4 product above the tiled crossover
+        if (R.conv_mode == 0 && macs / lead_pairs < R.tiled_min_macs) return false;
+        size_t need = 0;
+        if (!conv_tiled_f64(R.stream, tx, ty, tz, sub, nullptr, 0, &need, nullptr, 0)) return false;
+        if (need > R.conv_ws_bytes) {
+            size_t want = std::max<size_t>(std::max(need, std::min<size_t>(2 * R.conv_ws_bytes, (size_t)1 << 32)), (size_t)8 << 20);
+            if (R.conv_ws) HIP_OK(hipFree(R.conv_ws));
+            R.conv_ws = nullptr;
+            R.conv_ws_bytes = 0;
+            HIP_OK(hipMalloc(&R.conv_ws, want));
+            R.conv_ws_bytes = want;
+        }
+        if (++R.nf_epoch == 0) {
+            HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(R.d_flag + 2), 0, 1, R.stream));
+            R.nf_epoch = 1;
+        }
+        unsigned* flag = R.d_flag + 2;
+        // odometer over the leading output index u (axis 0 restricted to the slab range) and, inside, over j
+        unsigned u[MAXD] = {0}, j[MAXD] = {0};
+        for (int i = 0; i < extra; ++i) u[i] = i == 0 ? ash.slab_lo : 0;
+        const unsigned u0_hi = ash.slab_hi;
+        if (u0_hi <= ash.slab_lo) return true;
+        for (;;) {
+            size_t zoff = 0;
+            unsigned jlo[MAXD], jhi[MAXD];
+            bool any = true;
+            for (int i = 0; i < extra; ++i) {
+                zoff += (size_t)u[i] * ash.zstr[i];
+                jlo[i] = u[i] + 1 > ash.ys[i] ? u[i] + 1 - ash.ys[i] : 0;
+                jhi[i] = std::min(u[i], ash.xs[i] - 1);
+                if (jlo[i] > jhi[i]) any = false;
+                j[i] = jlo[i];
+            }
+            bool first = true;
+            if (!any) {  // no admissible j (compact operands): the block is zero
+                zero_elems(false, tz + zoff, (size_t)ash.zstr[extra - 1]);
+            } else {
+                for (;;) {
+                    size_t xoff = 0, yoff = 0;
+                    for (int i = 0; i < extra; ++i) {
+                        xoff += (size_t)j[i] * ash.xstr[i];
+                        yoff += (size_t)(u[i] - j[i]) * ash.ystr[i];
+                    }
+                    sub.accumulate = first ? 0 : 1;
+                    first = false;
+                    if (!conv_tiled_f64(R.stream, tx + xoff, ty + yoff, tz + zoff, sub, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch))
+                        throw Error("tiled convolution launch failed");
+                    int ax = extra - 1;
+                    for (; ax >= 0; --ax) {
+                        if (++j[ax] <= jhi[ax]) break;
+                        j[ax] = jlo[ax];
+                    }
+                    if (ax < 0) break;
+                }
+            }
+            int ax = extra - 1;
+            for (; ax >= 0; --ax) {
+                const unsigned hi = ax == 0 ? u0_hi : ash.zs[ax];
+                if (++u[ax] < hi) break;
+                u[ax] = ax == 0 ? ash.slab_lo : 0;
+            }
+            if (ax < 0) break;
+        }
+        R.stats[3]++;
+        // non-finite operands: the tiled launches left z alone from the launch that noticed on; the guarded reference-order
+        // launch recomputes ALL of z then (accumulate is off here, so nothing of the earlier partial sums survives)
+        ConvArgs g = a;
+        g.guard = flag;
+        g.guard_epoch = R.nf_epoch;
+        if (!conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, g, false))
+            K<E>::conv_naive(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, g);
+        return true;
     }
 
     static P mul_var(const P& self, const double* m, size_t v, const Dims& shape, const Dims& deg) {  // mt:589-608
@@ -3180,12 +3281,12 @@ struct Rccl {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     double min_macs = 1.0e10;  // gft_mul shards a general product at or above this many multiply-adds ("dist_min_macs")
-    int ev_slot = -1;          // "dist_event_slot": the next sharded products bracket their LOCAL kernels with the event
-                               // slots s, s+1 (then s += 2, up to 62): kernel time apart from the exchange (bench.py)
+    int ev_slot = -1;          // "dist_event_slot": the next sharded products record the event slots s (start), s + 1 (local
+                               // kernels done), s + 2 (exchange done), then s += 3: kernel-only and exchange-only time (bench.py)
 };
 Rccl D;
 void dist_set_min_macs(double v) { D.min_macs = v; }
-void dist_set_event_slot(double v) { D.ev_slot = (v >= 0 && v <= 62) ? (int)v : -1; }
+void dist_set_event_slot(double v) { D.ev_slot = (v >= 0 && v <= 61) ? (int)v : -1; }
 
 static void rccl_load() {
     if (D.lib) return;
@@ -3269,6 +3370,10 @@ static void dist_conv(const typename O::HV& x, const typename O::HV& y, const ty
     }
     }
     dist_exchange(z.p, n0, slab, !even);
+    if (ev >= 0 && ev + 2 <= 63) {  // slot s + 2: after the exchange (exchange-only time = [s + 1, s + 2])
+        (void)hipEventRecord(R.events[ev + 2], R.stream);
+        D.ev_slot = ev + 3 <= 61 ? ev + 3 : -1;
+    }
 }
 }  // namespace
 
@@ -3304,6 +3409,59 @@ int gft_dist_init(int rank, int world, const void* unique_id128) {
         NCCL_OK(D.CommInitRank(&D.comm, world, id, rank));
         D.rank = rank;
         D.world = world;
+        if (const char* st = getenv("GFT_DIST_SELFTEST"))  // every rank proves the exchange before anything is computed with it
+            if (atoi(st) != 0 && gft_dist_selftest() != 0) throw Error(g_err);
+        return 0;
+    });
+}
+// Every rank: two small sharded products (an even split -> all-gather + point-to-point, an uneven one -> zero-filled
+// all-reduce) through BOTH entries — the raw sharded product and gft_mul's auto-shard — compared with the rank's own
+// full product, computed by the reference-order kernel (bit-identical whatever the slab ranges, so any difference is
+// the exchange's).  0 = every slab arrived where it belongs; -1 (and gft_last_error) otherwise.
+int gft_dist_selftest(void) {
+    return guard_int([&] {
+        typedef Ops<EF64> O;
+        if (!D.comm) throw Error("gft_dist_selftest: gft_dist_init has not been called");
+        const int saved_mode = R.conv_mode;
+        const double saved_min = D.min_macs;
+        struct Restore {
+            int m;
+            double d;
+            ~Restore() {
+                R.conv_mode = m;
+                D.min_macs = d;
+            }
+        } restore{saved_mode, saved_min};
+        R.conv_mode = 1;  // reference order: the same bits from any slab range
+        D.min_macs = 0.0;
+        for (size_t n0 : {(size_t)16 * (size_t)std::max(1, D.world / 8 + (D.world % 8 ? 1 : 0)), (size_t)(2 * D.world + 1)}) {
+            const Dims shape{n0, 12, 10};
+            const size_t n = prod(shape);
+            std::vector<double> hx(n), hy(n);
+            unsigned long long sx = 0x9E3779B97F4A7C15ull * 7, sy = 0x9E3779B97F4A7C15ull * 11;
+            auto next = [](unsigned long long& st) {
+                st += 0x9E3779B97F4A7C15ull;
+                unsigned long long zz = st;
+                zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+                zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+                zz ^= zz >> 31;
+                return (double)(zz >> 11) * (1.0 / 9007199254740992.0) - 0.25;
+            };
+            for (size_t i = 0; i < n; ++i) {
+                hx[i] = next(sx);
+                hy[i] = next(sy);
+            }
+            gft_poly px = O::make(shape, shape), py = O::make(shape, shape);
+            HIP_OK(hipMemcpyAsync(dp<EF64>(px), hx.data(), sizeof(double) * n, hipMemcpyHostToDevice, R.stream));
+            HIP_OK(hipMemcpyAsync(dp<EF64>(py), hy.data(), sizeof(double) * n, hipMemcpyHostToDevice, R.stream));
+            HIP_OK(hipStreamSynchronize(R.stream));
+            gft_poly full = O::make(shape, shape), raw = O::make(shape, shape);
+            O::conv(O::view(px), O::view(py), O::view(full), 0, n0, false, false, 0, 0, 0);   // local, all slabs
+            dist_conv<O>(O::view(px), O::view(py), O::view(raw));                             // sharded, raw entry
+            gft_poly handle = O::mul(px, py);                                                 // sharded inside gft_mul
+            if (!O::equal(full, raw)) throw Error("gft_dist_selftest: the sharded raw product differs from the local product (n0 = " + std::to_string(n0) + ")");
+            if (!O::equal(full, handle)) throw Error("gft_dist_selftest: gft_mul's sharded product differs from the local product (n0 = " + std::to_string(n0) + ")");
+        }
         return 0;
     });
 }

@@ -128,6 +128,10 @@ int gft_dist_world(void);
 int gft_dist_rank(void);
 int gft_dist_comm_count(void);                                          /* ncclCommCount of the communicator (0: none) */
 int gft_dist_shutdown(void);
+/* Every rank (collective): small sharded products through both sharded entries — even split (all-gather + point-to-point)
+ * and uneven split (zero-filled all-reduce) — against the rank's own full product, bit for bit.  0 = the exchange
+ * delivers every slab; run automatically by gft_dist_init when GFT_DIST_SELFTEST=1 is in the environment. */
+int gft_dist_selftest(void);
 /* ncclBroadcast of `count` doubles at `buf` (device memory) from `root`: replicating operands that originate on one rank */
 int gft_dist_broadcast(double* buf, size_t count, int root);
 /* res = x (*) y like gft_conv_raw over ALL leading slabs, sharded over the communicator; x, y replicated on every rank,

@@ -81,3 +81,15 @@ def test_rccl_plumbing_world_1_and_sharded_entry_point():
     assert L.gft_dist_broadcast(ctypes.c_void_p(buf.data_ptr()), 16, 0) == 0
     L.gft_synchronize()
     assert bool(torch.equal(buf.cpu(), torch.arange(16, dtype=torch.float64)))
+    # the self-test every rank runs before a multi-GPU job is timed (bench.py, GFT_DIST_SELFTEST=1): both sharded entries,
+    # even and uneven split, bit for bit against the rank's own full product; conv mode and dist_min_macs are restored
+    assert L.gft_dist_selftest() == 0, L.gft_last_error()
+    # exchange-only event slot: start, local kernels done, exchange done
+    assert L.gft_set_option(b"dist_event_slot", 30.0) == 0
+    x = torch.from_numpy(rng.random((16, 12, 12))).cuda()
+    z = torch.zeros((16, 12, 12), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    genfer_amd.conv_raw_sharded(x.data_ptr(), (16, 12, 12), x.data_ptr(), (16, 12, 12), z.data_ptr(), (16, 12, 12))
+    L.gft_synchronize()
+    assert L.gft_event_elapsed_ms(30, 31) >= 0.0 and L.gft_event_elapsed_ms(31, 32) >= 0.0
+    L.gft_set_option(b"dist_event_slot", -1.0)

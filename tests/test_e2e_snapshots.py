@@ -262,3 +262,35 @@ def test_c3_limit100_hip_matches_oracle(prog, bounds, oracle_path):
         assert rc == 0, want
     assert "Total measure" in want and (want.count("p(") >= 100 or "clickGraph" in prog)  # clickGraph's result is continuous
     compare_reports(got, want)
+
+
+# ---- this repo's product-dominated programs (bench.py's e2e rows three_populations / four_populations) ----------------
+# Every statement couples two variables, so `eval` runs general Horner loops whose steps are rank-3 / rank-4 general
+# products (SURVEY §8 A3 / A7 on the path the headline kernel serves).  Checked against the oracle at limits the oracle
+# finishes in about a second.
+PRODUCT_PROGRAMS = [("bench/three_populations", "--limit 40"), ("bench/four_populations", "--limit 12")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,limit", PRODUCT_PROGRAMS, ids=[p.split("/")[-1] for p, _ in PRODUCT_PROGRAMS])
+def test_product_programs_hip_matches_oracle(prog, limit, oracle_path):
+    import genfer_amd
+
+    genfer_amd.lib()
+    path = os.path.join(SGCL, prog + ".sgcl")
+    rc, got = run_flags(path, genfer_amd.LIB_PATH, "gft_", "--no-timing " + limit)
+    assert rc == 0, got
+    rc, want = run_flags(path, oracle_path, "orc_", "--no-timing " + limit)
+    assert rc == 0, want
+    assert "Total measure" in want
+    compare_reports(got, want)
+
+
+@pytest.mark.parametrize("prog,limit", [("bench/three_populations", "--limit 12"), ("bench/four_populations", "--limit 6")],
+                         ids=["three_populations", "four_populations"])
+def test_product_programs_run_on_the_oracle(prog, limit, oracle_path):
+    """The programs parse and evaluate (CPU): Z is a probability, the masses are printed."""
+    rc, text = run_flags(os.path.join(SGCL, prog + ".sgcl"), oracle_path, "orc_", "--no-timing " + limit)
+    assert rc == 0, text
+    z = float(re.search(r"Z = (\S+)", text).group(1))
+    assert 0.0 < z < 1.0 and text.count("p(") >= 2 * int(limit.split()[-1])

@@ -1009,3 +1009,38 @@ def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, 
                 assert counts[0]["deferred_ops"] == 0
                 if tier == "device" and int(np.prod(shape)) >= 64:  # the tensors live in HBM
                     assert counts[1]["deferred_ops"] > 0 and counts[1]["launches"] < counts[0]["launches"], counts
+
+
+HIGH_RANK_SHAPES = [
+    ((3, 6, 7, 8, 9), (2, 5, 7, 6, 9), (4, 8, 9, 10, 12)),             # rank 5, ragged, compact operands
+    ((4, 4, 8, 8, 8), (4, 4, 8, 8, 8), (4, 4, 8, 8, 8)),               # rank 5, truncated at the operand shapes
+    ((2, 3, 4, 5, 6, 7), (3, 2, 4, 4, 5, 7), (4, 4, 6, 7, 8, 10)),     # rank 6
+    ((3, 1, 5, 6, 1, 7, 8), (2, 1, 4, 6, 1, 7, 5), (4, 1, 7, 9, 1, 10, 10)),  # rank 7 with unit axes: rank 5 after collapsing
+]
+
+
+@pytest.mark.parametrize("xs,ys,zs", HIGH_RANK_SHAPES)
+def test_conv_tiled_rank5_and_up_matches_reference_order_kernel(xs, ys, zs):
+    """Rank >= 5 general products (the reference's mul is rank-generic, mt:984-1012) on the tiled FMA kernel: the leading
+    axes beyond the kernel's four are walked on the host with accumulate-mode rank-4 launches.  Against the
+    reference-order kernel (bit-exact vs the oracle): 1e-10 per coefficient on positive data, normwise on mixed signs;
+    a leading-slab range writes only its slabs; non-finite operands fall back to the reference's result."""
+    import genfer_amd
+
+    x, y = rand(xs, 71), rand(ys, 72)
+    want = _conv_raw_gpu(1, x, y, zs)
+    before = genfer_amd.op_stats()["tiled"]
+    got = _conv_raw_gpu(2, x, y, zs)
+    assert genfer_amd.op_stats()["tiled"] > before, "the product did not take the tiled kernel"
+    assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / want).max()
+    xm, ym = 2 * x - 1, 2 * y - 1
+    bound = _conv_raw_gpu(1, np.abs(xm), np.abs(ym), zs)
+    assert np.all(np.abs(_conv_raw_gpu(2, xm, ym, zs) - _conv_raw_gpu(1, xm, ym, zs)) <= 1e-10 * bound)
+    lo, hi = zs[0] // 3, max(zs[0] // 3 + 1, (2 * zs[0]) // 3)
+    z0 = rand(zs, 73)
+    part = _conv_raw_gpu(2, x, y, zs, slab=(lo, hi), z0=z0)
+    assert np.array_equal(part[:lo], z0[:lo]) and np.array_equal(part[hi:], z0[hi:])
+    assert np.all(np.abs(part[lo:hi] - want[lo:hi]) <= 1e-10 * np.abs(want[lo:hi]))
+    xi = x.copy()
+    xi[(1,) * len(xs) if all(s > 1 for s in xs) else tuple(min(1, s - 1) for s in xs)] = np.inf
+    assert np.array_equal(_conv_raw_gpu(2, xi, y, zs), _conv_raw_gpu(1, xi, y, zs), equal_nan=True)
