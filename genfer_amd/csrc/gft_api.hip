@@ -151,6 +151,7 @@ struct Runtime {
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
+    bool div_wavefront = true;     // GFT_DIV_WAVEFRONT=0 / "div_wavefront": the blocked recurrence instead of the one-launch row wavefront
     bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
@@ -1875,8 +1876,31 @@ struct Ops {
             if (rs[i] == UMAX) throw Error("div: untruncated result shape (degrees_p1 == usize::MAX)");
         const bool host = tier_host(prod(rs), self, other) && est_macs(rs, other.shape, rs) <= R.host_max_macs;
         P out = make(rs, deg, host);
+        if (!host && div_wavefront(self, other, out)) return out;
         div_rec(view(self, host), view(other, host), view(out, host));
         return seal(out);
+    }
+    // The whole quotient in one launch (gft_div2d.hip k_div_wavefront): every row a task of one wave, consumed in the
+    // reference's order, dependencies through per-row flags.  Ranks 2-4 (after dropping the axes on which all three
+    // tensors are trivial) with rows of at most 64 coefficients and enough rows to be worth a persistent launch.
+    static bool div_wavefront(const P& self, const P& other, const P& out) {
+        if (!R.div_wavefront || !R.div2d) return false;
+        Dims keep = collapse_mask({&out.shape}, false);
+        if (keep.size() < 2 || keep.size() > 4) return false;
+        unsigned xs[4], ys[4], zs[4];
+        size_t rows = 1;
+        for (size_t i = 0; i < keep.size(); ++i) {
+            xs[i] = (unsigned)self.shape[keep[i]];
+            ys[i] = (unsigned)other.shape[keep[i]];
+            zs[i] = (unsigned)out.shape[keep[i]];
+            if (i + 1 < keep.size()) rows *= zs[i];
+        }
+        // dropped axes have extent 1 in the result, hence in both operands (shapes never exceed the result's)
+        if (zs[keep.size() - 1] > 64 || zs[keep.size() - 1] < 2 || rows < 64) return false;
+        std::shared_ptr<Buf> fl = alloc_doubles((rows + 1 + 1) / 2 + 1);
+        zero_elems(false, fl->p, (rows + 1 + 1) / 2 + 1);
+        return K<E>::div_wavefront(R.stream, dp<E>(self), self.numel, xs, dp<E>(other), other.numel, ys, dp<E>(out), out.numel, zs,
+                                   (int)keep.size(), reinterpret_cast<unsigned*>(fl->p));
     }
 
     // ---- exp / log (mt:406-430, 1270-1386) ---------------------------------------------------------------------
@@ -3088,6 +3112,7 @@ int gft_init(int device) {
         }
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
         if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
+        if (const char* dw = getenv("GFT_DIV_WAVEFRONT")) R.div_wavefront = atoi(dw) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
         if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
@@ -3197,6 +3222,7 @@ int gft_set_option(const char* name, double value) {
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "div2d") R.div2d = value != 0;
+    else if (n == "div_wavefront") R.div_wavefront = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "gft_kernels.hpp"
+#include <cstring>
 
 namespace gft {
 
@@ -665,6 +666,272 @@ bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
 }
 template bool K<EF64>::div_1d(hipStream_t, const double*, size_t, unsigned, const double*, size_t, unsigned, double*, size_t, unsigned, int);
 template bool K<EIv>::div_1d(hipStream_t, const double*, size_t, unsigned, const double*, size_t, unsigned, double*, size_t, unsigned, int);
+
+// ------------------------------------------------------------------------------------------
+// The whole division as a ROW WAVEFRONT (round 3)
+// ------------------------------------------------------------------------------------------
+// The blocked recurrence above finishes slab k0 before slab k0 + 1 starts: n0 slab divisions in a row, each a
+// single-workgroup chain of n1 lock-step row divisions — 4096 dependent row divisions for a 64^3 quotient, 22 of its 26
+// ms, on one CU of 256 (0.9 % of the FP64 roof).  But the recurrence's dependency graph is only n0 + n1 rows deep:
+// quotient row K = (k0, .., k_{L-1}) needs the rows J <= K (componentwise, J != K) and nothing else.  Here every row is a
+// TASK of one wave; tasks are claimed in lexicographic order from a global counter (so a claimed task only ever waits
+// for tasks claimed before it by running waves — no deadlock whatever the dispatch order), and a task consumes its
+// source rows in EXACTLY the reference's order (mt:1162-1192 with mt:984-1012 inside):
+//   for level l = 0 .. L-1:   S = 0
+//       for (j_l < k_l, j_{l+1} <= k_{l+1}, .., j_{L-1} <= k_{L-1}) in lexicographic order, each within the divisor's box:
+//           S += row_product(res[k_0 .. k_{l-1}, j_l .., j_{L-1}],  ys[0 .. 0, k_l - j_l, .., k_{L-1} - j_{L-1}])     (from zero, ascending j)
+//       r = (-S) + (l == 0 ? xs[K] inside its box : r of the level above)
+//   res[K] = r / ys[0 .. 0, :]   (the lock-step 1-d division)
+// waiting on a per-row flag (release / acquire at device scope) before it reads a row another wave produced.  Rows are
+// consumed as they become available, so by the time a row's LAST source arrives everything else is already summed: the
+// critical path is n0 + n1 row divisions plus one row product each, and the multiply-adds of all rows run side by side
+// on all CUs.  A row product keeps one coefficient per lane: the source row's coefficient j reaches all lanes by
+// v_readlane, the divisor row slides by one DPP wave shift per step (zeros enter at lane 0: the truncation).  Same
+// operations in the same order per coefficient as the host-driven recursion => the same bits (GFT_DIV_WAVEFRONT=0 A/B).
+struct DivWfArgs {
+    int L;                    // leading axes (tasks); the last axis is the row
+    unsigned n[3], m[3], xn[3];   // extents of res / ys / xs on the leading axes
+    unsigned nr, mr, xnr;     // row lengths
+    size_t rstr[3], ystr[3], xstr[3];  // strides of the leading axes (rows are contiguous)
+    unsigned ntasks;
+    unsigned* flags;          // [ntasks] row done; zeroed before the launch
+    unsigned* counter;        // next task; zeroed before the launch
+};
+
+template <class E>
+__device__ inline typename E::V ld_coherent(const double* p, size_t plane, size_t i);
+template <>
+__device__ inline double ld_coherent<EF64>(const double* p, size_t, size_t i) {
+    return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <>
+__device__ inline Iv ld_coherent<EIv>(const double* p, size_t plane, size_t i) {
+    return Iv{__hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + plane + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
+__device__ inline void st_coherent(double* p, size_t, size_t i, double v) { __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coherent(double* p, size_t plane, size_t i, Iv v) {
+    __hip_atomic_store(p + i, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + plane + i, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// inner[c] = sum_{j <= c, c - j < mr} a[j] * b[c - j], from zero, ascending j (mul_1d, mt:971-982): lane c holds a[c], b[c]
+// (zero beyond the rows' lengths).  Finite rows: positions outside the sum multiply an exact zero (inner + x * 0 == inner:
+// a partial sum formed from +0 is never -0) — no masks; otherwise the bounds are applied as predicates.
+// `stage`: 2 x 64 doubles of LDS owned by the calling wave — the source row's coefficient j reaches all lanes as a
+// broadcast LDS read (one DS instruction beside the VALU stream instead of two v_readlane in it).
+template <class E>
+__device__ inline typename E::V row_product(typename E::V a, typename E::V b, unsigned c, unsigned nr, unsigned mr, double* stage) {
+    typedef typename E::V V;
+    V inner = E::zero(), w = b;
+    if (!any_lane(!elem_finite<E>(a) || !elem_finite<E>(b))) {
+        E::st(stage, 64, c, a);
+#pragma unroll 8
+        for (unsigned j = 0; j < nr; ++j) {
+            inner = E::add(inner, E::mul(E::ld(stage, 64, j), w));
+            w = wave_shr1<E>(w);
+        }
+    } else {
+        for (unsigned j = 0; j < nr; ++j) {
+            const V t = E::add(inner, E::mul(bcast_lane<E>(a, j), w));
+            if (c >= j && c - j < mr) inner = t;
+            w = wave_shr1<E>(w);
+        }
+    }
+    return inner;
+}
+
+constexpr unsigned DWF_NW = 16;  // waves per task
+// Quotient rows start out as this bit pattern (a NaN payload no arithmetic produces): a consumer loads a source row with
+// ONE coherent load — requested a batch ahead — and sees from the row itself whether its producer has stored it (every
+// coefficient is an 8-byte store); the per-row flags (release / acquire) remain the authority when a row keeps looking
+// unwritten, so a genuine coefficient of that pattern only costs time.
+constexpr unsigned long long DWF_EMPTY = 0x7ff8dead0badf00dull;
+__global__ void __launch_bounds__(256) k_fill_bits(double* p, size_t n, unsigned long long bits) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<unsigned long long*>(p)[i] = bits;
+}
+__device__ inline bool is_empty_bits(double v) { return (unsigned long long)f64_bits(v) == DWF_EMPTY; }
+__device__ inline bool is_empty_bits(Iv v) { return (unsigned long long)f64_bits(v.lo) == DWF_EMPTY || (unsigned long long)f64_bits(v.hi) == DWF_EMPTY; }
+
+template <class E>
+__global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
+                                                               double* res, size_t rp, DivWfArgs g) {
+    typedef typename E::V V;
+    // A task (one quotient row) belongs to a WORKGROUP: its source rows are consumed in batches of DWF_NW — every wave waits
+    // for, loads and multiplies one source row (the row products of a batch run side by side on the CU's SIMDs, their
+    // global latencies overlap), then wave 0 adds the batch's products in the reference's order.  Same operations per
+    // coefficient in the same order as one wave doing everything, 1 / DWF_NW of the chain.
+    __shared__ double part[2][2][DWF_NW][64];  // [buffer][plane][wave][c]
+    __shared__ double stage[DWF_NW][2][64];    // per wave: the source row whose coefficients are broadcast (row_product)
+    __shared__ unsigned s_task;
+    const unsigned c = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = g.L;
+    const V y0row = c < g.mr ? E::ld(ys, yp, c) : E::zero();
+    const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
+    for (;;) {
+        if (threadIdx.x == 0) s_task = atomicAdd(g.counter, 1u);
+        __syncthreads();
+        const unsigned t = s_task;
+        __syncthreads();  // everyone has read s_task before the next claim overwrites it
+        if (t >= g.ntasks) break;
+        unsigned k[3] = {0, 0, 0};
+        {
+            unsigned r = t;
+            for (int a = L - 1; a >= 0; --a) {
+                k[a] = r % g.n[a];
+                r /= g.n[a];
+            }
+        }
+        V r_prev = E::zero();  // (meaningful in wave 0)
+        unsigned buf = 0;
+        for (int lev = 0; lev < L; ++lev) {
+            V S = E::zero();
+            // the level's source rows: j_lev in [lo_lev, k_lev), j_t in [lo_t, k_t] for t > lev, lexicographic, j_{L-1} fastest
+            unsigned lo[3], cnt[3];
+            unsigned total = 1;
+            for (int a = lev; a < L; ++a) {
+                lo[a] = k[a] + 1 > g.m[a] ? k[a] + 1 - g.m[a] : 0;
+                const unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
+                cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
+                total *= cnt[a];
+            }
+            // this wave's source row i of the level: where it lies, and its operands REQUESTED (consumed one batch later)
+            size_t roff_n = 0;
+            unsigned src_n = 0;
+            V a_n = E::zero(), b_n = E::zero();
+            auto request = [&](unsigned i) {
+                if (i >= total) return;
+                unsigned rem = i, j[3] = {0, 0, 0};
+                for (int a = L - 1; a >= lev; --a) {
+                    j[a] = lo[a] + rem % cnt[a];
+                    rem /= cnt[a];
+                }
+                size_t roff = 0, yoff = 0;
+                unsigned src = 0;
+                for (int a = 0; a < L; ++a) {
+                    const unsigned ja = a < lev ? k[a] : j[a];
+                    roff += (size_t)ja * g.rstr[a];
+                    src = src * g.n[a] + ja;
+                    if (a >= lev) yoff += (size_t)(k[a] - j[a]) * g.ystr[a];
+                }
+                roff_n = roff;
+                src_n = src;
+                b_n = c < g.mr ? E::ld(ys, yp, yoff + c) : E::zero();
+                a_n = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+            };
+            request(wave);
+            for (unsigned base = 0; base < total; base += DWF_NW) {
+                const unsigned i = base + wave;
+                V a_row = a_n;
+                const V b_row = b_n;
+                const size_t roff = roff_n;
+                const unsigned src = src_n;
+                request(i + DWF_NW);
+                if (i < total) {
+                    // a row that still shows the EMPTY pattern has not been stored by its producer (or, once in a blue moon,
+                    // holds that pattern for real: then the producer's flag says so)
+                    for (unsigned spins = 1; any_lane(c < g.nr && is_empty_bits(a_row)); ++spins) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((spins & 31u) == 0u && __hip_atomic_load(g.flags + src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                            a_row = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+                            break;
+                        }
+                        a_row = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+                    }
+                    E::st(&part[buf][0][wave][0], (size_t)DWF_NW * 64, c, row_product<E>(a_row, b_row, c, g.nr, g.mr, &stage[wave][0][0]));
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned nb = total - base < DWF_NW ? total - base : DWF_NW;
+                    for (unsigned w = 0; w < nb; ++w) S = E::add(S, E::ld(&part[buf][0][w][0], (size_t)DWF_NW * 64, c));
+                }
+                buf ^= 1u;  // the next batch writes the other buffer while wave 0 still reads this one
+            }
+            if (wave == 0) {
+                V r = E::neg(S);
+                if (lev == 0) {
+                    bool in_x = c < g.xnr;
+                    size_t xoff = 0;
+                    for (int a = 0; a < L; ++a) {
+                        if (k[a] >= g.xn[a]) in_x = false;
+                        xoff += (size_t)k[a] * g.xstr[a];
+                    }
+                    if (in_x) r = E::add(r, E::ld(xs, xp, xoff + c));
+                } else {
+                    r = E::add(r, r_prev);
+                }
+                r_prev = r;
+            }
+            __syncthreads();  // a level's last batch buffer is free again before the next level reuses it
+        }
+        if (wave == 0) {
+            // ---- the row's 1-d division by ys[0 .. 0, :] in lock step (mt:1162-1185): lane j's coefficient becomes final
+            // at step j and reaches the lanes above it by v_readlane; the divisor row slides by one DPP shift per step
+            V cur1 = E::zero(), mine = E::zero(), ysl = y0row;  // ysl[c] = y0[c - j] at step j (zero for c < j and beyond the divisor's row)
+            const bool fin = !any_lane(!elem_finite<E>(r_prev)) && !any_lane(!elem_finite<E>(y0row));
+            for (unsigned jj = 0; jj < g.nr; ++jj) {
+                const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r_prev), jj));
+                if (c == jj) mine = q;
+                const V tnew = E::add(cur1, E::mul(q, ysl));
+                if (fin && elem_finite<E>(q)) {
+                    cur1 = tnew;  // positions outside the sum multiply a shifted-in zero
+                } else if (c > jj && c - jj < g.mr) {
+                    cur1 = tnew;
+                }
+                ysl = wave_shr1<E>(ysl);
+            }
+            size_t qoff = 0;
+            for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
+            if (c < g.nr) st_coherent(res, rp, qoff + c, mine);
+            __threadfence();  // the row is visible device-wide before its flag is
+            if (c == 0) __hip_atomic_store(g.flags + t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <class E>
+bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
+                         const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, int nd, unsigned* flags_and_counter) {
+    if (nd < 2 || nd > 4) return false;
+    DivWfArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.L = nd - 1;
+    g.nr = rshape[nd - 1];
+    g.mr = yshape[nd - 1];
+    g.xnr = xshape[nd - 1];
+    if (g.nr < 2 || g.nr > 64 || g.mr > g.nr || g.xnr > g.nr) return false;
+    size_t rs = g.nr, ysd = g.mr, xsd = g.xnr, ntasks = 1;
+    for (int a = g.L - 1; a >= 0; --a) {
+        g.n[a] = rshape[a];
+        g.m[a] = yshape[a];
+        g.xn[a] = xshape[a];
+        if (g.m[a] > g.n[a] || g.xn[a] > g.n[a] || g.n[a] == 0) return false;
+        g.rstr[a] = rs;
+        g.ystr[a] = ysd;
+        g.xstr[a] = xsd;
+        rs *= rshape[a];
+        ysd *= yshape[a];
+        xsd *= xshape[a];
+        ntasks *= rshape[a];
+    }
+    if (ntasks > 0x7fffffffu) return false;
+    g.ntasks = (unsigned)ntasks;
+    g.flags = flags_and_counter;
+    g.counter = flags_and_counter + ntasks;
+    // enough waves to keep every SIMD busy with several tasks; all of them persistent (they claim tasks until none is left)
+    // persistent workgroups (they claim tasks until none is left): a few per CU so that the SIMDs stay busy while some wait
+    const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
+    for (int pl = 0; pl < E::W; ++pl) {
+        const size_t nel = ntasks * g.nr;
+        GFT_LAUNCH(k_fill_bits, dim3((unsigned)std::min<size_t>((nel + 255) / 256, 2048)), dim3(256), 0, st, res + (size_t)pl * r_plane, nel, DWF_EMPTY);
+    }
+    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DWF_NW), 0, st, xs, x_plane, ys, y_plane, res, r_plane, g);
+    return true;
+}
+template bool K<EF64>::div_wavefront(hipStream_t, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                     const unsigned*, int, unsigned*);
+template bool K<EIv>::div_wavefront(hipStream_t, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                    const unsigned*, int, unsigned*);
 
 template <class E>
 bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,

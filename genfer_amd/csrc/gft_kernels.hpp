@@ -278,6 +278,11 @@ struct K {
     static bool div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1, unsigned nx2, size_t x_rstride, const double* y,
                        size_t y_plane, unsigned ny1, unsigned ny2, double* res, size_t r_plane, unsigned n1, unsigned n2, int fused,
                        unsigned log_k = 0, double* res2 = nullptr, size_t r2_plane = 0);
+    // The whole quotient res = xs / ys (ranks 2-4, rows of at most 64 coefficients) as a row wavefront in ONE launch
+    // (gft_div2d.hip): bit-identical to the host-driven recursion.  `flags_and_counter`: (rows + 1) zeroed device words.
+    // false: shape outside the kernel's domain, nothing launched.
+    static bool div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
+                              const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, int nd, unsigned* flags_and_counter);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);

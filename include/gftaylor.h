@@ -87,7 +87,7 @@ int gft_set_conv_mode(int mode);
  * tiled product), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
- * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div2d" (0: host-driven division
+ * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div_wavefront" (0: the slab-by-slab blocked division instead of the one-launch row wavefront), "div2d" (0: host-driven division
  * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "async_launch" (0: kernels are launched by the
  * calling thread instead of the library's launch thread), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
  * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init). */

@@ -292,8 +292,9 @@ def test_conv_tiled_random_shapes(seed):
     ((2, 3, 2, 3, 2, 3), (3, 2, 3, 2, 3, 2), (4, 4, 4, 4, 4, 4)),  # rank 6
 ])
 def test_conv_outside_tiled_domain_falls_back_bit_exactly(xs, ys, zs):
-    """Shapes the tiled kernel does not take: forcing it is an error, and the automatic dispatch computes them on the
-    reference-order kernels — bit-identical to the one-thread-per-output kernel (itself bit-exact against the oracle)."""
+    """Shapes the tiled kernel does not take (rank 1): forcing it is an error; small products of any rank: the automatic
+    dispatch computes them on the reference-order kernels — bit-identical to the one-thread-per-output kernel (itself
+    bit-exact against the oracle)."""
     import torch
 
     import genfer_amd
@@ -302,17 +303,22 @@ def test_conv_outside_tiled_domain_falls_back_bit_exactly(xs, ys, zs):
     x, y = _rand(xs, 71), _rand(ys, 72)
     tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 
-    def run(mode):
+    def run(mode, a=None, b=None):
+        a, b = (tx if a is None else a), (ty if b is None else b)
         out = torch.full(zs, float("nan"), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         L.gft_set_conv_mode(mode)
         try:
-            genfer_amd.conv_raw(tx.data_ptr(), xs, ty.data_ptr(), ys, out.data_ptr(), zs)
+            genfer_amd.conv_raw(a.data_ptr(), xs, b.data_ptr(), ys, out.data_ptr(), zs)
         finally:
             L.gft_set_conv_mode(0)
         L.gft_synchronize()
         return out
 
-    with pytest.raises(genfer_amd.TaylorError, match="not supported"):
-        run(2)
-    assert bool(torch.equal(run(0), run(1)))
+    if len(zs) < 2:
+        with pytest.raises(genfer_amd.TaylorError, match="not supported"):
+            run(2)
+    else:  # rank >= 5: in the tiled domain since round 3 (host loop over the leading axes), within the tiled contract
+        bound = run(1, tx.abs(), ty.abs())  # mixed-sign data: normwise against |x| (*) |y|
+        assert bool(torch.all((run(2) - run(1)).abs() <= 1e-10 * bound))
+    assert bool(torch.equal(run(0), run(1)))  # small products: the automatic dispatch stays on the reference-order kernels

@@ -1044,3 +1044,44 @@ def test_conv_tiled_rank5_and_up_matches_reference_order_kernel(xs, ys, zs):
     xi = x.copy()
     xi[(1,) * len(xs) if all(s > 1 for s in xs) else tuple(min(1, s - 1) for s in xs)] = np.inf
     assert np.array_equal(_conv_raw_gpu(2, xi, y, zs), _conv_raw_gpu(1, xi, y, zs), equal_nan=True)
+
+
+WAVEFRONT_SHAPES = [
+    # (quotient shape, divisor shape, dividend shape)
+    ((40, 40, 40), (40, 40, 40), (40, 40, 40)),
+    ((30, 20, 33), (7, 20, 12), (30, 5, 33)),        # compact divisor and dividend
+    ((12, 10, 9, 16), (12, 10, 9, 16), (12, 10, 9, 16)),  # rank 4
+    ((200, 48), (200, 48), (200, 48)),               # rank 2, many rows
+    ((70, 64), (3, 64), (70, 1)),                    # rows of exactly 64, thin operands
+]
+
+
+@pytest.mark.parametrize("zs,ys,xs", WAVEFRONT_SHAPES)
+def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
+    """The division as a row wavefront (one launch, every quotient row a task of one wave, dependencies through per-row
+    flags) consumes its terms in the reference's order (mt:1162-1192 over mt:984-1012): bit-exact against the oracle,
+    and identical to the slab-by-slab blocked recurrence (`div_wavefront` = 0); finite, non-finite and interval data."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    x, y = rand(xs, 81, -1.0, 1.0), rand(ys, 82, -0.2, 0.2)
+    y[(0,) * len(ys)] = 1.5
+    deg = list(zs)
+    cases = [(OTP, GTP, x, y)]
+    xi, yi = x.copy(), y.copy()
+    xi[tuple(min(2, s - 1) for s in xs)] = np.inf
+    yi[tuple(min(1, s - 1) for s in ys)] = np.nan
+    cases.append((OTP, GTP, xi, y))
+    cases.append((OTP, GTP, x, yi))
+    if int(np.prod(zs)) <= 20000:  # interval oracle: ~80 instructions a multiply-add
+        cases.append((OTPI, GTPI, np.stack([x, x + 1e-9]), np.stack([y, y + 1e-9])))
+    for O, G, a, b in cases:
+        want = O.new(a, deg) / O.new(b, deg)
+        got = {}
+        for wf in (1, 0):
+            assert L.gft_set_option(b"div_wavefront", float(wf)) == 0
+            try:
+                got[wf] = G.new(a, deg) / G.new(b, deg)
+                check(want, got[wf])
+            finally:
+                L.gft_set_option(b"div_wavefront", 1.0)
