@@ -52,9 +52,23 @@ struct StagedArgs {
 // recomputed with the general mac if some lane of the wave hit a case mac_pos cannot represent.
 template <class E>
 __device__ inline typename E::V inner_sum(const double* xl, size_t xcap, const double* yl, size_t ycap, unsigned xb, unsigned yb,
-                                          unsigned lo, unsigned hi, bool pos) {
+                                          unsigned lo, unsigned hi, int regime) {
     typedef typename E::V V;
+    const bool pos = regime == 1;
     if constexpr (E::HAS_POS) {
+        if (regime == 2) {
+            // finite regime (gft_elem.hpp): no staged element can short-circuit; unguarded outward steps, one test of the
+            // finished sum, the general mac below for a sum that fails it
+            V inner = E::zero();
+            bool bad = false;
+            if (lo < hi) {
+                inner = E::mul_fin(E::ld(xl, xcap, xb + lo), E::ld(yl, ycap, yb - lo));  // [0,0] + m returns m unchanged
+#pragma unroll 4
+                for (unsigned j = lo + 1; j < hi; ++j) inner = E::mac_fin(inner, E::ld(xl, xcap, xb + j), E::ld(yl, ycap, yb - j));
+                bad = !E::fin_result_ok(inner);
+            }
+            if (!any_lane(bad)) return inner;
+        }
         if (pos) {
             // No per-term checks: the two ways a term can leave the regime poison the running sum — a product that
             // underflows to zero makes dec_pos produce a NaN pattern, an upper bound that reaches inf makes inc_pos
@@ -221,24 +235,27 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
         // Interval tensors: while staging, note whether every staged element is in the positive regime
         // (gft_elem.hpp EIv::pos_ok); the block then runs its inner sums with mac_pos (same bits, ~1/4 of the
         // instructions) and falls back to the general mac for the sums mac_pos cannot represent.
-        int not_pos = 0;
+        int not_pos = 0, not_fin = 0;
         if (S == 1 && rows > 1) {
             for (unsigned i = tid; i < rows * xcols; i += NT) {
                 unsigned r = i / xcols, c = i - r * xcols;
                 V v = E::ld(x, xp, xoff + (size_t)r * xpitch + c);
                 if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                if (E::HAS_POS && !E::fin_ok(v)) not_fin = 1;
                 E::st(xl, g.xcap, i, v);
             }
             for (unsigned i = tid; i < rows * ycols; i += NT) {
                 unsigned r = i / ycols, c = i - r * ycols;
                 V v = E::ld(y, yp, yoff + (size_t)r * ypitch + c);
                 if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                if (E::HAS_POS && !E::fin_ok(v)) not_fin = 1;
                 E::st(yl, g.ycap, i, v);
             }
         } else {
         for (unsigned i = tid; i < nx; i += NT) {
             V v = E::ld(x, xp, xoff + i);
             if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                if (E::HAS_POS && !E::fin_ok(v)) not_fin = 1;
             E::st(xl, g.xcap, i, v);
         }
         if (S == 2 && g.syb != g.nb) {
@@ -246,17 +263,26 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                 unsigned r = i / g.syb, c = i - r * g.syb;
                 V v = E::ld(y, yp, yoff + i);
                 if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                if (E::HAS_POS && !E::fin_ok(v)) not_fin = 1;
                 E::st(yl, g.ycap, (size_t)r * g.nb + c, v);
             }
         } else {
             for (unsigned i = tid; i < ny; i += NT) {
                 V v = E::ld(y, yp, yoff + i);
                 if (E::HAS_POS && !E::pos_ok(v)) not_pos = 1;
+                if (E::HAS_POS && !E::fin_ok(v)) not_fin = 1;
                 E::st(yl, g.ycap, i, v);
             }
         }
         }
-        const bool regime_pos = E::HAS_POS ? (__syncthreads_or(not_pos) == 0) : (__syncthreads(), false);
+        // regime of the block's inner sums: 1 positive, 2 finite (no operand can short-circuit), 0 general
+        int regime_pos = 0;
+        if (E::HAS_POS) {
+            if (__syncthreads_or(not_pos) == 0) regime_pos = 1;            // (block-uniform branch)
+            else if (__syncthreads_or(not_fin) == 0) regime_pos = 2;
+        } else {
+            __syncthreads();
+        }
 
         if (S == 2 && INNER0 && rw > 1) {
             // plane mode: the rows j_a of the staged plane play the role of the batch rows, 8 at a time
