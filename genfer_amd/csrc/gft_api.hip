@@ -2046,6 +2046,7 @@ struct Ops {
         log_rec(xs.index0(0), res.index0(0), seed);
         size_t n0 = res.shape[0];
         if (n0 <= 1) return;
+        if (!host && log_wavefront(xs, res)) return;
         // rs[j] = res[j] * j, filled slab by slab as res becomes known (mt:1362-1365)
         std::shared_ptr<Buf> rsbuf = alloc_tier(host, res.numel() * W);
         HV rs{rsbuf->p, res.numel(), res.shape, host};
@@ -2102,6 +2103,28 @@ struct Ops {
             }
         }
         if (right) join_side();
+    }
+    // The slabs k0 >= 1 of the log recurrence in one launch (gft_div2d.hip k_div_wavefront, log_mode): every row a task,
+    // consumed in the reference's order (mt:1335-1386), same bits.  Shapes: no unit axes in the result, rows of at most 64
+    // coefficients, a divisor xs[0] with more than one coefficient (Div's general path, mt:1194-1231), enough rows.
+    static bool log_wavefront(const HV& xs, const HV& res) {
+        if (!R.div_wavefront || !R.div2d) return false;
+        const size_t nd = res.shape.size();
+        if (nd < 2 || nd > 4 || xs.shape.size() != nd) return false;
+        unsigned xsh[4], rsh[4];
+        size_t rows = 1, x0n = 1;
+        for (size_t i = 0; i < nd; ++i) {
+            if (res.shape[i] < 2 || xs.shape[i] > res.shape[i] || res.shape[i] > 0x7fffffffu) return false;
+            xsh[i] = (unsigned)xs.shape[i];
+            rsh[i] = (unsigned)res.shape[i];
+            if (i + 1 < nd) rows *= res.shape[i];
+            if (i > 0) x0n *= xs.shape[i];
+        }
+        if (rsh[nd - 1] > 64 || rows < 64 || x0n < 2 || nonunit_axes(xs.shape) < 2) return false;
+        std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);
+        std::shared_ptr<Buf> fl = alloc_doubles((rows + 2) / 2 + 1);
+        zero_elems(false, fl->p, (rows + 2) / 2 + 1);
+        return K<E>::log_wavefront(R.stream, xs.p, xs.plane, xsh, res.p, res.plane, rsh, (int)nd, qb->p, res.numel(), reinterpret_cast<unsigned*>(fl->p));
     }
     // Div's dispatcher (mt:1194-1231) for the slab division inside log.  tp<E>() serves a device caller whatever side
     // the quotient is on; a host caller needs it in host memory.

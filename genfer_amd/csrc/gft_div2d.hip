@@ -694,8 +694,16 @@ struct DivWfArgs {
     unsigned nr, mr, xnr;     // row lengths
     size_t rstr[3], ystr[3], xstr[3];  // strides of the leading axes (rows are contiguous)
     unsigned ntasks;
-    unsigned* flags;          // [ntasks] row done; zeroed before the launch
+    unsigned* flags;          // [rows] row done; zeroed before the launch
     unsigned* counter;        // next task; zeroed before the launch
+    // log_mode (mt:1335-1386): res = log(xs) for the slabs k0 >= 1 (slab 0, a log one dimension down, is the caller's).
+    //   level 0:  S = sum_{j0 = max(k0 + 1 - xn0, 1)}^{k0 - 1} sum_{j' lexicographic} rowproduct(xs[k0 - j0, j'], j0 * res[j0, k - j'])
+    //             r = (-S) + k0 * xs[K]
+    //   levels >= 1 and the row division: the division of the slab by xs[0] — as above with ys = xs[0], on the rows q of
+    //             the slab's own quotient (kept in `qb`); finally res[K] = q / k0.
+    int log_mode;
+    double* qb;               // log_mode: the quotient rows before the division by k0 (same layout as res)
+    size_t qbp;
 };
 
 template <class E>
@@ -766,6 +774,7 @@ __global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __r
     __shared__ unsigned s_task;
     const unsigned c = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = g.L;
+    const bool lg = g.log_mode != 0;
     const V y0row = c < g.mr ? E::ld(ys, yp, c) : E::zero();
     const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
     for (;;) {
@@ -775,30 +784,47 @@ __global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __r
         __syncthreads();  // everyone has read s_task before the next claim overwrites it
         if (t >= g.ntasks) break;
         unsigned k[3] = {0, 0, 0};
+        unsigned row_id = 0;  // the row's index among ALL rows of res (flags)
         {
             unsigned r = t;
-            for (int a = L - 1; a >= 0; --a) {
+            for (int a = L - 1; a >= 1; --a) {
                 k[a] = r % g.n[a];
                 r /= g.n[a];
             }
+            k[0] = r + (lg ? 1u : 0u);
+            for (int a = 0; a < L; ++a) row_id = row_id * g.n[a] + k[a];
         }
         V r_prev = E::zero();  // (meaningful in wave 0)
         unsigned buf = 0;
         for (int lev = 0; lev < L; ++lev) {
             V S = E::zero();
-            // the level's source rows: j_lev in [lo_lev, k_lev), j_t in [lo_t, k_t] for t > lev, lexicographic, j_{L-1} fastest
-            unsigned lo[3], cnt[3];
+            const bool lg0 = lg && lev == 0;
+            // the level's source rows, in the reference's order (the last axis of the odometer fastest):
+            //   division (and log's levels >= 1): result row (k_0 .. k_{lev-1}, j_lev .. j_{L-1}) with j_lev in [lo_lev, k_lev),
+            //     j_t in [lo_t, k_t]; the other operand's row is (0 .., k_lev - j_lev, ..)
+            //   log's level 0: j0 in [max(lo_0, 1), k_0), then j'_t in [0, min(k_t, xn_t - 1)] = the row index in xs[k0 - j0];
+            //     the result row is (j0, k_1 - j'_1, ..)
+            unsigned lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
             unsigned total = 1;
             for (int a = lev; a < L; ++a) {
-                lo[a] = k[a] + 1 > g.m[a] ? k[a] + 1 - g.m[a] : 0;
-                const unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
-                cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
+                if (lg0 && a > 0) {
+                    lo[a] = 0;
+                    cnt[a] = (k[a] < g.xn[a] ? k[a] : g.xn[a] - 1) + 1;
+                } else {
+                    const unsigned mm = lg0 ? g.xn[a] : g.m[a];
+                    lo[a] = k[a] + 1 > mm ? k[a] + 1 - mm : 0;
+                    if (lg0 && lo[a] < 1) lo[a] = 1;
+                    const unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
+                    cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
+                }
                 total *= cnt[a];
             }
+            const double* const coh_base = (lg && lev > 0) ? g.qb : res;  // where the result-side rows live
+            const size_t coh_plane = (lg && lev > 0) ? g.qbp : rp;
             // this wave's source row i of the level: where it lies, and its operands REQUESTED (consumed one batch later)
             size_t roff_n = 0;
-            unsigned src_n = 0;
-            V a_n = E::zero(), b_n = E::zero();
+            unsigned src_n = 0, j0_n = 0;
+            V coh_n = E::zero(), oth_n = E::zero();
             auto request = [&](unsigned i) {
                 if (i >= total) return;
                 unsigned rem = i, j[3] = {0, 0, 0};
@@ -806,39 +832,54 @@ __global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __r
                     j[a] = lo[a] + rem % cnt[a];
                     rem /= cnt[a];
                 }
-                size_t roff = 0, yoff = 0;
+                size_t roff = 0, ooff = 0;
                 unsigned src = 0;
                 for (int a = 0; a < L; ++a) {
-                    const unsigned ja = a < lev ? k[a] : j[a];
-                    roff += (size_t)ja * g.rstr[a];
-                    src = src * g.n[a] + ja;
-                    if (a >= lev) yoff += (size_t)(k[a] - j[a]) * g.ystr[a];
+                    unsigned ra;  // the result row's index on this axis
+                    if (a < lev) ra = k[a];
+                    else if (lg0 && a > 0) ra = k[a] - j[a];
+                    else ra = j[a];
+                    roff += (size_t)ra * g.rstr[a];
+                    src = src * g.n[a] + ra;
+                    if (a >= lev) {
+                        if (lg0) ooff += (size_t)(a == 0 ? k[0] - j[0] : j[a]) * g.xstr[a];
+                        else ooff += (size_t)(k[a] - j[a]) * g.ystr[a];
+                    }
                 }
                 roff_n = roff;
                 src_n = src;
-                b_n = c < g.mr ? E::ld(ys, yp, yoff + c) : E::zero();
-                a_n = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+                j0_n = j[0];
+                if (lg0) oth_n = c < g.xnr ? E::ld(xs, xp, ooff + c) : E::zero();
+                else oth_n = c < g.mr ? E::ld(ys, yp, ooff + c) : E::zero();
+                coh_n = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
             };
             request(wave);
             for (unsigned base = 0; base < total; base += DWF_NW) {
                 const unsigned i = base + wave;
-                V a_row = a_n;
-                const V b_row = b_n;
+                V coh = coh_n;
+                const V oth = oth_n;
                 const size_t roff = roff_n;
-                const unsigned src = src_n;
+                const unsigned src = src_n, j0 = j0_n;
                 request(i + DWF_NW);
                 if (i < total) {
                     // a row that still shows the EMPTY pattern has not been stored by its producer (or, once in a blue moon,
                     // holds that pattern for real: then the producer's flag says so)
-                    for (unsigned spins = 1; any_lane(c < g.nr && is_empty_bits(a_row)); ++spins) {
+                    for (unsigned spins = 1; any_lane(c < g.nr && is_empty_bits(coh)); ++spins) {
                         __builtin_amdgcn_s_sleep(2);
                         if ((spins & 31u) == 0u && __hip_atomic_load(g.flags + src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                            a_row = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+                            coh = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
                             break;
                         }
-                        a_row = c < g.nr ? ld_coherent<E>(res, rp, roff + c) : E::zero();
+                        coh = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
                     }
-                    E::st(&part[buf][0][wave][0], (size_t)DWF_NW * 64, c, row_product<E>(a_row, b_row, c, g.nr, g.mr, &stage[wave][0][0]));
+                    V prod;
+                    if (lg0) {  // mul_1d(xs row, j0 * res row): the input's coefficient is the broadcast one
+                        const V scaled = c < g.nr ? E::mul(coh, E::from_u32(j0)) : E::zero();
+                        prod = row_product<E>(oth, scaled, c, g.xnr, g.nr, &stage[wave][0][0]);
+                    } else {
+                        prod = row_product<E>(coh, oth, c, g.nr, g.mr, &stage[wave][0][0]);
+                    }
+                    E::st(&part[buf][0][wave][0], (size_t)DWF_NW * 64, c, prod);
                 }
                 __syncthreads();
                 if (wave == 0) {
@@ -856,7 +897,10 @@ __global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __r
                         if (k[a] >= g.xn[a]) in_x = false;
                         xoff += (size_t)k[a] * g.xstr[a];
                     }
-                    if (in_x) r = E::add(r, E::ld(xs, xp, xoff + c));
+                    if (in_x) {
+                        const V xin = E::ld(xs, xp, xoff + c);
+                        r = E::add(r, lg ? E::mul(E::from_u32(k[0]), xin) : xin);
+                    }
                 } else {
                     r = E::add(r, r_prev);
                 }
@@ -882,9 +926,16 @@ __global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __r
             }
             size_t qoff = 0;
             for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
-            if (c < g.nr) st_coherent(res, rp, qoff + c, mine);
+            if (c < g.nr) {
+                if (lg) {  // res[K] = q / k0 (mt:1384); the slab's own later rows read q itself
+                    st_coherent(g.qb, g.qbp, qoff + c, mine);
+                    st_coherent(res, rp, qoff + c, E::div(mine, E::from_u32(k[0])));
+                } else {
+                    st_coherent(res, rp, qoff + c, mine);
+                }
+            }
             __threadfence();  // the row is visible device-wide before its flag is
-            if (c == 0) __hip_atomic_store(g.flags + t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -928,6 +979,53 @@ bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DWF_NW), 0, st, xs, x_plane, ys, y_plane, res, r_plane, g);
     return true;
 }
+// res[1..] = log(xs)[1..] (slabs k0 >= 1; mt:1335-1386) as the same row wavefront.  `qbuf`: a tensor like res for the slab
+// quotients before the division by k0; `flags_and_counter`: (rows of res + 1) zeroed words.
+template <class E>
+bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
+                         const unsigned* rshape, int nd, double* qbuf, size_t q_plane, unsigned* flags_and_counter) {
+    if (nd < 2 || nd > 4) return false;
+    DivWfArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.L = nd - 1;
+    g.log_mode = 1;
+    g.nr = rshape[nd - 1];
+    g.xnr = xshape[nd - 1];
+    g.mr = g.xnr;  // the divisor of the slab divisions is xs[0]
+    if (g.nr < 2 || g.nr > 64 || g.xnr > g.nr || rshape[0] < 2) return false;
+    size_t rs = g.nr, xsd = g.xnr, rows = 1;
+    for (int a = g.L - 1; a >= 0; --a) {
+        g.n[a] = rshape[a];
+        g.xn[a] = xshape[a];
+        g.m[a] = xshape[a];
+        if (g.xn[a] > g.n[a] || g.n[a] == 0 || g.xn[a] == 0) return false;
+        g.rstr[a] = rs;
+        g.xstr[a] = xsd;
+        g.ystr[a] = xsd;
+        rs *= rshape[a];
+        xsd *= xshape[a];
+        rows *= rshape[a];
+    }
+    const size_t slab_rows = rows / rshape[0], ntasks = rows - slab_rows;
+    if (rows > 0x7fffffffu) return false;
+    g.ntasks = (unsigned)ntasks;
+    g.flags = flags_and_counter;
+    g.counter = flags_and_counter + rows;
+    g.qb = qbuf;
+    g.qbp = q_plane;
+    const size_t slab_el = slab_rows * g.nr, nel = ntasks * g.nr;
+    for (int pl = 0; pl < E::W; ++pl) {
+        const unsigned fb = (unsigned)std::min<size_t>((nel + 255) / 256, 2048);
+        GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, res + (size_t)pl * r_plane + slab_el, nel, DWF_EMPTY);
+        GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, qbuf + (size_t)pl * q_plane + slab_el, nel, DWF_EMPTY);
+    }
+    const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
+    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DWF_NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
+    return true;
+}
+template bool K<EF64>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
+template bool K<EIv>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
+
 template bool K<EF64>::div_wavefront(hipStream_t, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
                                      const unsigned*, int, unsigned*);
 template bool K<EIv>::div_wavefront(hipStream_t, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,

@@ -283,6 +283,9 @@ struct K {
     // false: shape outside the kernel's domain, nothing launched.
     static bool div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
                               const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, int nd, unsigned* flags_and_counter);
+    // res[1..] = log(xs)[1..]: the slabs k0 >= 1 of the log recurrence as the same row wavefront (slab 0 is the caller's)
+    static bool log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
+                              const unsigned* rshape, int nd, double* qbuf, size_t q_plane, unsigned* flags_and_counter);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);

@@ -1085,3 +1085,17 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
                 check(want, got[wf])
             finally:
                 L.gft_set_option(b"div_wavefront", 1.0)
+    # the log recurrence (mt:1335-1386) through the same wavefront: slabs k0 >= 1 in one launch, slab 0 one dimension down
+    ylog = rand(ys, 83, -0.2, 0.2)
+    ylog[(0,) * len(ys)] = 1.5
+    lcases = [(OTP, GTP, ylog)]
+    if int(np.prod(zs)) <= 20000:
+        lcases.append((OTPI, GTPI, np.stack([ylog, ylog + 1e-9])))
+    for O, G, b in lcases:
+        want = O.new(b, deg).log()
+        for wf in (1, 0):
+            assert L.gft_set_option(b"div_wavefront", float(wf)) == 0
+            try:
+                check(want, G.new(b, deg).log())
+            finally:
+                L.gft_set_option(b"div_wavefront", 1.0)

@@ -1,6 +1,5 @@
 mkdir -p gpurun_out/r03
 export HIP_FORCE_DEV_KERNARG=1
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03/pytest_wf.log 2>&1
-grep -E "passed|failed|FAILED|Error" gpurun_out/r03/pytest_wf.log | head
-timeout 900 python tools/bench_recurrence.py 32x32x32 64x64x64 200x200 24x24x24x24 400x400 48x48x48 100x64 > gpurun_out/r03/recurrences.txt 2>&1
-grep -v amdgpu gpurun_out/r03/recurrences.txt
+timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q -k "wavefront or recurrences or binary_ops or exp_log or division or expression_trees" 2>&1 | grep -E "passed|failed|FAILED|Error|assert" | head
+timeout 900 python tools/bench_recurrence.py 32x32x32 64x64x64 24x24x24x24 100x64 48x48x48 > gpurun_out/r03/recurrences.txt 2>&1
+grep -v amdgpu gpurun_out/r03/recurrences.txt | grep -E "div|log"
