@@ -350,6 +350,11 @@ struct Pend {
     Dims base_shape;            // shape of the base tensor in `buf` (its axes align with the handle's leading axes)
     size_t base_numel = 1;      // = plane stride of the base
     size_t base_off = 0;        // element offset of the handle's element 0 inside the base (a sub-box view)
+    // zeros in front (mul_var, mt:589-608: the operand shifted up along one axis): the handle's index k reads base index
+    // k - pad[ax], valid inside src_box[ax]; the recorded stages apply to the data only, the padding stays +0 — which is
+    // why no stage may be added AFTER a pad (c * 0 would have to flip the zero's sign): such a chain is materialised first
+    bool padded = false;
+    Dims pad, src_box;
     int n = 0;
     PendStage st[gft::CHAIN_MAX];
     std::shared_ptr<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
@@ -411,6 +416,11 @@ static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
     for (size_t j = 0; j < keep.size(); ++j) {
         const size_t ax = keep[j];
         c.box[j] = (unsigned)(ax < p.shape.size() ? p.shape[ax] : 1);
+        c.pad[j] = 0;
+        if (p.pend && p.pend->padded && ax < p.pend->pad.size()) {
+            c.pad[j] = (int)p.pend->pad[ax];
+            c.box[j] = (unsigned)p.pend->src_box[ax];
+        }
         c.stride[j] = ax < bs.size() ? st[ax] : 0;
     }
     if (p.pend) {
@@ -442,9 +452,11 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
     for (size_t a = 0; a < shape.size(); ++a) {
         bool k = shape[a] != 1;
         for (const gft_poly* p : ops)
-            if (p->pend)
+            if (p->pend) {
                 for (int i = 0; i < p->pend->n; ++i)
                     if (p->pend->st[i].kind == gft::CH_MUL_TAB && (size_t)p->pend->st[i].axis == a) k = true;
+                if (p->pend->padded && a < p->pend->pad.size() && p->pend->pad[a] > 0) k = true;  // the pad is applied per kept axis
+            }
         if (k) keep.push_back(a);
     }
     return keep;
@@ -721,7 +733,7 @@ struct Ops {
     // from the materialised tensor.)
     static P deferred(const P& src, const Dims& out_shape, const Dims& out_deg, int extra) {
         check_invariants(out_shape, out_deg);
-        if (src.pend && (src.pend->n + extra > CHAIN_MAX || src.pend->mat)) settle<E>(src);
+        if (src.pend && (src.pend->n + extra > CHAIN_MAX || src.pend->mat || src.pend->padded)) settle<E>(src);
         P r;
         r.width = W;
         r.shape = out_shape;
@@ -747,6 +759,7 @@ struct Ops {
     static void push_stage(P& r, int kind, const double* sv, int axis = 0, std::shared_ptr<TabEntry> tab = nullptr) {
         Pend& q = *r.pend;
         if (q.n >= CHAIN_MAX) throw Error("internal: deferred chain overflow");
+        if (q.padded) throw Error("internal: stage after a pad");
         PendStage& g = q.st[q.n++];
         g.kind = kind;
         g.axis = axis;
@@ -903,6 +916,35 @@ struct Ops {
             if (inside && shifted && src.pend)
                 for (int i = 0; i < src.pend->n; ++i)
                     if (src.pend->st[i].kind >= CH_FIRST_ADD) inside = false;  // FIRST_* and MUL_TAB are positional
+            // zeros in front (mul_var: shift -1 along one axis, the source cut at src_len): the same view with a pad
+            bool front = !inside && out_shape.size() <= src.shape.size();
+            if (front) {
+                bool any_neg = false;
+                for (size_t ax = 0; ax < out_shape.size() && front; ++ax) {
+                    if (shift[ax] > 0) front = false;
+                    if (shift[ax] < 0) any_neg = true;
+                }
+                if (!any_neg) front = false;
+                if (front && src.pend)
+                    for (int i = 0; i < src.pend->n; ++i)
+                        if (src.pend->st[i].kind >= CH_FIRST_ADD) front = false;
+                if (front && src.pend && src.pend->padded) front = false;
+            }
+            if (front) {
+                P r = deferred(src, out_shape, out_deg, op == OP_COPY ? 0 : 1);
+                if (op != OP_COPY) push_stage(r, op == OP_MUL_S ? CH_MUL_S : (op == OP_DIV_S ? CH_DIV_S : (op == OP_NEG ? CH_NEG : CH_LMUL_S)), s);
+                Pend& q = *r.pend;
+                q.padded = true;
+                q.pad = Dims(out_shape.size(), 0);
+                q.src_box = Dims(out_shape.size(), 0);
+                for (size_t ax = 0; ax < out_shape.size(); ++ax) {
+                    q.pad[ax] = (size_t)(-shift[ax]);
+                    q.src_box[ax] = std::min(src_len[ax], src.shape[ax]);
+                }
+                r.c0_known = true;  // element 0 lies in the padding
+                r.c0[0] = r.c0[1] = 0.0;
+                return r;
+            }
             if (inside) {
                 P r = deferred(src, out_shape, out_deg, op == OP_COPY ? 0 : 1);
                 if (shifted) {

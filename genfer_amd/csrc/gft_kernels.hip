@@ -498,11 +498,13 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
             const unsigned kk = (unsigned)(r % d);
             r /= d;
             k[ax] = kk;
-            if (kk >= a.box[ax]) ina = false;
-            aoff += (size_t)kk * a.stride[ax];
+            const unsigned ka = kk - (unsigned)a.pad[ax];  // (wraps below the pad: fails the box test)
+            if (ka >= a.box[ax]) ina = false;
+            aoff += (size_t)ka * a.stride[ax];
             if (TWO) {
-                if (kk >= b.box[ax]) inb = false;
-                boff += (size_t)kk * b.stride[ax];
+                const unsigned kb = kk - (unsigned)b.pad[ax];
+                if (kb >= b.box[ax]) inb = false;
+                boff += (size_t)kb * b.stride[ax];
             }
         }
         const bool first = lin == 0;

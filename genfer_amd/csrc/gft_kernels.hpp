@@ -85,7 +85,8 @@ struct ChainStage {
 struct ChainSrc {
     const double* p;           // base tensor (contiguous)
     size_t plane;
-    unsigned box[MAXD];        // extent of the operand per output axis: an output index at or beyond it reads padding (zero)
+    unsigned box[MAXD];        // extent of the operand's data per output axis (base coordinates): outside it the operand is zero
+    int pad[MAXD];             // output index k reads base index k - pad (>= 0: zeros in front — mul_var's shift, mt:589-608)
     size_t stride[MAXD];       // base strides per output axis
     int nstages;
     ChainStage st[CHAIN_MAX];

@@ -986,6 +986,11 @@ def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, 
         # sub-box views that do not start at element 0 (slab extraction): deferred on position-independent chains only
         outs.append((A * T.from_scalar(sc(2.0))).coefficients_of_term(v, 1) + q.coefficients_of_term(v, 0))
         outs.append(((-B).coefficients_of_term(v, min(2, deg[v] - 1)) * T.from_scalar(sc(0.75))) - p.coefficients_of_term(v, 1))
+        # mul by a linear polynomial c + m x_v (mul_linear, mt:611-623): mul_var's shifted operand is a front-padded view
+        lin = T.var(v, sc(0.8), deg[v]) * T.from_scalar(sc(0.2)) + T.from_scalar(sc(0.64))
+        outs.append(A * lin)
+        outs.append((B * T.from_scalar(sc(-1.5))) * lin)          # a chain under the pad
+        outs.append(A.mul_var(sc(-0.5), v, [min(d_ + (1 if i_ == v else 0), g_) for i_, (d_, g_) in enumerate(zip(A.coeffs_shape(), deg))], deg) * T.from_scalar(sc(-2.0)))
         return outs, [p.constant_term(), q.constant_term(), n.constant_term(), seven.constant_term()]
 
     for shape, deg in (((24, 20), [30, 22]), ((6, 7, 9), [8, 8, 9]), ((40,), [64]), ((3, 1, 12), [5, 4, 12])):
