@@ -732,12 +732,16 @@ __device__ inline typename E::V row_product(typename E::V a, typename E::V b, un
     typedef typename E::V V;
     V inner = E::zero(), w = b;
     if (!any_lane(!elem_finite<E>(a) || !elem_finite<E>(b))) {
-        E::st(stage, 64, c, a);
+        // both rows through the wave's LDS stage: a[j] is a broadcast read, b[c - j] a read at a per-lane address that walks
+        // down one coefficient per step into 64 zeros staged in front of the row (the truncation) — two DS instructions
+        // beside two VALU instructions per step; a DPP wave shift of the sliding row costs ~6 VALU slots per step instead
+        // (tools/microbench_rowconv.hip).  Layout per plane: [a: 64][zeros: 64][b: 64].
+        E::st(stage, 192, c, a);
+        E::st(stage, 192, 64 + c, E::zero());
+        E::st(stage, 192, 128 + c, b);
+        const double* bl = stage + 128 + c;
 #pragma unroll 8
-        for (unsigned j = 0; j < nr; ++j) {
-            inner = E::add(inner, E::mul(E::ld(stage, 64, j), w));
-            w = wave_shr1<E>(w);
-        }
+        for (unsigned j = 0; j < nr; ++j) inner = E::add(inner, E::mul(E::ld(stage, 192, j), E::ld(bl - j, 192, 0)));
     } else {
         for (unsigned j = 0; j < nr; ++j) {
             const V t = E::add(inner, E::mul(bcast_lane<E>(a, j), w));
@@ -748,7 +752,10 @@ __device__ inline typename E::V row_product(typename E::V a, typename E::V b, un
     return inner;
 }
 
-constexpr unsigned DWF_NW = 16;  // waves per task
+template <class E>
+struct DwfCfg {
+    static constexpr unsigned NW = E::W == 1 ? 16 : 8;  // waves per task (the LDS stages of an interval task are twice as large)
+};
 // Quotient rows start out as this bit pattern (a NaN payload no arithmetic produces): a consumer loads a source row with
 // ONE coherent load — requested a batch ahead — and sees from the row itself whether its producer has stored it (every
 // coefficient is an 8-byte store); the per-row flags (release / acquire) remain the authority when a row keeps looking
@@ -762,15 +769,16 @@ __device__ inline bool is_empty_bits(double v) { return (unsigned long long)f64_
 __device__ inline bool is_empty_bits(Iv v) { return (unsigned long long)f64_bits(v.lo) == DWF_EMPTY || (unsigned long long)f64_bits(v.hi) == DWF_EMPTY; }
 
 template <class E>
-__global__ void __launch_bounds__(64 * DWF_NW) k_div_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
+__global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
                                                                double* res, size_t rp, DivWfArgs g) {
     typedef typename E::V V;
     // A task (one quotient row) belongs to a WORKGROUP: its source rows are consumed in batches of DWF_NW — every wave waits
     // for, loads and multiplies one source row (the row products of a batch run side by side on the CU's SIMDs, their
     // global latencies overlap), then wave 0 adds the batch's products in the reference's order.  Same operations per
     // coefficient in the same order as one wave doing everything, 1 / DWF_NW of the chain.
-    __shared__ double part[2][2][DWF_NW][64];  // [buffer][plane][wave][c]
-    __shared__ double stage[DWF_NW][2][64];    // per wave: the source row whose coefficients are broadcast (row_product)
+    constexpr unsigned DWF_NW = DwfCfg<E>::NW;
+    __shared__ double part[2][E::W][DWF_NW][64];  // [buffer][plane][wave][c]
+    __shared__ double stage[DWF_NW][E::W][192];   // per wave and plane: {broadcast row, 64 zeros, sliding row} of row_product
     __shared__ unsigned s_task;
     const unsigned c = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = g.L;
@@ -976,7 +984,7 @@ bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
         const size_t nel = ntasks * g.nr;
         GFT_LAUNCH(k_fill_bits, dim3((unsigned)std::min<size_t>((nel + 255) / 256, 2048)), dim3(256), 0, st, res + (size_t)pl * r_plane, nel, DWF_EMPTY);
     }
-    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DWF_NW), 0, st, xs, x_plane, ys, y_plane, res, r_plane, g);
+    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, ys, y_plane, res, r_plane, g);
     return true;
 }
 // res[1..] = log(xs)[1..] (slabs k0 >= 1; mt:1335-1386) as the same row wavefront.  `qbuf`: a tensor like res for the slab
@@ -1020,7 +1028,7 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
         GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, qbuf + (size_t)pl * q_plane + slab_el, nel, DWF_EMPTY);
     }
     const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
-    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DWF_NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
+    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
     return true;
 }
 template bool K<EF64>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
