@@ -2009,16 +2009,20 @@ struct Ops {
         }
         exp_rec(xs.index0(0), res.index0(0), seed);
         if (res.shape[0] <= 1) return;
+        // below the right-looking tiled path's crossover (and for intervals at every size): the row wavefront, one launch,
+        // the reference's summation order
+        double total = 1.0;
+        for (size_t i = 0; i < res.shape.size(); ++i) total *= 0.5 * (double)res.shape[i] * (double)std::min(xs.shape[i], res.shape[i]) + 0.5;
+        const bool right_tiled = !res.host && W == 1 && R.conv_mode == 0 && R.exp_right && total >= 64.0 * R.tiled_min_macs;
+        if (!res.host && !right_tiled && exp_wavefront(xs, res)) return;
         HV xsc;
         std::shared_ptr<Buf> hold = scaled_by_index(xs, &xsc);
         // Large f64 exponentials (their slab steps would take the tiled kernel anyway, i.e. the 1e-10 contract, not the
         // reference's summation order): RIGHT-LOOKING.  As soon as res[i] is final one wide product adds
         // (j xs[j]) (*) res[i] for j = 1..m into the m slabs that follow — 64 wide launches at full tile efficiency
         // instead of 64 single-slab launches that are all launch / reduce overhead (64^3: 15.6 -> see recurrences.txt).
-        double total = 1.0;
-        for (size_t i = 0; i < res.shape.size(); ++i) total *= 0.5 * (double)res.shape[i] * (double)std::min(xs.shape[i], res.shape[i]) + 0.5;
         const size_t n0 = res.shape[0];
-        if (!res.host && W == 1 && R.conv_mode == 0 && R.exp_right && total >= 64.0 * R.tiled_min_macs) {
+        if (right_tiled) {
             Dims rest(res.shape.begin() + 1, res.shape.end()), xrest(xs.shape.begin() + 1, xs.shape.end());
             HV tail = res.index0(1);
             zero_elems(false, tail.p, res.numel() - prod(rest));
@@ -2043,6 +2047,23 @@ struct Ops {
             conv(xsc, res, res, k, k + 1, false, true, 1, 0, 0);
             x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
         }
+    }
+    static bool exp_wavefront(const HV& xs, const HV& res) {
+        if (!R.div_wavefront || !R.div2d) return false;
+        const size_t nd = res.shape.size();
+        if (nd < 2 || nd > 4 || xs.shape.size() != nd) return false;
+        unsigned xsh[4], rsh[4];
+        size_t rows = 1;
+        for (size_t i = 0; i < nd; ++i) {
+            if (res.shape[i] < 2 || xs.shape[i] > res.shape[i] || xs.shape[i] == 0 || res.shape[i] > 0x7fffffffu) return false;
+            xsh[i] = (unsigned)xs.shape[i];
+            rsh[i] = (unsigned)res.shape[i];
+            if (i + 1 < nd) rows *= res.shape[i];
+        }
+        if (rsh[nd - 1] > 64 || rows < 8) return false;  // (the alternative is two launches per slab)
+        std::shared_ptr<Buf> fl = alloc_doubles((rows + 2) / 2 + 1);
+        zero_elems(false, fl->p, (rows + 2) / 2 + 1);
+        return K<E>::exp_wavefront(R.stream, xs.p, xs.plane, xsh, res.p, res.plane, rsh, (int)nd, reinterpret_cast<unsigned*>(fl->p));
     }
     static Dims explog_shape(const P& a) {
         Dims rs = a.deg;
@@ -2162,7 +2183,7 @@ struct Ops {
             if (i + 1 < nd) rows *= res.shape[i];
             if (i > 0) x0n *= xs.shape[i];
         }
-        if (rsh[nd - 1] > 64 || rows < 64 || x0n < 2 || nonunit_axes(xs.shape) < 2) return false;
+        if (rsh[nd - 1] > 64 || rows < 8 || x0n < 2 || nonunit_axes(xs.shape) < 2) return false;  // (the alternative is 2+ launches per slab)
         std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);
         std::shared_ptr<Buf> fl = alloc_doubles((rows + 2) / 2 + 1);
         zero_elems(false, fl->p, (rows + 2) / 2 + 1);
@@ -3205,6 +3226,7 @@ void gft_shutdown(void) {
     lq_shutdown();
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
+    dwf_release_orders();
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
     for (auto& kv : R.host_blocks)
         for (void* q : kv.second) std::free(q);

@@ -17,6 +17,8 @@
 
 #include "gft_kernels.hpp"
 #include <cstring>
+#include <map>
+#include <vector>
 
 namespace gft {
 
@@ -701,7 +703,11 @@ struct DivWfArgs {
     //             r = (-S) + k0 * xs[K]
     //   levels >= 1 and the row division: the division of the slab by xs[0] — as above with ys = xs[0], on the rows q of
     //             the slab's own quotient (kept in `qb`); finally res[K] = q / k0.
+    // log_mode == 2: res = exp(xs) for the slabs k0 >= 1 (mt:1271-1300; slab 0, an exp one dimension down, is the caller's):
+    //   res[K] = ( sum_{j0 = 1}^{min(k0, xn0 - 1)} sum_{j' lexicographic} rowproduct(j0 * xs[j0, j'], res[k0 - j0, k - j']) ) / k0
     int log_mode;
+    const unsigned* order;    // task t works on row order[t] of the task rows (anti-diagonal order, see dwf_order); null: t
+    int pack;                 // rows <= 32: two source rows per wave (GFT_DWF_PACK=0: one, for A/B)
     double* qb;               // log_mode: the quotient rows before the division by k0 (same layout as res)
     size_t qbp;
 };
@@ -722,31 +728,30 @@ __device__ inline void st_coherent(double* p, size_t plane, size_t i, Iv v) {
     __hip_atomic_store(p + plane + i, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// inner[c] = sum_{j <= c, c - j < mr} a[j] * b[c - j], from zero, ascending j (mul_1d, mt:971-982): lane c holds a[c], b[c]
+// inner[c] = sum_{j <= c, c - j < mr} a[j] * b[c - j], from zero, ascending j (mul_1d, mt:971-982): the lane holds a[c], b[c]
 // (zero beyond the rows' lengths).  Finite rows: positions outside the sum multiply an exact zero (inner + x * 0 == inner:
 // a partial sum formed from +0 is never -0) — no masks; otherwise the bounds are applied as predicates.
-// `stage`: 2 x 64 doubles of LDS owned by the calling wave — the source row's coefficient j reaches all lanes as a
-// broadcast LDS read (one DS instruction beside the VALU stream instead of two v_readlane in it).
+// `stage`: the LDS region of this lane's row pair, {a: R}{zeros: R}{b: R} doubles per plane (planes DWF_STG apart): a[j] is
+// a broadcast read, b[c - j] a read at a per-lane address that walks down one coefficient per step into the zeros staged
+// in front of the row (the truncation) — two DS instructions beside two VALU instructions per step; a DPP wave shift of
+// the sliding row costs ~6 VALU slots per step instead (tools/microbench_rowconv.hip).  R = 64: one row pair per wave;
+// R = 32 (rows <= 32): the two halves of the wave work on two row pairs, each in its own region.
+constexpr unsigned DWF_STG = 200;   // doubles per wave and plane: 3 x 64, or 2 regions of 100 (3 x 32, pitched off the other half's banks)
 template <class E>
-__device__ inline typename E::V row_product(typename E::V a, typename E::V b, unsigned c, unsigned nr, unsigned mr, double* stage) {
+__device__ inline typename E::V row_product(typename E::V a, typename E::V b, unsigned c, unsigned nr, unsigned mr, double* stage, unsigned R) {
     typedef typename E::V V;
-    V inner = E::zero(), w = b;
+    V inner = E::zero();
+    E::st(stage, DWF_STG, c, a);
+    E::st(stage, DWF_STG, R + c, E::zero());
+    E::st(stage, DWF_STG, 2 * R + c, b);
+    const double* bl = stage + 2 * R + c;
     if (!any_lane(!elem_finite<E>(a) || !elem_finite<E>(b))) {
-        // both rows through the wave's LDS stage: a[j] is a broadcast read, b[c - j] a read at a per-lane address that walks
-        // down one coefficient per step into 64 zeros staged in front of the row (the truncation) — two DS instructions
-        // beside two VALU instructions per step; a DPP wave shift of the sliding row costs ~6 VALU slots per step instead
-        // (tools/microbench_rowconv.hip).  Layout per plane: [a: 64][zeros: 64][b: 64].
-        E::st(stage, 192, c, a);
-        E::st(stage, 192, 64 + c, E::zero());
-        E::st(stage, 192, 128 + c, b);
-        const double* bl = stage + 128 + c;
 #pragma unroll 8
-        for (unsigned j = 0; j < nr; ++j) inner = E::add(inner, E::mul(E::ld(stage, 192, j), E::ld(bl - j, 192, 0)));
+        for (unsigned j = 0; j < nr; ++j) inner = E::add(inner, E::mul(E::ld(stage, DWF_STG, j), E::ld(bl - j, DWF_STG, 0)));
     } else {
         for (unsigned j = 0; j < nr; ++j) {
-            const V t = E::add(inner, E::mul(bcast_lane<E>(a, j), w));
+            const V t = E::add(inner, E::mul(E::ld(stage, DWF_STG, j), E::ld(bl - j, DWF_STG, 0)));
             if (c >= j && c - j < mr) inner = t;
-            w = wave_shr1<E>(w);
         }
     }
     return inner;
@@ -761,6 +766,10 @@ struct DwfCfg {
 // coefficient is an 8-byte store); the per-row flags (release / acquire) remain the authority when a row keeps looking
 // unwritten, so a genuine coefficient of that pattern only costs time.
 constexpr unsigned long long DWF_EMPTY = 0x7ff8dead0badf00dull;
+static const int dwf_pack = [] {
+    const char* e = getenv("GFT_DWF_PACK");
+    return e ? atoi(e) : 1;
+}();
 __global__ void __launch_bounds__(256) k_fill_bits(double* p, size_t n, unsigned long long bits) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         reinterpret_cast<unsigned long long*>(p)[i] = bits;
@@ -778,12 +787,20 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
     // coefficient in the same order as one wave doing everything, 1 / DWF_NW of the chain.
     constexpr unsigned DWF_NW = DwfCfg<E>::NW;
     __shared__ double part[2][E::W][DWF_NW][64];  // [buffer][plane][wave][c]
-    __shared__ double stage[DWF_NW][E::W][192];   // per wave and plane: {broadcast row, 64 zeros, sliding row} of row_product
+    __shared__ double stage[DWF_NW][E::W][DWF_STG];   // per wave and plane: row_product's {broadcast row, zeros, sliding row}
     __shared__ unsigned s_task;
-    const unsigned c = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // rows of at most 32 coefficients: the two halves of a wave take two source rows of a batch (PK = 2); `c` is the lane's
+    // coefficient in the row products and sums, `lane` its coefficient in the row's 1-d division (wave 0, lower half)
+    const bool packed = g.pack && g.nr <= 32;
+    const unsigned PK = packed ? 2u : 1u, R = packed ? 32u : 64u;
+    const unsigned c = packed ? (lane & 31u) : lane, half = packed ? (lane >> 5) : 0u;
+    double* const my_stage = &stage[wave][0][0] + (packed ? half * 100u : 0u);
     const int L = g.L;
-    const bool lg = g.log_mode != 0;
-    const V y0row = c < g.mr ? E::ld(ys, yp, c) : E::zero();
+    const bool lg = g.log_mode == 1, ex = g.log_mode == 2;
+    unsigned slab_rows = 1;  // rows of one slab (exp: the rows of slab 0 are the caller's and complete)
+    for (int a = 1; a < L; ++a) slab_rows *= g.n[a];
+    const V y0row = lane < g.mr ? E::ld(ys, yp, lane) : E::zero();
     const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
     for (;;) {
         if (threadIdx.x == 0) s_task = atomicAdd(g.counter, 1u);
@@ -794,19 +811,19 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
         unsigned k[3] = {0, 0, 0};
         unsigned row_id = 0;  // the row's index among ALL rows of res (flags)
         {
-            unsigned r = t;
+            unsigned r = g.order ? g.order[t] : t;
             for (int a = L - 1; a >= 1; --a) {
                 k[a] = r % g.n[a];
                 r /= g.n[a];
             }
-            k[0] = r + (lg ? 1u : 0u);
+            k[0] = r + ((lg || ex) ? 1u : 0u);
             for (int a = 0; a < L; ++a) row_id = row_id * g.n[a] + k[a];
         }
         V r_prev = E::zero();  // (meaningful in wave 0)
         unsigned buf = 0;
-        for (int lev = 0; lev < L; ++lev) {
+        for (int lev = 0; lev < (ex ? 1 : L); ++lev) {
             V S = E::zero();
-            const bool lg0 = lg && lev == 0;
+            const bool lg0 = (lg && lev == 0) || ex;  // the other operand's rows come from xs, the odometer runs over ITS rows
             // the level's source rows, in the reference's order (the last axis of the odometer fastest):
             //   division (and log's levels >= 1): result row (k_0 .. k_{lev-1}, j_lev .. j_{L-1}) with j_lev in [lo_lev, k_lev),
             //     j_t in [lo_t, k_t]; the other operand's row is (0 .., k_lev - j_lev, ..)
@@ -822,7 +839,11 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
                     const unsigned mm = lg0 ? g.xn[a] : g.m[a];
                     lo[a] = k[a] + 1 > mm ? k[a] + 1 - mm : 0;
                     if (lg0 && lo[a] < 1) lo[a] = 1;
-                    const unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
+                    unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
+                    if (ex) {  // j0 = the index of the xs slab: 1 .. min(k0, xn0 - 1)
+                        lo[a] = 1;
+                        hi = (k[0] < g.xn[0] ? k[0] : g.xn[0] - 1) + 1;
+                    }
                     cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
                 }
                 total *= cnt[a];
@@ -833,24 +854,34 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             size_t roff_n = 0;
             unsigned src_n = 0, j0_n = 0;
             V coh_n = E::zero(), oth_n = E::zero();
-            auto request = [&](unsigned i) {
-                if (i >= total) return;
-                unsigned rem = i, j[3] = {0, 0, 0};
+            auto request = [&](unsigned i0) {  // i0: the wave's first source row of the batch (wave-uniform)
+                if (i0 + half >= total) return;
+                unsigned rem = i0, j[3] = {0, 0, 0};
                 for (int a = L - 1; a >= lev; --a) {
-                    j[a] = lo[a] + rem % cnt[a];
+                    j[a] = rem % cnt[a];
                     rem /= cnt[a];
                 }
+                if (half) {  // the upper half's row is the next one of the odometer
+                    bool carry = true;
+                    for (int a = L - 1; a >= lev; --a)
+                        if (carry) {
+                            if (++j[a] == cnt[a]) j[a] = 0;
+                            else carry = false;
+                        }
+                }
+                for (int a = lev; a < L; ++a) j[a] += lo[a];
                 size_t roff = 0, ooff = 0;
                 unsigned src = 0;
                 for (int a = 0; a < L; ++a) {
                     unsigned ra;  // the result row's index on this axis
                     if (a < lev) ra = k[a];
-                    else if (lg0 && a > 0) ra = k[a] - j[a];
+                    else if (ex || (lg0 && a > 0)) ra = k[a] - j[a];
                     else ra = j[a];
                     roff += (size_t)ra * g.rstr[a];
                     src = src * g.n[a] + ra;
                     if (a >= lev) {
-                        if (lg0) ooff += (size_t)(a == 0 ? k[0] - j[0] : j[a]) * g.xstr[a];
+                        if (ex) ooff += (size_t)j[a] * g.xstr[a];
+                        else if (lg0) ooff += (size_t)(a == 0 ? k[0] - j[0] : j[a]) * g.xstr[a];
                         else ooff += (size_t)(k[a] - j[a]) * g.ystr[a];
                     }
                 }
@@ -861,40 +892,65 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
                 else oth_n = c < g.mr ? E::ld(ys, yp, ooff + c) : E::zero();
                 coh_n = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
             };
-            request(wave);
-            for (unsigned base = 0; base < total; base += DWF_NW) {
-                const unsigned i = base + wave;
-                V coh = coh_n;
-                const V oth = oth_n;
+            request(wave * PK);
+            for (unsigned base = 0; base < total; base += DWF_NW * PK) {
+                const unsigned i0 = base + wave * PK;
+                const bool live = i0 + half < total;
+                V coh = live ? coh_n : E::zero();
+                const V oth = live ? oth_n : E::zero();
                 const size_t roff = roff_n;
                 const unsigned src = src_n, j0 = j0_n;
-                request(i + DWF_NW);
-                if (i < total) {
+                request(i0 + DWF_NW * PK);
+                if (i0 < total) {
                     // a row that still shows the EMPTY pattern has not been stored by its producer (or, once in a blue moon,
                     // holds that pattern for real: then the producer's flag says so)
-                    for (unsigned spins = 1; any_lane(c < g.nr && is_empty_bits(coh)); ++spins) {
+                    bool confirmed = ex && src < slab_rows;
+                    for (unsigned spins = 1; any_lane(live && !confirmed && c < g.nr && is_empty_bits(coh)); ++spins) {
                         __builtin_amdgcn_s_sleep(2);
-                        if ((spins & 31u) == 0u && __hip_atomic_load(g.flags + src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                            coh = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
-                            break;
-                        }
-                        coh = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
+                        if (live && (spins & 31u) == 0u && __hip_atomic_load(g.flags + src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                            confirmed = true;  // (what the reload below returns is the row)
+                        if (live) coh = c < g.nr ? ld_coherent<E>(coh_base, coh_plane, roff + c) : E::zero();
                     }
                     V prod;
-                    if (lg0) {  // mul_1d(xs row, j0 * res row): the input's coefficient is the broadcast one
+                    if (ex) {  // mul_1d(j0 * xs row, res row)
+                        const V scaled = c < g.xnr ? E::mul(oth, E::from_u32(j0)) : E::zero();
+                        prod = row_product<E>(scaled, coh, c, g.xnr, g.nr, my_stage, R);
+                    } else if (lg0) {  // mul_1d(xs row, j0 * res row): the input's coefficient is the broadcast one
                         const V scaled = c < g.nr ? E::mul(coh, E::from_u32(j0)) : E::zero();
-                        prod = row_product<E>(oth, scaled, c, g.xnr, g.nr, &stage[wave][0][0]);
+                        prod = row_product<E>(oth, scaled, c, g.xnr, g.nr, my_stage, R);
                     } else {
-                        prod = row_product<E>(coh, oth, c, g.nr, g.mr, &stage[wave][0][0]);
+                        prod = row_product<E>(coh, oth, c, g.nr, g.mr, my_stage, R);
                     }
-                    E::st(&part[buf][0][wave][0], (size_t)DWF_NW * 64, c, prod);
+                    E::st(&part[buf][0][wave][0], (size_t)DWF_NW * 64, lane, prod);  // = [source row of the batch][c]
                 }
                 __syncthreads();
                 if (wave == 0) {
-                    const unsigned nb = total - base < DWF_NW ? total - base : DWF_NW;
-                    for (unsigned w = 0; w < nb; ++w) S = E::add(S, E::ld(&part[buf][0][w][0], (size_t)DWF_NW * 64, c));
+                    // (full batches: constant trip counts, so that the LDS reads are issued together ahead of the chain of
+                    // adds instead of one read latency per add)
+                    const unsigned nb = total - base < DWF_NW * PK ? total - base : DWF_NW * PK;
+                    const double* pb = &part[buf][0][0][0];
+                    if (nb == DWF_NW * 2) {
+                        V pv[DWF_NW * 2];
+#pragma unroll
+                        for (unsigned w = 0; w < DWF_NW * 2; ++w) pv[w] = E::ld(pb, (size_t)DWF_NW * 64, (size_t)w * 32 + c);
+#pragma unroll
+                        for (unsigned w = 0; w < DWF_NW * 2; ++w) S = E::add(S, pv[w]);
+                    } else if (nb == DWF_NW && !packed) {
+                        V pv[DWF_NW];
+#pragma unroll
+                        for (unsigned w = 0; w < DWF_NW; ++w) pv[w] = E::ld(pb, (size_t)DWF_NW * 64, (size_t)w * 64 + c);
+#pragma unroll
+                        for (unsigned w = 0; w < DWF_NW; ++w) S = E::add(S, pv[w]);
+                    } else {
+                        for (unsigned w = 0; w < nb; ++w) S = E::add(S, E::ld(pb, (size_t)DWF_NW * 64, (size_t)w * R + c));
+                    }
                 }
                 buf ^= 1u;  // the next batch writes the other buffer while wave 0 still reads this one
+            }
+            if (ex) {
+                if (wave == 0) r_prev = S;
+                __syncthreads();
+                break;
             }
             if (wave == 0) {
                 V r = E::neg(S);
@@ -916,36 +972,112 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             }
             __syncthreads();  // a level's last batch buffer is free again before the next level reuses it
         }
+        if (ex) {
+            if (wave == 0) {
+                size_t qoff = 0;
+                for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
+                if (lane < g.nr) st_coherent(res, rp, qoff + lane, E::div(r_prev, E::from_u32(k[0])));  // mt:1298
+                __threadfence();
+                if (lane == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else
         if (wave == 0) {
             // ---- the row's 1-d division by ys[0 .. 0, :] in lock step (mt:1162-1185): lane j's coefficient becomes final
             // at step j and reaches the lanes above it by v_readlane; the divisor row slides by one DPP shift per step
+            if (lane >= g.nr) r_prev = E::zero();  // (packed rows: the upper half only mirrored the lower half's sums)
             V cur1 = E::zero(), mine = E::zero(), ysl = y0row;  // ysl[c] = y0[c - j] at step j (zero for c < j and beyond the divisor's row)
             const bool fin = !any_lane(!elem_finite<E>(r_prev)) && !any_lane(!elem_finite<E>(y0row));
             for (unsigned jj = 0; jj < g.nr; ++jj) {
                 const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r_prev), jj));
-                if (c == jj) mine = q;
+                if (lane == jj) mine = q;
                 const V tnew = E::add(cur1, E::mul(q, ysl));
                 if (fin && elem_finite<E>(q)) {
                     cur1 = tnew;  // positions outside the sum multiply a shifted-in zero
-                } else if (c > jj && c - jj < g.mr) {
+                } else if (lane > jj && lane - jj < g.mr) {
                     cur1 = tnew;
                 }
                 ysl = wave_shr1<E>(ysl);
             }
             size_t qoff = 0;
             for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
-            if (c < g.nr) {
+            if (lane < g.nr) {
                 if (lg) {  // res[K] = q / k0 (mt:1384); the slab's own later rows read q itself
-                    st_coherent(g.qb, g.qbp, qoff + c, mine);
-                    st_coherent(res, rp, qoff + c, E::div(mine, E::from_u32(k[0])));
+                    st_coherent(g.qb, g.qbp, qoff + lane, mine);
+                    st_coherent(res, rp, qoff + lane, E::div(mine, E::from_u32(k[0])));
                 } else {
-                    st_coherent(res, rp, qoff + c, mine);
+                    st_coherent(res, rp, qoff + lane, mine);
                 }
             }
             __threadfence();  // the row is visible device-wide before its flag is
-            if (c == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// Claim order of the tasks.  Any order in which a row comes after the rows it reads is deadlock-free (a claimed task only
+// waits for tasks claimed before it, and those belong to running workgroups).  Lexicographic order has every row wait for
+// the row claimed just before it — (k0, k1 - 1) is the LAST source of (k0, k1), so the rows of a slab run as a chain of
+// row divisions; in order of the ANTI-DIAGONAL k0 + .. + k_{L-1} (lexicographic within one) a row's sources are all at
+// least one diagonal — dozens of tasks — older, and the rows of a diagonal are independent.  The table (one word per
+// task row) is built on the host once per shape and kept on the device.
+struct DwfOrderKey {
+    unsigned L, n[3], first;
+    bool operator<(const DwfOrderKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
+};
+static std::map<DwfOrderKey, unsigned*>& dwf_orders() {
+    static std::map<DwfOrderKey, unsigned*> m;
+    return m;
+}
+static const int dwf_diag = [] {
+    const char* e = getenv("GFT_DWF_DIAG");
+    return e ? atoi(e) : 1;
+}();
+// rows (k0 >= first, k1, ..) of an n[0] x .. x n[L-1] grid, task-relative index (row index - first * rows per slab)
+static const unsigned* dwf_order(int L, const unsigned* n, unsigned first) {
+    if (!dwf_diag || L < 2) return nullptr;
+    DwfOrderKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.L = (unsigned)L;
+    for (int a = 0; a < L; ++a) key.n[a] = n[a];
+    key.first = first;
+    auto it = dwf_orders().find(key);
+    if (it != dwf_orders().end()) return it->second;
+    size_t slab = 1, maxd = 0;
+    for (int a = 1; a < L; ++a) slab *= n[a];
+    for (int a = 0; a < L; ++a) maxd += n[a] - 1;
+    const size_t ntasks = (size_t)(n[0] - first) * slab;
+    std::vector<unsigned> start(maxd + 2, 0), tab(ntasks);
+    auto diag_of = [&](size_t t) {
+        size_t r = t, d = 0;
+        for (int a = L - 1; a >= 1; --a) {
+            d += r % n[a];
+            r /= n[a];
+        }
+        return d + r + first;
+    };
+    for (size_t t = 0; t < ntasks; ++t) start[diag_of(t) + 1]++;
+    for (size_t d = 0; d + 1 < start.size(); ++d) start[d + 1] += start[d];
+    for (size_t t = 0; t < ntasks; ++t) tab[start[diag_of(t)]++] = (unsigned)t;   // (ascending t within a diagonal)
+    unsigned* dev = nullptr;
+    if (hipMalloc(&dev, sizeof(unsigned) * ntasks) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipMemcpy(dev, tab.data(), sizeof(unsigned) * ntasks, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(dev);
+        return nullptr;
+    }
+    if (dwf_orders().size() >= 64) {  // (shapes of a run are few; bound the cache anyway)
+        for (auto& kv : dwf_orders()) (void)hipFree(kv.second);
+        dwf_orders().clear();
+    }
+    dwf_orders()[key] = dev;
+    return dev;
+}
+void dwf_release_orders() {
+    for (auto& kv : dwf_orders()) (void)hipFree(kv.second);
+    dwf_orders().clear();
 }
 
 template <class E>
@@ -955,6 +1087,7 @@ bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     DivWfArgs g;
     std::memset(&g, 0, sizeof(g));
     g.L = nd - 1;
+    g.pack = dwf_pack;
     g.nr = rshape[nd - 1];
     g.mr = yshape[nd - 1];
     g.xnr = xshape[nd - 1];
@@ -977,6 +1110,7 @@ bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     g.ntasks = (unsigned)ntasks;
     g.flags = flags_and_counter;
     g.counter = flags_and_counter + ntasks;
+    g.order = dwf_order(g.L, g.n, 0);
     // enough waves to keep every SIMD busy with several tasks; all of them persistent (they claim tasks until none is left)
     // persistent workgroups (they claim tasks until none is left): a few per CU so that the SIMDs stay busy while some wait
     const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
@@ -996,6 +1130,7 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     DivWfArgs g;
     std::memset(&g, 0, sizeof(g));
     g.L = nd - 1;
+    g.pack = dwf_pack;
     g.log_mode = 1;
     g.nr = rshape[nd - 1];
     g.xnr = xshape[nd - 1];
@@ -1019,6 +1154,7 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     g.ntasks = (unsigned)ntasks;
     g.flags = flags_and_counter;
     g.counter = flags_and_counter + rows;
+    g.order = dwf_order(g.L, g.n, 1);
     g.qb = qbuf;
     g.qbp = q_plane;
     const size_t slab_el = slab_rows * g.nr, nel = ntasks * g.nr;
@@ -1031,6 +1167,48 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
     return true;
 }
+// res[1..] = exp(xs)[1..] (slabs k0 >= 1; mt:1271-1300) as the same row wavefront: no division, the row sum / k0.
+template <class E>
+bool K<E>::exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
+                         const unsigned* rshape, int nd, unsigned* flags_and_counter) {
+    if (nd < 2 || nd > 4) return false;
+    DivWfArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.L = nd - 1;
+    g.pack = dwf_pack;
+    g.log_mode = 2;
+    g.nr = rshape[nd - 1];
+    g.xnr = xshape[nd - 1];
+    g.mr = g.xnr;
+    if (g.nr < 2 || g.nr > 64 || g.xnr > g.nr || rshape[0] < 2) return false;
+    size_t rs = g.nr, xsd = g.xnr, rows = 1;
+    for (int a = g.L - 1; a >= 0; --a) {
+        g.n[a] = rshape[a];
+        g.xn[a] = xshape[a];
+        g.m[a] = xshape[a];
+        if (g.xn[a] > g.n[a] || g.n[a] == 0 || g.xn[a] == 0) return false;
+        g.rstr[a] = rs;
+        g.xstr[a] = xsd;
+        g.ystr[a] = xsd;
+        rs *= rshape[a];
+        xsd *= xshape[a];
+        rows *= rshape[a];
+    }
+    const size_t slab_rows = rows / rshape[0], ntasks = rows - slab_rows;
+    if (rows > 0x7fffffffu) return false;
+    g.ntasks = (unsigned)ntasks;
+    g.flags = flags_and_counter;
+    g.counter = flags_and_counter + rows;
+    g.order = dwf_order(g.L, g.n, 1);
+    const size_t slab_el = slab_rows * g.nr, nel = ntasks * g.nr;
+    for (int pl = 0; pl < E::W; ++pl)
+        GFT_LAUNCH(k_fill_bits, dim3((unsigned)std::min<size_t>((nel + 255) / 256, 2048)), dim3(256), 0, st, res + (size_t)pl * r_plane + slab_el, nel, DWF_EMPTY);
+    const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
+    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
+    return true;
+}
+template bool K<EF64>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*);
+template bool K<EIv>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*);
 template bool K<EF64>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
 template bool K<EIv>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
 

@@ -287,6 +287,9 @@ struct K {
     // res[1..] = log(xs)[1..]: the slabs k0 >= 1 of the log recurrence as the same row wavefront (slab 0 is the caller's)
     static bool log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
                               const unsigned* rshape, int nd, double* qbuf, size_t q_plane, unsigned* flags_and_counter);
+    // res[1..] = exp(xs)[1..] likewise (slab 0, an exp one dimension down, is the caller's and complete in stream order)
+    static bool exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
+                              const unsigned* rshape, int nd, unsigned* flags_and_counter);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);
@@ -314,6 +317,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 
 // Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
+void dwf_release_orders();  // frees the row wavefront's cached claim-order tables (gft_shutdown)
 void tiled_set_lane_tile(int tsh);  // 0 = planner's choice, 3..6 = force T1 = 1 << tsh lanes along k1 (tests, A/B)
 void tiled_pad_rows_f64(hipStream_t st, const double* in, double* out, size_t rows, unsigned len, unsigned P, unsigned B);
 void tiled_fold_rows_f64(hipStream_t st, const double* zt, double* z, size_t rows, size_t row_lo, size_t row_hi, unsigned Pz,

@@ -1058,6 +1058,9 @@ WAVEFRONT_SHAPES = [
     ((12, 10, 9, 16), (12, 10, 9, 16), (12, 10, 9, 16)),  # rank 4
     ((200, 48), (200, 48), (200, 48)),               # rank 2, many rows
     ((70, 64), (3, 64), (70, 1)),                    # rows of exactly 64, thin operands
+    ((21, 19, 31), (5, 19, 31), (21, 7, 9)),         # rows <= 32: two source rows per wave, odd row counts
+    ((9, 11, 32), (9, 11, 32), (9, 11, 32)),         # rows of exactly 32
+    ((13, 5, 7, 24), (13, 2, 7, 24), (4, 5, 7, 24)),  # rank 4, packed rows
 ]
 
 
@@ -1104,3 +1107,23 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
                 check(want, G.new(b, deg).log())
             finally:
                 L.gft_set_option(b"div_wavefront", 1.0)
+    # the exp recurrence (mt:1271-1300) likewise: slabs k0 >= 1 in one launch — no division, the row sum / k0.  (Large f64
+    # exponentials take the right-looking tiled path, 1e-10 contract: switched off here so that both forms keep the order.)
+    xe = rand(xs, 84, -0.3, 0.3)
+    ecases = [(OTP, GTP, xe)]
+    if int(np.prod(zs)) <= 20000:
+        ecases.append((OTPI, GTPI, np.stack([xe, xe + 1e-9])))
+    L.gft_set_option(b"exp_right", 0.0)
+    L.gft_set_option(b"tiled_min_macs", 1e30)
+    try:
+        for O, G, b in ecases:
+            want = O.new(b, deg).exp()
+            for wf in (1, 0):
+                assert L.gft_set_option(b"div_wavefront", float(wf)) == 0
+                try:
+                    check(want, G.new(b, deg).exp())
+                finally:
+                    L.gft_set_option(b"div_wavefront", 1.0)
+    finally:
+        L.gft_set_option(b"exp_right", 1.0)
+        L.gft_set_option(b"tiled_min_macs", 2e5)
