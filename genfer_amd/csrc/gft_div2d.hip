@@ -17,6 +17,7 @@
 
 #include "gft_kernels.hpp"
 #include <cstring>
+#include <type_traits>
 #include <map>
 #include <vector>
 
@@ -777,7 +778,10 @@ __global__ void __launch_bounds__(256) k_fill_bits(double* p, size_t n, unsigned
 __device__ inline bool is_empty_bits(double v) { return (unsigned long long)f64_bits(v) == DWF_EMPTY; }
 __device__ inline bool is_empty_bits(Iv v) { return (unsigned long long)f64_bits(v.lo) == DWF_EMPTY || (unsigned long long)f64_bits(v.hi) == DWF_EMPTY; }
 
-template <class E>
+// (L, the number of leading axes, is a template parameter: the odometers over those axes are then straight-line code on
+// registers — with a run-time L they were loops over dynamically indexed arrays, ~400 instructions per source row, more than
+// the row product itself)
+template <class E, int L>
 __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
                                                                double* res, size_t rp, DivWfArgs g) {
     typedef typename E::V V;
@@ -796,9 +800,9 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
     const unsigned PK = packed ? 2u : 1u, R = packed ? 32u : 64u;
     const unsigned c = packed ? (lane & 31u) : lane, half = packed ? (lane >> 5) : 0u;
     double* const my_stage = &stage[wave][0][0] + (packed ? half * 100u : 0u);
-    const int L = g.L;
     const bool lg = g.log_mode == 1, ex = g.log_mode == 2;
     unsigned slab_rows = 1;  // rows of one slab (exp: the rows of slab 0 are the caller's and complete)
+#pragma unroll
     for (int a = 1; a < L; ++a) slab_rows *= g.n[a];
     const V y0row = lane < g.mr ? E::ld(ys, yp, lane) : E::zero();
     const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
@@ -812,16 +816,19 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
         unsigned row_id = 0;  // the row's index among ALL rows of res (flags)
         {
             unsigned r = g.order ? g.order[t] : t;
+#pragma unroll
             for (int a = L - 1; a >= 1; --a) {
                 k[a] = r % g.n[a];
                 r /= g.n[a];
             }
             k[0] = r + ((lg || ex) ? 1u : 0u);
+#pragma unroll
             for (int a = 0; a < L; ++a) row_id = row_id * g.n[a] + k[a];
         }
         V r_prev = E::zero();  // (meaningful in wave 0)
         unsigned buf = 0;
-        for (int lev = 0; lev < (ex ? 1 : L); ++lev) {
+        auto level = [&](auto lev_c) {
+            constexpr int lev = decltype(lev_c)::value;
             V S = E::zero();
             const bool lg0 = (lg && lev == 0) || ex;  // the other operand's rows come from xs, the odometer runs over ITS rows
             // the level's source rows, in the reference's order (the last axis of the odometer fastest):
@@ -831,6 +838,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             //     the result row is (j0, k_1 - j'_1, ..)
             unsigned lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
             unsigned total = 1;
+#pragma unroll
             for (int a = lev; a < L; ++a) {
                 if (lg0 && a > 0) {
                     lo[a] = 0;
@@ -857,21 +865,25 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             auto request = [&](unsigned i0) {  // i0: the wave's first source row of the batch (wave-uniform)
                 if (i0 + half >= total) return;
                 unsigned rem = i0, j[3] = {0, 0, 0};
+#pragma unroll
                 for (int a = L - 1; a >= lev; --a) {
                     j[a] = rem % cnt[a];
                     rem /= cnt[a];
                 }
                 if (half) {  // the upper half's row is the next one of the odometer
                     bool carry = true;
+#pragma unroll
                     for (int a = L - 1; a >= lev; --a)
                         if (carry) {
                             if (++j[a] == cnt[a]) j[a] = 0;
                             else carry = false;
                         }
                 }
+#pragma unroll
                 for (int a = lev; a < L; ++a) j[a] += lo[a];
                 size_t roff = 0, ooff = 0;
                 unsigned src = 0;
+#pragma unroll
                 for (int a = 0; a < L; ++a) {
                     unsigned ra;  // the result row's index on this axis
                     if (a < lev) ra = k[a];
@@ -950,13 +962,14 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             if (ex) {
                 if (wave == 0) r_prev = S;
                 __syncthreads();
-                break;
+                return;
             }
             if (wave == 0) {
                 V r = E::neg(S);
                 if (lev == 0) {
                     bool in_x = c < g.xnr;
                     size_t xoff = 0;
+#pragma unroll
                     for (int a = 0; a < L; ++a) {
                         if (k[a] >= g.xn[a]) in_x = false;
                         xoff += (size_t)k[a] * g.xstr[a];
@@ -971,10 +984,16 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
                 r_prev = r;
             }
             __syncthreads();  // a level's last batch buffer is free again before the next level reuses it
+        };
+        level(std::integral_constant<int, 0>{});
+        if (!ex) {
+            if constexpr (L > 1) level(std::integral_constant<int, 1>{});
+            if constexpr (L > 2) level(std::integral_constant<int, 2>{});
         }
         if (ex) {
             if (wave == 0) {
                 size_t qoff = 0;
+#pragma unroll
                 for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
                 if (lane < g.nr) st_coherent(res, rp, qoff + lane, E::div(r_prev, E::from_u32(k[0])));  // mt:1298
                 __threadfence();
@@ -999,6 +1018,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
                 ysl = wave_shr1<E>(ysl);
             }
             size_t qoff = 0;
+#pragma unroll
             for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
             if (lane < g.nr) {
                 if (lg) {  // res[K] = q / k0 (mt:1384); the slab's own later rows read q itself
@@ -1012,6 +1032,14 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
             if (lane == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+template <class E>
+static void launch_dwf(hipStream_t st, unsigned blocks, const double* xs, size_t xp, const double* ys, size_t yp, double* res, size_t rp, const DivWfArgs& g) {
+    const dim3 grid(blocks), block(64 * DwfCfg<E>::NW);
+    if (g.L == 1) GFT_LAUNCH((k_div_wavefront<E, 1>), grid, block, 0, st, xs, xp, ys, yp, res, rp, g);
+    else if (g.L == 2) GFT_LAUNCH((k_div_wavefront<E, 2>), grid, block, 0, st, xs, xp, ys, yp, res, rp, g);
+    else GFT_LAUNCH((k_div_wavefront<E, 3>), grid, block, 0, st, xs, xp, ys, yp, res, rp, g);
 }
 
 // Claim order of the tasks.  Any order in which a row comes after the rows it reads is deadlock-free (a claimed task only
@@ -1118,7 +1146,7 @@ bool K<E>::div_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
         const size_t nel = ntasks * g.nr;
         GFT_LAUNCH(k_fill_bits, dim3((unsigned)std::min<size_t>((nel + 255) / 256, 2048)), dim3(256), 0, st, res + (size_t)pl * r_plane, nel, DWF_EMPTY);
     }
-    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, ys, y_plane, res, r_plane, g);
+    launch_dwf<E>(st, blocks, xs, x_plane, ys, y_plane, res, r_plane, g);
     return true;
 }
 // res[1..] = log(xs)[1..] (slabs k0 >= 1; mt:1335-1386) as the same row wavefront.  `qbuf`: a tensor like res for the slab
@@ -1164,7 +1192,7 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
         GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, qbuf + (size_t)pl * q_plane + slab_el, nel, DWF_EMPTY);
     }
     const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
-    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
+    launch_dwf<E>(st, blocks, xs, x_plane, xs, x_plane, res, r_plane, g);
     return true;
 }
 // res[1..] = exp(xs)[1..] (slabs k0 >= 1; mt:1271-1300) as the same row wavefront: no division, the row sum / k0.
@@ -1204,7 +1232,7 @@ bool K<E>::exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     for (int pl = 0; pl < E::W; ++pl)
         GFT_LAUNCH(k_fill_bits, dim3((unsigned)std::min<size_t>((nel + 255) / 256, 2048)), dim3(256), 0, st, res + (size_t)pl * r_plane + slab_el, nel, DWF_EMPTY);
     const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
-    GFT_LAUNCH(k_div_wavefront<E>, dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, xs, x_plane, res, r_plane, g);
+    launch_dwf<E>(st, blocks, xs, x_plane, xs, x_plane, res, r_plane, g);
     return true;
 }
 template bool K<EF64>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*);
