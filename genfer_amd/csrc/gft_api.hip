@@ -3227,6 +3227,7 @@ void gft_shutdown(void) {
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
     dwf_release_orders();
+    staged_release_scratch();
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
     for (auto& kv : R.host_blocks)
         for (void* q : kv.second) std::free(q);
@@ -3315,6 +3316,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "defer") R.defer = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
+    else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default

@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <map>
 
 #include "gft_kernels.hpp"
 
@@ -377,6 +380,366 @@ bool launch(hipStream_t st, const double* x, size_t xp, const double* y, size_t 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// Register-blocked rows (round 3): the large interval product
+// ------------------------------------------------------------------------------------------
+// k_conv_staged spends, per interval multiply-add, four 8-byte LDS reads (x and y, two planes each) beside ~10 VALU
+// instructions, and a wave that owns 64 consecutive outputs c of a row runs j up to its HIGHEST c: a third of its lane
+// slots lie outside the triangle j <= c.  At 128^3 it reaches 23 % of the VALU-issue roof (tools/bench_interval.py).  Here
+//   * a lane owns TWO outputs, (.., k1, c) and (.., k1 + 1, c) — neighbours on the last outer axis P.  Their terms pair up
+//     on the SAME y row: x[j_lead, k1 - t, :] (*) y[K - j_lead, t, :] goes to the first, x[j_lead, k1 + 1 - t, :] (*) the same y
+//     row to the second; walking t downwards is ascending j1 for both, so each output still receives its row sums in
+//     the reference's order (mt:984-1012), each formed from zero in ascending j (mt:971-982).  One y read (two planes)
+//     serves two multiply-adds;
+//   * a wave is 4 row pairs x 16 columns (a workgroup: 8 output rows, all columns): the steps j < c0 below a 16-column
+//     tile are full, only the 16 steps of its own triangle are masked — 11 % of the lane slots outside the triangle
+//     instead of 33 %.  A wave takes the tiles ct and ntiles - 1 - ct one after the other, so all waves of a workgroup do
+//     the same number of steps;
+//   * x rows are staged with their two planes interleaved: the coefficient (lo, hi) of a step is ONE 16-byte read, four
+//     distinct addresses per wave (one per row pair).
+// Regimes (positive / finite / general, gft_elem.hpp) are chosen per y row from per-row flags computed by one pass over the
+// operands (k_row_flags) — worst case over the x rows the workgroup pairs with it.  A sum that fails its regime's test is
+// recomputed with the general multiply-add, as in k_conv_staged.  Same operations on the same values in the same order =>
+// same bits (tests: conv_rb_min_macs A/B, the oracle).
+struct RbArgs {
+    int no;               // outer axes = nd - 1 (1..3); the last of them is the paired axis P
+    unsigned n_pg;        // groups of 8 output rows along P
+    unsigned ntiles;      // 16-column tiles of a row
+    unsigned n2, nx2;     // output (= y) / x row lengths
+    unsigned tb;          // y rows staged per barrier pair
+    size_t xrs[MAXO], yrs[MAXO];  // strides of the outer axes in ROWS
+    const unsigned char* xflags;  // per row: bit 0 = some element is not pos_ok, bit 1 = some element is not fin_ok
+    const unsigned char* yflags;
+};
+constexpr unsigned RB_ROWS = 8;  // output rows of a workgroup (4 lane groups x 2 outputs per lane)
+
+template <class E>
+__global__ void __launch_bounds__(256) k_row_flags(const double* p, size_t plane, size_t rows, unsigned len, unsigned char* flags) {
+    const size_t row = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned lane = threadIdx.x & 63u;
+    bool np = false, nf = false;
+    for (unsigned i = lane; i < len; i += 64) {
+        const typename E::V v = E::ld(p, plane, row * len + i);
+        np = np || !E::pos_ok(v);
+        nf = nf || !E::fin_ok(v);
+    }
+    const bool anp = any_lane(np), anf = any_lane(nf);
+    if (lane == 0) flags[row] = (unsigned char)((anp ? 1 : 0) | (anf ? 2 : 0));
+}
+
+// the finished row sums of one y row against the lane's two x rows, for the 16-column tile at c0; REG 1 positive, 2
+// finite, 0 general.  x0 / x1: staged x rows, (lo, hi) interleaved; yl: the lane's position c in the staged y row.
+// (Measured and dropped: the x coefficient through scalar loads — it is not wave-uniform with four row pairs per wave, and
+// with one pair per wave the triangle is back; through one LDS read per 16 steps and a DPP row broadcast per step —
+// 8 extra VALU slots per step cost more than the LDS reads they replace, 506 vs 400 ms at 128^3.)
+template <class E, int REG>
+__device__ __forceinline__ void rb_sums(const double* x0, const double* x1, const double* yl, unsigned ypl, unsigned c, unsigned c0,
+                                        unsigned nx2, typename E::V& s0, typename E::V& s1) {
+    typedef typename E::V V;
+    auto first = [](V xv, V yv) {
+        if (REG == 1) return E::mul_pos(xv, yv);
+        if (REG == 2) return E::mul_fin(xv, yv);
+        return E::mac(E::zero(), xv, yv);
+    };
+    auto next = [](V acc, V xv, V yv) {
+        if (REG == 1) return E::mac_pos_unchecked(acc, xv, yv);
+        if (REG == 2) return E::mac_fin(acc, xv, yv);
+        return E::mac(acc, xv, yv);
+    };
+    const unsigned jend = nx2 < c0 + 16 ? nx2 : c0 + 16;  // no lane of this tile has a term beyond
+    {   // j = 0: every lane's first term
+        const V yv = Iv{yl[0], yl[ypl]};
+        s0 = first(Iv{x0[0], x0[1]}, yv);
+        s1 = first(Iv{x1[0], x1[1]}, yv);
+    }
+    unsigned j = 1;
+    // steps every lane of the tile takes part in: j <= c0 (eight at a time; the long general multiply-add gains nothing
+    // from unrolling)
+    const unsigned jfull = c0 + 1 < jend ? c0 + 1 : jend;
+    constexpr int UN = REG == 0 ? 1 : 8;
+    for (; j + UN <= jfull; j += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const V yv = Iv{yl[-(int)(j + u)], yl[(int)ypl - (int)(j + u)]};
+            s0 = next(s0, Iv{x0[2 * (j + u)], x0[2 * (j + u) + 1]}, yv);
+            s1 = next(s1, Iv{x1[2 * (j + u)], x1[2 * (j + u) + 1]}, yv);
+        }
+    }
+    for (; j < jfull; ++j) {
+        const V yv = Iv{yl[-(int)j], yl[(int)ypl - (int)j]};
+        s0 = next(s0, Iv{x0[2 * j], x0[2 * j + 1]}, yv);
+        s1 = next(s1, Iv{x1[2 * j], x1[2 * j + 1]}, yv);
+    }
+    // the tile's own triangle: lane c takes part while j <= c
+#pragma unroll 5
+    for (; j < jend; ++j) {
+        if (j <= c) {
+            const V yv = Iv{yl[-(int)j], yl[(int)ypl - (int)j]};
+            s0 = next(s0, Iv{x0[2 * j], x0[2 * j + 1]}, yv);
+            s1 = next(s1, Iv{x1[2 * j], x1[2 * j + 1]}, yv);
+        }
+    }
+}
+
+// one y row against one tile: both outputs of the lane.  v0 / v1: the lane's outputs take this row (else what it computes
+// — on a clamped, staged x row — is discarded)
+template <class E>
+__device__ __forceinline__ void rb_row(int regime, bool v0, bool v1, const double* x0, const double* x1, const double* yl, unsigned ypl,
+                                       unsigned c, unsigned c0, unsigned nx2, typename E::V& acc0, typename E::V& acc1) {
+    typedef typename E::V V;
+    V s0 = E::zero(), s1 = E::zero();
+    bool redo = true;
+    if (regime == 1) {
+        rb_sums<E, 1>(x0, x1, yl, ypl, c, c0, nx2, s0, s1);
+        const bool bad = (v0 && (!E::pos_first_ok(s0) || !E::pos_result_ok(s0))) || (v1 && (!E::pos_first_ok(s1) || !E::pos_result_ok(s1)));
+        redo = any_lane(bad);
+    } else if (regime == 2) {
+        rb_sums<E, 2>(x0, x1, yl, ypl, c, c0, nx2, s0, s1);
+        const bool bad = (v0 && !E::fin_result_ok(s0)) || (v1 && !E::fin_result_ok(s1));
+        redo = any_lane(bad);
+    }
+    if (redo) rb_sums<E, 0>(x0, x1, yl, ypl, c, c0, nx2, s0, s1);
+    if (v0) acc0 = E::add(acc0, s0);
+    if (v1) acc1 = E::add(acc1, s1);
+}
+
+template <class E>
+__global__ void __launch_bounds__(512) k_conv_rows_rb(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+                                                      double* __restrict__ z, size_t zp, ConvArgs a, RbArgs g) {
+    typedef typename E::V V;
+    // [tb][2][n2] staged y rows (+ 16 doubles of slack), [tb + 7][nx2][2] staged x rows, then the rows' flags
+    extern __shared__ __align__(16) double smem[];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned q = lane >> 4, cl = lane & 15u;
+    const int P = g.no - 1;
+    double* const ys_l = smem;
+    double* const xs_l = smem + (size_t)g.tb * 2 * g.n2 + 16;
+    const unsigned xpitch = 2 * g.nx2 + 2;  // doubles per staged x row: the rows of a wave's four pairs start in different banks
+    unsigned char* const fl_l = reinterpret_cast<unsigned char*>(xs_l + (size_t)(g.tb + RB_ROWS - 1) * xpitch);  // [tb] y flags, [tb + 7] x flags
+    // the wave's two column tiles
+    const unsigned ctA = wave, ctB = g.ntiles - 1 - wave;
+    const bool twoB = ctB != ctA;
+    const unsigned c0A = ctA * 16, c0B = ctB * 16, cA = c0A + cl, cB = c0B + cl;
+    // ---- which outputs: heaviest first, the row group fastest
+    unsigned long long b = (unsigned long long)(gridDim.x - 1 - blockIdx.x);
+    const unsigned pg = (unsigned)(b % g.n_pg);
+    b /= g.n_pg;
+    const unsigned k1g = RB_ROWS * pg;  // the group's first output row on P
+    unsigned K[MAXO], lo[MAXO], cnt[MAXO], pos[MAXO];
+    unsigned long long lead_steps = 1;
+    size_t zoff = 0;
+#pragma unroll
+    for (int ax = MAXO - 1; ax >= 0; --ax) {
+        K[ax] = lo[ax] = pos[ax] = 0;
+        cnt[ax] = 1;
+        if (ax < P) {
+            unsigned d = a.zs[ax], base = 0;
+            if (ax == 0) {
+                d = a.slab_hi - a.slab_lo;
+                base = a.slab_lo;
+            }
+            K[ax] = base + (unsigned)(b % d);
+            b /= d;
+            zoff += (size_t)K[ax] * a.zstr[ax];
+            lo[ax] = K[ax] + 1 > a.ys[ax] ? K[ax] + 1 - a.ys[ax] : 0;
+            const unsigned h = K[ax] + 1 < a.xs[ax] ? K[ax] + 1 : a.xs[ax];
+            cnt[ax] = h > lo[ax] ? h - lo[ax] : 0;
+            lead_steps *= cnt[ax];
+        }
+    }
+    unsigned nP = 1, nxP = 1, nyP = 1;
+    size_t zstrP = 0;
+#pragma unroll
+    for (int ax = 0; ax < MAXO; ++ax)
+        if (ax == P) {
+            nP = a.zs[ax];
+            nxP = a.xs[ax];
+            nyP = a.ys[ax];
+            zstrP = a.zstr[ax];
+        }
+    // the group's y rows: t from t_hi down to t_lo (the group's first output row reaches lowest)
+    const unsigned ktop = k1g + RB_ROWS - 1 < nP - 1 ? k1g + RB_ROWS - 1 : nP - 1;
+    const int t_hi = (int)(ktop < nyP - 1 ? ktop : nyP - 1);
+    const int t_lo = k1g + 1 > nxP ? (int)(k1g + 1 - nxP) : 0;
+    // this lane's pair of output rows
+    const unsigned k1 = k1g + 2 * q;
+    const bool has0 = k1 < nP, has1 = k1 + 1 < nP;
+    V accA0 = E::zero(), accA1 = E::zero(), accB0 = E::zero(), accB1 = E::zero();
+    const unsigned ypl = g.n2;
+    for (unsigned long long step = 0; step < lead_steps; ++step) {
+        size_t xrow_lead = 0, yrow_lead = 0;
+#pragma unroll
+        for (int ax = 0; ax < MAXO; ++ax)
+            if (ax < P) {
+                const unsigned j = lo[ax] + pos[ax];
+                xrow_lead += (size_t)j * g.xrs[ax];
+                yrow_lead += (size_t)(K[ax] - j) * g.yrs[ax];
+            }
+        for (int tt = t_hi; tt >= t_lo; tt -= (int)g.tb) {
+            const int rows = tt - t_lo + 1 < (int)g.tb ? tt - t_lo + 1 : (int)g.tb;  // y rows tt, tt - 1, .., tt - rows + 1
+            const int tbot = tt - rows + 1;
+            // x rows the batch touches: j1 = k' - t over the group's output rows k' and the batch's rows t
+            const int jlo = (int)k1g - tt > 0 ? (int)k1g - tt : 0;
+            int jhi = (int)ktop - tbot;
+            if (jhi > (int)nxP - 1) jhi = (int)nxP - 1;
+            const int xrows = jhi >= jlo ? jhi - jlo + 1 : 0;
+            __syncthreads();  // everyone is done with the previous batch
+            // y rows (contiguous: P is the last outer axis): slot r holds row tt - r
+            for (unsigned i = tid; i < (unsigned)rows * g.n2; i += blockDim.x) {
+                const unsigned rr = i / g.n2, cc = i - rr * g.n2;
+                const size_t src = (yrow_lead + (size_t)(tbot + (int)rr)) * g.n2 + cc;
+                double* dst = ys_l + (size_t)((unsigned)rows - 1 - rr) * 2 * g.n2 + cc;
+                dst[0] = y[src];
+                dst[g.n2] = y[yp + src];
+            }
+            // x rows jlo .. jhi (contiguous), planes interleaved
+            for (unsigned i = tid; i < (unsigned)xrows * g.nx2; i += blockDim.x) {
+                const size_t src = (xrow_lead + (size_t)jlo) * g.nx2 + i;
+                const unsigned xr = i / g.nx2, xc = i - xr * g.nx2;
+                reinterpret_cast<double2*>(xs_l + (size_t)xr * xpitch)[xc] = double2{x[src], x[xp + src]};
+            }
+            if (tid < (unsigned)rows) fl_l[tid] = g.yflags[yrow_lead + (size_t)(tt - (int)tid)];
+            if (tid >= 64 && tid - 64 < (unsigned)xrows) fl_l[g.tb + tid - 64] = g.xflags[xrow_lead + (size_t)jlo + (tid - 64)];
+            __syncthreads();
+            if (xrows > 0) {
+                for (int r = 0; r < rows; ++r) {
+                    const int t = tt - r;
+                    // the x rows the group pairs with this y row: k' - t for k' = k1g .. ktop, inside x's box
+                    int ja = (int)k1g - t, jb = (int)ktop - t;
+                    if (ja < 0) ja = 0;
+                    if (jb > (int)nxP - 1) jb = (int)nxP - 1;
+                    if (jb < ja) continue;  // (block-uniform)
+                    unsigned f = fl_l[r];
+                    for (int jj = ja; jj <= jb; ++jj) f |= fl_l[g.tb + (unsigned)(jj - jlo)];
+                    const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
+                    const bool v0 = has0 && t <= (int)k1 && k1 - (unsigned)t < nxP;
+                    const bool v1 = has1 && t <= (int)k1 + 1 && k1 + 1 - (unsigned)t < nxP;
+                    // (a lane without a term computes on a clamped row of [ja, jb] and discards the sums)
+                    int j10 = (int)k1 - t, j11 = (int)k1 + 1 - t;
+                    j10 = j10 < ja ? ja : (j10 > jb ? jb : j10);
+                    j11 = j11 < ja ? ja : (j11 > jb ? jb : j11);
+                    const double* x0 = xs_l + (size_t)(j10 - jlo) * xpitch;
+                    const double* x1 = xs_l + (size_t)(j11 - jlo) * xpitch;
+                    const double* yrow = ys_l + (size_t)r * 2 * g.n2;
+                    if (cA < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cA, ypl, cA, c0A, g.nx2, accA0, accA1);
+                    if (twoB && cB < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cB, ypl, cB, c0B, g.nx2, accB0, accB1);
+                }
+            }
+        }
+        // advance the lead odometer (last lead axis fastest)
+        bool carry = true;
+#pragma unroll
+        for (int ax = MAXO - 1; ax >= 0; --ax)
+            if (ax < P && carry) {
+                if (++pos[ax] == cnt[ax]) pos[ax] = 0;
+                else carry = false;
+            }
+    }
+    if (has0 && cA < g.n2) E::st(z, zp, zoff + (size_t)k1 * zstrP + cA, accA0);
+    if (has1 && cA < g.n2) E::st(z, zp, zoff + (size_t)(k1 + 1) * zstrP + cA, accA1);
+    if (twoB && has0 && cB < g.n2) E::st(z, zp, zoff + (size_t)k1 * zstrP + cB, accB0);
+    if (twoB && has1 && cB < g.n2) E::st(z, zp, zoff + (size_t)(k1 + 1) * zstrP + cB, accB1);
+}
+
+// per-stream scratch for the row flags (grow-only; a stream's launches are ordered, so one buffer per stream is enough)
+struct RbScratch {
+    unsigned char* p = nullptr;
+    size_t bytes = 0;
+};
+static std::map<hipStream_t, RbScratch>& rb_scratch() {
+    static std::map<hipStream_t, RbScratch> m;
+    return m;
+}
+// worth it where the workgroups (8 output rows each) outnumber the CUs several times over: measured crossover against
+// k_conv_staged between 96^3 and 112^3 (profiles/r03/interval_product.txt)
+static double rb_min_macs = [] {
+    const char* e = getenv("GFT_CONV_RB_MIN_MACS");
+    return e ? atof(e) : 1.5e11;
+}();
+void staged_set_rb_min_macs(double v) { rb_min_macs = v; }  // "conv_rb_min_macs" (tests; negative = never)
+void staged_release_scratch() {
+    for (auto& kv : rb_scratch())
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    rb_scratch().clear();
+}
+
+// The plain full product of large contiguous interval tensors; false = not this kernel's case (nothing launched).
+template <class E>
+static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a) {
+    static const int on = [] {
+        const char* e = getenv("GFT_CONV_RB");  // A/B knob (0 = k_conv_staged for these products too)
+        return e ? atoi(e) : 1;
+    }();
+    const int nd = a.nd;
+    if (!on || !E::HAS_POS || nd < 2 || nd > 4) return false;
+    if (a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || !a.inner_from_zero || a.guard) return false;
+    const int P = nd - 2;
+    const unsigned n2 = a.zs[nd - 1], nx2 = a.xs[nd - 1];
+    if (a.ys[nd - 1] != n2 || n2 < 64 || n2 > 256 || nx2 == 0) return false;
+    if (P == 0 && (a.slab_lo != 0 || a.slab_hi != a.zs[0])) return false;
+    // contiguous operands and result
+    size_t xs_ = 1, ys_ = 1, zs_ = 1;
+    for (int ax = nd - 1; ax >= 0; --ax) {
+        if (a.xstr[ax] != xs_ || a.ystr[ax] != ys_ || a.zstr[ax] != zs_) return false;
+        if (a.xs[ax] == 0 || a.ys[ax] == 0 || a.xs[ax] > a.zs[ax] || a.ys[ax] > a.zs[ax]) return false;
+        xs_ *= a.xs[ax];
+        ys_ *= a.ys[ax];
+        zs_ *= a.zs[ax];
+    }
+    const size_t xrows = xs_ / nx2, yrows = ys_ / n2;
+    // worth it from a few 10^7 multiply-adds (two passes over the operands, a block per output row pair)
+    double macs = 1.0;
+    for (int ax = 0; ax < nd; ++ax) macs *= 0.5 * (double)a.zs[ax] * (double)std::min(a.xs[ax], a.ys[ax]);
+    if (rb_min_macs < 0.0 || macs < rb_min_macs) return false;
+    RbArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.no = nd - 1;
+    g.n_pg = (a.zs[P] + RB_ROWS - 1) / RB_ROWS;
+    g.ntiles = (n2 + 15) / 16;
+    g.n2 = n2;
+    g.nx2 = nx2;
+    static const unsigned tb_env = [] {
+        const char* e = getenv("GFT_RB_TB");  // tuning knob: y rows per batch
+        return (unsigned)(e ? std::max(1, atoi(e)) : 8);
+    }();
+    g.tb = tb_env;
+    auto lds_of = [&](unsigned tb) {
+        return ((size_t)tb * 2 * n2 + 16 + (size_t)(tb + RB_ROWS - 1) * (2 * nx2 + 2)) * sizeof(double) + 2 * tb + RB_ROWS + 8;
+    };
+    while (g.tb > 1 && lds_of(g.tb) > 60 * 1024) g.tb /= 2;
+    if (lds_of(g.tb) > 60 * 1024) return false;
+    for (int ax = 0; ax < g.no; ++ax) {
+        g.xrs[ax] = a.xstr[ax] / nx2;
+        g.yrs[ax] = a.ystr[ax] / n2;
+    }
+    RbScratch& sc = rb_scratch()[st];
+    if (sc.bytes < xrows + yrows) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr;
+        sc.bytes = 0;
+        const size_t want = std::max<size_t>((xrows + yrows) * 2, 1 << 16);
+        if (hipMalloc(&sc.p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            sc.p = nullptr;
+            return false;
+        }
+        sc.bytes = want;
+    }
+    g.xflags = sc.p;
+    g.yflags = sc.p + xrows;
+    GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
+    GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
+    unsigned long long blocks = g.n_pg;
+    for (int ax = 0; ax < P; ++ax) blocks *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
+    if (blocks == 0) return true;
+    if (blocks > 0x7fffffffULL) return false;
+    const unsigned threads = ((g.ntiles + 1) / 2) * 64;
+    const size_t lds = lds_of(g.tb);
+    GFT_LAUNCH(k_conv_rows_rb<E>, dim3((unsigned)blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
+    return true;
+}
+
 // Returns false (nothing launched) when the shape does not suit the staged kernel; the caller then
 // uses conv_naive.  `force`: ignore the "worth it" thresholds (tests).
 template <class E>
@@ -385,6 +748,9 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     const int nd = a.nd;
     if (nd < 1) return false;
     if (a.slab_hi <= a.slab_lo) return true;  // nothing to do
+    if constexpr (E::HAS_POS) {
+        if (conv_rows_rb<E>(st, x, xp, y, yp, z, zp, a)) return true;
+    }
     constexpr size_t LDS_MAX = 160 * 1024;
     const size_t W = E::W;
     StagedArgs g;

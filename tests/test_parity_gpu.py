@@ -1127,3 +1127,60 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
     finally:
         L.gft_set_option(b"exp_right", 1.0)
         L.gft_set_option(b"tiled_min_macs", 2e5)
+
+
+RB_SHAPES = [
+    # (x shape, y shape, result shape): the last axis of y spans the result's, 64 <= last axis <= 256
+    ((5, 7, 64), (5, 7, 64), (5, 7, 64)),
+    ((4, 5, 37), (3, 9, 100), (4, 9, 100)),        # narrow x rows (partial last chunk of 8), odd pair axis, short lead axis
+    ((9, 128), (9, 128), (9, 128)),                # rank 2: the pair axis is axis 0
+    ((3, 1, 129), (3, 6, 129), (3, 6, 129)),       # one x row per slab; three waves, the last one almost empty
+    ((3, 3, 5, 64), (2, 3, 5, 64), (3, 3, 5, 64)),  # rank 4
+    ((2, 6, 256), (2, 1, 256), (2, 6, 256)),       # one y row per slab, the longest rows
+]
+
+
+@pytest.mark.parametrize("xs,ys,zs", RB_SHAPES)
+def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
+    """Large interval products run on k_conv_rows_rb (two outputs per lane sharing each y read, x through scalar loads,
+    regimes from per-row flags): every output still receives its row sums in the reference's order (mt:971-1012) =>
+    bit-exact against the oracle and identical to k_conv_staged, for positive data (positive regime), mixed-sign data
+    (finite regime), data with exact zeros / ones / infinities (general regime) and sums that leave their regime
+    (underflow to zero, overflow: recomputed)."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    deg = list(zs)
+
+    def iv(lo, w):
+        return np.stack([lo, lo + w * np.abs(lo) + 1e-300])
+
+    xp, yp = rand(xs, 91, 0.1, 1.0), rand(ys, 92, 0.1, 1.0)
+    xm, ym = rand(xs, 93, -1.0, 1.0), rand(ys, 94, -1.0, 1.0)
+    cases = [(iv(xp, 1e-15), iv(yp, 1e-15)), (iv(xm, 1e-15), iv(ym, 1e-15))]
+    # special points: exact zeros and ones (short-circuits of iv:164-190), an infinity, a NaN
+    xz, yz = iv(xm, 1e-15), iv(yp, 1e-15)
+    xz[:, tuple(0 for _ in xs)] = 0.0
+    xz[(slice(None),) + tuple(min(1, s - 1) for s in xs)] = 1.0
+    yz[(slice(None),) + tuple(min(2, s - 1) for s in ys)] = 0.0
+    cases.append((xz, yz))
+    xi = iv(xp, 1e-15)
+    xi[1][tuple(min(1, s - 1) for s in xs)] = np.inf
+    yn = iv(yp, 1e-15)
+    yn[(slice(None),) + tuple(s - 1 for s in ys)] = np.nan
+    cases.append((xi, yn))
+    # positive data whose sums leave the positive regime: products underflow to zero / overflow
+    cases.append((iv(xp * 1e-200, 1e-15), iv(yp * 1e-200, 1e-15)))
+    cases.append((iv(xp * 1e200, 1e-15), iv(yp * 1e200, 1e-15)))
+    L.gft_set_option(b"host_max_elems", 0.0)  # everything on the device
+    try:
+        for a, b in cases:
+            want = OTPI.new(a, deg) * OTPI.new(b, deg)
+            for thr in (0.0, -1.0):
+                assert L.gft_set_option(b"conv_rb_min_macs", thr) == 0
+                try:
+                    check(want, GTPI.new(a, deg) * GTPI.new(b, deg))
+                finally:
+                    L.gft_set_option(b"conv_rb_min_macs", 1.5e11)
+    finally:
+        L.gft_set_option(b"host_max_elems", -1.0)
