@@ -406,7 +406,8 @@ struct RbArgs {
     unsigned n_pg;        // groups of 8 output rows along P
     unsigned ntiles;      // 16-column tiles of a row
     unsigned n2, nx2;     // output (= y) / x row lengths
-    unsigned tb;          // y rows staged per barrier pair
+    unsigned tb;          // y rows staged per barrier pair = wave groups of a workgroup (one row each)
+    unsigned ntw;         // waves of a group (two tiles each)
     size_t xrs[MAXO], yrs[MAXO];  // strides of the outer axes in ROWS
     const unsigned char* xflags;  // per row: bit 0 = some element is not pos_ok, bit 1 = some element is not fin_ok
     const unsigned char* yflags;
@@ -486,9 +487,7 @@ __device__ __forceinline__ void rb_sums(const double* x0, const double* x1, cons
 // — on a clamped, staged x row — is discarded)
 template <class E>
 __device__ __forceinline__ void rb_row(int regime, bool v0, bool v1, const double* x0, const double* x1, const double* yl, unsigned ypl,
-                                       unsigned c, unsigned c0, unsigned nx2, typename E::V& acc0, typename E::V& acc1) {
-    typedef typename E::V V;
-    V s0 = E::zero(), s1 = E::zero();
+                                       unsigned c, unsigned c0, unsigned nx2, typename E::V& s0, typename E::V& s1) {
     bool redo = true;
     if (regime == 1) {
         rb_sums<E, 1>(x0, x1, yl, ypl, c, c0, nx2, s0, s1);
@@ -500,30 +499,37 @@ __device__ __forceinline__ void rb_row(int regime, bool v0, bool v1, const doubl
         redo = any_lane(bad);
     }
     if (redo) rb_sums<E, 0>(x0, x1, yl, ypl, c, c0, nx2, s0, s1);
-    if (v0) acc0 = E::add(acc0, s0);
-    if (v1) acc1 = E::add(acc1, s1);
 }
 
 template <class E>
-__global__ void __launch_bounds__(512) k_conv_rows_rb(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+__global__ void __launch_bounds__(1024) k_conv_rows_rb(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
                                                       double* __restrict__ z, size_t zp, ConvArgs a, RbArgs g) {
     typedef typename E::V V;
-    // [tb][2][n2] staged y rows (+ 16 doubles of slack), [tb + 7][nx2][2] staged x rows, then the rows' flags
+    // [tb][2][n2] staged y rows (+ 16 doubles of slack), [tb + 7][nx2][2] staged x rows, the rows' flags, then the row sums
+    // of the wave groups 1 .. tb - 1: [group - 1][wave of the group][4 sums][2 planes][64 lanes]
+    // The y rows of a batch are independent until their sums are ADDED (each sum is formed from zero): wave group r forms
+    // the sums of row r, group 0 adds them in row order.  The longest chain of a workgroup — (k0 + 1)(k1 + 1) row sums for
+    // the last outputs, as long as the whole job's share of one SIMD at 128^3 — is cut by the number of groups.
     extern __shared__ __align__(16) double smem[];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned grp = wave_all / g.ntw, wave = wave_all - grp * g.ntw;
     const unsigned q = lane >> 4, cl = lane & 15u;
     const int P = g.no - 1;
     double* const ys_l = smem;
     double* const xs_l = smem + (size_t)g.tb * 2 * g.n2 + 16;
     const unsigned xpitch = 2 * g.nx2 + 2;  // doubles per staged x row: the rows of a wave's four pairs start in different banks
-    unsigned char* const fl_l = reinterpret_cast<unsigned char*>(xs_l + (size_t)(g.tb + RB_ROWS - 1) * xpitch);  // [tb] y flags, [tb + 7] x flags
+    unsigned char* const fl_l = reinterpret_cast<unsigned char*>(xs_l + (size_t)(g.tb + RB_ROWS - 1) * xpitch);
+    double* const sums_l = xs_l + (size_t)(g.tb + RB_ROWS - 1) * xpitch + (2 * g.tb + RB_ROWS + 8 + 7) / 8;  // [tb] y flags, [tb + 7] x flags
     // the wave's two column tiles
     const unsigned ctA = wave, ctB = g.ntiles - 1 - wave;
     const bool twoB = ctB != ctA;
     const unsigned c0A = ctA * 16, c0B = ctB * 16, cA = c0A + cl, cB = c0B + cl;
     // ---- which outputs: heaviest first, the row group fastest
     unsigned long long b = (unsigned long long)(gridDim.x - 1 - blockIdx.x);
-    const unsigned pg = (unsigned)(b % g.n_pg);
+    // (consecutive workgroups go to consecutive XCDs: with the row group simply the fastest index and a power-of-two number
+    // of groups, an XCD would only ever see the groups pg = x (mod 8) — up to 2.4x the work of its neighbour's; the rotation
+    // by the slower index spreads every residue over all XCDs: 128^3 424 -> see interval_product.txt)
+    const unsigned pg = (unsigned)((b % g.n_pg + b / g.n_pg) % g.n_pg);
     b /= g.n_pg;
     const unsigned k1g = RB_ROWS * pg;  // the group's first output row on P
     unsigned K[MAXO], lo[MAXO], cnt[MAXO], pos[MAXO];
@@ -602,28 +608,66 @@ __global__ void __launch_bounds__(512) k_conv_rows_rb(const double* __restrict__
             if (tid < (unsigned)rows) fl_l[tid] = g.yflags[yrow_lead + (size_t)(tt - (int)tid)];
             if (tid >= 64 && tid - 64 < (unsigned)xrows) fl_l[g.tb + tid - 64] = g.xflags[xrow_lead + (size_t)jlo + (tid - 64)];
             __syncthreads();
-            if (xrows > 0) {
-                for (int r = 0; r < rows; ++r) {
-                    const int t = tt - r;
-                    // the x rows the group pairs with this y row: k' - t for k' = k1g .. ktop, inside x's box
-                    int ja = (int)k1g - t, jb = (int)ktop - t;
-                    if (ja < 0) ja = 0;
-                    if (jb > (int)nxP - 1) jb = (int)nxP - 1;
-                    if (jb < ja) continue;  // (block-uniform)
+            // this group's row r = grp of the batch: its sums (for the lane's two outputs in the wave's two tiles)
+            V sA0 = E::zero(), sA1 = E::zero(), sB0 = E::zero(), sB1 = E::zero();
+            auto row_terms = [&](int r, bool& v0, bool& v1, int& ja, int& jb) {  // which of the lane's outputs take row r
+                const int t = tt - r;
+                ja = (int)k1g - t;
+                jb = (int)ktop - t;
+                if (ja < 0) ja = 0;
+                if (jb > (int)nxP - 1) jb = (int)nxP - 1;
+                v0 = jb >= ja && has0 && t <= (int)k1 && k1 - (unsigned)t < nxP;
+                v1 = jb >= ja && has1 && t <= (int)k1 + 1 && k1 + 1 - (unsigned)t < nxP;
+            };
+            if ((int)grp < rows && xrows > 0) {
+                const int r = (int)grp, t = tt - r;
+                bool v0, v1;
+                int ja, jb;
+                row_terms(r, v0, v1, ja, jb);
+                if (jb >= ja) {  // (uniform)
+                    // the x rows the workgroup pairs with this y row: k' - t for k' = k1g .. ktop, inside x's box
                     unsigned f = fl_l[r];
                     for (int jj = ja; jj <= jb; ++jj) f |= fl_l[g.tb + (unsigned)(jj - jlo)];
                     const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
-                    const bool v0 = has0 && t <= (int)k1 && k1 - (unsigned)t < nxP;
-                    const bool v1 = has1 && t <= (int)k1 + 1 && k1 + 1 - (unsigned)t < nxP;
-                    // (a lane without a term computes on a clamped row of [ja, jb] and discards the sums)
+                    // (a lane without a term computes on a clamped row of [ja, jb]; its sums are not added)
                     int j10 = (int)k1 - t, j11 = (int)k1 + 1 - t;
                     j10 = j10 < ja ? ja : (j10 > jb ? jb : j10);
                     j11 = j11 < ja ? ja : (j11 > jb ? jb : j11);
                     const double* x0 = xs_l + (size_t)(j10 - jlo) * xpitch;
                     const double* x1 = xs_l + (size_t)(j11 - jlo) * xpitch;
                     const double* yrow = ys_l + (size_t)r * 2 * g.n2;
-                    if (cA < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cA, ypl, cA, c0A, g.nx2, accA0, accA1);
-                    if (twoB && cB < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cB, ypl, cB, c0B, g.nx2, accB0, accB1);
+                    if (cA < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cA, ypl, cA, c0A, g.nx2, sA0, sA1);
+                    if (twoB && cB < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cB, ypl, cB, c0B, g.nx2, sB0, sB1);
+                }
+                if (grp > 0) {
+                    double* sl = sums_l + ((size_t)(grp - 1) * g.ntw + wave) * 512 + lane;
+                    E::st(sl, 64, 0, sA0);
+                    E::st(sl + 128, 64, 0, sA1);
+                    E::st(sl + 256, 64, 0, sB0);
+                    E::st(sl + 384, 64, 0, sB1);
+                }
+            }
+            if (g.tb > 1) __syncthreads();
+            if (grp == 0 && xrows > 0) {
+                for (int r = 0; r < rows; ++r) {
+                    bool v0, v1;
+                    int ja, jb;
+                    row_terms(r, v0, v1, ja, jb);
+                    if (r > 0) {
+                        const double* sl = sums_l + ((size_t)(r - 1) * g.ntw + wave) * 512 + lane;
+                        sA0 = E::ld(sl, 64, 0);
+                        sA1 = E::ld(sl + 128, 64, 0);
+                        sB0 = E::ld(sl + 256, 64, 0);
+                        sB1 = E::ld(sl + 384, 64, 0);
+                    }
+                    if (v0) {
+                        accA0 = E::add(accA0, sA0);
+                        accB0 = E::add(accB0, sB0);
+                    }
+                    if (v1) {
+                        accA1 = E::add(accA1, sA1);
+                        accB1 = E::add(accB1, sB1);
+                    }
                 }
             }
         }
@@ -636,6 +680,7 @@ __global__ void __launch_bounds__(512) k_conv_rows_rb(const double* __restrict__
                 else carry = false;
             }
     }
+    if (grp != 0) return;
     if (has0 && cA < g.n2) E::st(z, zp, zoff + (size_t)k1 * zstrP + cA, accA0);
     if (has1 && cA < g.n2) E::st(z, zp, zoff + (size_t)(k1 + 1) * zstrP + cA, accA1);
     if (twoB && has0 && cB < g.n2) E::st(z, zp, zoff + (size_t)k1 * zstrP + cB, accB0);
@@ -651,11 +696,10 @@ static std::map<hipStream_t, RbScratch>& rb_scratch() {
     static std::map<hipStream_t, RbScratch> m;
     return m;
 }
-// worth it where the workgroups (8 output rows each) outnumber the CUs several times over: measured crossover against
-// k_conv_staged between 96^3 and 112^3 (profiles/r03/interval_product.txt)
+// measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
 static double rb_min_macs = [] {
     const char* e = getenv("GFT_CONV_RB_MIN_MACS");
-    return e ? atof(e) : 1.5e11;
+    return e ? atof(e) : 2.0e10;
 }();
 void staged_set_rb_min_macs(double v) { rb_min_macs = v; }  // "conv_rb_min_macs" (tests; negative = never)
 void staged_release_scratch() {
@@ -699,16 +743,24 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     g.ntiles = (n2 + 15) / 16;
     g.n2 = n2;
     g.nx2 = nx2;
-    static const unsigned tb_env = [] {
-        const char* e = getenv("GFT_RB_TB");  // tuning knob: y rows per batch
-        return (unsigned)(e ? std::max(1, atoi(e)) : 8);
+    static const unsigned rg_env = [] {
+        const char* e = getenv("GFT_RB_GROUPS");  // tuning knob: wave groups (= y rows per batch) of a workgroup
+        return (unsigned)(e ? std::max(1, atoi(e)) : 0);
     }();
-    g.tb = tb_env;
+    g.ntw = (g.ntiles + 1) / 2;
+    // groups cut the longest chain of a workgroup (what bounds mid sizes) but leave one workgroup per CU with nothing to
+    // overlap its staging with; two groups once the workgroups outnumber the CUs ~6 times (128^3: 257 ms with 2, 299 with 4;
+    // 96^3: 77 with 2, 68 with 4)
+    unsigned long long nblk = g.n_pg;
+    for (int ax = 0; ax < P; ++ax) nblk *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
+    const unsigned want = rg_env ? rg_env : (nblk >= 1536 ? 2u : 4u);
+    g.tb = std::max(1u, std::min(want, 16u / g.ntw));
     auto lds_of = [&](unsigned tb) {
-        return ((size_t)tb * 2 * n2 + 16 + (size_t)(tb + RB_ROWS - 1) * (2 * nx2 + 2)) * sizeof(double) + 2 * tb + RB_ROWS + 8;
+        return ((size_t)tb * 2 * n2 + 16 + (size_t)(tb + RB_ROWS - 1) * (2 * nx2 + 2) + (2 * tb + RB_ROWS + 8 + 7) / 8 + (size_t)(tb - 1) * g.ntw * 512) *
+               sizeof(double);
     };
-    while (g.tb > 1 && lds_of(g.tb) > 60 * 1024) g.tb /= 2;
-    if (lds_of(g.tb) > 60 * 1024) return false;
+    while (g.tb > 1 && lds_of(g.tb) > 150 * 1024) g.tb /= 2;
+    if (lds_of(g.tb) > 150 * 1024) return false;
     for (int ax = 0; ax < g.no; ++ax) {
         g.xrs[ax] = a.xstr[ax] / nx2;
         g.yrs[ax] = a.ystr[ax] / n2;
@@ -734,8 +786,16 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     for (int ax = 0; ax < P; ++ax) blocks *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
     if (blocks == 0) return true;
     if (blocks > 0x7fffffffULL) return false;
-    const unsigned threads = ((g.ntiles + 1) / 2) * 64;
+    const unsigned threads = g.ntw * g.tb * 64;
     const size_t lds = lds_of(g.tb);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_rows_rb<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
     GFT_LAUNCH(k_conv_rows_rb<E>, dim3((unsigned)blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
     return true;
 }

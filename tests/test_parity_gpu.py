@@ -1181,6 +1181,6 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
                 try:
                     check(want, GTPI.new(a, deg) * GTPI.new(b, deg))
                 finally:
-                    L.gft_set_option(b"conv_rb_min_macs", 1.5e11)
+                    L.gft_set_option(b"conv_rb_min_macs", 2.0e10)
     finally:
         L.gft_set_option(b"host_max_elems", -1.0)

@@ -15,7 +15,7 @@ ROOF_POS, ROOF_GENERAL = 4.9, 1.40  # interval-TMAC/s
 genfer_amd.init(0)
 L = genfer_amd.lib()
 TPI = genfer_amd.IntervalTaylorPoly
-sizes = [int(a) for a in sys.argv[1:]] or [32, 64, 128]
+sizes = [int(a) for a in sys.argv[1:]] or [32, 64, 80, 96, 112, 128]
 for n in sizes:
     rng = np.random.default_rng(0)
     lo = rng.random((n, n, n)); x = np.stack([lo, lo * (1 + 1e-15)])
