@@ -131,7 +131,10 @@ k_conv_staged(const double* __restrict__ x, size_t xp, const double* __restrict_
                 d = a.slab_hi - a.slab_lo;
                 base = a.slab_lo;
             }
-            K[ax] = base + (unsigned)(ko_lin % d);
+            // (the fastest outer index rotates by the slower ones: consecutive workgroups go to consecutive XCDs, and with a
+            // power-of-two extent an XCD would otherwise only see the indices k = x (mod 8) — see k_conv_rows_rb)
+            const bool rot = ax == g.no - 1 && ax > 0;
+            K[ax] = base + (unsigned)(rot ? (ko_lin % d + ko_lin / d) % d : ko_lin % d);
             ko_lin /= d;
             zoff += (size_t)K[ax] * a.zstr[ax];
             unsigned l = (K[ax] + 1 > a.ys[ax]) ? (K[ax] + 1 - a.ys[ax]) : 0;
