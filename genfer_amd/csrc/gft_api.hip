@@ -461,6 +461,7 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
     }
     return keep;
 }
+static void trace_settle();  // GFT_TRACE_API: which entry point materialised a chain (below)
 // Materialise a deferred chain (one launch; every copy of the handle shares the result).
 template <class E>
 static void settle(const gft_poly& p) {
@@ -474,6 +475,7 @@ static void settle(const gft_poly& p) {
         sh.nd = (int)keep.size();
         for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)p.shape[keep[j]];
         K<E>::chain_copy(R.stream, out->p, p.numel, sh, chain_src<E>(p, keep));
+        trace_settle();
         q.mat = out;
         q.mat_shape = p.shape;
         R.stats_ex[1]++;
@@ -925,9 +927,8 @@ struct Ops {
                     if (shift[ax] < 0) any_neg = true;
                 }
                 if (!any_neg) front = false;
-                if (front && src.pend)
-                    for (int i = 0; i < src.pend->n; ++i)
-                        if (src.pend->st[i].kind >= CH_FIRST_ADD) front = false;
+                // (positional stages of the source chain — FIRST_*, MUL_TAB — are evaluated in the view's own coordinates
+                // by k_chain, so they ride along under the pad; a pad on a pad is materialised by deferred())
                 if (front && src.pend && src.pend->padded) front = false;
             }
             if (front) {
@@ -3089,7 +3090,10 @@ struct ApiTrace {
     std::map<std::string, size_t> counts;
     std::map<std::string, size_t> tiny;  // results of at most 2 elements that live in DEVICE memory, by entry point
     std::map<std::string, double> secs;  // host wall time inside the entry point (host-tier ops: their compute time)
+    std::map<std::string, size_t> settles;  // deferred chains materialised (one launch each), by the entry point that needed the values
+    const char* cur = "?";
     void hit(const char* fn) {
+        cur = fn;
         if (on) counts[fn]++;
     }
     struct Timer {
@@ -3110,9 +3114,13 @@ struct ApiTrace {
         if (!on) return;
         for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %10zu calls %10.4f s\n", kv.first.c_str(), kv.second, secs[kv.first]);
         for (auto& kv : tiny) fprintf(stderr, "[gft api] tiny device result from %-22s %zu\n", kv.first.c_str(), kv.second);
+        for (auto& kv : settles) fprintf(stderr, "[gft api] chains materialised for %-24s %zu\n", kv.first.c_str(), kv.second);
     }
 };
 static ApiTrace g_api_trace;
+static void trace_settle() {
+    if (g_api_trace.on) g_api_trace.settles[g_api_trace.cur]++;
+}
 
 // Genfer-style programs are launch-bound (10^5 dependent kernels of 2-6 us): the HIP runtime places kernel arguments in
 // device memory when HIP_FORCE_DEV_KERNARG=1, which shortens every launch (hmm -25 %, mixture -9 % on the same box).  The

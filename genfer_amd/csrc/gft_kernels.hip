@@ -477,7 +477,7 @@ __device__ __forceinline__ typename E::V chain_eval(const ChainSrc& c, size_t of
                 if (first) x = E::sub(x, E::from(g.s));
                 x = E::neg(x);
                 break;
-            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab, g.tab_plane, k[g.axis])); break;
+            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab, g.tab_plane, k[g.axis] - (unsigned)c.pad[g.axis])); break;  // (the view's own coordinate)
             default: break;
         }
     }
@@ -491,6 +491,9 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
         size_t r = lin, aoff = 0, boff = 0;
         bool ina = true, inb = true;
+        // positional stages (FIRST_*, MUL_TAB) look at the coordinates of the chain's OWN view — what lies under a front
+        // pad is the view shifted, its element 0 is the output's element `pad`
+        bool firsta = true, firstb = true;
         unsigned k[MAXD];
 #pragma unroll 1
         for (int ax = sh.nd - 1; ax >= 0; --ax) {
@@ -500,22 +503,23 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
             k[ax] = kk;
             const unsigned ka = kk - (unsigned)a.pad[ax];  // (wraps below the pad: fails the box test)
             if (ka >= a.box[ax]) ina = false;
+            if (ka != 0) firsta = false;
             aoff += (size_t)ka * a.stride[ax];
             if (TWO) {
                 const unsigned kb = kk - (unsigned)b.pad[ax];
                 if (kb >= b.box[ax]) inb = false;
+                if (kb != 0) firstb = false;
                 boff += (size_t)kb * b.stride[ax];
             }
         }
-        const bool first = lin == 0;
         V v;
         if (!TWO) {
-            v = ina ? chain_eval<E>(a, aoff, k, first) : E::zero();
+            v = ina ? chain_eval<E>(a, aoff, k, firsta) : E::zero();
         } else {
             v = E::zero();
-            if (ina) v = E::add(v, chain_eval<E>(a, aoff, k, first));
+            if (ina) v = E::add(v, chain_eval<E>(a, aoff, k, firsta));
             if (inb) {
-                V w = chain_eval<E>(b, boff, k, first);
+                V w = chain_eval<E>(b, boff, k, firstb);
                 v = subtract ? E::sub(v, w) : E::add(v, w);
             }
         }
