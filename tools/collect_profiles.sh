@@ -60,5 +60,11 @@ python3 tools/bench_horner.py > "$OUT/summary/horner_loop.txt" 2> "$OUT/horner.e
 python3 tools/bench_div2d.py 32 64 > "$OUT/summary/div2d_slab.txt" 2> "$OUT/div2d.err"
 (cd /tmp && rm -rf /tmp/gft_e2e_mix && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mix -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only > "$OUT/e2e_mix_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mix -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_kernel_stats.csv")
 (cd /tmp && rm -rf /tmp/gft_e2e_mixb && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mixb -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only --bounds > "$OUT/e2e_mixb_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mixb -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_bounds_kernel_stats.csv")
+for prog in hmm; do
+  (cd /tmp && rm -rf /tmp/gft_e2e_$prog && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_$prog -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only $prog --gpu-only > "$OUT/e2e_${prog}_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_$prog -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_${prog}_kernel_stats.csv")
+  (cd /tmp && rm -rf /tmp/gft_e2e_${prog}b && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_${prog}b -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only $prog --gpu-only --bounds > "$OUT/e2e_${prog}b_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_${prog}b -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_${prog}_bounds_kernel_stats.csv")
+done
 python3 tools/bench_e2e.py --limit 100 --runs 3 > "$OUT/e2e.log" 2>&1; tail -1 "$OUT/e2e.log" > "$OUT/summary/e2e_neurips_limit100.json"
+grep -v '^{' "$OUT/e2e.log" > "$OUT/summary/e2e_neurips_limit100.txt"
+grep -v '^{' "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.txt"
 ls -la "$OUT/summary"
