@@ -179,6 +179,10 @@ E2E_PROGRAMS = (
     ("two_populations2000", "test_expect/slow/two_populations2000.sgcl", "", 2),
     ("three_populations", "bench/three_populations.sgcl", "--limit 100", 1),
     ("four_populations", "bench/four_populations.sgcl", "--limit 24", 1),
+    # TaylorPoly<Interval<F64>> (`--bounds`): GPU only — the CPU oracle needs 26 s (hmm) and 12 minutes (mixture) for these
+    # (profiles/r02/e2e_neurips_limit100_bounds_with_cpu_oracle_earlier_collection.json)
+    ("hmm_bounds", "neurips2023/approx/hmm/hmm.sgcl", "--limit 100 --bounds", 0),
+    ("mixture_bounds", "neurips2023/approx/mixture/mixture.sgcl", "--limit 100 --bounds", 0),
 )
 
 
@@ -197,7 +201,8 @@ def e2e_seconds(gpu_runs=5):
         if first.startswith("# flags:"):  # the fixture's own flags (tests/integration.rs protocol)
             flags = (first[len("# flags:"):].strip() + " " + flags).strip()
         row = {"flags": flags}
-        for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs), ("cpu_oracle_s", oracle, "orc_", cpu_runs)):
+        for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs if cpu_runs else min(gpu_runs, 3)),
+                                       ("cpu_oracle_s", oracle, "orc_", cpu_runs)):
             best = None
             for _ in range(runs):
                 before = genfer_amd.op_stats() if key == "gpu_s" else None
@@ -217,32 +222,55 @@ def e2e_seconds(gpu_runs=5):
     return {"unit": "s", "protocol": "best-of-N Total inference time (flags per program)", "programs": rows}
 
 
-def sclk_under_load(one_step):
+_CLOCK_HELPER = r"""
+import shutil, subprocess, sys
+exe = shutil.which("rocm-smi")
+line = sys.stdin.readline()
+if line.strip() == "go" and exe:
+    try:
+        sys.stdout.write(subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout)
+    except Exception:
+        pass
+"""
+
+
+def start_clock_helper():
+    """A child that will run `rocm-smi` when told to.  It is started BEFORE this process touches the GPU: a process that has
+    initialised HIP must not fork + exec (this pool refuses it, and it can take the box down), so the sampler cannot be
+    spawned at the time of the sample.  Returns None where that is not possible (e.g. under rocprofv3 --pmc, whose preloaded
+    tool has initialised the GPU before main() runs — use --no-clock there)."""
+    import subprocess
+    try:
+        return subprocess.Popen([sys.executable, "-c", _CLOCK_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True)
+    except Exception:  # noqa: BLE001 - informational only
+        return None
+
+
+def sclk_under_load(one_step, helper):
     """The shader clock and socket power while the product runs (untimed, after the timed region): `peak` is the
     contract's 78.6 TFLOP/s at the nominal 2.4 GHz; under sustained FP64 load the part runs at its power limit below that
     (profiles/r03/clock_under_load.txt), so the line also states the fraction of the peak at the clock actually observed.
     Informational: `frac` stays achieved / peak."""
     import re
-    import shutil
-    import subprocess
 
     import torch
-    exe = shutil.which("rocm-smi")
-    if not exe:
+    if helper is None or helper.poll() is not None:
         return None
     try:
         for _ in range(50):  # ~1 s of load before the sample
             one_step()
-        proc = subprocess.Popen([exe, "--showclocks", "--showpower"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-        t_end = time.perf_counter() + 10.0
-        while proc.poll() is None and time.perf_counter() < t_end:
+        helper.stdin.write("go\n")
+        helper.stdin.flush()
+        t_end = time.perf_counter() + 25.0
+        while helper.poll() is None and time.perf_counter() < t_end:
             for _ in range(5):
                 one_step()
             torch.cuda.synchronize()
-        if proc.poll() is None:
-            proc.kill()
+        if helper.poll() is None:
+            helper.kill()
             return None
-        text = proc.stdout.read()
+        text = helper.stdout.read()
         m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", text)
         w = re.search(r"Package Power \(W\):\s*([0-9.]+)", text)
         out = {}
@@ -264,7 +292,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end seconds of the NeurIPS'23 programs (N = 1 only)")
     ap.add_argument("--conv-mode", type=int, default=0, help="0 auto, 1 reference-order kernel, 2 tiled kernel")
+    ap.add_argument("--no-clock", action="store_true", help="do not sample the shader clock under load (rocm-smi)")
     args = ap.parse_args()
+
+    # (before anything initialises the GPU: see start_clock_helper)
+    clock_helper = None
+    if not args.no_clock and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        clock_helper = start_clock_helper()
 
     import torch
     import torch.distributed as dist
@@ -441,12 +475,17 @@ def main():
     }
 
     if rank == 0 and world == 1:
-        clk = sclk_under_load(lambda: step(False))
+        clk = sclk_under_load(lambda: step(False), clock_helper)
         if clk:
             out["roofline"].update(clk)
             if clk.get("sclk_mhz_under_load"):
                 peak_at = FP64_PEAK_TFLOPS * clk["sclk_mhz_under_load"] / 2400.0
                 out["roofline"]["frac_at_observed_clock"] = achieved_tflops / peak_at
+    if clock_helper is not None and clock_helper.poll() is None:
+        try:
+            clock_helper.stdin.close()  # never told to sample: let it go
+        except Exception:  # noqa: BLE001
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref_slabs, slabs = cpu_baseline(shape, xh, yh)
         out["cpu_baseline"] = base

@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT/summary"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_kt -o kt -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > "$OUT/kt.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_kt -o kt -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-clock > "$OUT/kt.log" 2>&1
 cp "$(find /tmp/gft_kt -name '*kernel_stats.csv' | head -1)" "$OUT/summary/kernel_stats.csv"
 grep -o '{"metric".*' "$OUT/kt.log" | tail -1 > "$OUT/summary/bench_c2_n1_under_rocprof.json"
 n=0
@@ -18,7 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
            "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD"; do
   n=$((n+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/gft_pmc_$n -o pmc -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/pmc_$n.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/gft_pmc_$n -o pmc -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock > "$OUT/pmc_$n.log" 2>&1
   f=$(find /tmp/gft_pmc_$n -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/pmc_$n.csv"
 done
@@ -46,7 +46,7 @@ print(json.dumps({k: v for k, v in agg.items() if k not in ("_note", "workload")
 PY
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/summary/bench_c2_n1.json" 2> "$OUT/bench_c2.err"
-python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench_fp64.hip -o /tmp/microbench_fp64 2> "$OUT/mb.err" && /tmp/microbench_fp64 > "$OUT/summary/microbench_fp64.txt" 2>&1
 python3 tools/bench_recurrence.py > "$OUT/summary/recurrences.txt" 2> "$OUT/rec.err"
 python3 tools/bench_interval.py > "$OUT/summary/interval_product.txt" 2> "$OUT/iv.err"
