@@ -206,7 +206,8 @@ def e2e_seconds(gpu_runs=5):
             best = None
             for _ in range(runs):
                 before = genfer_amd.op_stats() if key == "gpu_s" else None
-                rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, prefix)
+                pfx = prefix[:-1] + "i_" if "--bounds" in flags.split() else prefix  # the Interval<F64> entry points
+                rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, pfx)
                 if rc != 0:
                     row[key + "_error"] = text[-200:]
                     best = None

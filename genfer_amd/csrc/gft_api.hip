@@ -1259,6 +1259,51 @@ struct Ops {
             *var = p.lazy_var;
             return true;
         }
+        if (p.pend && !p.pend->mat) {
+            // a deferred chain whose first consumer asks this question: materialise it and scan it in ONE launch
+            // (k_chain_scan); the verdict is memoised on the new buffer like any other
+            Pend& q = *p.pend;
+            Dims ckeep = chain_keep(p.shape, {&p});
+            if (ckeep.size() <= (size_t)MAXD && ckeep.size() <= 32) {
+                std::shared_ptr<Buf> outb = alloc_doubles(p.numel * E::W);
+                Shape sh;
+                sh.nd = (int)ckeep.size();
+                unsigned cm = 0;
+                for (size_t j = 0; j < ckeep.size(); ++j) {
+                    sh.d[j] = (unsigned)p.shape[ckeep[j]];
+                    if (p.shape[ckeep[j]] >= 2) cm |= 1u << j;
+                }
+                Mailbox mb = next_mail();
+                K<E>::chain_copy_scan(R.stream, outb->p, p.numel, sh, chain_src<E>(p, ckeep), cm, R.d_flag + 8, mb);
+                trace_settle();
+                R.stats_ex[1]++;
+                R.stats[0]++;
+                g_scan_trace.hit(p.numel, ckeep.size());
+                q.mat = outb;
+                q.mat_shape = p.shape;
+                p.buf = q.mat;
+                p.pend = nullptr;
+                double res[5];
+                wait_mail(mb, res, 5);
+                const unsigned got = (unsigned)res[0];
+                if (!got) {
+                    p.buf->lin_state = 1;
+                    return false;
+                }
+                size_t ci = 0;
+                while (!((got >> ci) & 1u)) ci++;
+                c[0] = res[1];
+                c[1] = res[2];
+                m[0] = res[3];
+                m[1] = res[4];
+                *var = ckeep[ci];
+                p.buf->lin_state = 2;
+                p.buf->lin_c[0] = c[0]; p.buf->lin_c[1] = c[1];
+                p.buf->lin_m[0] = m[0]; p.buf->lin_m[1] = m[1];
+                p.buf->lin_var = *var;
+                return true;
+            }
+        }
         settle<E>(p);  // the verdict is memoised per buffer: a deferred chain is materialised first
         if (p.buf && p.buf->lin_state) {
             if (p.buf->lin_state == 1) return false;

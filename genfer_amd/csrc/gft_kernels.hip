@@ -526,6 +526,87 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
         E::st(out, out_plane, lin, v);
     }
 }
+// k_chain<E, false> and k_linear_scan in one launch: the accumulator of a Horner step is a deferred chain whose FIRST
+// consumer is Mul's `extract_linear` (mt:1014-1072 asks `self` first) — materialise it and settle the question in the same
+// pass (one launch and its gap less per subst_var of a `--bounds` program).  Verdict and mailbox as in k_linear_scan.
+template <class E>
+__global__ void __launch_bounds__(256) k_chain_scan(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, unsigned axes_mask,
+                                                    unsigned* state, Mailbox mb, size_t total) {
+    typedef typename E::V V;
+    unsigned local = axes_mask;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
+        size_t r = lin, aoff = 0;
+        bool ina = true, firsta = true;
+        unsigned k[MAXD];
+        int nonzero_axes = 0, which = -1;
+        bool unit = true;
+#pragma unroll 1
+        for (int ax = sh.nd - 1; ax >= 0; --ax) {
+            const unsigned d = sh.d[ax];
+            const unsigned kk = (unsigned)(r % d);
+            r /= d;
+            k[ax] = kk;
+            if (kk != 0) {
+                nonzero_axes++;
+                which = ax;
+                if (kk != 1) unit = false;
+            }
+            const unsigned ka = kk - (unsigned)a.pad[ax];
+            if (ka >= a.box[ax]) ina = false;
+            if (ka != 0) firsta = false;
+            aoff += (size_t)ka * a.stride[ax];
+        }
+        const V v = ina ? chain_eval<E>(a, aoff, k, firsta) : E::zero();
+        E::st(out, out_plane, lin, v);
+        if (local != 0 && nonzero_axes != 0 && !E::is_zero(v)) {
+            if (nonzero_axes == 1 && unit) local &= (1u << which);
+            else local = 0;
+        }
+    }
+    __threadfence();  // this thread's elements are visible device-wide before the block takes its ticket
+    for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
+    __shared__ unsigned s_and[4];
+    __shared__ unsigned s_last;
+    if ((threadIdx.x & 63) == 0) s_and[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned blk = s_and[0] & s_and[1] & s_and[2] & s_and[3];
+        unsigned cur = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur & ~blk) atomicAnd(&state[0], blk);
+        __threadfence();
+        unsigned ticket = atomicAdd(&state[1], 1u);
+        s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    double* res = mb.payload;
+    unsigned m = atomicAnd(&state[0], 0xffffffffu);  // device-scope read of the combined mask
+    res[0] = (double)m;
+    res[1] = res[2] = res[3] = res[4] = 0.0;
+    if (m) {
+        int ax = __ffs((int)m) - 1;
+        size_t stride = 1;
+        for (int i = sh.nd - 1; i > ax; --i) stride *= sh.d[i];
+        res[1] = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res[3] = __hip_atomic_load(out + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (E::W == 2) {
+            res[2] = __hip_atomic_load(out + out_plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            res[4] = __hip_atomic_load(out + out_plane + stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    atomicExch(&state[0], 0xffffffffu);  // restore for the next call on this stream
+    atomicExch(&state[1], 0u);
+    mailbox_publish(mb);
+}
+template <class E>
+void K<E>::chain_copy_scan(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, unsigned axes_mask,
+                           unsigned* state, const Mailbox& mb) {
+    size_t total = 1;
+    for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
+    if (total == 0) return;
+    GFT_LAUNCH(k_chain_scan<E>, dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, axes_mask, state, mb, total);
+}
 template <class E>
 void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a) {
     size_t total = 1;

@@ -216,6 +216,9 @@ struct K {
                        const GatherArgs& a);
     // out[k] = chain(base[k]) inside the operand's box, zero outside: materialises a deferred chain
     static void chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a);
+    // the same plus linear_scan's verdict on the materialised tensor, in one launch (state / mailbox as linear_scan)
+    static void chain_copy_scan(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a, unsigned axes_mask,
+                                unsigned* state, const Mailbox& mb);
     // out[k] = ((0 + A[k]?) +/- B[k]?) like addsub_padded, A / B deferred chains evaluated on the fly
     static void chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a,
                              const ChainSrc& b, int subtract);
