@@ -462,6 +462,7 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
     return keep;
 }
 static void trace_settle();  // GFT_TRACE_API: which entry point materialised a chain (below)
+static void trace_mirror(size_t numel);  // ... and which one mirrored a host-tier tensor to the device
 // Materialise a deferred chain (one launch; every copy of the handle shares the result).
 template <class E>
 static void settle(const gft_poly& p) {
@@ -507,6 +508,7 @@ static double* dp(const gft_poly& p) {
             b->dev = alloc_doubles(p.numel * E::W);
             upload_small(R.stream, b->dev->p, b->p, p.numel * E::W);
             R.stats[7]++;
+            trace_mirror(p.numel);
         }
         return b->dev->p;
     }
@@ -2640,6 +2642,7 @@ struct Ops {
     // on every step whether the accumulator is linear (a device scan + host round trip for device tensors, free on the
     // host tier).
     static P horner_exact(const P& ca, size_t v, const P& subst, const Dims& deg) {
+        ScanCtx sc_he("subst_var.horner_exact");
         P res = zero_with(deg);
         for (size_t i = ca.shape[v]; i-- > 0;) res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
         return res;
@@ -2657,6 +2660,7 @@ struct Ops {
     static constexpr size_t WIT_SLOTS = 8192;
     static bool horner_speculative(const P& ca, size_t v, const P& subst, const Dims& deg, bool lin_known, const double c[2],
                                    const double m[2], size_t w, P* result) {
+        ScanCtx sc_hs("subst_var.horner_speculative");
         P res = zero_with(deg);
         bool res_nonlinear_seen = false;
         unsigned slots = 0;  // speculated accumulators so far (sticky witness words R.d_wit[0 .. slots))
@@ -3165,6 +3169,11 @@ struct ApiTrace {
 static ApiTrace g_api_trace;
 static void trace_settle() {
     if (g_api_trace.on) g_api_trace.settles[g_api_trace.cur]++;
+}
+static void trace_mirror(size_t numel) {
+    if (g_api_trace.on)
+        g_api_trace.settles[std::string("(host-tier tensor mirrored to the device, ") + (numel <= 2 ? "<= 2" : (numel <= 64 ? "<= 64" : "> 64")) + " elements, in " +
+                            (g_scan_trace.ctx ? g_scan_trace.ctx : "-") + ") " + g_api_trace.cur]++;
 }
 
 // Genfer-style programs are launch-bound (10^5 dependent kernels of 2-6 us): the HIP runtime places kernel arguments in
