@@ -764,7 +764,16 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     if (tiles.empty()) return false;
     unsigned wg_per_cu = std::min<unsigned>(16u / P.NW, (unsigned)(160 * 1024 / P.lds_bytes));
     if (wg_per_cu < 1) wg_per_cu = 1;
+    // Ranges per resident workgroup slot: with exactly one range per slot every workgroup runs from the first to the last
+    // cycle of the launch and the slowest (its CU's clock, its neighbours' traffic) sets the time; four ranges per slot let
+    // the dispatcher even that out — worth it once a range is still >= 10^6 steps long (128^3 27.4 -> 28.4 TMAC/s, 96^3
+    // 23.7 -> 24.5, 100^3 20.1 -> 20.7; 64^3, 1.7*10^5 steps per slot, loses 4 % to the extra partial slabs).
+    static const int wg_mult_env = [] {
+        const char* e = getenv("GFT_TILED_WG_MULT");  // tuning knob (0 = the rule above)
+        return e ? std::max(0, atoi(e)) : 0;
+    }();
     unsigned long long n_wg = (unsigned long long)num_cus() * wg_per_cu;
+    n_wg *= wg_mult_env ? (unsigned)wg_mult_env : (S / n_wg >= 1000000ull ? 4u : 1u);
     // Every range pays a window fill and, if it splits a tile, a 4 KB-per-block partial slab plus its share of the
     // reduction, so small products must not be cut into confetti.  A step costs ~ (chunk pairs + 3) units
     // (pairs = nb(nb+1)/2 8x8x8 chunk products per lane tile, 3 ~ barriers + refill) and the fixed part grows
