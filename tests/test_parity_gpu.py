@@ -971,13 +971,17 @@ def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, 
     sc = (lambda x: (x, x)) if interval else (lambda x: x)
     L = genfer_amd.lib()
 
-    def program(T, A, B, v, d, deg):
+    def program(T, A, B, v, d, deg, Z):
         s = T.var(v, sc(0.0), deg[v]) * T.from_scalar(sc(0.9048374180359595))  # m * x_v
         p = (A.subst_var(v, s) + T.from_scalar(sc(0.25))) * T.from_scalar(sc(0.5))
         q = (B.subst_var(v, s).truncate_to_degree_p1(d) - T.from_scalar(sc(1.5))) / T.from_scalar(sc(3.0))
         n = T.from_scalar(sc(2.0)) - (-q)                      # scalar - tensor: FIRST_SUB_NEG_ALL after a neg stage
         outs = [p + q, p - q, n + p, (p + q).truncate_to_degree_p1(max(d - 1, 1))]
         outs.append(p * q)                                     # a consumer that needs the tensors in memory
+        # Mul asks `self.extract_linear()` first (mt:1014-1072): on a chain that is one launch — materialise and scan
+        # (k_chain_scan) — whatever the verdict; Z * 3 IS linear (two non-zero coefficients in a full-size tensor)
+        outs.append((Z * T.from_scalar(sc(3.0))) * q)
+        outs.append(((Z + T.from_scalar(sc(0.5))) * T.from_scalar(sc(-0.25))) * (q + p))
         outs.append((p + T.from_scalar(sc(1.0))).derivative(v, 1))
         seven = p
         for k in range(8):                                     # longer than CHAIN_MAX: the chain restarts
@@ -997,13 +1001,17 @@ def test_deferred_chains_bit_exact_and_fewer_launches(interval, OTP, GTP, OTPI, 
         a, b = rand(shape, 201, 0.1, 1.0), rand(shape, 202, -1.0, 1.0)
         for v in range(len(shape)):
             for d in (3, 7, 100):
-                want, wc = program(O, O.new(mk(a), deg), O.new(mk(b), deg), v, d, deg)
+                zl = np.zeros(shape)
+                zl[(0,) * len(shape)] = 0.7
+                if shape[v] >= 2:
+                    zl[tuple(1 if i_ == v else 0 for i_ in range(len(shape)))] = 0.3
+                want, wc = program(O, O.new(mk(a), deg), O.new(mk(b), deg), v, d, deg, O.new(mk(zl), deg))
                 counts = {}
                 for defer in (1, 0):
                     assert L.gft_set_option(b"defer", float(defer)) == 0
                     try:
                         before = genfer_amd.op_stats()
-                        got, gc = program(G, G.new(mk(a), deg), G.new(mk(b), deg), v, d, deg)
+                        got, gc = program(G, G.new(mk(a), deg), G.new(mk(b), deg), v, d, deg, G.new(mk(zl), deg))
                         for o, g in zip(want, got):
                             check(o, g)
                         assert gc == wc
