@@ -766,14 +766,19 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     if (wg_per_cu < 1) wg_per_cu = 1;
     // Ranges per resident workgroup slot: with exactly one range per slot every workgroup runs from the first to the last
     // cycle of the launch and the slowest (its CU's clock, its neighbours' traffic) sets the time; four ranges per slot let
-    // the dispatcher even that out — worth it once a range is still >= 10^6 steps long (128^3 27.4 -> 28.4 TMAC/s, 96^3
-    // 23.7 -> 24.5, 100^3 20.1 -> 20.7; 64^3, 1.7*10^5 steps per slot, loses 4 % to the extra partial slabs).
+    // the dispatcher even that out — as many (2, 4, 8) as leave a range >= ~190 steps (128^3: 2312 steps per slot, eight ranges, 27.0 -> 28.7
+    // TMAC/s in three alternating runs on one box; 96^3 and 100^3 four, +3 %; 64^3, 81 steps per slot, stays at one: two
+    // are neutral, four lose 4 % to the extra partial slabs).
     static const int wg_mult_env = [] {
         const char* e = getenv("GFT_TILED_WG_MULT");  // tuning knob (0 = the rule above)
         return e ? std::max(0, atoi(e)) : 0;
     }();
     unsigned long long n_wg = (unsigned long long)num_cus() * wg_per_cu;
-    n_wg *= wg_mult_env ? (unsigned)wg_mult_env : (S / n_wg >= 1000000ull ? 4u : 1u);
+    const unsigned long long per_slot = S / n_wg;  // steps (one lane tile x one (ju, j0, j1)) per resident slot
+    const unsigned long long fit = per_slot / 190;  // ranges of >= ~190 steps
+    n_wg *= wg_mult_env ? (unsigned)wg_mult_env : (fit >= 8 ? 8u : (fit >= 4 ? 4u : (fit >= 2 ? 2u : 1u)));
+    static const bool plan_debug = getenv("GFT_TILED_PLAN_DEBUG") != nullptr;
+    if (plan_debug) fprintf(stderr, "[gft tiled plan] zU=%u z0=%u z1=%u zI=%u steps=%llu slots=%llu steps/slot=%llu ranges=%llu\n", T.zU, T.z0, T.z1, T.zI, S, n_wg / (n_wg / ((unsigned long long)num_cus() * wg_per_cu) ? n_wg / ((unsigned long long)num_cus() * wg_per_cu) : 1), per_slot, n_wg);
     // Every range pays a window fill and, if it splits a tile, a 4 KB-per-block partial slab plus its share of the
     // reduction, so small products must not be cut into confetti.  A step costs ~ (chunk pairs + 3) units
     // (pairs = nb(nb+1)/2 8x8x8 chunk products per lane tile, 3 ~ barriers + refill) and the fixed part grows
