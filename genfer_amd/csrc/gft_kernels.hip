@@ -729,6 +729,28 @@ void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsig
     GFT_LAUNCH(k_linear_scan<E>, dim3(blocks), dim3(256), 0, st, t, axes_mask, state, mb, total);
 }
 
+// The observation step's interval arithmetic, operation for operation the reference's (derivative * factor, * 1 inside
+// mul_linear's mul_var, 0 + A, x * D, + B, * c), with two of its guaranteed short-circuits resolved where they stand —
+//   X * [1,1]  is X, except that an exact zero interval of either sign becomes [+0,+0] (iv:164-190 tests for zero first),
+//   a derivative factor of exactly 1 (the first coefficient's) is that same identity,
+// so that the remaining products and sums can take the wave-checked general formulas (E::mulw / E::addw: ~80 instead
+// of ~135 instructions each) in every wave that holds no OTHER special operand.  F64: the literal operations.
+template <class E>
+__device__ __forceinline__ typename E::V obs_mul_one(typename E::V x) {
+    if constexpr (E::W == 1) return E::mul(x, E::one());
+    else return E::is_zero(x) ? E::zero() : x;
+}
+template <class E>
+__device__ __forceinline__ typename E::V obs_mul_tab(typename E::V x, typename E::V t) {
+    if constexpr (E::W == 1) {
+        return E::mul(x, t);
+    } else {
+        const bool one = E::is_one(t);
+        const typename E::V r = E::mulw(x, one ? E::from_u32(2u) : t), i = obs_mul_one<E>(x);
+        return Iv{one ? i.lo : r.lo, one ? i.hi : r.hi};
+    }
+}
+
 template <class E>
 __global__ void __launch_bounds__(256) k_observe_step(const double* __restrict__ a, size_t ap, double* __restrict__ out,
                                                       size_t op, ObserveArgs g, size_t total) {
@@ -756,25 +778,17 @@ __global__ void __launch_bounds__(256) k_observe_step(const double* __restrict__
         V res;
         if (g.x_is_zero) {  // mul_var only (mt:619-621): zeros, then slab assignment
             res = E::zero();
-            if (in_d && kv >= 1 && kv - 1 < dl) {
-                V dj = E::mul(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1));
-                res = E::mul(dj, E::one());
-            }
+            if (in_d && kv >= 1 && kv - 1 < dl) res = obs_mul_one<E>(obs_mul_tab<E>(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1)));
         } else {  // mul_var(...) + self * from(x): zeros += A; += B  (mt:622, 873-880)
-            res = E::zero();
             V A = E::zero();
-            if (in_d && kv >= 1 && kv - 1 < dl) {
-                V dj = E::mul(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1));
-                A = E::mul(dj, E::one());
-            }
-            res = E::add(res, A);
+            if (in_d && kv >= 1 && kv - 1 < dl) A = obs_mul_one<E>(obs_mul_tab<E>(E::ld(a, ap, off + (size_t)kv * sv), E::ld(g.tab, g.tab_plane, kv - 1)));
+            res = E::add0(A);  // (0 + A)
             if (in_d && kv < dl) {
-                V di = E::mul(E::ld(a, ap, off + (size_t)(kv + 1) * sv), E::ld(g.tab, g.tab_plane, kv));
-                V B = g.x_is_one ? di : E::mul(xv, di);
-                res = E::add(res, B);
+                const V di = obs_mul_tab<E>(E::ld(a, ap, off + (size_t)(kv + 1) * sv), E::ld(g.tab, g.tab_plane, kv));
+                res = E::addw(res, g.x_is_one ? di : E::mulw(xv, di));
             }
         }
-        if (!g.c_is_one) res = E::mul(cv, res);
+        if (!g.c_is_one) res = E::mulw(cv, res);
         E::st(out, op, lin, res);
     }
 }
@@ -828,17 +842,17 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
             V res = E::zero();
             const bool mine = kv == k0;
             if (g.x_is_zero) {
-                if (kv >= 1 && kv - 1 < dlt) res = E::mul(E::mul(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
+                if (kv >= 1 && kv - 1 < dlt) res = obs_mul_one<E>(obs_mul_tab<E>(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)));
             } else {
                 V A = E::zero();
-                if (kv >= 1 && kv - 1 < dlt) A = E::mul(E::mul(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)), E::one());
-                res = E::add(res, A);
+                if (kv >= 1 && kv - 1 < dlt) A = obs_mul_one<E>(obs_mul_tab<E>(src(kv), mine ? tab_lo : E::ld(g.tab, g.tab_plane, kv - 1)));
+                res = E::add0(A);  // (0 + A)
                 if (kv < dlt) {
-                    const V di = E::mul(src(kv + 1), mine ? tab_hi : E::ld(g.tab, g.tab_plane, kv));
-                    res = E::add(res, g.x_is_one ? di : E::mul(xv, di));
+                    const V di = obs_mul_tab<E>(src(kv + 1), mine ? tab_hi : E::ld(g.tab, g.tab_plane, kv));
+                    res = E::addw(res, g.x_is_one ? di : E::mulw(xv, di));
                 }
             }
-            if (!c_one) res = E::mul(cv, res);
+            if (!c_one) res = E::mulw(cv, res);
             if (last) E::st(out, op, ooff + (size_t)kv * svo, res);
             else E::st(dst_l, g.lw_pad, kv, res);
         }

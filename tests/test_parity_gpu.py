@@ -752,13 +752,24 @@ def test_observe_step_interval(OTPI, GTPI):
     for xs, ys, deg in SHAPES[:8]:
         lo = rand(xs, 52, -1, 1)
         x = np.stack([lo, lo + rand(xs, 53, 0, 1e-3)])
-        ox, gx = OTPI.new(x, deg), GTPI.new(x, deg)
-        for v in range(len(xs)):
-            if not (1 < deg[v]):
-                continue
-            for xv, c in (((0.0, 0.0), (0.5, 0.5)), ((1.0, 1.0), (1.0, 1.0)), ((0.3, 0.31), (0.2, 0.21))):
-                want = (ox.derivative(v, 1).truncate_to_degree_p1(3) * OTPI.var(v, xv, 3)) * OTPI.from_scalar(c)
-                check(want, gx.observe_step(v, xv, c, 3))
+        # the short-circuit operands of iv:126-190 among the coefficients: exact zeros of both signs, the points 1 and -1,
+        # a non-finite bound (the kernel resolves `* [1,1]` and `0 + A` where they stand and takes the wave-checked general
+        # formulas elsewhere: every one of these must still come out as the reference's if-chain has it)
+        xs_ = x.copy()
+        flat = xs_.reshape(2, -1)
+        n = flat.shape[1]
+        for i, (l, h) in enumerate(((0.0, 0.0), (-0.0, -0.0), (1.0, 1.0), (-1.0, -1.0), (-0.0, 0.0), (0.5, np.inf), (np.nan, 1.0))):
+            if i < n:
+                flat[0, (3 * i + 1) % n] = l
+                flat[1, (3 * i + 1) % n] = h
+        for data in (x, xs_):
+            ox, gx = OTPI.new(data, deg), GTPI.new(data, deg)
+            for v in range(len(xs)):
+                if not (1 < deg[v]):
+                    continue
+                for xv, c in (((0.0, 0.0), (0.5, 0.5)), ((1.0, 1.0), (1.0, 1.0)), ((0.3, 0.31), (0.2, 0.21)), ((-1.0, -1.0), (-0.5, 0.25))):
+                    want = (ox.derivative(v, 1).truncate_to_degree_p1(3) * OTPI.var(v, xv, 3)) * OTPI.from_scalar(c)
+                    check(want, gx.observe_step(v, xv, c, 3))
 
 
 @pytest.mark.parametrize("interval", [False, True])
@@ -806,6 +817,13 @@ def test_observe_chain_fused_equals_stepwise_reference(interval, OTP, GTP, OTPI,
     for shape, deg, v, n in cases:
         a = rand(shape, 5 + n, 0.1, 1.0)
         o, g = O.new(mk(a), deg), G.new(mk(a), deg)
+        # (the same chain on data with exact zeros of both signs, ones, minus ones and a non-finite coefficient)
+        sp = a.copy().reshape(-1)
+        for i, val in enumerate((0.0, -0.0, 1.0, -1.0, np.inf)):
+            sp[(5 * i + 2) % sp.size] = val
+        osp, gsp = O.new(mk(sp.reshape(shape)), deg), G.new(mk(sp.reshape(shape)), deg)
+        cs_sp = [sc(float(c)) for c in rng.uniform(0.2, 1.5, size=n)]
+        check(osp.observe_chain(v, sc(0.7), cs_sp, max(deg)), gsp.observe_chain(v, sc(0.7), cs_sp, max(deg)))
         for x in (0.7, 0.0, 1.0):
             cs = [sc(float(c)) for c in rng.uniform(0.2, 1.5, size=n)]
             for d in (1, 3, max(deg)):
