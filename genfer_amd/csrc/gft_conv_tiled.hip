@@ -49,6 +49,7 @@ struct TileSeg {
 struct RedTile {
     unsigned u, a, b;
     unsigned first, count;           // pieces: red_slots[first .. first+count)
+    unsigned slot0;                  // red_slots == null: the pieces are the workspace slots slot0 .. slot0 + count - 1
 };
 
 struct TiledArgs {
@@ -506,7 +507,11 @@ __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red
         }
         const unsigned lo = (unsigned)((unsigned long long)rt.count * q / 4), hi = (unsigned)((unsigned long long)rt.count * (q + 1) / 4);
         for (unsigned p = lo; p < hi; ++p) {
-            const double* w = A.ws + (size_t)A.red_slots[rt.first + p] * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
+            // (a tile's partial slabs are consecutive workspace slots — the plan's ranges are contiguous in tile order — so
+            // the slab address follows from the tile's entry alone: one dependent load less in a launch that is nothing
+            // but a few memory latencies)
+            const unsigned slot = A.red_slots ? A.red_slots[rt.first + p] : rt.slot0 + p;
+            const double* w = A.ws + (size_t)slot * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += w[r];
         }
@@ -833,6 +838,7 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     wg_begin[P.n_wg] = (unsigned)segs.size();
     std::vector<RedTile> red;
     std::vector<unsigned> red_slots;
+    bool slots_consecutive = true;
     for (size_t i = 0; i < tiles.size(); ++i) {
         if (tile_direct[i] || tile_slots[i].empty()) continue;
         RedTile r;
@@ -841,6 +847,9 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
         r.b = tiles[i].b;
         r.first = (unsigned)red_slots.size();
         r.count = (unsigned)tile_slots[i].size();
+        r.slot0 = tile_slots[i][0];
+        for (size_t q = 0; q < tile_slots[i].size(); ++q)
+            if (tile_slots[i][q] != r.slot0 + q) slots_consecutive = false;
         for (unsigned sl : tile_slots[i]) red_slots.push_back(sl);
         red.push_back(r);
     }
@@ -885,6 +894,7 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     T.wg_begin = (const unsigned*)put(wg_begin.data(), b_wg);
     T.red = (const RedTile*)put(red.data(), b_red);
     T.red_slots = (const unsigned*)put(red_slots.data(), b_rs);
+    if (slots_consecutive) T.red_slots = nullptr;  // k_conv_reduce derives the slots from RedTile::slot0
     if (hbase && hipMemcpyAsync(base, hbase, off, hipMemcpyHostToDevice, st) != hipSuccess) return false;
     return true;
 }
