@@ -54,11 +54,7 @@ def cpu_baseline(shape, x, y, budget_hint_s=20.0):
     """Time the oracle (oracle/liborc.so: same loop nest / summation order as mt:971-1012, one
     thread, -O2 -ffp-contract=off) on a bounded sample of the SAME product: a few leading-axis
     output slabs, chosen so that the sample is ~10-30 s of CPU work."""
-    import subprocess
-
-    so = os.path.join(ROOT, "oracle", "liborc.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    so = os.path.join(ROOT, "oracle", "liborc.so")  # built by ensure_oracle() before the GPU was initialised
     lib = ctypes.CDLL(so)
     lib.orc_mul_slabs_timed.restype = ctypes.c_double
     szp = ctypes.POINTER(ctypes.c_size_t)
@@ -140,7 +136,7 @@ def cpu_baseline_all_cores(shape, x, y, max_threads=64):
     }
 
 
-PROFILE_ROUNDS = ("r03", "r02", "r01")  # newest first
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first
 
 
 def pmc_traffic(world, workload):
@@ -168,59 +164,91 @@ def pmc_traffic(world, workload):
     return None, "no committed PMC profile of this workload"
 
 
-# (name, program under tests/golden/sgcl/, flags, CPU-oracle runs).  The first four are the NeurIPS'23 programs BASELINE
-# names; two_populations2000 is the reference's own slow/ fixture of general Horner loops; three_ / four_populations are
-# this repo's programs in which rank-3 / rank-4 GENERAL products dominate (the kernel the headline metric measures).
+# (name, program under tests/golden/sgcl/, flags, CPU-oracle runs, committed oracle report or None, recorded CPU seconds or
+# None).  The first four are the NeurIPS'23 programs BASELINE names; two_populations2000 is the reference's own slow/ fixture of
+# general Horner loops; three_ / four_populations are this repo's programs in which rank-3 / rank-4 GENERAL products dominate.
+# Every row is CHECKED at the size it is timed at: against the oracle report computed in the same call, or — where the oracle
+# needs minutes — against the committed oracle report (tests/golden/make_c3_limit100_golden.py).
 E2E_PROGRAMS = (
-    ("hmm", "neurips2023/approx/hmm/hmm.sgcl", "--limit 100", 2),
-    ("mixture", "neurips2023/approx/mixture/mixture.sgcl", "--limit 100", 1),
-    ("two_populations", "neurips2023/approx/two_populations/two_populations.sgcl", "--limit 100", 2),
-    ("switchpoint", "neurips2023/approx/switchpoint/switchpoint.sgcl", "--limit 100", 2),
-    ("two_populations2000", "test_expect/slow/two_populations2000.sgcl", "", 2),
-    ("three_populations", "bench/three_populations.sgcl", "--limit 100", 1),
-    ("four_populations", "bench/four_populations.sgcl", "--limit 24", 1),
-    # TaylorPoly<Interval<F64>> (`--bounds`): GPU only — the CPU oracle needs 26 s (hmm) and 12 minutes (mixture) for these
-    # (profiles/r02/e2e_neurips_limit100_bounds_with_cpu_oracle_earlier_collection.json)
-    ("hmm_bounds", "neurips2023/approx/hmm/hmm.sgcl", "--limit 100 --bounds", 0),
-    ("mixture_bounds", "neurips2023/approx/mixture/mixture.sgcl", "--limit 100 --bounds", 0),
+    ("hmm", "neurips2023/approx/hmm/hmm.sgcl", "--limit 100", 2, None, None),
+    ("mixture", "neurips2023/approx/mixture/mixture.sgcl", "--limit 100", 1, None, None),
+    ("two_populations", "neurips2023/approx/two_populations/two_populations.sgcl", "--limit 100", 2, None, None),
+    ("switchpoint", "neurips2023/approx/switchpoint/switchpoint.sgcl", "--limit 100", 2, None, None),
+    ("two_populations2000", "test_expect/slow/two_populations2000.sgcl", "", 2, None, None),
+    ("three_populations", "bench/three_populations.sgcl", "--limit 100", 1, "three_populations.oracle.txt", None),
+    ("four_populations", "bench/four_populations.sgcl", "--limit 24", 1, "four_populations.oracle.txt", None),
+    # TaylorPoly<Interval<F64>> (`--bounds`): the CPU oracle needs ~26 s for hmm (run once here) and 12 minutes for mixture
+    # (recorded figure + committed oracle report)
+    ("hmm_bounds", "neurips2023/approx/hmm/hmm.sgcl", "--limit 100 --bounds", 1, "hmm-bounds.oracle.txt", None),
+    ("mixture_bounds", "neurips2023/approx/mixture/mixture.sgcl", "--limit 100 --bounds", 0, "mixture-bounds.oracle.txt",
+     (717.0, "profiles/r02/e2e_neurips_limit100_bounds_with_cpu_oracle_earlier_collection.json (round 2, another box)")),
 )
 
 
-def e2e_seconds(gpu_runs=5):
+def e2e_seconds(gpu_runs=5, oracle_available=True):
     """BASELINE's second metric: end-to-end seconds ("Total inference time", best of N — the protocol of the
     reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105) on NeurIPS'23 programs at --limit 100: the host
     interpreter over libgftaylor (GPU, best of 5) and, beside it, the same interpreter over the CPU oracle on this
-    box's host (1 thread; best of 2, a single run for the 20-second mixture)."""
+    box's host (1 thread; best of 2, a single run for the long ones).  `parity`: the GPU report of the timed
+    configuration against the oracle's report (genfer_amd/reports.py: 1e-10 on primary quantities) — "ok" or the first
+    difference; a difference makes bench.py exit non-zero."""
     import genfer_amd
+    from genfer_amd.reports import first_difference
 
     oracle = os.path.join(ROOT, "oracle", "liborc.so")
     rows = {}
-    for name, rel, flags, cpu_runs in E2E_PROGRAMS:
+    failed = False
+    for name, rel, flags, cpu_runs, stored, recorded in E2E_PROGRAMS:
         src = open(os.path.join(ROOT, "tests", "golden", "sgcl", rel)).read()
         first = src.splitlines()[0] if src else ""
         if first.startswith("# flags:"):  # the fixture's own flags (tests/integration.rs protocol)
             flags = (first[len("# flags:"):].strip() + " " + flags).strip()
         row = {"flags": flags}
+        run_flags = "--no-timing " + flags  # the seconds come back beside the report; the report then has no clock in it
+        texts = {}
+        if not oracle_available:
+            cpu_runs = 0
         for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs if cpu_runs else min(gpu_runs, 3)),
                                        ("cpu_oracle_s", oracle, "orc_", cpu_runs)):
             best = None
             for _ in range(runs):
                 before = genfer_amd.op_stats() if key == "gpu_s" else None
                 pfx = prefix[:-1] + "i_" if "--bounds" in flags.split() else prefix  # the Interval<F64> entry points
-                rc, text, t = genfer_amd.run_sgcl_with_backend(src, flags, lib, pfx)
+                rc, text, t = genfer_amd.run_sgcl_with_backend(src, run_flags, lib, pfx)
                 if rc != 0:
                     row[key + "_error"] = text[-200:]
                     best = None
+                    if key == "gpu_s":
+                        failed = True
                     break
+                texts[key] = text
                 best = t["time_infer"] if best is None else min(best, t["time_infer"])
                 if before is not None:  # what one run of the program costs (the same every run)
                     after = genfer_amd.op_stats()
-                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged"):
+                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged", "per_output"):
                         row[k] = after[k] - before[k]
             row[key] = best
             row[key.replace("_s", "_runs")] = runs
+        if recorded and row.get("cpu_oracle_s") is None:
+            row["cpu_oracle_s_recorded"] = {"value": recorded[0], "source": recorded[1]}
+        # parity of the timed configuration, at the timed size
+        want, against = None, None
+        if "cpu_oracle_s" in texts:
+            want, against = texts["cpu_oracle_s"], "the oracle's report computed in this call"
+        elif stored and os.path.exists(os.path.join(ROOT, "tests", "golden", "c3_limit100", stored)):
+            want = open(os.path.join(ROOT, "tests", "golden", "c3_limit100", stored)).read()
+            against = f"committed oracle report tests/golden/c3_limit100/{stored}"
+        if "gpu_s" in texts and want is not None:
+            diff = first_difference(texts["gpu_s"], want)
+            row["parity"] = "ok" if diff is None else diff
+            row["parity_against"] = against
+            if diff is not None:
+                failed = True
+        else:
+            row["parity"] = "unchecked (no oracle report available)"
         rows[name] = row
-    return {"unit": "s", "protocol": "best-of-N Total inference time (flags per program)", "programs": rows}
+    return {"unit": "s", "protocol": "best-of-N Total inference time (flags per program)", "programs": rows,
+            "parity_failed": failed}
 
 
 _CLOCK_HELPER = r"""
@@ -233,6 +261,22 @@ if line.strip() == "go" and exe:
     except Exception:
         pass
 """
+
+
+def ensure_oracle():
+    """The checker / CPU baseline (oracle/liborc.so) must exist BEFORE this process touches the GPU: building it spawns
+    `make`, and a process that has initialised HIP must not fork + exec on this pool.  *.so files are git-ignored, so a
+    fresh checkout needs this.  Returns whether the library is there; without it the CPU legs are skipped with a note."""
+    import subprocess
+
+    so = os.path.join(ROOT, "oracle", "liborc.so")
+    if os.path.exists(so):
+        return True
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001
+        return False
+    return os.path.exists(so)
 
 
 def start_clock_helper():
@@ -296,7 +340,8 @@ def main():
     ap.add_argument("--no-clock", action="store_true", help="do not sample the shader clock under load (rocm-smi)")
     args = ap.parse_args()
 
-    # (before anything initialises the GPU: see start_clock_helper)
+    # (before anything initialises the GPU: see start_clock_helper / ensure_oracle — nothing below spawns a process)
+    have_oracle = ensure_oracle() if int(os.environ.get("RANK", "0")) == 0 else os.path.exists(os.path.join(ROOT, "oracle", "liborc.so"))
     clock_helper = None
     if not args.no_clock and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         clock_helper = start_clock_helper()
@@ -452,8 +497,7 @@ def main():
                            f"({'inside libgftaylor (gft_conv_raw_sharded)' if exchange == 'abi' else 'torch.distributed'})",
         },
         "roofline": {
-            "bound": "valu_fma_f64",
-            "bound_contract_class": "mfma",  # the contract's two classes are "hbm" | "mfma": this is the compute one
+            "bound": "valu_fma_f64",  # (compute-bound, but not on the matrix pipe: see bound_detail)
             "bound_detail": "FP64 FMA issue rate of the vector pipe (v_fma_f64); no MFMA instruction is issued — on gfx950 "
                             "the FP64 matrix peak is the same 78.6 TFLOP/s and measured lower (profiles/r02/microbench_fp64.txt)",
             "achieved": achieved_tflops,
@@ -487,7 +531,10 @@ def main():
             clock_helper.stdin.close()  # never told to sample: let it go
         except Exception:  # noqa: BLE001
             pass
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not have_oracle:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "oracle/liborc.so is missing and could not be built before GPU initialisation; CPU legs skipped"
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref_slabs, slabs = cpu_baseline(shape, xh, yh)
         out["cpu_baseline"] = base
         out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(shape, xh, yh)
@@ -534,7 +581,9 @@ def main():
             if exchange_note:
                 out["exchange_note"] = exchange_note
     if rank == 0 and world == 1 and not args.no_e2e and args.workload == "c2":
-        out["e2e"] = e2e_seconds()
+        out["e2e"] = e2e_seconds(oracle_available=have_oracle)
+        if out["e2e"].pop("parity_failed"):
+            out["parity_failed"] = True
     bad = bool(out.get("parity_failed")) or any(t < 0 for t in kern_ms)
     if rank == 0:
         print(json.dumps(out))

@@ -17,7 +17,7 @@ import os
 
 # Launch-bound programs (10^5 small dependent kernels) run measurably faster with kernel arguments in device memory; the
 # HIP runtime reads the flag when it initialises, so it is set as early as this package can (a user's own value wins).
-# libgftaylor sets it too when it is loaded (gft_api.hip, prefer_device_kernargs).
+# This is the HOST's choice: libgftaylor itself never touches the environment.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from .taylor import USIZE_MAX, TaylorError, bind  # noqa: F401
@@ -156,15 +156,16 @@ def run_sgcl(source: str, flags: str = ""):
 
 OP_STATS = ("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops",
             "host_to_device_mirrors")
-OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_launches")
+OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_launches", "launches_in_place", "shallow_products",
+               "fused_horner_steps")
 
 
 def op_stats() -> dict:
     """Cumulative counters of the library since gft_init (gft_op_stats + gft_op_stats_ex) by name."""
     L = lib()
-    a, b = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)()
+    a, b = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 16)()
     L.gft_op_stats(a)
-    n = L.gft_op_stats_ex(b, 8)
+    n = min(L.gft_op_stats_ex(b, 16), 16)
     out = dict(zip(OP_STATS, (int(v) for v in a)))
     out.update(dict(zip(OP_STATS_EX, (int(v) for v in b[:n]))))
     return out

@@ -153,6 +153,12 @@ struct Runtime {
     bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
     bool div_wavefront = true;     // GFT_DIV_WAVEFRONT=0 / "div_wavefront": the blocked recurrence instead of the one-launch row wavefront
     bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
+    // Shallow products (round 4): a plain product whose outputs receive at most this many terms each (prod_i min(xs_i, ys_i):
+    // one operand is a stencil — the substitutions of `+~ Binomial(other, p)` statements are 3-6 coefficients) runs on the
+    // reference-order one-thread-per-output kernel with the Horner step's Add fused in (K<E>::conv_shallow) instead of the
+    // tiled / staged kernels.  0 = off ("shallow_max_terms" / GFT_SHALLOW_MAX_TERMS; A/B and bisecting).
+    size_t shallow_max_terms = 64;
+    size_t stats_shallow[2] = {0, 0};  // {shallow products, of which fused Horner steps}
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
     void* conv_ws = nullptr;
@@ -360,6 +366,8 @@ struct Pend {
     std::shared_ptr<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
     Dims mat_shape;
 };
+
+std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<TabEntry>> g_pow_tabs[2];  // Ops<E>::pow_table
 
 }  // namespace
 
@@ -639,14 +647,14 @@ struct Ops {
         if (host) std::memcpy(dst, src, sizeof(double) * n);
         else {
             hipStream_t st = R.stream;
-            enqueue_task([=] { (void)(hipMemcpyAsync)(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st); });
+            enqueue_task([=] { lq_note((hipMemcpyAsync)(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st), nullptr, "hipMemcpyAsync (device to device)"); });
         }
     }
     static void zero_elems(bool host, double* dst, size_t n) {
         if (host) std::memset(dst, 0, sizeof(double) * n);
         else {
             hipStream_t st = R.stream;
-            enqueue_task([=] { (void)(hipMemsetAsync)(dst, 0, sizeof(double) * n, st); });
+            enqueue_task([=] { lq_note((hipMemsetAsync)(dst, 0, sizeof(double) * n, st), nullptr, "hipMemsetAsync"); });
         }
     }
     static DView dview(const HV& v, const Dims* keep = nullptr) {
@@ -777,7 +785,8 @@ struct Ops {
     // host tier's functor, kept on the device per value of m (a longer request re-forms the table: the running product
     // makes every table a prefix of the longer one)
     static std::shared_ptr<TabEntry> pow_table(const double m[2], size_t len) {
-        static std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<TabEntry>> cache;
+        // (file-scope registry, one per element width: gft_shutdown releases it with the pool it allocates from)
+        std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<TabEntry>>& cache = g_pow_tabs[W - 1];
         unsigned long long k0, k1 = 0;
         std::memcpy(&k0, &m[0], 8);
         if (W == 2) std::memcpy(&k1, &m[1], 8);
@@ -1446,6 +1455,23 @@ struct Ops {
         }
         if (x.host || y.host) throw Error("internal: device product with a host operand");
 
+        // Shallow product (a stencil): few terms per output, HBM-bound streaming work — the reference-order per-output
+        // kernel (bit-exact) beats the compute-bound tiled kernel and the barrier-per-step staged one by an order of
+        // magnitude there (three_populations' Horner steps: 80 -> 8 us).
+        if (R.conv_mode == 0 && R.shallow_max_terms && !slab_mode && !accumulate && a.nd >= 1 && a.slab_lo == 0 && a.slab_hi == a.zs[0]) {
+            size_t terms = 1;
+            for (int i = 0; i < a.nd; ++i) terms *= std::min(a.xs[i], a.ys[i]);
+            if (terms <= R.shallow_max_terms) {
+                ConvEpi e;
+                std::memset(&e, 0, sizeof(e));
+                for (int i = 0; i < a.nd; ++i) e.os[i] = a.zs[i];
+                if (K<E>::conv_shallow(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, e)) {
+                    R.stats[5]++;
+                    R.stats_shallow[0]++;
+                    return;
+                }
+            }
+        }
         bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
         // A recurrence step (one output slab k with j0 >= j0_min and/or j0 < k) is a plain slab product of shifted
         // operand views:  sum_{j0 >= m, j0 <= k - e} x[j0] y[k - j0]  =  slab k - m - e of  x[m:] (*) y[e:]  (e = 1
@@ -1825,8 +1851,8 @@ struct Ops {
             hipStream_t ms = R.stream, ss = R.side;
             hipEvent_t ev = R.ev_main;
             enqueue_task([=] {  // slab final (+ critical update): the bulk may read it
-                (void)(hipEventRecord)(ev, ms);
-                (void)(hipStreamWaitEvent)(ss, ev, 0);
+                lq_note((hipEventRecord)(ev, ms), nullptr, "hipEventRecord (main stream)");
+                lq_note((hipStreamWaitEvent)(ss, ev, 0), nullptr, "hipStreamWaitEvent (side stream)");
             });
         }
         std::swap(R.stream, R.side);
@@ -1840,7 +1866,7 @@ struct Ops {
         {
             hipStream_t ss = R.side;
             hipEvent_t ev = R.ev_bulk;
-            enqueue_task([=] { (void)(hipEventRecord)(ev, ss); });
+            enqueue_task([=] { lq_note((hipEventRecord)(ev, ss), nullptr, "hipEventRecord (side stream)"); });
         }
         R.side_pending = true;
     }
@@ -1849,7 +1875,8 @@ struct Ops {
     struct SideDrain {
         ~SideDrain() {
             if (R.side_pending && std::uncaught_exceptions()) {
-                (void)hipStreamSynchronize(R.side);
+                launch_drain_nothrow();  // (a destructor during unwinding: a latched launch failure stays latched)
+                (void)(hipStreamSynchronize)(R.side);
                 R.side_pending = false;
             }
         }
@@ -1860,7 +1887,7 @@ struct Ops {
         {
             hipStream_t ms = R.stream;
             hipEvent_t ev = R.ev_bulk;
-            enqueue_task([=] { (void)(hipStreamWaitEvent)(ms, ev, 0); });
+            enqueue_task([=] { lq_note((hipStreamWaitEvent)(ms, ev, 0), nullptr, "hipStreamWaitEvent (main stream)"); });
         }
         R.side_pending = false;
     }
@@ -2716,6 +2743,7 @@ struct Ops {
                 continue;
             }
             if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
+            bool witnessed = false;
             if (lin_known && res.shape.size() == deg.size()) {
                 // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
                 if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots)) {
@@ -2724,14 +2752,22 @@ struct Ops {
                 }
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
             } else {
-                res = addsub(mul_horner(res, subst), horner_coeff(ca, v, i, deg), false);
+                P nxt;
+                if (horner_general_step_fused(res, subst, ca, v, i, deg, (i > 0 && !proven) ? R.d_wit + slots : nullptr, &nxt)) {
+                    res = nxt;
+                    witnessed = true;  // (the step's kernel raised the witness word itself)
+                } else {
+                    res = addsub(mul_horner(res, subst), horner_coeff(ca, v, i, deg), false);
+                }
             }
             if (on_host(res) || res.numel == 1) return false;  // left the speculated regime: take the exact loop
             if (i == 0) break;  // the last accumulator is the result: nothing is speculated about it
             if (!proven) {
-                Dims keep = collapse_mask({&res.shape}, false);
-                HV rv = view(res);
-                K<E>::witness(R.stream, dview(rv, &keep), R.d_wit + slots);
+                if (!witnessed) {
+                    Dims keep = collapse_mask({&res.shape}, false);
+                    HV rv = view(res);
+                    K<E>::witness(R.stream, dview(rv, &keep), R.d_wit + slots);
+                }
                 slots++;
             }
         }
@@ -2769,6 +2805,87 @@ struct Ops {
         P out = make(shape, deg);
         conv(view(self), view(other), view(out), 0, shape.empty() ? 1 : shape[0], false, false, 0, 0, 0);
         return out;
+    }
+    // One GENERAL Horner step  res * subst + a[.., i, ..]  (mt:569-579) in ONE launch when the product is shallow (`subst`
+    // a stencil of a few coefficients — the compound-distribution substitutions of Genfer's programs): the product's
+    // reference-order sums, then Add's operations on each finished sum ((0 + prod) + slab, or element 0 += slab for a
+    // 1-element slab), then the witness of non-linearity the speculative loop needs — instead of product (+ prep / reduce /
+    // guard launches on the tiled kernel) + slab gather + add + witness.  Operation for operation what
+    // addsub(mul_horner(res, subst), horner_coeff(ca, v, i, deg)) computes (the product on the reference-order kernel), so
+    // the result carries the reference's bits.  false: not this case — nothing launched, the caller takes that sequence.
+    static bool horner_general_step_fused(const P& res, const P& subst, const P& ca, size_t v, size_t i, const Dims& deg,
+                                          unsigned* wit, P* result) {
+        if (!R.shallow_max_terms || R.conv_mode != 0) return false;
+        if (res.numel == 1 || subst.numel == 1 || on_host(res)) return false;
+        P self = res, other = subst;
+        Dims mdeg = min_degrees(self, other);
+        broadcast(self, other);
+        Dims shape = sum_shape(self, other);
+        const size_t nd = shape.size();
+        if (nd != deg.size() || ca.shape.size() != nd) return false;
+        for (size_t ax = 0; ax < nd; ++ax)  // nothing to truncate (the loop's accumulators never exceed deg)
+            if (self.shape[ax] > mdeg[ax] || other.shape[ax] > mdeg[ax]) return false;
+        size_t terms = 1;
+        for (size_t ax = 0; ax < nd; ++ax) terms *= std::min(self.shape[ax], other.shape[ax]);
+        if (terms > R.shallow_max_terms) return false;
+        {
+            double c[2], m[2];
+            size_t u;
+            if (extract_linear(other, c, m, &u)) return false;  // (memoised on subst's buffer) the mul_linear path is the reference's
+        }
+        // the Add: degrees, the slab's box, the result's shape (mt:854-882)
+        Dims rd(nd, UMAX), oc = ca.shape;
+        oc[v] = 1;
+        for (size_t ax = 0; ax < nd; ++ax) {
+            rd[ax] = std::min(mdeg[ax], deg[ax]);
+            oc[ax] = std::min(oc[ax], deg[ax]);
+            if (shape[ax] > rd[ax] || oc[ax] > rd[ax]) return false;
+        }
+        const bool slab_scalar = prod(oc) == 1;
+        Dims oshape = shape;
+        if (!slab_scalar)
+            for (size_t ax = 0; ax < nd; ++ax) oshape[ax] = std::max(shape[ax], oc[ax]);
+        // the kernel's loop nest is the reference's only if the product's own non-unit axes are the output's
+        for (size_t ax = 0; ax < nd; ++ax)
+            if ((oshape[ax] > 1) != (shape[ax] > 1)) return false;
+        Dims keep = collapse_mask({&shape}, false);
+        if (keep.empty() || keep.size() > 6) return false;
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        ConvEpi e;
+        std::memset(&e, 0, sizeof(e));
+        a.nd = (int)keep.size();
+        Dims xs = pick(self.shape, keep), ys = pick(other.shape, keep), zs = pick(shape, keep);
+        Dims xst = c_strides(xs), yst = c_strides(ys), zst = c_strides(zs), cst = c_strides(ca.shape);
+        for (int j = 0; j < a.nd; ++j) {
+            a.xs[j] = (unsigned)xs[j];
+            a.ys[j] = (unsigned)ys[j];
+            a.zs[j] = (unsigned)zs[j];
+            a.xstr[j] = xst[j];
+            a.ystr[j] = yst[j];
+            a.zstr[j] = zst[j];
+            e.os[j] = (unsigned)oshape[keep[j]];
+            e.abox[j] = (unsigned)oc[keep[j]];
+            e.astr[j] = keep[j] == v ? 0 : cst[keep[j]];
+        }
+        a.slab_lo = 0;
+        a.slab_hi = a.zs[0];
+        a.inner_from_zero = 1;  // every kept axis is non-unit: the last one is the reference's 1-d base case (mt:992-1000)
+        a.variant = R.conv_variant;
+        e.mode = slab_scalar ? 2 : 1;
+        const double* cap = dp<E>(ca);  // (a deferred / host-tier coefficient tensor is materialised once for the whole loop)
+        e.ap = cap + i * cst[v];
+        e.aplane = ca.numel;
+        e.wit = wit;
+        const double* xp_ = dp<E>(self);
+        const double* yp_ = dp<E>(other);
+        P out = make(oshape, rd);
+        if (!K<E>::conv_shallow(R.stream, xp_, self.numel, yp_, other.numel, out.buf->p, out.numel, a, e)) return false;
+        R.stats[5]++;
+        R.stats_shallow[0]++;
+        R.stats_shallow[1]++;
+        *result = out;
+        return true;
     }
     // res * (c + m*eps_w) + a[.., i, ..] in one launch (k_horner_linear), element for element the sequence
     // mul -> mul_linear -> mul_var / scale / add -> add that the generic loop above performs.  The generic mul
@@ -3271,6 +3388,7 @@ int gft_init(int device) {
         if (const char* hm = getenv("GFT_HOST_MAX_ELEMS")) R.host_max_elems = (size_t)atoll(hm);
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
+        if (const char* sm = getenv("GFT_SHALLOW_MAX_TERMS")) R.shallow_max_terms = (size_t)atoll(sm);
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;
@@ -3288,6 +3406,7 @@ void gft_shutdown(void) {
     lq_shutdown();
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
+    for (auto& c : g_pow_tabs) c.clear();  // device tables of this context: back into the pool before it is freed
     dwf_release_orders();
     staged_release_scratch();
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
@@ -3338,9 +3457,10 @@ void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
 size_t gft_op_stats_ex(size_t* out, size_t cap) {
-    const size_t v[4] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2]};
-    for (size_t i = 0; i < 4 && i < cap; ++i) out[i] = v[i];
-    return 4;
+    const size_t v[7] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
+                         R.stats_shallow[0], R.stats_shallow[1]};
+    for (size_t i = 0; i < 7 && i < cap; ++i) out[i] = v[i];
+    return 7;
 }
 void gft_pool_stats(size_t out[3]) {
     out[0] = R.in_use;
@@ -3377,6 +3497,8 @@ int gft_set_option(const char* name, double value) {
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
+    else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 64 : (size_t)value;  // < 0: default
+    else if (n == "debug_fail_next_launch") g_fail_next_launch.store(value != 0 ? 1 : 0);  // test knob (gft_launch.hpp)
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
@@ -3532,7 +3654,8 @@ static void dist_conv(const typename O::HV& x, const typename O::HV& y, const ty
         int ev;
         ~AfterLocal() {
             if (ev >= 0) {
-                (void)hipEventRecord(R.events[ev + 1], R.stream);
+                launch_drain_nothrow();  // (destructor: a latched launch failure is raised by the next throwing drain)
+                (void)(hipEventRecord)(R.events[ev + 1], R.stream);
                 D.ev_slot = ev + 2 <= 62 ? ev + 2 : -1;
             }
         }

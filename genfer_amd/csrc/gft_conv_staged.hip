@@ -768,6 +768,11 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.xrs[ax] = a.xstr[ax] / nx2;
         g.yrs[ax] = a.ystr[ax] / n2;
     }
+    // (every "not this kernel" exit comes before the first launch: a false return promises that nothing was launched)
+    unsigned long long blocks = g.n_pg;
+    for (int ax = 0; ax < P; ++ax) blocks *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
+    if (blocks == 0) return true;
+    if (blocks > 0x7fffffffULL) return false;
     RbScratch& sc = rb_scratch()[st];
     if (sc.bytes < xrows + yrows) {
         if (sc.p) (void)hipFree(sc.p);
@@ -785,10 +790,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     g.yflags = sc.p + xrows;
     GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
     GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
-    unsigned long long blocks = g.n_pg;
-    for (int ax = 0; ax < P; ++ax) blocks *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
-    if (blocks == 0) return true;
-    if (blocks > 0x7fffffffULL) return false;
     const unsigned threads = g.ntw * g.tb * 64;
     const size_t lds = lds_of(g.tb);
     static bool attr_set = false;

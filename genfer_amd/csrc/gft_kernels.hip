@@ -8,17 +8,20 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
+#include <string>
 #include <thread>
 
 namespace gft {
 
 unsigned long long g_launches = 0;
+unsigned long long g_launches_in_place = 0;
 
 // ------------------------------------------------------------------------------------------
 // the launch thread (gft_launch.hpp): single-producer / single-consumer ring of launch closures
 // ------------------------------------------------------------------------------------------
 namespace {
-constexpr uint64_t LQ_SLOTS = 1024;  // power of two; 2 MB of slots
+constexpr uint64_t LQ_SLOTS = 1024;  // power of two; 4 MB of slots
 struct LaunchQueue {
     std::atomic<uint64_t> head{0};   // consumer: slots [0, head) have been issued
     std::atomic<uint64_t> tail{0};   // producer: slots [0, tail) have been written
@@ -81,6 +84,41 @@ struct LaunchQueue {
 LaunchQueue g_lq;
 }  // namespace
 
+std::atomic<int> g_fail_next_launch{0};
+namespace {
+std::mutex g_lq_err_m;
+std::atomic<bool> g_lq_err_set{false};
+hipError_t g_lq_err = hipSuccess;
+const void* g_lq_err_kernel = nullptr;
+const char* g_lq_err_what = nullptr;
+}  // namespace
+void lq_note(hipError_t e, const void* kernel, const char* what) {
+    if (e == hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_lq_err_m);
+    if (g_lq_err_set.load(std::memory_order_relaxed)) return;  // the first failure is the one that explains the rest
+    g_lq_err = e;
+    g_lq_err_kernel = kernel;
+    g_lq_err_what = what;
+    g_lq_err_set.store(true, std::memory_order_release);
+}
+static void lq_raise() {
+    if (!g_lq_err_set.load(std::memory_order_acquire)) return;
+    std::string msg;
+    {
+        std::lock_guard<std::mutex> lk(g_lq_err_m);
+        msg = std::string("HIP error: ") + hipGetErrorString(g_lq_err);
+        if (g_lq_err_kernel) {
+            const char* name = hipKernelNameRefByPtr(g_lq_err_kernel, nullptr);
+            msg += std::string(" launching ") + (name ? name : "a kernel");
+        } else if (g_lq_err_what) {
+            msg += std::string(" in queued ") + g_lq_err_what;
+        }
+        msg += " (issued by the launch thread; results computed since are invalid)";
+        g_lq_err_set.store(false, std::memory_order_relaxed);
+    }
+    throw std::runtime_error(msg);
+}
+
 bool lq_enabled() { return g_lq.enabled; }
 int lq_debug() {
     static const int d = [] {
@@ -94,8 +132,15 @@ void lq_configure(int device, bool enabled) {
     g_lq.device = device;
     g_lq.enabled = enabled;
 }
-void lq_shutdown() { g_lq.shutdown(); }
-void launch_drain() { g_lq.drain(); }
+void lq_shutdown() {
+    g_lq.shutdown();
+    g_lq_err_set.store(false);  // a failure nobody asked about dies with the runtime
+}
+void launch_drain_nothrow() { g_lq.drain(); }
+void launch_drain() {
+    g_lq.drain();
+    lq_raise();
+}
 LaunchSlot* lq_begin() {
     if (!g_lq.worker.joinable()) g_lq.start();
     const uint64_t t = g_lq.tail.load(std::memory_order_relaxed);
@@ -1253,6 +1298,83 @@ void K<E>::conv_naive(hipStream_t st, const double* x, size_t x_plane, const dou
     else launch_conv_naive<E, false>(st, x, x_plane, y, y_plane, z, z_plane, a);
 }
 
+// ------------------------------------------------------------------------------------------
+// Shallow products with a fused Add (round 4): the GENERAL Horner step  res * subst + slab_i  (mt:569-579) in one launch.
+// The substitutions Genfer's programs produce (`b +~ Binomial(a, p)`: a -> a (1 - p + p b)) are 3-6 coefficient
+// tensors, so a step's product is a small STENCIL over the accumulator: a handful of terms per output, HBM-bound
+// streaming work for which the compute-bound tiled kernel (8x8x8 chunk products over zero padding, plus its prep /
+// reduce / guard launches) was 10x too slow.  Same loop nest as k_conv_naive (the reference's order: bit-exact), 32-bit
+// index arithmetic, and the consumer's operations applied to the finished sum where it stands:
+//   mode 1   out[k] = ((0 + prod[k])? + slab[k]?)   on the leading boxes of out — Add of two tensors (mt:873-880)
+//   mode 2   out = prod, element 0 = prod[0] + slab[0]                         — Add of a 1-element slab (mt:862-869)
+//   mode 0   out = prod
+// and, optionally, the speculative Horner loop's witness of non-linearity on the result (k_witness).
+// ------------------------------------------------------------------------------------------
+template <class E, int ND, bool INNER0>
+__global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__ x, size_t xp, const double* __restrict__ y,
+                                                      size_t yp, double* __restrict__ out, size_t op, ConvArgs a, ConvEpi e,
+                                                      unsigned total) {
+    typedef typename E::V V;
+    int found = 0;
+    for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < total; lin += gridDim.x * 256u) {
+        unsigned k[ND];
+        unsigned r = lin;
+        bool inz = true, ina = e.mode == 1, big = false;
+        int nz = 0;
+        size_t aoff = 0;
+#pragma unroll
+        for (int ax = ND - 1; ax >= 0; --ax) {
+            const unsigned d = e.os[ax];
+            const unsigned kk = r % d;
+            r /= d;
+            k[ax] = kk;
+            if (kk >= a.zs[ax]) inz = false;
+            if (kk >= e.abox[ax]) ina = false;
+            aoff += (size_t)kk * e.astr[ax];
+            if (kk) nz++;
+            if (kk >= 2) big = true;
+        }
+        V v = E::zero();
+        if (inz) {
+            V acc = E::zero();
+            ConvLoop<E, 0, ND, INNER0>::run(a, k, x, xp, y, yp, 0, 0, acc);
+            v = e.mode == 1 ? E::add(v, acc) : acc;
+        }
+        if (e.mode == 1) {
+            if (ina) v = E::add(v, E::ld(e.ap, e.aplane, aoff));
+        } else if (e.mode == 2 && lin == 0) {
+            v = E::add(v, E::ld(e.ap, e.aplane, 0));
+        }
+        E::st(out, op, lin, v);
+        if (e.wit && (big || nz >= 2) && !E::is_zero(v)) found = 1;
+    }
+    if (e.wit) {  // (kernel argument: uniform)
+        if (__syncthreads_or(found) && threadIdx.x == 0) __hip_atomic_store(e.wit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <class E>
+bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* out,
+                        size_t out_plane, const ConvArgs& a, const ConvEpi& e) {
+    if (a.nd < 1 || a.nd > 6 || a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || a.guard) return false;
+    if (a.slab_lo != 0 || a.slab_hi != a.zs[0]) return false;
+    unsigned long long total = 1;
+    for (int i = 0; i < a.nd; ++i) total *= e.os[i];
+    if (total == 0 || total > 0x7fffffffull) return false;
+    dim3 g(grid_for((size_t)total)), b(256);
+#define GFT_CASE(N)                                                                                                        \
+    case N:                                                                                                                \
+        if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
+        else GFT_LAUNCH((k_conv_shallow<E, N, false>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
+        break;
+    switch (a.nd) {
+        GFT_CASE(1) GFT_CASE(2) GFT_CASE(3) GFT_CASE(4) GFT_CASE(5) GFT_CASE(6)
+        default: return false;
+    }
+#undef GFT_CASE
+    return true;
+}
+
 template <class E>
 __global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict__ res, size_t rp, const double* __restrict__ a,
                                                        size_t ap, double* __restrict__ out, size_t op, HornerArgs g,
@@ -1335,8 +1457,8 @@ __device__ inline Iv wave_shr1_any<EIv>(Iv v) { return Iv{wave_shr1_d(v.lo), wav
 // nor merge and whose result register it tracks like any other load's (round 3 first wrote these as inline-asm ds_read
 // with a later s_waitcnt: the compiler, thinking the register defined at the asm statement, was free to copy it before
 // the data arrived — wrong bounds in a fraction of the runs) — and looks at it a step later; an EMPTY slot is polled.
-// Should a genuine value ever carry the EMPTY pattern the reader accepts it after ~1 s of polling (the writer is long
-// done by then): slow, never wrong.
+// Should a genuine value ever carry the EMPTY pattern (an input NaN with exactly that payload) the reader accepts it
+// after 2^24 polls (ring_receive: the bound counts co-resident polls, so the writer is long done by then): slow, never wrong.
 constexpr unsigned long long RING_EMPTY = 0x7ff8dead5a5a0badull;
 __device__ inline unsigned long long ring_load_bits(const double* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1365,8 +1487,13 @@ __device__ inline Iv ring_value<EIv>(const RingWord& w) { return Iv{bits_f64((lo
 // the value of `slot`, requested earlier as `w`: polls while it is still EMPTY
 template <class E>
 __device__ inline typename E::V ring_receive(const double* slot, size_t plane, RingWord w) {
-    for (unsigned spins = 0; !ring_ready<E>(w) && spins < (1u << 22); ++spins) {
-        __builtin_amdgcn_s_sleep(1);
+    // The bound counts POLLS OF THIS WAVE, not wall-clock time: producer and consumer are waves of one workgroup, which is
+    // dispatched, preempted and resumed as a whole, so the count only advances while the producer is resident too — a
+    // pre-empted / context-saved queue stops both.  2^24 polls (seconds of co-resident time; the producer needs one step,
+    // ~1 us) are only exhausted if a genuine value carries the EMPTY pattern: it is then accepted, late, never wrong.
+    for (unsigned spins = 0; !ring_ready<E>(w) && spins < (1u << 24); ++spins) {
+        if (spins < 4096) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(4);
         w = ring_request<E>(slot, plane);
     }
     return ring_value<E>(w);

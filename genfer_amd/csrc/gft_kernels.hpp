@@ -209,6 +209,19 @@ struct ConvArgs {
     unsigned guard_epoch;       // (fallback for non-finite operands of the tiled kernel, decided on the device)
 };
 
+// What a shallow product's kernel does with each finished sum (K<E>::conv_shallow): the Add that follows the product in
+// a general Horner step  res * subst + slab_i  (mt:569-579), applied where the sum stands.
+struct ConvEpi {
+    int mode;              // 0: out = prod; 1: out[k] = ((0 + prod[k])? + slab[k]?) on the boxes zs / abox of the output
+                           // shape os (mt:873-880); 2: out = prod with element 0 = prod[0] + slab[0] (mt:862-869)
+    unsigned os[MAXD];     // output shape (collapsed axes; modes 0 / 2: == zs)
+    unsigned abox[MAXD];   // slab box (mode 1)
+    size_t astr[MAXD];     // slab strides in its source tensor (mode 1)
+    const double* ap;      // slab element 0 (modes 1, 2); interval: hi plane `aplane` doubles further
+    size_t aplane;
+    unsigned* wit;         // optional: *wit = 1 if the result has a non-linearity witness (K<E>::witness's predicate)
+};
+
 template <class E>
 struct K {
     // out[k] = f(src[k + shift]) or zero outside the source box
@@ -305,6 +318,10 @@ struct K {
     // reference-order truncated N-d Cauchy product, one thread per output element (mt:984-1012)
     static void conv_naive(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane,
                            double* z, size_t z_plane, const ConvArgs& a);
+    // the same loop nest (bit-exact) for products with few terms per output, with the following Add (and the Horner
+    // loop's witness) fused in: ConvEpi.  false: outside the kernel's domain, nothing launched.
+    static bool conv_shallow(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* out,
+                             size_t out_plane, const ConvArgs& a, const ConvEpi& e);
 };
 
 enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };

@@ -30,7 +30,9 @@ namespace gft {
 
 extern unsigned long long g_launches;  // launches requested so far (gft_op_stats_ex)
 
-constexpr size_t LQ_SLOT_BYTES = 2048;  // largest argument block that travels through the ring (bigger: launched in place)
+constexpr size_t LQ_SLOT_BYTES = 4096;  // (k_upload_small's 480 doubles by value are the largest block: 3.9 KB)
+extern unsigned long long g_launches_in_place;  // closures too large for a slot: launched on the calling thread after a full drain
+  // largest argument block that travels through the ring (bigger: launched in place)
 struct LaunchSlot {
     void (*run)(void*);
     alignas(16) unsigned char payload[LQ_SLOT_BYTES];
@@ -41,12 +43,22 @@ void lq_configure(int device, bool enabled);  // gft_init / options
 void lq_shutdown();                           // drains and stops the worker
 LaunchSlot* lq_begin();                       // next free slot (waits while the ring is full; starts the worker on first use)
 void lq_commit();                             // publishes the slot written since lq_begin
-void launch_drain();                          // returns when the worker has issued everything queued before this call
+void launch_drain();                          // returns when the worker has issued everything queued before this call;
+                                              // THROWS std::runtime_error if a queued launch / stream operation failed
+// Failures of queued work.  HIP's last-error state is per thread, so the API thread cannot see what happened to a launch
+// the worker issued: the worker (and the in-place path) hands every status to lq_note, which latches the FIRST failure
+// with the kernel's address; launch_drain() — i.e. every value inspection, gft_synchronize and every wrapped hip* call —
+// raises it (once) as an exception that reaches the caller through gft_last_error().
+void launch_drain_nothrow();                  // the same wait without raising (destructors, shutdown)
+void lq_note(hipError_t e, const void* kernel, const char* what);
+// test knob (gft_set_option("debug_fail_next_launch", 1)): the next kernel launch requests 1 MB of LDS and fails
+extern std::atomic<int> g_fail_next_launch;
 
 template <class F>
 inline void enqueue(F&& f) {
     typedef typename std::decay<F>::type Fn;
     if (!lq_enabled() || sizeof(Fn) > LQ_SLOT_BYTES) {
+        if (lq_enabled()) ++g_launches_in_place;
         launch_drain();
         f();
         return;
@@ -76,8 +88,11 @@ template <class... KArgs, class... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
     ++g_launches;
     std::tuple<typename std::decay<KArgs>::type...> t(std::forward<Args>(args)...);
+    if (g_fail_next_launch.load(std::memory_order_relaxed) && g_fail_next_launch.exchange(0)) lds = (size_t)1 << 20;
     enqueue([kernel, grid, block, lds, st, t]() mutable {
         std::apply([&](auto&... a) { hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, a...); }, t);
+        const hipError_t e = hipGetLastError();  // this thread's state: the launch just made
+        if (e != hipSuccess) lq_note(e, reinterpret_cast<const void*>(kernel), nullptr);
     });
 }
 

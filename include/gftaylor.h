@@ -73,7 +73,10 @@ void gft_pool_stats(size_t out[3]);
 void gft_op_stats(size_t out[8]);
 /* More counters (returns how many exist, writes min(cap, that many)): {kernel launches of the library, elementwise
  * operations deferred into a chain instead of launched, chains materialised by a consumer that needed the tensor in
- * memory, add/sub launches that evaluated deferred chains on the fly}.  Diagnostics; bench.py's e2e rows. */
+ * memory, add/sub launches that evaluated deferred chains on the fly, launches whose argument block did not fit a
+ * slot of the launch ring and were issued in place after a full drain, shallow (stencil) products on the fused
+ * reference-order kernel, of which whole general Horner steps res * subst + slab in one launch}.  Diagnostics; bench.py's
+ * e2e rows. */
 size_t gft_op_stats_ex(size_t* out, size_t cap);
 /* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);

@@ -4,6 +4,7 @@ benchmarked size.  Only programs whose oracle run is too long to repeat inside t
 (mixture `--bounds`: ~12 minutes of one host core); the others are recomputed by the test itself.
 
     python tests/golden/make_c3_limit100_golden.py            # all entries of STORED
+    python tests/golden/make_c3_limit100_golden.py hmm three  # only the entries whose program name contains a word
 """
 import os
 import sys
@@ -12,7 +13,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-STORED = [("approx/mixture/mixture", True)]
+# (program under tests/golden/sgcl/, --bounds?, flags): mixture --bounds at the NeurIPS size (12 minutes), hmm --bounds (26 s), and
+# this repo's product-dominated programs at the sizes bench.py's e2e rows time them (6-30 s each)
+STORED = [("neurips2023/approx/mixture/mixture", True, "--limit 100"),
+          ("neurips2023/approx/hmm/hmm", True, "--limit 100"),
+          ("bench/three_populations", False, "--limit 100"),
+          ("bench/four_populations", False, "--limit 24")]
 OUT = os.path.join(ROOT, "tests", "golden", "c3_limit100")
 
 
@@ -25,9 +31,12 @@ def main():
 
     os.makedirs(OUT, exist_ok=True)
     oracle = os.path.join(ROOT, "oracle", "liborc.so")
-    for prog, bounds in STORED:
-        src = open(os.path.join(ROOT, "tests", "golden", "sgcl", "neurips2023", prog + ".sgcl")).read()
-        flags = "--no-timing --limit 100" + (" --bounds" if bounds else "")
+    only = sys.argv[1:]
+    for prog, bounds, limit in STORED:
+        if only and not any(o in prog for o in only):
+            continue
+        src = open(os.path.join(ROOT, "tests", "golden", "sgcl", prog + ".sgcl")).read()
+        flags = "--no-timing " + limit + (" --bounds" if bounds else "")
         t0 = time.time()
         rc, text, _ = genfer_amd.run_sgcl_with_backend(src, flags, oracle, "orci_" if bounds else "orc_")
         assert rc == 0, text

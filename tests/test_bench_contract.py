@@ -20,13 +20,17 @@ def test_e2e_programs_are_committed_fixtures():
             progs = ast.literal_eval(node.value)
     assert progs, "E2E_PROGRAMS not found"
     names = set()
-    for name, rel, flags, cpu_runs in progs:
+    for name, rel, flags, cpu_runs, stored, recorded in progs:
         assert name not in names
         names.add(name)
         assert os.path.isfile(os.path.join(ROOT, "tests", "golden", "sgcl", rel)), rel
         assert isinstance(flags, str) and isinstance(cpu_runs, int) and cpu_runs >= 0
-        if "--bounds" in flags.split():
-            assert cpu_runs == 0  # the CPU oracle needs minutes for these
+        # every row has a checker at the size it is timed at: an oracle run in the same call, or a committed oracle report
+        assert cpu_runs > 0 or stored, name
+        if stored:
+            assert os.path.isfile(os.path.join(ROOT, "tests", "golden", "c3_limit100", stored)), stored
+        if cpu_runs == 0:  # no CPU seconds measured in the run: the recorded figure names its source
+            assert recorded and recorded[0] > 0 and "profiles/" in recorded[1]
     assert {"hmm", "mixture", "three_populations", "four_populations", "hmm_bounds", "mixture_bounds"} <= names
 
 
@@ -35,6 +39,26 @@ def test_clock_helper_starts_before_the_gpu_is_touched():
     main = src[src.index("def main():"):]
     assert main.index("start_clock_helper()") < main.index("import torch"), "the rocm-smi helper must be forked before HIP can be initialised"
     assert "subprocess.Popen" not in src[src.index("def sclk_under_load"):src.index("def main():")], "no fork + exec after GPU initialisation"
+
+
+def test_nothing_spawns_a_process_after_gpu_initialisation():
+    """A process that has initialised HIP must not fork + exec on this pool: the oracle library is built (if missing)
+    by ensure_oracle() BEFORE `import torch`; cpu_baseline / e2e_seconds / main's body after that point spawn nothing."""
+    src = _bench_source()
+    main = src[src.index("def main():"):]
+    assert main.index("ensure_oracle()") < main.index("import torch")
+    for fn in ("def cpu_baseline(", "def cpu_baseline_all_cores(", "def e2e_seconds("):
+        body = src[src.index(fn):]
+        body = body[:body.index("\n\n\n")]
+        assert "subprocess" not in body and "os.system" not in body and "Popen" not in body, fn
+    after = main[main.index("import torch"):]
+    assert "subprocess" not in after and "os.system" not in after and "Popen(" not in after
+
+
+def test_e2e_rows_carry_a_parity_verdict():
+    src = _bench_source()
+    body = src[src.index("def e2e_seconds("):src.index("_CLOCK_HELPER")]
+    assert "first_difference" in body and '"parity"' in body and "failed = True" in body
 
 
 def test_contract_keys_are_present():

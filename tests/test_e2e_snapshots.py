@@ -82,37 +82,7 @@ def test_example_sgcl_matches_readme_and_closed_form(oracle_path):
     assert seen == 26
 
 
-NUM = re.compile(r"[-+]?(?:\d+\.\d+(?:e-?\d+)?|\d+e-?\d+|inf|NaN)")
-
-
-def numbers(line):
-    return [float(x) for x in NUM.findall(line)]
-
-
-def compare_reports(got, want):
-    gl, wl = got.splitlines(), want.splitlines()
-    assert len(gl) == len(wl), "different number of report lines"
-    raw = {}
-    for g, w in zip(gl, wl):
-        gs, ws = NUM.sub("#", g), NUM.sub("#", w)
-        assert gs == ws, f"report text differs:\n{g}\n{w}"
-        gn, wn = numbers(g), numbers(w)
-        if not wn:
-            continue
-        primary = any(k in w for k in ("Total measure", "Expected value", "raw moment", "p(")) and "<=" not in w
-        if "Expected value" in w:
-            raw["E"] = abs(wn[-1])
-        if "4th raw moment" in w:
-            raw["m4"] = abs(wn[-1])
-        for a, b in zip(gn, wn):
-            if a != a and b != b:  # NaN in both reports (e.g. skewness of a point mass)
-                continue
-            if primary:
-                assert abs(a - b) <= 1e-10 * abs(b) or a == b or abs(b) < 1e-300, f"{g} vs {w}"
-            else:
-                # central / standardised moments and tail bounds: differences of raw moments
-                scale = max(abs(b), raw.get("m4", 1.0), 1.0)
-                assert abs(a - b) <= 1e-9 * scale or a == b, f"{g} vs {w}"
+from genfer_amd.reports import compare_reports  # noqa: E402  (the parity contract of SURVEY §4; shared with bench.py)
 
 
 @pytest.mark.gpu
@@ -283,6 +253,31 @@ def test_product_programs_hip_matches_oracle(prog, limit, oracle_path):
     rc, want = run_flags(path, oracle_path, "orc_", "--no-timing " + limit)
     assert rc == 0, want
     assert "Total measure" in want
+    compare_reports(got, want)
+
+
+# ... and at exactly the sizes bench.py's e2e rows time them, against the committed oracle reports
+# (tests/golden/make_c3_limit100_golden.py: 6-30 s of one host core each)
+PRODUCT_PROGRAMS_BENCH = [("bench/three_populations", "--limit 100"), ("bench/four_populations", "--limit 24")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,limit", PRODUCT_PROGRAMS_BENCH, ids=[p.split("/")[-1] + "@bench" for p, _ in PRODUCT_PROGRAMS_BENCH])
+def test_product_programs_at_bench_size_match_committed_oracle(prog, limit):
+    import conftest
+    import genfer_amd
+
+    genfer_amd.lib()
+    stored = c3_stored(prog, False)
+    assert os.path.exists(stored), stored
+    conftest._set_tier("host")  # the library's default dispatch — the configuration bench.py times
+    try:
+        rc, got = run_flags(os.path.join(SGCL, prog + ".sgcl"), genfer_amd.LIB_PATH, "gft_", "--no-timing " + limit)
+        assert rc == 0, got
+    finally:
+        conftest._set_tier("device")
+    want = open(stored).read()
+    assert "Total measure" in want and want.count("p(") >= int(limit.split()[-1])
     compare_reports(got, want)
 
 

@@ -92,3 +92,105 @@ def test_near_linear_accumulators_random(seed, OTP, GTP):
     o = OTP.new(a, deg).subst_var(0, OTP.new(s, deg))
     g = GTP.new(a, deg).subst_var(0, GTP.new(s, deg))
     _check(o, g)
+
+
+# ---- round 4: the general Horner step with a stencil substitution in ONE launch (K<E>::conv_shallow) --------------------
+# `b +~ Binomial(a, p)` substitutes a -> a (1 - p + p b): a 2 x 2 coefficient tensor that is not linear, so every step of
+# subst_var's loop is a GENERAL product of the accumulator with a handful of coefficients plus a slab (mt:569-579).  The
+# fused kernel keeps the reference's loop nest per output and applies Add's operations to each finished sum, so the
+# result is the oracle's bit for bit — also where the slab is a single coefficient (Add touches element 0 only), where it
+# is larger than the product on some axis, and for intervals.
+def _binomial_like(v, w, nd, p, x0=0.0, y0=0.0):
+    """subst = (x0 + eps_v) * (1 - p + p * (y0 + eps_w)) minus its constant term, as a compact tensor"""
+    s = np.zeros([2 if ax in (v, w) else 1 for ax in range(nd)])
+    idx = lambda i, j: tuple((i if ax == v else (j if ax == w else 0)) for ax in range(nd))
+    c = 1 - p + p * y0
+    s[idx(0, 0)] = 0.0           # the evaluator strips the constant term (gf:609-627)
+    s[idx(1, 0)] = c
+    s[idx(0, 1)] = x0 * p
+    s[idx(1, 1)] = p
+    return s
+
+
+FUSED_CASES = [
+    # (shape of a, degrees, v, w, p)
+    ((9, 7), [12, 12], 0, 1, 0.3),
+    ((6, 5, 4), [9, 9, 6], 0, 1, 0.25),
+    ((6, 5, 4), [9, 9, 6], 1, 2, 0.4),
+    ((5, 4, 6), [7, 7, 7], 2, 0, 0.125),
+    ((4, 3, 3, 4), [6, 5, 5, 6], 0, 3, 0.3),
+    ((12, 1, 5), [14, 3, 8], 0, 2, 0.7),       # slabs with a unit axis; the substitution brings axis 2 in
+    ((7, 3), [7, 3], 0, 1, 0.5),               # degrees cap the growth at once
+]
+
+
+@pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
+@pytest.mark.parametrize("case", range(len(FUSED_CASES)))
+def test_general_horner_step_fused_bit_exact(case, interval, OTP, GTP, OTPI, GTPI):
+    import genfer_amd
+
+    shape, deg, v, w, p = FUSED_CASES[case]
+    rng = np.random.default_rng(100 + case)
+    a = rng.random(shape) * (rng.random(shape) < 0.8)   # some exact zeros (signed-zero and short-circuit paths)
+    a[tuple(-1 for _ in shape)] = 0.75                   # the top slab is not empty
+    s = _binomial_like(v, w, len(shape), p, x0=0.5, y0=0.25)
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    if interval:
+        ai = np.stack([a * (1 - 1e-16), a * (1 + 1e-16)])
+        si = np.stack([s * (1 - 1e-16), s * (1 + 1e-16)])
+    else:
+        ai, si = a, s
+    L = genfer_amd.lib()
+    want = O.new(ai, deg).subst_var(v, O.new(si, deg))
+    results = {}
+    for terms in (-1.0, 0.0):   # default (fused) / off (product, gather, add, witness as separate launches)
+        assert L.gft_set_option(b"shallow_max_terms", terms) == 0
+        try:
+            before = genfer_amd.op_stats()
+            g = G.new(ai, deg).subst_var(v, G.new(si, deg))
+            _check(want, g)
+            after = genfer_amd.op_stats()
+            results[terms] = (after["fused_horner_steps"] - before["fused_horner_steps"], after["launches"] - before["launches"])
+        finally:
+            L.gft_set_option(b"shallow_max_terms", -1.0)
+    assert results[0.0][0] == 0
+    # on the device tier the loop really took the fused kernel, and with fewer launches
+    if results[-1.0][0]:
+        assert results[-1.0][1] < results[0.0][1], results
+
+
+def test_general_horner_fused_runs_on_the_device_tier(OTP, GTP):
+    """A tensor above the host tier's size: the steps after the first non-linear accumulator are fused launches."""
+    import genfer_amd
+
+    rng = np.random.default_rng(7)
+    a = rng.random((40, 40, 6))
+    deg = [48, 48, 8]
+    s = _binomial_like(0, 1, 3, 0.3, x0=1.0, y0=1.0)
+    before = genfer_amd.op_stats()
+    g = GTP.new(a, deg).subst_var(0, GTP.new(s, deg))
+    after = genfer_amd.op_stats()
+    _check(OTP.new(a, deg).subst_var(0, OTP.new(s, deg)), g)
+    # (under the default dispatch the first ~18 accumulators are host-resident: those steps run on the host tier)
+    assert after["fused_horner_steps"] - before["fused_horner_steps"] >= 15, (before, after)
+
+
+@pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
+@pytest.mark.parametrize("xs,ys,deg", [((30, 28, 9), (2, 2, 1), [31, 29, 9]), ((30, 28, 9), (1, 2, 2), [31, 29, 10]),
+                                        ((1, 1, 24), (24, 24, 1), [24, 24, 24]), ((24, 1, 1), (24, 24, 24), [24, 24, 24]),
+                                        ((40, 50), (3, 2), [41, 50]), ((5, 4, 3, 20), (2, 1, 2, 3), [6, 4, 4, 20])])
+def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI, tier):
+    """Products whose outputs receive few terms each (one operand a stencil, or an outer product) run on the reference-
+    order kernel: bit-exact against the oracle, both operand orders."""
+    import genfer_amd
+
+    rng = np.random.default_rng(3)
+    x, y = rng.random(xs) - 0.3, rng.random(ys) - 0.3
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    if interval:
+        x, y = np.stack([x - 1e-3, x + 1e-3]), np.stack([y - 1e-3, y + 1e-3])
+    before = genfer_amd.op_stats()["shallow_products"]
+    _check(O.new(x, deg) * O.new(y, deg), G.new(x, deg) * G.new(y, deg))
+    _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
+    if tier == "device":
+        assert genfer_amd.op_stats()["shallow_products"] == before + 2, "the products did not take the shallow kernel"

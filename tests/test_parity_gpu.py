@@ -1210,3 +1210,40 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
                     L.gft_set_option(b"conv_rb_min_macs", 2.0e10)
     finally:
         L.gft_set_option(b"host_max_elems", -1.0)
+
+
+@pytest.mark.parametrize("async_launch", [1, 0])
+def test_failed_kernel_launch_is_reported_not_swallowed(OTP, GTP, async_launch):
+    """Launches are issued by the library's worker thread (gft_launch.hpp) and HIP's last-error state is per thread: the
+    worker latches the first failing launch with the kernel's name, and the next drain — a value inspection or
+    gft_synchronize — raises it through gft_last_error().  The test knob makes ONE launch request 1 MB of LDS."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    assert L.gft_set_option(b"host_max_elems", 0.0) == 0  # everything on the device
+    assert L.gft_set_option(b"async_launch", float(async_launch)) == 0
+    try:
+        x = rand((40, 40), 5)
+        gx = GTP.new(x, [40, 40])
+        assert L.gft_synchronize() == 0
+        assert L.gft_set_option(b"debug_fail_next_launch", 1.0) == 0
+        gs = gx + gx  # one kernel launch, which fails on the worker
+        rc = L.gft_synchronize()
+        assert rc != 0, "a failed launch went unnoticed"
+        msg = (L.gft_last_error() or b"").decode()
+        assert "HIP error" in msg and "launching" in msg and "k_" in msg, msg
+        del gs
+        # the failure is reported once; the runtime keeps working afterwards
+        assert L.gft_synchronize() == 0
+        ox = OTP.new(x, [40, 40])
+        check(ox + ox, gx + gx)
+        # a value inspection surfaces it too
+        assert L.gft_set_option(b"debug_fail_next_launch", 1.0) == 0
+        gs = gx + gx
+        with pytest.raises(genfer_amd.TaylorError):
+            gs.array()
+        assert L.gft_synchronize() == 0
+    finally:
+        L.gft_set_option(b"debug_fail_next_launch", 0.0)
+        L.gft_set_option(b"async_launch", 1.0)
+        L.gft_set_option(b"host_max_elems", -1.0)
