@@ -2753,9 +2753,14 @@ struct Ops {
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
             } else {
                 P nxt;
-                if (horner_general_step_fused(res, subst, ca, v, i, deg, (i > 0 && !proven) ? R.d_wit + slots : nullptr, &nxt)) {
+                static const int shallow_diag = [] {
+                    const char* e = getenv("GFT_SHALLOW_DIAG");  // 1: witness in its own launch (A/B)
+                    return e ? atoi(e) : 0;
+                }();
+                const bool fuse_wit = !(shallow_diag & 1);
+                if (horner_general_step_fused(res, subst, ca, v, i, deg, (fuse_wit && i > 0 && !proven) ? R.d_wit + slots : nullptr, &nxt)) {
                     res = nxt;
-                    witnessed = true;  // (the step's kernel raised the witness word itself)
+                    witnessed = fuse_wit;  // (the step's kernel raised the witness word itself)
                 } else {
                     res = addsub(mul_horner(res, subst), horner_coeff(ca, v, i, deg), false);
                 }

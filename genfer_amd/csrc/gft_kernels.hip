@@ -1298,6 +1298,18 @@ void K<E>::conv_naive(hipStream_t st, const double* x, size_t x_plane, const dou
     else launch_conv_naive<E, false>(st, x, x_plane, y, y_plane, z, z_plane, a);
 }
 
+// Raising a sticky witness word (read by a LATER kernel on the same stream, k_witness_verdict).  Many waves / workgroups
+// raise the same word, and write-through stores to one address — agent-scope atomics, and `volatile` stores, which hipcc
+// also emits with sc0 sc1 — serialise in the memory system at ~26 ns each: 2048 workgroups of k_conv_shallow made a 13 us
+// kernel take 60 us, one store per wave 217 us.  So: an ORDINARY (L2 write-back) store — stores of the one value ever
+// written merge in each XCD's L2 and reach memory at the end of the kernel.  wit_raise_once first looks (an ordinary load:
+// within an XCD the first store makes every later load hit in L2); the Horner pipelines store without looking — a load
+// would have to be waited for, and with it their whole prefetch ring.
+__device__ inline void wit_raise(unsigned* w) { *w = 1u; }
+__device__ inline void wit_raise_once(unsigned* w) {
+    if (*w == 0u) *w = 1u;
+}
+
 // ------------------------------------------------------------------------------------------
 // Shallow products with a fused Add (round 4): the GENERAL Horner step  res * subst + slab_i  (mt:569-579) in one launch.
 // The substitutions Genfer's programs produce (`b +~ Binomial(a, p)`: a -> a (1 - p + p b)) are 3-6 coefficient
@@ -1349,7 +1361,8 @@ __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__
         if (e.wit && (big || nz >= 2) && !E::is_zero(v)) found = 1;
     }
     if (e.wit) {  // (kernel argument: uniform)
-        if (__syncthreads_or(found) && threadIdx.x == 0) __hip_atomic_store(e.wit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (every workgroup of a dense result raises the word: see wit_raise for why that must not be a write-through store)
+        if (__syncthreads_or(found) && threadIdx.x == 0) wit_raise_once(e.wit);
     }
 }
 
@@ -1721,7 +1734,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
             // shared-memory reduction with several barriers of its own, paid on every step of this latency chain
             // (a plain store, no load-and-test first: a load would have to be waited for, and with it the whole prefetch ring)
             if (wit && !last && any_lane(witness != 0) && (threadIdx.x & 63u) == 0)
-                __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wit_raise(&wit[t]);
             if (!(g.diag & 2)) lds_barrier();  // the line passes from step to step through LDS; global loads (the ring) stay in flight
         }
     }
@@ -1859,7 +1872,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
             if (last) continue;
             // publish this wave's last position for the wave above: value, then counter (in-order LDS queue)
             if (lane == 63 && wave + 1 < nw) ring_put(ring_a + t, nslots, cur);
-            if (wit && any_lane(witness != 0) && lane == 0) __hip_atomic_store(&wit[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wit && any_lane(witness != 0) && lane == 0) wit_raise(&wit[t]);
             if constexpr (POINT) {
                 if (wave == 0) c_cur = c_nxt;
             }
@@ -2036,7 +2049,7 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __rest
     const unsigned nloop = g.nsteps - 1;  // steps [0, nloop) publish and request; the last step does neither
     // the witness words of steps [t0, t0 + 64) that lie before the last step
     auto flush_witnesses = [&](unsigned t0) {
-        if (((wmask >> lane) & 1ull) && t0 + lane < nloop) __hip_atomic_store(&wit[t0 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((wmask >> lane) & 1ull) && t0 + lane < nloop) wit_raise(&wit[t0 + lane]);
         wmask = 0;
     };
     // STEADY STATE: lean steps [t, t_end), all before the last step, written as one tight loop per role (W0: the wave that
