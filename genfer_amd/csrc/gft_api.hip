@@ -256,9 +256,11 @@ struct Buf {
     }
 };
 
+// (+ 8 doubles of slack: the tiled product reads operands in place and its pipelined x loads request one 64-byte chunk
+// beyond the last one they use — gft_conv_tiled.hip, ConvArgs::operands_slack)
 static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     auto b = std::make_shared<Buf>();
-    b->p = (double*)pool_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
+    b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
     return b;
 }
 static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
@@ -607,6 +609,7 @@ struct Ops {
         size_t plane;
         Dims shape;
         bool host = false;  // p is host memory (host tier)
+        bool slack = false; // device memory from the library's pool: 64 bytes after the tensor's last element are readable (alloc_doubles)
         size_t numel() const { return prod(shape); }
         HV index0(size_t k) const {
             HV r;
@@ -615,10 +618,15 @@ struct Ops {
             r.plane = plane;
             r.shape = sub;
             r.host = host;
+            r.slack = slack;
             return r;
         }
     };
-    static HV view(const P& p, bool host = false) { return HV{tp<E>(p, host), p.numel, p.shape, host}; }
+    static HV view(const P& p, bool host = false) {
+        HV v{tp<E>(p, host), p.numel, p.shape, host};
+        v.slack = !host && p.buf && !p.buf->borrowed;  // (tp() has given lazy handles / host-tier tensors their pool buffer)
+        return v;
+    }
 
     // ---- size-threshold dispatch ------------------------------------------------------------
     // An operation runs on the host tier iff every operand is host-resident and its result is small.
@@ -1441,6 +1449,7 @@ struct Ops {
         a.j0_excl = j0_excl;
         a.j0_desc = j0_desc;
         a.variant = R.conv_variant;
+        a.operands_slack = (x.slack && W == 1) ? 1 : 0;
         // number of non-unit axes that take part in the reference's "1-d like" inner product
         int first_inner_axis = slab_mode ? 1 : 0;
         int nonunit = 0;
@@ -1518,6 +1527,7 @@ struct Ops {
             ConvArgs at = ash;
             unsigned B = 0;
             const bool split = plan_inner_split(ash, at, &B);
+            if (split) at.operands_slack = 0;  // its operands are zero-padded pieces: packed and scanned (the non-finite verdict)
             size_t need = 0;
             bool ok = true;
             if (R.conv_mode == 0) {
@@ -1560,8 +1570,9 @@ struct Ops {
                     R.nf_epoch = 1;
                 }
                 unsigned* flag = R.d_flag + 2;
+                bool guarded = true;
                 if (!split) {
-                    if (!conv_tiled_f64(R.stream, tx, ty, tz, ash, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch))
+                    if (!conv_tiled_f64(R.stream, tx, ty, tz, ash, R.conv_ws, R.conv_ws_bytes, &need, flag, R.nf_epoch, &guarded))
                         throw Error("tiled convolution launch failed");
                 } else {
                     const ConvArgs& a = ash;  // the (possibly shifted) problem; the guarded fallback below uses the original
@@ -1589,6 +1600,7 @@ struct Ops {
                                         a.accumulate, flag, R.nf_epoch);
                 }
                 R.stats[3]++;
+                if (!guarded) return;  // operands read in place: no zero padding, no verdict, nothing to fall back from
                 a.guard = flag;
                 a.guard_epoch = R.nf_epoch;
                 if (!conv_staged<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, false))
@@ -2562,7 +2574,19 @@ struct Ops {
         os[v] = a.shape[v] - n;
         Shifts sh0(os.size(), 0);
         sh0[v] = (long long)n;
-        P out = gather(a, os, d, sh0, a.shape, OP_COPY, nullptr, -1, nullptr, 0, nullptr, host);
+        // (a real copy, not a deferred view: slab 0 of the result is updated in place below, so a view would only be
+        // materialised at once — by the chain kernel, which indexes per element and was 30 % slower than the gather's
+        // 16-byte path at 384^3: profiles/r03 vs r02 streaming_384.json)
+        struct NoDefer {
+            bool prev;
+            NoDefer() : prev(R.defer) { R.defer = false; }
+            ~NoDefer() { R.defer = prev; }
+        };
+        P out;
+        {
+            NoDefer nd_;
+            out = gather(a, os, d, sh0, a.shape, OP_COPY, nullptr, -1, nullptr, 0, nullptr, host);
+        }
         Dims ss = a.shape;
         ss[v] = 1;
         std::shared_ptr<Buf> s = alloc_tier(host, prod(ss) * W);

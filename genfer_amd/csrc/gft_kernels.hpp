@@ -205,6 +205,7 @@ struct ConvArgs {
     int j0_desc;                // iterate j0 downwards (log's summation order)
     int inner_from_zero;        // last axis' partial sum is formed from zero, then added (mul_1d, mt:971-982)
     int variant;                // tiled-kernel variant (gft_set_conv_variant; -1 = library default)
+    int operands_slack;         // tiled kernel: 64 bytes after x's last element are readable (the library's own buffers)
     const unsigned* guard;      // optional device word: the reference-order kernels run only if *guard == guard_epoch
     unsigned guard_epoch;       // (fallback for non-finite operands of the tiled kernel, decided on the device)
 };
@@ -332,8 +333,10 @@ enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };
 // `nf_flag`/`nf_epoch`: the packing/scan kernels raise *nf_flag to nf_epoch if an operand holds inf/NaN, in which
 // case the main and reduce kernels leave z untouched (zero padding times inf would create NaNs the reference
 // does not produce) and the caller's guarded reference-order launch computes z instead — no host round trip.
+// `guarded` (optional): set to false when the launch read its operands in place — no zero padding, hence no verdict and
+// no guarded fallback launch needed (ConvArgs::operands_slack; round 4) — true otherwise.
 bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z, const ConvArgs& a, void* ws,
-                    size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch);
+                    size_t ws_bytes, size_t* ws_needed, unsigned* nf_flag, unsigned nf_epoch, bool* guarded = nullptr);
 
 // Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
