@@ -576,6 +576,9 @@ def main():
         counts = [r["comm_count"] for r in per_rank]
         if rank == 0:
             out["exchange"] = exchange
+            out["exchange_requested"] = os.environ.get("GFT_BENCH_EXCHANGE", "abi")
+            if exchange != out["exchange_requested"]:
+                out["exchange_fell_back"] = True  # the library's RCCL communicator could not be created: see exchange_note
             out["per_rank"] = per_rank
             out["rccl_comm_count_per_rank"] = counts
             if exchange_note:

@@ -152,6 +152,7 @@ struct Runtime {
     bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
     bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
     bool div_wavefront = true;     // GFT_DIV_WAVEFRONT=0 / "div_wavefront": the blocked recurrence instead of the one-launch row wavefront
+    bool rows_wavefront = true;    // GFT_ROWS_WAVEFRONT=0 / "rows_wavefront": rank-2 recurrences with rows > 64 row by row (A/B, bisecting)
     bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
     // Shallow products (round 4): a plain product whose outputs receive at most this many terms each (prod_i min(xs_i, ys_i):
     // one operand is a stencil — the substitutions of `+~ Binomial(other, p)` statements are 3-6 coefficients) runs on the
@@ -2025,6 +2026,14 @@ struct Ops {
             if (i + 1 < keep.size()) rows *= zs[i];
         }
         // dropped axes have extent 1 in the result, hence in both operands (shapes never exceed the result's)
+        if (keep.size() == 2 && zs[1] > 64 && zs[1] <= 4096 && rows >= 8 && R.rows_wavefront) {
+            // long rows, rank 2: the coefficient-level wavefront (tasks are 64-coefficient segments of rows)
+            const size_t words = rows * ((zs[1] + 63) / 64) + 1;
+            std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
+            zero_elems(false, fl->p, (words + 1) / 2 + 1);
+            return K<E>::rows_wavefront(R.stream, 0, dp<E>(self), self.numel, xs, dp<E>(other), other.numel, ys, dp<E>(out), out.numel, zs, nullptr, 0,
+                                        reinterpret_cast<unsigned*>(fl->p));
+        }
         if (zs[keep.size() - 1] > 64 || zs[keep.size() - 1] < 2 || rows < 64) return false;
         std::shared_ptr<Buf> fl = alloc_doubles((rows + 1 + 1) / 2 + 1);
         zero_elems(false, fl->p, (rows + 1 + 1) / 2 + 1);
@@ -2101,7 +2110,12 @@ struct Ops {
         double total = 1.0;
         for (size_t i = 0; i < res.shape.size(); ++i) total *= 0.5 * (double)res.shape[i] * (double)std::min(xs.shape[i], res.shape[i]) + 0.5;
         const bool right_tiled = !res.host && W == 1 && R.conv_mode == 0 && R.exp_right && total >= 64.0 * R.tiled_min_macs;
-        if (!res.host && !right_tiled && exp_wavefront(xs, res)) return;
+        // (rank 2 with long rows: the coefficient-level wavefront keeps the reference's order AND beats the right-looking tiled
+        // form — 400^2: see profiles/r04/recurrences.txt)
+        // rank 2 where the right-looking tiled form would be taken: the wavefront kernels with each row's terms in the order of
+        // their ARRIVAL (that form's order, same 1e-10 contract) — 400^2 62 -> 4.5 ms, 1000 x 32 10.6 -> see recurrences.txt
+        const bool wf_2d = res.shape.size() == 2 && res.shape[1] <= 4096 && R.rows_wavefront;
+        if (!res.host && (!right_tiled || wf_2d) && exp_wavefront(xs, res, right_tiled)) return;
         HV xsc;
         std::shared_ptr<Buf> hold = scaled_by_index(xs, &xsc);
         // Large f64 exponentials (their slab steps would take the tiled kernel anyway, i.e. the 1e-10 contract, not the
@@ -2135,7 +2149,9 @@ struct Ops {
             x_map_inplace(cur, MAP_DIV_U32, (unsigned)k);
         }
     }
-    static bool exp_wavefront(const HV& xs, const HV& res) {
+    // `arrival_order`: the caller would otherwise take the right-looking tiled form (1e-10 contract) — the long-row kernel may
+    // then add each row's terms in the order the source rows become available instead of the reference's
+    static bool exp_wavefront(const HV& xs, const HV& res, bool arrival_order = false) {
         if (!R.div_wavefront || !R.div2d) return false;
         const size_t nd = res.shape.size();
         if (nd < 2 || nd > 4 || xs.shape.size() != nd) return false;
@@ -2147,10 +2163,17 @@ struct Ops {
             rsh[i] = (unsigned)res.shape[i];
             if (i + 1 < nd) rows *= res.shape[i];
         }
+        if (nd == 2 && rsh[1] > 64 && rsh[1] <= 4096 && rows >= 8 && R.rows_wavefront) {  // long rows: the coefficient-level wavefront
+            const size_t words = rows * ((rsh[1] + 63) / 64) + 1;
+            std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
+            zero_elems(false, fl->p, (words + 1) / 2 + 1);
+            return K<E>::rows_wavefront(R.stream, arrival_order ? 2 | 4 : 2, xs.p, xs.plane, xsh, xs.p, xs.plane, xsh, res.p, res.plane, rsh, nullptr, 0,
+                                        reinterpret_cast<unsigned*>(fl->p));
+        }
         if (rsh[nd - 1] > 64 || rows < 8) return false;  // (the alternative is two launches per slab)
         std::shared_ptr<Buf> fl = alloc_doubles((rows + 2) / 2 + 1);
         zero_elems(false, fl->p, (rows + 2) / 2 + 1);
-        return K<E>::exp_wavefront(R.stream, xs.p, xs.plane, xsh, res.p, res.plane, rsh, (int)nd, reinterpret_cast<unsigned*>(fl->p));
+        return K<E>::exp_wavefront(R.stream, xs.p, xs.plane, xsh, res.p, res.plane, rsh, (int)nd, reinterpret_cast<unsigned*>(fl->p), arrival_order ? 1 : 0);
     }
     static Dims explog_shape(const P& a) {
         Dims rs = a.deg;
@@ -2269,6 +2292,15 @@ struct Ops {
             rsh[i] = (unsigned)res.shape[i];
             if (i + 1 < nd) rows *= res.shape[i];
             if (i > 0) x0n *= xs.shape[i];
+        }
+        if (nd == 2 && rsh[1] > 64 && rsh[1] <= 4096 && rows >= 8 && x0n >= 2 && nonunit_axes(xs.shape) >= 2 && R.rows_wavefront) {
+            // long rows: the coefficient-level wavefront
+            std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);
+            const size_t words = rows * ((rsh[1] + 63) / 64) + 1;
+            std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
+            zero_elems(false, fl->p, (words + 1) / 2 + 1);
+            return K<E>::rows_wavefront(R.stream, 1, xs.p, xs.plane, xsh, xs.p, xs.plane, xsh, res.p, res.plane, rsh, qb->p, res.numel(),
+                                        reinterpret_cast<unsigned*>(fl->p));
         }
         if (rsh[nd - 1] > 64 || rows < 8 || x0n < 2 || nonunit_axes(xs.shape) < 2) return false;  // (the alternative is 2+ launches per slab)
         std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);
@@ -3407,6 +3439,7 @@ int gft_init(int device) {
         if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
         if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
         if (const char* dw = getenv("GFT_DIV_WAVEFRONT")) R.div_wavefront = atoi(dw) != 0;
+        if (const char* rw = getenv("GFT_ROWS_WAVEFRONT")) R.rows_wavefront = atoi(rw) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
         if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
@@ -3522,6 +3555,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "fuse_horner") R.fuse_horner = value != 0;
     else if (n == "div2d") R.div2d = value != 0;
     else if (n == "div_wavefront") R.div_wavefront = value != 0;
+    else if (n == "rows_wavefront") R.rows_wavefront = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;

@@ -707,6 +707,8 @@ struct DivWfArgs {
     // log_mode == 2: res = exp(xs) for the slabs k0 >= 1 (mt:1271-1300; slab 0, an exp one dimension down, is the caller's):
     //   res[K] = ( sum_{j0 = 1}^{min(k0, xn0 - 1)} sum_{j' lexicographic} rowproduct(j0 * xs[j0, j'], res[k0 - j0, k - j']) ) / k0
     int log_mode;
+    int rev;                  // log_mode 2: the source SLABS in descending j0 — the order in which they become available (1e-10 contract,
+                              // see k_rows_wavefront); set by the caller where it would otherwise take the right-looking tiled form
     const unsigned* order;    // task t works on row order[t] of the task rows (anti-diagonal order, see dwf_order); null: t
     int pack;                 // rows <= 32: two source rows per wave (GFT_DWF_PACK=0: one, for A/B)
     double* qb;               // log_mode: the quotient rows before the division by k0 (same layout as res)
@@ -879,6 +881,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
                             else carry = false;
                         }
                 }
+                if (ex && g.rev) j[0] = cnt[0] - 1u - j[0];
 #pragma unroll
                 for (int a = lev; a < L; ++a) j[a] += lo[a];
                 size_t roff = 0, ooff = 0;
@@ -1198,10 +1201,11 @@ bool K<E>::log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
 // res[1..] = exp(xs)[1..] (slabs k0 >= 1; mt:1271-1300) as the same row wavefront: no division, the row sum / k0.
 template <class E>
 bool K<E>::exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
-                         const unsigned* rshape, int nd, unsigned* flags_and_counter) {
+                         const unsigned* rshape, int nd, unsigned* flags_and_counter, int arrival_order) {
     if (nd < 2 || nd > 4) return false;
     DivWfArgs g;
     std::memset(&g, 0, sizeof(g));
+    g.rev = arrival_order;
     g.L = nd - 1;
     g.pack = dwf_pack;
     g.log_mode = 2;
@@ -1235,8 +1239,8 @@ bool K<E>::exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const
     launch_dwf<E>(st, blocks, xs, x_plane, xs, x_plane, res, r_plane, g);
     return true;
 }
-template bool K<EF64>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*);
-template bool K<EIv>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*);
+template bool K<EF64>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*, int);
+template bool K<EIv>::exp_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, unsigned*, int);
 template bool K<EF64>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
 template bool K<EIv>::log_wavefront(hipStream_t, const double*, size_t, const unsigned*, double*, size_t, const unsigned*, int, double*, size_t, unsigned*);
 
@@ -1301,5 +1305,340 @@ template bool K<EF64>::div_2d(hipStream_t, const double*, size_t, unsigned, unsi
                               double*, size_t, unsigned, unsigned, int, unsigned, double*, size_t);
 template bool K<EIv>::div_2d(hipStream_t, const double*, size_t, unsigned, unsigned, size_t, const double*, size_t, unsigned, unsigned,
                              double*, size_t, unsigned, unsigned, int, unsigned, double*, size_t);
+
+
+// ------------------------------------------------------------------------------------------
+// Rank-2 quotients / logarithms / exponentials with LONG rows (round 4): the coefficient-level wavefront
+// ------------------------------------------------------------------------------------------
+// k_div_wavefront keeps a row (<= 64 coefficients) in one wave.  Longer rows — 200^2, 400^2: what two-variable programs
+// with a few hundred observations produce — ran as a chain of per-row launches (right-looking update + 1-d division),
+// 400^2 div 38 ms = 0.4 % of the FP64 roof.  The dependency graph is finer than rows: coefficient c of row k0 needs the
+// coefficients <= c of the rows above it (mt:1162-1192 over mt:971-982) and the coefficients < c of its own row (the 1-d
+// division).  So a TASK is one 64-coefficient SEGMENT (k0, s) of a row, claimed in row-major order — every task comes
+// after the tasks it reads, so a claimed task only ever waits for tasks claimed earlier by running workgroups — and
+// row k0 + 1 divides its segment s while row k0 is still busy with segment s + 1: the critical path is n0 + nseg
+// segment steps instead of n0 whole-row divisions.
+//   * sum over the rows above: source row j0 contributes  sum_{j <= c} A[j] * B[c - j]  formed from zero in ascending j
+//     (mul_1d), the sums added in ascending j0: the waves of the workgroup take the source rows of a batch side by side, wave 0
+//     adds the batch's sums in order (k_div_wavefront's scheme).  A segment's sum runs over the 64-coefficient chunks
+//     t = 0 .. s of A against the two chunks of B that slide past it ({A_t}{B_{s-t-1}}{B_{s-t}} in the wave's LDS stage, the
+//     layout of row_product with the previous chunk where that one stages zeros): same additions in the same order;
+//   * the row's own division: cur[c] = sum_{j < c} q[j] * y0[c - j] — first over the chunks of q that earlier segments of
+//     this row have published (wave 0, same chunk product), then in lock step inside the segment (lane jj's coefficient is
+//     final at step jj and reaches the others by v_readlane; y0[l - jj] does not depend on the segment);
+//   * publication as in k_div_wavefront: result rows start out as the EMPTY pattern, every coefficient is one coherent
+//     8-byte store, per-segment release / acquire flags are the authority for a chunk that keeps looking unwritten.
+// mode 0: res = xs / ys.  mode 1: rows k0 >= 1 of log(xs) — S = sum_{j0 >= 1} xs[k0 - j0] (*) (j0 res[j0]),
+// r = (-S) + k0 xs[k0], q = r / xs[0] (1-d), res[k0] = q / k0 (q kept in `qb`: later segments of the row divide with it).
+// mode 2: rows k0 >= 1 of exp(xs) — res[k0] = (sum_{j0 >= 1} (j0 xs[j0]) (*) res[k0 - j0]) / k0.  Row 0 of log / exp is
+// the caller's (a 1-d log / exp, complete in stream order).  Same operations per coefficient in the same order as the
+// host-driven recursion => the same bits.
+// exp's sum starts with j0 = 1, i.e. with the row finished LAST (res[k0 - 1]): in the reference's order every row waits for
+// its predecessor before it can add anything, and the wavefront degenerates into a chain of whole rows (400^2: 116 ms).
+// `rev` takes the source rows in descending j0 — the oldest result row first, the order in which they become available,
+// the right-looking tiled form's order of arrival — under that form's contract (1e-10, measured ~1e-15: all terms of an
+// exponential's recurrence carry the same sign pattern as the series itself); the caller sets it exactly where it would
+// otherwise take the right-looking tiled form (f64, `exp_right`).
+struct RowsWfArgs {
+    unsigned n0, nr, m0, mr, xn0, xnr;   // rows / row lengths of res, ys (mode 0), xs
+    unsigned nseg, ntasks, first_row;
+    int mode;
+    unsigned* flags;                     // [n0 * nseg] segment stored; zeroed before the launch
+    unsigned* counter;                   // next task; zeroed before the launch
+    double* qb;                          // mode 1: the quotient rows before the division by k0
+    size_t qbp;
+    int rev;                             // mode 2: take the source rows in DESCENDING j0 (see k_rows_wavefront)
+};
+
+// inner += sum_{i < 64} a[i] * bwin[64 + l - i]   (bwin = {bprev[64], bcur[64]}), ascending i — one chunk of a row product.
+// jbase = 64 t (the chunk's first j), c = the lane's coefficient, alen / blen = the rows' lengths: positions outside the
+// sum hold zeros (finite rows: inner + x * 0 == inner, a sum formed from +0 is never -0); non-finite rows apply the
+// bounds as predicates.
+template <class E>
+__device__ inline typename E::V chunk_mac(typename E::V inner, typename E::V a_l, typename E::V bp_l, typename E::V bc_l, unsigned l,
+                                          double* stage, unsigned jbase, unsigned c, unsigned alen, unsigned blen) {
+    typedef typename E::V V;
+    // (A's coefficient as a broadcast LDS read: v_readlane pairs instead — a scalar operand of the multiply — were measured
+    // slower, 400^2 div 7.3 -> 8.4 ms)
+    E::st(stage, 192, l, a_l);
+    E::st(stage, 192, 64 + l, bp_l);
+    E::st(stage, 192, 128 + l, bc_l);
+    const double* bl = stage + 128 + l;
+    if (!any_lane(!elem_finite<E>(a_l) || !elem_finite<E>(bp_l) || !elem_finite<E>(bc_l))) {
+#pragma unroll 8
+        for (unsigned i = 0; i < 64; ++i) inner = E::add(inner, E::mul(E::ld(stage, 192, i), E::ld(bl - i, 192, 0)));
+    } else {
+        for (unsigned i = 0; i < 64; ++i) {
+            const V t = E::add(inner, E::mul(E::ld(stage, 192, i), E::ld(bl - i, 192, 0)));
+            const unsigned j = jbase + i;
+            if (j <= c && j < alen && c - j < blen) inner = t;
+        }
+    }
+    return inner;
+}
+
+template <class E>
+__global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_rows_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
+                                                                 double* res, size_t rp, RowsWfArgs g) {
+    typedef typename E::V V;
+    constexpr unsigned NW = DwfCfg<E>::NW;
+    __shared__ double part[2][E::W][NW][64];
+    __shared__ double stage[NW][E::W][192];
+    __shared__ double cur_l[E::W][64];
+    __shared__ unsigned s_task;
+    const unsigned lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* const my_stage = &stage[wave][0][0];
+    const bool lg = g.mode == 1, ex = g.mode == 2;
+    // div / log: the last wave takes no source rows — during the LAST batch (the one that holds the row finished last) it forms
+    // the part of the 1-d division's running sum that comes from this row's earlier segments, so that after the last source
+    // only one chunk product, the batch's sum and the 64 lock steps remain on the critical path
+    const unsigned NS = ex ? NW : NW - 1u;
+    // the divisor's first row (the 1-d divisions divide by it): ys[0] or, for log, xs[0]
+    const double* const d0 = lg ? xs : ys;
+    const size_t d0p = lg ? xp : yp;
+    const unsigned d0len = lg ? g.xnr : g.mr;
+    const V y0row = (!ex && lane < d0len) ? E::ld(d0, d0p, lane) : E::zero();
+    const SlabDiv<E> div_y00(ex ? E::one() : E::ld(d0, d0p, 0));
+    // a chunk of a row that other workgroups of this launch produce: one coherent load, polled while it shows the EMPTY
+    // pattern (the segment's flag is the authority after a while); `confirmed`: the row was complete before the launch
+    auto coherent_raw = [&](const double* base, size_t plane, unsigned row, unsigned chunk, unsigned len) -> V {
+        const unsigned idx = 64u * chunk + lane;
+        return idx < len ? ld_coherent<E>(base, plane, (size_t)row * g.nr + idx) : E::zero();
+    };
+    auto coherent_confirm = [&](V v, const double* base, size_t plane, unsigned row, unsigned chunk, unsigned len, bool confirmed) -> V {
+        const unsigned idx = 64u * chunk + lane;
+        const bool in = idx < len;
+        const size_t off = (size_t)row * g.nr + idx;
+        for (unsigned spins = 1; !confirmed && any_lane(in && is_empty_bits(v)); ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins & 31u) == 0u && __hip_atomic_load(g.flags + (size_t)row * g.nseg + chunk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                confirmed = true;  // (what the reload below returns is the chunk)
+            v = in ? ld_coherent<E>(base, plane, off) : E::zero();
+        }
+        return v;
+    };
+    auto plain_chunk = [&](const double* base, size_t plane, size_t rowoff, int chunk, unsigned len) -> V {
+        if (chunk < 0) return E::zero();
+        const unsigned idx = 64u * (unsigned)chunk + lane;
+        return idx < len ? E::ld(base, plane, rowoff + idx) : E::zero();
+    };
+    // cur[c] = sum_{j < 64 s} q[j] * y0[c - j], ascending j: the chunks of this row's quotient that its earlier segments have
+    // published against the divisor's first row (chunk t meets y0 at 64 (s - t) - 63 .. 64 (s - t) + 63)
+    auto division_prefix = [&](unsigned k0, unsigned s, unsigned c) -> V {
+        const double* const qbase = lg ? g.qb : res;
+        const size_t qplane = lg ? g.qbp : rp;
+        V cur1 = E::zero();
+        const unsigned t_lo = s > (d0len + 62u) / 64u ? s - (d0len + 62u) / 64u : 0u;
+        if (t_lo < s) {
+            V bc = plain_chunk(d0, d0p, 0, (int)s - (int)t_lo, d0len);
+            V a_n = coherent_raw(qbase, qplane, k0, t_lo, g.nr);
+            for (unsigned tt = t_lo; tt < s; ++tt) {
+                const V a = coherent_confirm(a_n, qbase, qplane, k0, tt, g.nr, false);
+                const V bp = plain_chunk(d0, d0p, 0, (int)s - (int)tt - 1, d0len);
+                if (tt + 1 < s) a_n = coherent_raw(qbase, qplane, k0, tt + 1, g.nr);
+                cur1 = chunk_mac<E>(cur1, a, bp, bc, lane, my_stage, 64u * tt, c, g.nr, d0len);
+                bc = bp;
+            }
+        }
+        return cur1;
+    };
+    for (;;) {
+        if (threadIdx.x == 0) s_task = atomicAdd(g.counter, 1u);
+        __syncthreads();
+        const unsigned t = s_task;
+        __syncthreads();  // everyone has read s_task before the next claim overwrites it
+        if (t >= g.ntasks) break;
+        const unsigned k0 = g.first_row + t / g.nseg, s = t % g.nseg;
+        const unsigned c = 64u * s + lane;
+        // the source rows j0 of this row's sum, in the reference's order (ascending)
+        unsigned jlo, jhi;
+        if (ex) {
+            jlo = 1;
+            jhi = (k0 < g.xn0 ? k0 : g.xn0 - 1) + 1;
+        } else if (lg) {
+            jlo = k0 + 1 > g.xn0 ? k0 + 1 - g.xn0 : 0;
+            if (jlo < 1) jlo = 1;
+            jhi = k0;
+        } else {
+            jlo = k0 + 1 > g.m0 ? k0 + 1 - g.m0 : 0;
+            jhi = k0;
+        }
+        const unsigned cnt = jhi > jlo ? jhi - jlo : 0;
+        V S = E::zero();
+        unsigned buf = 0;
+        for (unsigned base = 0; base < cnt; base += NS) {
+            const unsigned i = base + wave;
+            if (!ex && wave == NW - 1u) {
+                if (base + NS >= cnt) E::st(&cur_l[0][0], 64, lane, division_prefix(k0, s, c));
+            } else if (i < cnt) {
+                const unsigned j0 = g.rev ? jhi - 1u - i : jlo + i;
+                // A = the operand whose coefficient j is broadcast, B = the one read at c - j
+                //   div: A = res[j0] (produced here), B = ys[k0 - j0]
+                //   log: A = xs[k0 - j0],              B = j0 * res[j0] (produced here)
+                //   exp: A = j0 * xs[j0],              B = res[k0 - j0] (produced here; row 0 is the caller's)
+                const unsigned alen = (lg || ex) ? g.xnr : g.nr, blen = (lg || ex) ? g.nr : g.mr;
+                const unsigned coh_row = ex ? k0 - j0 : j0;
+                const size_t plain_off = ex ? (size_t)j0 * g.xnr : (lg ? (size_t)(k0 - j0) * g.xnr : (size_t)(k0 - j0) * g.mr);
+                const V scale = E::from_u32(j0);
+                const bool confirmed = ex && coh_row == 0;
+                // raw_*: the loads; fix_*: wait for the producer where the chunk is one of this launch's results, then scale
+                auto raw_a = [&](unsigned tt) -> V {
+                    if (!lg && !ex) return coherent_raw(res, rp, coh_row, tt, g.nr);
+                    return plain_chunk(xs, xp, plain_off, (int)tt, g.xnr);
+                };
+                auto fix_a = [&](V v, unsigned tt) -> V {
+                    if (!lg && !ex) return coherent_confirm(v, res, rp, coh_row, tt, g.nr, false);
+                    if (ex && 64u * tt + lane < g.xnr) v = E::mul(v, scale);
+                    return v;
+                };
+                auto raw_b = [&](int ch) -> V {
+                    if (ch < 0) return E::zero();
+                    if (!lg && !ex) return plain_chunk(ys, yp, plain_off, ch, g.mr);
+                    return coherent_raw(res, rp, coh_row, (unsigned)ch, g.nr);
+                };
+                auto fix_b = [&](V v, int ch) -> V {
+                    if (ch < 0 || (!lg && !ex)) return v;
+                    v = coherent_confirm(v, res, rp, coh_row, (unsigned)ch, g.nr, confirmed);
+                    if (lg && 64u * (unsigned)ch + lane < g.nr) v = E::mul(v, scale);
+                    return v;
+                };
+                // chunks t of A with any coefficient (j < alen) whose partner B[c - j] can exist (c - j < blen for some c of the segment)
+                // (chunk t meets B at the indices 64 (s - t) - 63 .. 64 (s - t) + 63: below t_lo every one of them is >= blen — terms
+                // the reference's sum does not have)
+                const unsigned t_hi = (alen + 63u) / 64u - 1u < s ? (alen + 63u) / 64u - 1u : s;
+                const unsigned t_lo = s > (blen + 62u) / 64u ? s - (blen + 62u) / 64u : 0u;
+                V inner = E::zero();
+                if (t_lo <= t_hi) {
+                    // the next chunk's loads are requested before this chunk's 64 multiply-add steps (confirmed — polled if
+                    // their producer has not stored them yet — when they are needed)
+                    V bc = fix_b(raw_b((int)s - (int)t_lo), (int)s - (int)t_lo);
+                    V a_n = raw_a(t_lo), bp_n = raw_b((int)s - (int)t_lo - 1);
+                    for (unsigned tt = t_lo; tt <= t_hi; ++tt) {
+                        const V a = fix_a(a_n, tt);
+                        const V bp = fix_b(bp_n, (int)s - (int)tt - 1);
+                        if (tt < t_hi) {
+                            a_n = raw_a(tt + 1);
+                            bp_n = raw_b((int)s - (int)tt - 2);
+                        }
+                        inner = chunk_mac<E>(inner, a, bp, bc, lane, my_stage, 64u * tt, c, alen, blen);
+                        bc = bp;  // the next chunk of A meets this one as its upper window
+                    }
+                }
+                E::st(&part[buf][0][wave][0], (size_t)NW * 64, lane, inner);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned nb = cnt - base < NS ? cnt - base : NS;
+                const double* pb = &part[buf][0][0][0];
+                if (nb == NW - 1u) {
+                    V pv[NW - 1];
+#pragma unroll
+                    for (unsigned w = 0; w < NW - 1; ++w) pv[w] = E::ld(pb, (size_t)NW * 64, (size_t)w * 64 + lane);
+#pragma unroll
+                    for (unsigned w = 0; w < NW - 1; ++w) S = E::add(S, pv[w]);
+                } else if (nb == NW) {
+                    V pv[NW];
+#pragma unroll
+                    for (unsigned w = 0; w < NW; ++w) pv[w] = E::ld(pb, (size_t)NW * 64, (size_t)w * 64 + lane);
+#pragma unroll
+                    for (unsigned w = 0; w < NW; ++w) S = E::add(S, pv[w]);
+                } else {
+                    for (unsigned w = 0; w < nb; ++w) S = E::add(S, E::ld(pb, (size_t)NW * 64, (size_t)w * 64 + lane));
+                }
+            }
+            buf ^= 1u;  // the next batch writes the other buffer while wave 0 still reads this one
+        }
+        if (wave == 0) {
+            const size_t qoff = (size_t)k0 * g.nr + c;
+            if (ex) {
+                if (c < g.nr) st_coherent(res, rp, qoff, E::div(S, E::from_u32(k0)));  // mt:1298
+            } else {
+                V r = E::neg(S);
+                if (k0 < g.xn0 && c < g.xnr) {
+                    const V xin = E::ld(xs, xp, (size_t)k0 * g.xnr + c);
+                    r = E::add(r, lg ? E::mul(E::from_u32(k0), xin) : xin);
+                }
+                if (c >= g.nr) r = E::zero();
+                // the 1-d division (mt:1162-1185): cur[c] = sum_{j < c} q[j] * y0[c - j], ascending j — the chunks of q the
+                // earlier segments of this row have published, then lock step inside the segment
+                // (its part from this row's earlier segments: formed by the last wave during the last batch, or here if the row
+                // has no source rows at all)
+                V cur1 = cnt ? E::ld(&cur_l[0][0], 64, lane) : division_prefix(k0, s, c);
+                V mine = E::zero(), ysl = y0row;  // ysl[l] = y0[l - jj] at step jj (zero for l < jj and beyond the divisor's row)
+                const bool fin = !any_lane(!elem_finite<E>(r)) && !any_lane(!elem_finite<E>(y0row)) && !any_lane(!elem_finite<E>(cur1));
+                const unsigned nsteps = g.nr - 64u * s < 64u ? g.nr - 64u * s : 64u;
+                for (unsigned jj = 0; jj < nsteps; ++jj) {
+                    const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r), jj));
+                    if (lane == jj) mine = q;
+                    const V tnew = E::add(cur1, E::mul(q, ysl));
+                    if (fin && elem_finite<E>(q)) {
+                        cur1 = tnew;  // positions outside the sum multiply a shifted-in zero
+                    } else if (lane > jj && lane - jj < d0len) {
+                        cur1 = tnew;
+                    }
+                    ysl = wave_shr1<E>(ysl);
+                }
+                if (c < g.nr) {
+                    if (lg) {  // res[k0] = q / k0 (mt:1384); the row's later segments divide with q itself
+                        st_coherent(g.qb, g.qbp, qoff, mine);
+                        st_coherent(res, rp, qoff, E::div(mine, E::from_u32(k0)));
+                    } else {
+                        st_coherent(res, rp, qoff, mine);
+                    }
+                }
+            }
+            __threadfence();  // the segment is visible device-wide before its flag is
+            if (lane == 0) __hip_atomic_store(g.flags + (size_t)k0 * g.nseg + s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// mode 0: res = xs / ys;  1: rows >= 1 of log(xs) (qbuf: a tensor like res);  2: rows >= 1 of exp(xs).  Rank 2, rows of
+// 65 .. 4096 coefficients.  `flags_and_counter`: n0 * ceil(nr / 64) + 1 zeroed words.  false: outside the kernel's domain,
+// nothing launched.
+template <class E>
+bool K<E>::rows_wavefront(hipStream_t st, int mode, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
+                          const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, double* qbuf, size_t q_plane,
+                          unsigned* flags_and_counter) {
+    RowsWfArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.rev = (mode & 4) ? 1 : 0;  // mode 2 | 4: exp with the source rows in descending order (1e-10 contract)
+    mode &= 3;
+    g.mode = mode;
+    g.n0 = rshape[0];
+    g.nr = rshape[1];
+    g.xn0 = xshape[0];
+    g.xnr = xshape[1];
+    g.m0 = mode == 0 ? yshape[0] : xshape[0];
+    g.mr = mode == 0 ? yshape[1] : xshape[1];
+    if (g.nr <= 64 || g.nr > 4096 || g.n0 == 0 || g.xn0 == 0 || g.xnr == 0 || g.m0 == 0 || g.mr == 0) return false;
+    if (g.xn0 > g.n0 || g.xnr > g.nr || g.m0 > g.n0 || g.mr > g.nr) return false;
+    g.first_row = mode == 0 ? 0u : 1u;
+    if (g.n0 <= g.first_row) return false;
+    g.nseg = (g.nr + 63u) / 64u;
+    const size_t ntasks = (size_t)(g.n0 - g.first_row) * g.nseg;
+    if (ntasks > 0x7fffffffu) return false;
+    g.ntasks = (unsigned)ntasks;
+    g.flags = flags_and_counter;
+    g.counter = flags_and_counter + (size_t)g.n0 * g.nseg;
+    g.qb = qbuf;
+    g.qbp = q_plane;
+    if (mode == 1 && !qbuf) return false;
+    const size_t skip = (size_t)g.first_row * g.nr, nel = (size_t)(g.n0 - g.first_row) * g.nr;
+    for (int pl = 0; pl < E::W; ++pl) {
+        const unsigned fb = (unsigned)std::min<size_t>((nel + 255) / 256, 2048);
+        GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, res + (size_t)pl * r_plane + skip, nel, DWF_EMPTY);
+        if (mode == 1) GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, qbuf + (size_t)pl * q_plane + skip, nel, DWF_EMPTY);
+    }
+    // persistent workgroups (they claim tasks until none is left): two per CU so that the SIMDs stay busy while some wait
+    const unsigned blocks = (unsigned)std::min<size_t>(ntasks, (size_t)256 * 2);
+    GFT_LAUNCH((k_rows_wavefront<E>), dim3(blocks), dim3(64 * DwfCfg<E>::NW), 0, st, xs, x_plane, mode == 0 ? ys : xs, mode == 0 ? y_plane : x_plane,
+               res, r_plane, g);
+    return true;
+}
+template bool K<EF64>::rows_wavefront(hipStream_t, int, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                      const unsigned*, double*, size_t, unsigned*);
+template bool K<EIv>::rows_wavefront(hipStream_t, int, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                     const unsigned*, double*, size_t, unsigned*);
 
 }  // namespace gft

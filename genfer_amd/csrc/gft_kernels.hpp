@@ -305,8 +305,16 @@ struct K {
     static bool log_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
                               const unsigned* rshape, int nd, double* qbuf, size_t q_plane, unsigned* flags_and_counter);
     // res[1..] = exp(xs)[1..] likewise (slab 0, an exp one dimension down, is the caller's and complete in stream order)
+    // `arrival_order`: the source slabs of each row's sum in descending j0 (1e-10 contract instead of the reference's order)
     static bool exp_wavefront(hipStream_t st, const double* xs, size_t x_plane, const unsigned* xshape, double* res, size_t r_plane,
-                              const unsigned* rshape, int nd, unsigned* flags_and_counter);
+                              const unsigned* rshape, int nd, unsigned* flags_and_counter, int arrival_order = 0);
+    // Rank-2 quotient (mode 0), or the rows >= 1 of a rank-2 log (1) / exp (2), with rows of 65 .. 4096 coefficients as a
+    // coefficient-level wavefront in ONE launch (gft_div2d.hip k_rows_wavefront): tasks are 64-coefficient segments of rows,
+    // bit-identical to the host-driven recursion.  `flags_and_counter`: rows * ceil(row length / 64) + 1 zeroed words;
+    // `qbuf` (mode 1): a tensor like res.  false: outside the kernel's domain, nothing launched.
+    static bool rows_wavefront(hipStream_t st, int mode, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys,
+                               size_t y_plane, const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, double* qbuf,
+                               size_t q_plane, unsigned* flags_and_counter);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);

@@ -1087,11 +1087,17 @@ WAVEFRONT_SHAPES = [
     ((21, 19, 31), (5, 19, 31), (21, 7, 9)),         # rows <= 32: two source rows per wave, odd row counts
     ((9, 11, 32), (9, 11, 32), (9, 11, 32)),         # rows of exactly 32
     ((13, 5, 7, 24), (13, 2, 7, 24), (4, 5, 7, 24)),  # rank 4, packed rows
+    # rank 2 with rows > 64: the coefficient-level wavefront (tasks are 64-coefficient segments of rows; round 4)
+    ((24, 130), (24, 130), (24, 130)),               # three segments, the last one partial
+    ((60, 200), (7, 70), (45, 150)),                 # compact divisor (its rows end inside segment 1) and dividend
+    ((150, 65), (150, 65), (150, 2)),                # one coefficient into the second segment; a thin dividend
+    ((33, 256), (33, 100), (33, 256)),               # whole segments; divisor rows shorter than the quotient's
+    ((130, 130), (130, 130), (130, 130)),
 ]
 
 
 @pytest.mark.parametrize("zs,ys,xs", WAVEFRONT_SHAPES)
-def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
+def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier):
     """The division as a row wavefront (one launch, every quotient row a task of one wave, dependencies through per-row
     flags) consumes its terms in the reference's order (mt:1162-1192 over mt:984-1012): bit-exact against the oracle,
     and identical to the slab-by-slab blocked recurrence (`div_wavefront` = 0); finite, non-finite and interval data."""
@@ -1115,8 +1121,12 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI):
         for wf in (1, 0):
             assert L.gft_set_option(b"div_wavefront", float(wf)) == 0
             try:
+                before = genfer_amd.op_stats()["launches"]
                 got[wf] = G.new(a, deg) / G.new(b, deg)
                 check(want, got[wf])
+                if wf and len(zs) == 2 and zs[1] > 64 and tier == "device":
+                    # one launch (+ the fill of the result with the EMPTY pattern, + the flags' memset): not one per row
+                    assert genfer_amd.op_stats()["launches"] - before <= 8, "the long-row quotient did not take the one-launch wavefront"
             finally:
                 L.gft_set_option(b"div_wavefront", 1.0)
     # the log recurrence (mt:1335-1386) through the same wavefront: slabs k0 >= 1 in one launch, slab 0 one dimension down
