@@ -2787,6 +2787,10 @@ struct Ops {
                     double c_[2], m_[2];
                     size_t u_;
                     if (!extract_linear(res, c_, m_, &u_)) {
+                        // (the host scan's verdict carries over when the accumulator outgrows the host tier: proven — it
+                        // stays non-linear; otherwise the speculation the device steps make anyway, verified by their witnesses.
+                        // Without this the first device accumulator was scanned again: a launch and a host round trip)
+                        res_nonlinear_seen = true;
                         // proven (interval, non-zero finite constant): the accumulator stays non-linear for the rest of the
                         // loop, so every remaining step runs in one host loop — two ping-pong buffers, no per-step scan,
                         // handle or shape vectors (they cost as much as the arithmetic on ~100-element tensors)

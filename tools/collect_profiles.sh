@@ -48,7 +48,6 @@ cd "$ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/summary/bench_c2_n1.json" 2> "$OUT/bench_c2.err"
 python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench_fp64.hip -o /tmp/microbench_fp64 2> "$OUT/mb.err" && /tmp/microbench_fp64 > "$OUT/summary/microbench_fp64.txt" 2>&1
-python3 tools/bench_recurrence.py > "$OUT/summary/recurrences.txt" 2> "$OUT/rec.err"
 python3 tools/bench_interval.py > "$OUT/summary/interval_product.txt" 2> "$OUT/iv.err"
 python3 tools/xover_host.py > "$OUT/summary/xover_host.txt" 2> "$OUT/xover.err"
 python3 tools/bench_e2e.py --limit 100 --runs 2 --bounds --only approx --gpu-only > "$OUT/e2e_bounds.log" 2>&1; tail -1 "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.json"
@@ -57,6 +56,13 @@ python3 tools/bench_staged.py > "$OUT/staged.log" 2>&1; cp gpurun_out/staged_vs_
 python3 tools/sweep_tiled.py > "$OUT/summary/tiled_size_sweep.txt" 2> "$OUT/sweep.err"
 python3 tools/bench_sync.py > "$OUT/summary/host_round_trip.txt" 2> "$OUT/sync.err"
 python3 tools/bench_horner.py > "$OUT/summary/horner_loop.txt" 2> "$OUT/horner.err"
+python3 tools/bench_shallow.py > "$OUT/summary/shallow_products.txt" 2> "$OUT/shallow.err"
+python3 tools/bench_recurrence.py 32x32x32 64x64x64 24x24x24x24 200x200 400x400 1000x32 100x64 > "$OUT/summary/recurrences.txt" 2> "$OUT/rec2.err"
+GFT_ROWS_WAVEFRONT=0 python3 tools/bench_recurrence.py 200x200 400x400 1000x32 > "$OUT/summary/recurrences_rows_wavefront_off.txt" 2> "$OUT/rec3.err"
+for prog in three_populations:100 four_populations:24; do
+  n=${prog%%:*}; l=${prog##*:}
+  (cd /tmp && rm -rf /tmp/gft_e2e_$n && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_$n -o kt -- python3 "$ROOT/tools/run_sgcl.py" bench/$n.sgcl "--limit $l" 1 > "$OUT/e2e_${n}_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_$n -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_${n}_kernel_stats.csv")
+done
 python3 tools/bench_div2d.py 32 64 > "$OUT/summary/div2d_slab.txt" 2> "$OUT/div2d.err"
 (cd /tmp && rm -rf /tmp/gft_e2e_mix && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mix -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only > "$OUT/e2e_mix_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mix -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_kernel_stats.csv")
 (cd /tmp && rm -rf /tmp/gft_e2e_mixb && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gft_e2e_mixb -o kt -- python3 "$ROOT/tools/bench_e2e.py" --limit 100 --runs 1 --only mixture --gpu-only --bounds > "$OUT/e2e_mixb_trace.log" 2>&1; cp "$(find /tmp/gft_e2e_mixb -name '*kernel_stats.csv' | head -1)" "$OUT/summary/e2e_mixture_bounds_kernel_stats.csv")
