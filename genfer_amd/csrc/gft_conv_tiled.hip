@@ -311,7 +311,7 @@ constexpr unsigned YPAD = 8;  // front padding of every LDS row (doubles)
 // slower at every size: 32^3 48.7 -> 48.4 us, 64^3 447 -> 521 us, 378^2 310 -> 443 us.  Every arrival needs a device-scope
 // release + acquire around its counter, which on this part is a write-back and an invalidate of the XCD's whole L2 —
 // paid by a thousand workgroups while their neighbours are still streaming y windows through that L2 — and the call kept
-// 116 bytes of scratch in the kernel.  The separate launch got 16 waves per (tile, block) instead: k_conv_reduce.)
+// 116 bytes of scratch in the kernel.)
 
 template <int NW, int VAR, int TSH>
 __global__ void __launch_bounds__(NW * 64, 4)  // 4 waves per SIMD = 16 waves per CU => <= 128 VGPRs
@@ -486,26 +486,15 @@ k_conv_tiled(TiledArgs A) {
     }
 }
 
-// Fixed-order sum of the partial slabs of split tiles.  One workgroup per (tile, 8-wide output block); its RW waves each
-// sum a contiguous share of the tile's partial slabs — four slabs' loads in flight at a time, added in slab order — and
-// the shares are added in wave order through LDS: the order depends on the plan only, so results are deterministic.
-// Round 4: 16 waves instead of 4 (a 32^3 product's heaviest tile has 93 slabs: 23 dependent memory latencies per wave
-// were 18 us — a third of the whole product; now 6 per wave).
-constexpr unsigned RW = 16;
-__device__ inline void slab_ld8(double (&d)[8], const double* p) {
-    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double2 t = q[i];
-        d[2 * i] = t.x;
-        d[2 * i + 1] = t.y;
-    }
-}
-__global__ void __launch_bounds__(RW * 64) k_conv_reduce(TiledArgs A, unsigned n_red) {
+// Fixed-order sum of the partial slabs of split tiles.  One workgroup per (tile, 8-wide output block); its four waves
+// each sum a contiguous quarter of the tile's partial slabs and the quarters are added in order through LDS — the order
+// depends on the plan only, so results are deterministic.  (A slab step of a recurrence has few tiles and many partial
+// slabs: one workgroup per tile walking all of them serially took 140 us at 64^3, 2x the product itself.)
+__global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red) {
     const unsigned ti = blockIdx.x, c = blockIdx.y;
     if (ti >= n_red) return;
     if (A.guard && *A.guard == A.guard_epoch) return;
-    __shared__ double part[RW - 1][64][8];
+    __shared__ double part[3][64][8];
     const RedTile rt = A.red[ti];
     const unsigned lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
     const unsigned k0 = (64u >> A.tsh) * rt.a + (lane >> A.tsh), k1 = (rt.b << A.tsh) + (lane & ((1u << A.tsh) - 1u));
@@ -524,29 +513,15 @@ __global__ void __launch_bounds__(RW * 64) k_conv_reduce(TiledArgs A, unsigned n
                 if (k2 < A.zI) v[r] = zrow[k2];
             }
         }
-        const unsigned lo = (unsigned)((unsigned long long)rt.count * q / RW), hi = (unsigned)((unsigned long long)rt.count * (q + 1) / RW);
-        // (a tile's partial slabs are consecutive workspace slots — the plan's ranges are contiguous in tile order — so
-        // the slab address follows from the tile's entry alone unless the plan says otherwise)
-        const size_t slab_doubles = (size_t)A.nb * 512, off = ((size_t)c * 64 + lane) * 8;
-        auto slab = [&](unsigned p) {
+        const unsigned lo = (unsigned)((unsigned long long)rt.count * q / 4), hi = (unsigned)((unsigned long long)rt.count * (q + 1) / 4);
+        for (unsigned p = lo; p < hi; ++p) {
+            // (a tile's partial slabs are consecutive workspace slots — the plan's ranges are contiguous in tile order — so
+            // the slab address follows from the tile's entry alone: one dependent load less in a launch that is nothing
+            // but a few memory latencies)
             const unsigned slot = A.red_slots ? A.red_slots[rt.first + p] : rt.slot0 + p;
-            return A.ws + (size_t)slot * slab_doubles + off;
-        };
-        unsigned p = lo;
-        for (; p + 4 <= hi; p += 4) {
-            double a0[8], a1[8], a2[8], a3[8];
-            slab_ld8(a0, slab(p));
-            slab_ld8(a1, slab(p + 1));
-            slab_ld8(a2, slab(p + 2));
-            slab_ld8(a3, slab(p + 3));
+            const double* w = A.ws + (size_t)slot * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = (((v[r] + a0[r]) + a1[r]) + a2[r]) + a3[r];
-        }
-        for (; p < hi; ++p) {
-            double a0[8];
-            slab_ld8(a0, slab(p));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += a0[r];
+            for (int r = 0; r < 8; ++r) v[r] += w[r];
         }
         if (q > 0) {
 #pragma unroll
@@ -555,7 +530,8 @@ __global__ void __launch_bounds__(RW * 64) k_conv_reduce(TiledArgs A, unsigned n
     }
     __syncthreads();
     if (q == 0 && lane_in) {
-        for (unsigned g = 0; g + 1 < RW; ++g)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += part[g][lane][r];
 #pragma unroll
@@ -565,6 +541,8 @@ __global__ void __launch_bounds__(RW * 64) k_conv_reduce(TiledArgs A, unsigned n
         }
     }
 }
+// (Round 4 tried 16 waves per (tile, block) with four slabs' loads in flight: 32^3 18 -> 16 us, but 128^3 65 -> 233 us — 60 KB of
+// static LDS per workgroup leaves two of them per CU to read 285 MB of slabs.  Kept as it was.)
 
 // out[row][i] = i < len ? in[row][i] : 0, rows x n8
 // Operand preparation: rows are copied into the zero-padded packed layout and, on the way, *flag is raised to
@@ -1065,15 +1043,18 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     size_t x_rows = (size_t)B.xU * B.x0 * B.x1, y_rows = (size_t)B.yU * B.y0 * B.y1;
     // Operands are read in place where their own layout IS the packed one (round 4): rows of whole chunks, y 16-byte
     // aligned (window loads are 16-byte), and 64 readable bytes after x's last element (the pipelined path requests one
-    // chunk beyond the one it uses; the library's own buffers have that slack, a caller's raw pointer may not).  There is
-    // then no zero padding anywhere, so inf / NaN operands cannot create NaNs the reference does not produce: no verdict,
+    // chunk beyond the one it uses; the library's own buffers have that slack, a caller's raw pointer may not), both spanning
+    // every chunk of the result's rows.  There is then no zero padding anywhere, so inf / NaN operands cannot create NaNs the reference does not produce: no verdict,
     // no guarded fallback launch — ONE launch per product.  Everything else is packed by k_prep_operands (rows padded to
     // whole chunks plus one chunk of slack after the last row), which also takes the non-finite verdict.
     static const bool inplace_env = [] {
         const char* e = getenv("GFT_TILED_INPLACE");  // A/B knob: 0 = always pack
         return e ? atoi(e) != 0 : true;
     }();
-    const bool inplace = inplace_env && a.operands_slack && B.nx8 == B.xI && B.ny8 == B.yI && !((uintptr_t)y & 15) && !((uintptr_t)x & 7);
+    // (full inner extents only: the compact-operand path multiplies a zero window where a block reaches beyond y's last chunk —
+    // artificial zeros again, which need the verdict)
+    const bool inplace = inplace_env && a.operands_slack && B.nx8 == B.xI && B.ny8 == B.yI && B.nxc >= B.nb && B.nyc >= B.nb &&
+                         !((uintptr_t)y & 15) && !((uintptr_t)x & 7);
     if (guarded) *guarded = !inplace;
     bool pack_y = !inplace && (B.ny8 != B.yI || ((uintptr_t)y & 15));  // window loads are 16-byte
     // (sized for the packed layout whether or not this call packs: a query and the launches that follow it — the high-rank
@@ -1150,7 +1131,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     }
     if (e != hipSuccess) return false;
     if (P.n_red) {
-        GFT_LAUNCH(k_conv_reduce, dim3(P.n_red, T.nb), dim3(RW * 64), 0, st, T, P.n_red);
+        GFT_LAUNCH(k_conv_reduce, dim3(P.n_red, T.nb), dim3(256), 0, st, T, P.n_red);
     }
     return true;
 }

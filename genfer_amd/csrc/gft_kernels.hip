@@ -571,6 +571,49 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
         E::st(out, out_plane, lin, v);
     }
 }
+// The same when every operand is its whole base tensor in the output's own layout (no sub-box, no pad, no table stage): the
+// element index IS the offset — no per-element odometer (64-bit divisions per axis: the general kernel reached 33 % of the
+// HBM roof at 384^3, tools/bench_streaming.py), two elements per thread and iteration in flight.
+template <class E, bool TWO>
+__global__ void __launch_bounds__(256) k_chain_flat(double* __restrict__ out, size_t out_plane, ChainSrc a, ChainSrc b, int subtract, size_t total) {
+    typedef typename E::V V;
+    const unsigned k0[MAXD] = {0};
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += 2 * step) {
+        const size_t lin2 = lin + step;
+        const bool two = lin2 < total;
+        V v0, v1 = E::zero();
+        if (!TWO) {
+            v0 = chain_eval<E>(a, lin, k0, lin == 0);
+            if (two) v1 = chain_eval<E>(a, lin2, k0, false);
+        } else {
+            const V a0 = chain_eval<E>(a, lin, k0, lin == 0), b0 = chain_eval<E>(b, lin, k0, lin == 0);
+            V a1 = E::zero(), b1 = E::zero();
+            if (two) {
+                a1 = chain_eval<E>(a, lin2, k0, false);
+                b1 = chain_eval<E>(b, lin2, k0, false);
+            }
+            v0 = E::add(E::zero(), a0);
+            v0 = subtract ? E::sub(v0, b0) : E::add(v0, b0);
+            v1 = E::add(E::zero(), a1);
+            v1 = subtract ? E::sub(v1, b1) : E::add(v1, b1);
+        }
+        E::st(out, out_plane, lin, v0);
+        if (two) E::st(out, out_plane, lin2, v1);
+    }
+}
+// the operand is its whole base tensor, laid out like the output, and none of its stages looks at coordinates beyond "element 0"
+static bool chain_is_flat(const ChainSrc& c, const Shape& sh) {
+    size_t stride = 1;
+    for (int ax = sh.nd - 1; ax >= 0; --ax) {
+        if (c.pad[ax] != 0 || c.box[ax] != sh.d[ax] || c.stride[ax] != stride) return false;
+        stride *= sh.d[ax];
+    }
+    for (int i = 0; i < c.nstages; ++i)
+        if (c.st[i].kind == CH_MUL_TAB) return false;
+    return true;
+}
+
 // k_chain<E, false> and k_linear_scan in one launch: the accumulator of a Horner step is a deferred chain whose FIRST
 // consumer is Mul's `extract_linear` (mt:1014-1072 asks `self` first) — materialise it and settle the question in the same
 // pass (one launch and its gap less per subst_var of a `--bounds` program).  Verdict and mailbox as in k_linear_scan.
@@ -657,6 +700,10 @@ void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape
     size_t total = 1;
     for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
     if (total == 0) return;
+    if (total >= 4096 && chain_is_flat(a, sh)) {
+        GFT_LAUNCH((k_chain_flat<E, false>), dim3(grid_for((total + 1) / 2)), dim3(256), 0, st, out, out_plane, a, a, 0, total);
+        return;
+    }
     GFT_LAUNCH((k_chain<E, false>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
 }
 template <class E>
@@ -665,6 +712,10 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
     size_t total = 1;
     for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
     if (total == 0) return;
+    if (total >= 4096 && chain_is_flat(a, sh) && chain_is_flat(b, sh)) {
+        GFT_LAUNCH((k_chain_flat<E, true>), dim3(grid_for((total + 1) / 2)), dim3(256), 0, st, out, out_plane, a, b, subtract, total);
+        return;
+    }
     GFT_LAUNCH((k_chain<E, true>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
 }
 

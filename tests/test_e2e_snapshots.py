@@ -207,7 +207,8 @@ def test_oracle_c3_stored_reports_are_wellformed():
     assert files
     for f in files:
         text = open(f).read()
-        assert text.count("p(") >= 100 and "Total measure" in text
+        # (--limit 100 for the NeurIPS programs and three_populations; four_populations is timed at --limit 24)
+        assert text.count("p(") >= (24 if "four_populations" in f else 100) and "Total measure" in text
 
 
 @pytest.mark.gpu
