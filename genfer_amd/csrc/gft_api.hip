@@ -315,6 +315,7 @@ static Mailbox next_mail() {
     mb.payload = R.d_mail;
     mb.seq = (unsigned long long*)(R.d_mail + 8);
     mb.value = ++R.mail_seq;
+    mb.dev_word = R.d_flag + 16;  // the scans also leave their verdict in device memory (guards of speculative launches)
     return mb;
 }
 static void wait_mail(const Mailbox& mb, double* out, unsigned n) {
@@ -1268,16 +1269,33 @@ struct Ops {
     }
 
     // ---- extract_linear (mt:275-294) --------------------------------------------------------------------
-    static bool extract_linear(const P& p, double c[2], double m[2], size_t* var) {
+    // extract_linear in two halves (round 4): `begin` answers from the host where it can (done = true) and otherwise launches
+    // the device scan WITHOUT waiting for it; `end` waits for the mailbox and memoises the verdict on the buffer.  Between
+    // the two the caller may queue work that is guarded on the device by the scan's verdict word (Mailbox::dev_word): the
+    // speculative Horner loop runs behind the scan instead of behind a host round trip (horner_speculative).
+    struct ScanToken {
+        bool done = false, result = false;   // answered without a device scan
+        double c[2] = {0, 0}, m[2] = {0, 0};
+        size_t var = 0;
+        Mailbox mb;
+        Dims keep;                           // collapsed axes the kernel's mask bits refer to
+        std::shared_ptr<Buf> buf;            // the buffer the verdict belongs to
+    };
+    static ScanToken extract_linear_begin(const P& p) {
+        ScanToken t;
         unsigned mask = 0;
         for (size_t v = 0; v < p.shape.size(); ++v)
             if (p.shape[v] >= 2) mask |= 1u << v;
-        if (!mask) return false;
+        if (!mask) {
+            t.done = true;
+            return t;
+        }
         if (!p.buf && p.lazy_lin) {
-            c[0] = p.cv[0]; c[1] = p.cv[1];
-            m[0] = p.cv1[0]; m[1] = p.cv1[1];
-            *var = p.lazy_var;
-            return true;
+            t.done = t.result = true;
+            t.c[0] = p.cv[0]; t.c[1] = p.cv[1];
+            t.m[0] = p.cv1[0]; t.m[1] = p.cv1[1];
+            t.var = p.lazy_var;
+            return t;
         }
         if (p.pend && !p.pend->mat) {
             // a deferred chain whose first consumer asks this question: materialise it and scan it in ONE launch
@@ -1293,8 +1311,8 @@ struct Ops {
                     sh.d[j] = (unsigned)p.shape[ckeep[j]];
                     if (p.shape[ckeep[j]] >= 2) cm |= 1u << j;
                 }
-                Mailbox mb = next_mail();
-                K<E>::chain_copy_scan(R.stream, outb->p, p.numel, sh, chain_src<E>(p, ckeep), cm, R.d_flag + 8, mb);
+                t.mb = next_mail();
+                K<E>::chain_copy_scan(R.stream, outb->p, p.numel, sh, chain_src<E>(p, ckeep), cm, R.d_flag + 8, t.mb);
                 trace_settle();
                 R.stats_ex[1]++;
                 R.stats[0]++;
@@ -1303,70 +1321,82 @@ struct Ops {
                 q.mat_shape = p.shape;
                 p.buf = q.mat;
                 p.pend = nullptr;
-                double res[5];
-                wait_mail(mb, res, 5);
-                const unsigned got = (unsigned)res[0];
-                if (!got) {
-                    p.buf->lin_state = 1;
-                    return false;
-                }
-                size_t ci = 0;
-                while (!((got >> ci) & 1u)) ci++;
-                c[0] = res[1];
-                c[1] = res[2];
-                m[0] = res[3];
-                m[1] = res[4];
-                *var = ckeep[ci];
-                p.buf->lin_state = 2;
-                p.buf->lin_c[0] = c[0]; p.buf->lin_c[1] = c[1];
-                p.buf->lin_m[0] = m[0]; p.buf->lin_m[1] = m[1];
-                p.buf->lin_var = *var;
-                return true;
+                t.keep = ckeep;
+                t.buf = p.buf;
+                return t;
             }
         }
         settle<E>(p);  // the verdict is memoised per buffer: a deferred chain is materialised first
         if (p.buf && p.buf->lin_state) {
-            if (p.buf->lin_state == 1) return false;
-            c[0] = p.buf->lin_c[0]; c[1] = p.buf->lin_c[1];
-            m[0] = p.buf->lin_m[0]; m[1] = p.buf->lin_m[1];
-            *var = p.buf->lin_var;
-            return true;
+            t.done = true;
+            t.result = p.buf->lin_state == 2;
+            if (t.result) {
+                t.c[0] = p.buf->lin_c[0]; t.c[1] = p.buf->lin_c[1];
+                t.m[0] = p.buf->lin_m[0]; t.m[1] = p.buf->lin_m[1];
+                t.var = p.buf->lin_var;
+            }
+            return t;
         }
         // kernel works on the collapsed view; map collapsed axis bits back to real axes
         Dims keep = collapse_mask({&p.shape}, false);
         unsigned cmask = 0;
         for (size_t i = 0; i < keep.size(); ++i)
             if (p.shape[keep[i]] >= 2) cmask |= 1u << i;
-        double res[5];
+        t.keep = keep;
+        t.buf = p.buf;
         if (p.buf->host) {
+            double res[5];
             HV v = view(p, true);
             res[0] = (double)HK<E>::linear_scan(dview(v, &keep), cmask, res + 1, res + 3);  // {mask, c.lo, c.hi, m.lo, m.hi}
-        } else {
-            HV v = view(p);
-            DView dv = dview(v, &keep);
-            Mailbox mb = next_mail();
-            K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, mb);  // one launch (state words 8, 9), result by mailbox
-            R.stats[0]++;
-            g_scan_trace.hit(p.numel, keep.size());
-            wait_mail(mb, res, 5);
+            t.done = true;
+            finish_scan(t, res);
+            return t;
         }
-        unsigned got = (unsigned)res[0];
+        HV v = view(p);
+        DView dv = dview(v, &keep);
+        t.mb = next_mail();
+        K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, t.mb);  // one launch (state words 8, 9), result by mailbox
+        R.stats[0]++;
+        g_scan_trace.hit(p.numel, keep.size());
+        return t;
+    }
+    static void finish_scan(ScanToken& t, const double res[5]) {
+        const unsigned got = (unsigned)res[0];
         if (!got) {
-            p.buf->lin_state = 1;
-            return false;
+            t.buf->lin_state = 1;
+            t.result = false;
+            return;
         }
         size_t ci = 0;
         while (!((got >> ci) & 1u)) ci++;
-        c[0] = res[1];
-        c[1] = res[2];
-        m[0] = res[3];
-        m[1] = res[4];
-        *var = keep[ci];
-        p.buf->lin_state = 2;
-        p.buf->lin_c[0] = c[0]; p.buf->lin_c[1] = c[1];
-        p.buf->lin_m[0] = m[0]; p.buf->lin_m[1] = m[1];
-        p.buf->lin_var = *var;
-        return true;
+        t.c[0] = res[1];
+        t.c[1] = res[2];
+        t.m[0] = res[3];
+        t.m[1] = res[4];
+        t.var = t.keep[ci];
+        t.buf->lin_state = 2;
+        t.buf->lin_c[0] = t.c[0]; t.buf->lin_c[1] = t.c[1];
+        t.buf->lin_m[0] = t.m[0]; t.buf->lin_m[1] = t.m[1];
+        t.buf->lin_var = t.var;
+        t.result = true;
+    }
+    static bool extract_linear_end(ScanToken& t, double c[2], double m[2], size_t* var) {
+        if (!t.done) {
+            double res[5];
+            wait_mail(t.mb, res, 5);
+            finish_scan(t, res);
+            t.done = true;
+        }
+        if (t.result) {
+            c[0] = t.c[0]; c[1] = t.c[1];
+            m[0] = t.m[0]; m[1] = t.m[1];
+            *var = t.var;
+        }
+        return t.result;
+    }
+    static bool extract_linear(const P& p, double c[2], double m[2], size_t* var) {
+        ScanToken t = extract_linear_begin(p);
+        return extract_linear_end(t, c, m, var);
     }
 
     // Inner-axis split for the tiled kernel (gft_conv_tiled.hip, k_pad_rows / k_fold_rows): rank 2/3 whose last axis
@@ -2740,6 +2770,13 @@ struct Ops {
     // A step without a witness (exact cancellation, or a support on unit positions of two axes) makes the function
     // return false and the caller redoes the loop with horner_exact: the stored shapes are the reference's in every
     // case, the extra cost is one round trip per subst_var instead of one per step.
+    // a device tensor copied into a host-tier tensor (the caller has decided that the host is the better machine for it)
+    static P to_host_tier(const P& dev) {
+        P h = make(dev.shape, dev.deg, true);
+        HIP_OK(hipMemcpyAsync(hp<E>(h), dp<E>(dev), sizeof(double) * dev.numel * W, hipMemcpyDeviceToHost, R.stream));
+        HIP_OK(hipStreamSynchronize(R.stream));
+        return h;
+    }
     static constexpr size_t WIT_SLOTS = 8192;
     static bool horner_speculative(const P& ca, size_t v, const P& subst, const Dims& deg, bool lin_known, const double c[2],
                                    const double m[2], size_t w, P* result) {
@@ -2767,6 +2804,25 @@ struct Ops {
         }();
         if (!verify) proven = true;
 #endif
+        // Host phase for LINEAR streaks (round 4).  The top coefficient slabs of a tensor with triangular support hold a
+        // coefficient or two each: the accumulator stays linear for several steps, and on the device every one of them is a
+        // scan, a host round trip and four launches of a few elements (hmm `--bounds`: 11 918 of its 16 300 scans said
+        // "linear").  After the first such verdict the accumulator and the next HBLK coefficient slabs are brought to the
+        // host tier (one gather, two copies) and the steps run there — the same reference steps on the same functors, their
+        // scans free — until the accumulator is no longer linear or outgrows the tier; then the device takes over again.
+        constexpr size_t HBLK = 8;
+        P ca_h;                       // host-tier copy of the slabs [ca_h_lo, ca_h_hi) of ca along v
+        size_t ca_h_lo = 0, ca_h_hi = 0;
+        static const bool host_phase_on = [] {
+            const char* e = getenv("GFT_HORNER_HOST_PHASE");  // A/B knob
+            return e ? atoi(e) != 0 : true;
+        }();
+        auto fetch_block = [&](size_t i_top) {
+            const size_t lo = i_top + 1 > HBLK ? i_top + 1 - HBLK : 0;
+            ca_h = to_host_tier(slab_range(ca, v, lo, i_top + 1, ca.deg, OP_COPY, -1, nullptr, 0, 0));
+            ca_h_lo = lo;
+            ca_h_hi = i_top + 1;
+        };
         for (size_t i = ca.shape[v]; i-- > 0;) {
             bool speculate = false;
             if (!on_host(res) && res.numel > 1) {
@@ -2774,7 +2830,59 @@ struct Ops {
                     double c_[2], m_[2];
                     size_t u_;
                     ScanCtx sc_res("subst_var.accumulator");
-                    if (!extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // memoised: the generic mul reuses it
+                    ScanToken tok = extract_linear_begin(res);
+                    if (g_scan_trace.on) {
+                        char key[160];
+                        snprintf(key, sizeof key, "horner scan: done=%d lin_known=%d rank_ok=%d i=%s proven=%d len_v=%s", (int)tok.done, (int)lin_known,
+                                 (int)(res.shape.size() == deg.size()), i == 0 ? "0" : (i == 1 ? "1" : ">1"), (int)proven, ca.shape[v] == 2 ? "2" : ">2");
+                        g_scan_trace.counts[key]++;
+                    }
+                    // The scan is in flight (or answered).  With a linear substitution the steps that follow a "not linear"
+                    // verdict are ONE launch (horner_linear_rest): queue it right behind the scan, guarded on the device by
+                    // the scan's verdict word, and only then wait for the verdict — the loop runs while the host reads its
+                    // mail instead of after a launch latency on top of the round trip (`--bounds` programs: one scan per
+                    // subst_var, 16-18 thousand of them).  A "linear" verdict (rare: the reference then multiplies the other
+                    // way round) makes the queued launch a no-op; its output is dropped and the reference step is taken.
+                    P ahead;
+                    bool queued = false;
+                    unsigned* ahead_wit = (proven || slots + (unsigned)i > WIT_SLOTS) ? nullptr : R.d_wit + slots;
+                    static const bool ahead_on = [] {
+                        const char* e = getenv("GFT_HORNER_AHEAD");  // A/B knob: 0 = wait for the verdict, then launch
+                        return e ? atoi(e) != 0 : true;
+                    }();
+                    bool queued_step = false;
+                    if (ahead_on && !tok.done && R.fuse_horner && lin_known && res.shape.size() == deg.size()) {
+                        if (i >= 1 && (proven || ahead_wit)) {
+                            if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
+                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16);
+                        }
+                        // ... or the single fused step where the whole-loop launch does not apply: the last step (nothing is
+                        // speculated about its result), or any step of a proven loop (no witness to raise)
+                        if (!queued && (i == 0 || proven)) {
+                            ahead = horner_linear_step(res, ca, v, i, c, m, w, deg, R.d_flag + 16);
+                            queued_step = true;
+                        }
+                    }
+                    if (!extract_linear_end(tok, c_, m_, &u_)) res_nonlinear_seen = true;  // memoised: the generic mul reuses it
+                    if (g_scan_trace.on) g_scan_trace.counts[res_nonlinear_seen ? "horner scan verdict: not linear" : "horner scan verdict: LINEAR"]++;
+                    if (queued && res_nonlinear_seen) {
+                        res = ahead;
+                        if (!proven) slots += (unsigned)i;
+                        break;
+                    }
+                    if (queued_step && res_nonlinear_seen) {
+                        res = ahead;
+                        if (i == 0) break;
+                        continue;
+                    }
+                    // (queued and linear: `ahead` is dropped — its launch returned at the guard)
+                    if (!res_nonlinear_seen && host_phase_on && R.host_max_elems && res.numel <= R.host_max_elems && !on_host(ca) &&
+                        prod(ca.shape) / ca.shape[v] * HBLK <= 16 * R.host_max_elems) {
+                        res = to_host_tier(res);
+                        fetch_block(i);
+                        ++i;  // this step is taken again, on the host tier
+                        continue;
+                    }
                 }
                 speculate = res_nonlinear_seen;
             }
@@ -2783,6 +2891,16 @@ struct Ops {
                 // (gft_host.hpp horner_linear: the element order of mul -> mul_linear -> add -> add, no intermediate
                 // tensors) — `--bounds` programs live on this path because subst - constant_term(subst) keeps a widened
                 // constant.  Linearity is re-checked on every step (a host scan), so the stored shapes are the reference's.
+                // (a host accumulator of a DEVICE tensor: the host phase above — its slabs come from the fetched block)
+                const bool in_block = on_host(res) && !on_host(ca) && ca_h_hi > ca_h_lo;
+                if (in_block && i < ca_h_lo) fetch_block(i);  // the streak outlasted the block
+                if (in_block) {
+                    double c_[2], m_[2];
+                    size_t u_;
+                    if (res.numel > 1 && !extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // (the device steps need not ask again)
+                    res = addsub(mul(res, subst), horner_coeff(ca_h, v, i - ca_h_lo, deg), false);
+                    continue;
+                }
                 if (lin_known && on_host(res) && on_host(ca) && res.numel > 1 && res.shape.size() == deg.size()) {
                     double c_[2], m_[2];
                     size_t u_;
@@ -2960,7 +3078,7 @@ struct Ops {
     // Steps i, i-1, .., 0 in one launch (k_horner_linear_loop) when the final tensor is small enough for a single
     // workgroup to be the faster machine (a launch per step costs ~4 us of host time + ~4 us on the device).
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
-                                   const Dims& deg, P* result, unsigned* wit) {
+                                   const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr) {
         const size_t nd = deg.size();
         Dims oc = ca.shape;
         oc[v] = 1;
@@ -3025,6 +3143,7 @@ struct Ops {
             }
             g.stat = d_stat;
         }
+        g.guard = guard;
         K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
         *result = out;
         return true;
@@ -3096,7 +3215,7 @@ struct Ops {
         return true;
     }
     static P horner_linear_step(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
-                                const Dims& deg) {
+                                const Dims& deg, const unsigned* guard = nullptr) {
         const size_t nd = deg.size();
         Dims rs = res.shape, sh = res.shape, oc = ca.shape;
         sh[w] = std::min(deg[w], sh[w] + 1);
@@ -3136,6 +3255,7 @@ struct Ops {
             HK<E>::horner_linear(hp<E>(res), res.numel, hp<E>(ca), ca.numel, hp<E>(out), out.numel, g);
             return seal(out);
         }
+        g.guard = guard;
         K<E>::horner_linear(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), out.numel, g);
         return out;
     }

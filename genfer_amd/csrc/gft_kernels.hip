@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(256) k_chain_scan(double* __restrict__ out, si
     }
     atomicExch(&state[0], 0xffffffffu);  // restore for the next call on this stream
     atomicExch(&state[1], 0u);
+    if (mb.dev_word) *mb.dev_word = m;  // (read by kernels queued behind this one: HornerLoopArgs::guard)
     mailbox_publish(mb);
 }
 template <class E>
@@ -814,6 +815,7 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
     }
     atomicExch(&state[0], 0xffffffffu);  // restore for the next call on this stream
     atomicExch(&state[1], 0u);
+    if (mb.dev_word) *mb.dev_word = m;  // (read by kernels queued behind this one: HornerLoopArgs::guard)
     mailbox_publish(mb);
 }
 template <class E>
@@ -1444,6 +1446,7 @@ __global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict_
                                                        size_t ap, double* __restrict__ out, size_t op, HornerArgs g,
                                                        size_t total) {
     typedef typename E::V V;
+    if (g.guard && *g.guard != 0u) return;  // the scan queued before this launch found the accumulator linear
     const V cv = E::from(g.c), mv = E::from(g.m);
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
          lin += (size_t)gridDim.x * blockDim.x) {
@@ -1678,6 +1681,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_loop(const double* __res
                                                              unsigned* __restrict__ wit) {
     typedef typename E::V V;
     extern __shared__ double hl_lds[];  // [buffer][plane][lw_pad]
+    if (g.guard && *g.guard != 0u) return;  // the scan queued before this launch found the accumulator linear: the speculation failed
     const unsigned lw = g.fs[g.w], lw_pad = g.lw_pad;
     // this block's line: position on the axes other than w
     size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
@@ -1813,6 +1817,7 @@ __global__ void __launch_bounds__(1024) k_horner_linear_pipe(const double* __res
                                                              unsigned* __restrict__ wit) {
     typedef typename E::V V;
     extern __shared__ double hp_lds[];  // [boundary b][plane][nsteps] ring (one slot per step), then the counters
+    if (g.guard && *g.guard != 0u) return;  // the scan queued before this launch found the accumulator linear: the speculation failed
     const unsigned lw = g.fs[g.w];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
     const unsigned nslots = g.nsteps;
@@ -2025,6 +2030,7 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __rest
     typedef typename E::V V;
     typedef LeanConsts<E> LC;
     extern __shared__ double hp_lds[];  // [boundary b][plane][nsteps] rings, [plane][nsteps] coefficients, counters, dummy area
+    if (g.guard && *g.guard != 0u) return;  // the scan queued before this launch found the accumulator linear: the speculation failed
     const unsigned lw = g.fs[g.w];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
     const unsigned nslots = g.nsteps;

@@ -148,6 +148,7 @@ struct HornerArgs {
     unsigned upper;            // mul_var: source indices 0 .. upper-1 along w
     Scalar2 c, m;
     int c_zero, c_one, coeff_scalar;
+    const unsigned* guard;     // optional (device kernel only): nothing is done if *guard != 0 — see HornerLoopArgs::guard
 };
 
 // ALL remaining Horner steps of a subst_var with a linear substitution in ONE launch: the recursion couples
@@ -171,6 +172,8 @@ struct HornerLoopArgs {
     int c_zero, c_one, coeff_scalar;
     int diag;                  // timing diagnostics (GFT_HORNER_DIAG, wrong results): 2 = no barrier
     unsigned long long* stat;  // GFT_HORNER_DIAG & 64: {lean wave-steps, wave-steps} of the POINT pipeline are added here
+    const unsigned* guard;     // optional: the launch does nothing if *guard != 0 — the verdict word of the linear scan queued just
+                               // before it said "the accumulator IS linear", i.e. the speculation this launch embodies failed
 };
 
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
@@ -180,6 +183,8 @@ struct Mailbox {
     double* payload;              // device-visible address of the pinned slot (8 doubles)
     unsigned long long* seq;      // payload + 8
     unsigned long long value;     // sequence number this kernel must publish
+    unsigned* dev_word;           // optional: the linear scans also store their verdict mask here, in DEVICE memory, for kernels
+                                  // queued behind them that must not run if the speculation they embody failed (HornerLoopArgs::guard)
 };
 __device__ inline void mailbox_publish(const Mailbox& mb) {
     __threadfence_system();
