@@ -158,7 +158,7 @@ struct Runtime {
     // one operand is a stencil — the substitutions of `+~ Binomial(other, p)` statements are 3-6 coefficients) runs on the
     // reference-order one-thread-per-output kernel with the Horner step's Add fused in (K<E>::conv_shallow) instead of the
     // tiled / staged kernels.  0 = off ("shallow_max_terms" / GFT_SHALLOW_MAX_TERMS; A/B and bisecting).
-    size_t shallow_max_terms = 64;
+    size_t shallow_max_terms = 256;  // (64 -> 256: hmm's [2,72,1] and mixture's [209,1] factors 67 -> 35 us, 99 -> 48 us; profiles/r04/shallow_max_terms.txt)
     size_t stats_shallow[2] = {0, 0};  // {shallow products, of which fused Horner steps}
     unsigned nf_epoch = 0;          // non-finite verdict stamp of the current tiled product (d_flag[2])
     int conv_variant = -1;
@@ -3684,7 +3684,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
-    else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 64 : (size_t)value;  // < 0: default
+    else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default
     else if (n == "debug_fail_next_launch") g_fail_next_launch.store(value != 0 ? 1 : 0);  // test knob (gft_launch.hpp)
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);

@@ -529,12 +529,16 @@ __device__ __forceinline__ typename E::V chain_eval(const ChainSrc& c, size_t of
     return x;
 }
 
-template <class E, bool TWO>
+// IDX: the type of the per-element odometer.  `unsigned` whenever the output and the base tensors have fewer than 2^31 elements
+// (always, in practice): 64-bit divisions by a run-time divisor are ~150 instructions each, and on the 10^4-10^5 element
+// tensors of the NeurIPS programs — one element per thread, one wave per SIMD — this kernel's duration IS its instruction
+// count (mixture: 12 000 launches of 5.7 us, hmm: 56 % of the kernel time).
+template <class E, bool TWO, typename IDX>
 __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, ChainSrc b,
                                                int subtract, size_t total) {
     typedef typename E::V V;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
-        size_t r = lin, aoff = 0, boff = 0;
+        IDX r = (IDX)lin, aoff = 0, boff = 0;
         bool ina = true, inb = true;
         // positional stages (FIRST_*, MUL_TAB) look at the coordinates of the chain's OWN view — what lies under a front
         // pad is the view shifted, its element 0 is the output's element `pad`
@@ -549,27 +553,34 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
             const unsigned ka = kk - (unsigned)a.pad[ax];  // (wraps below the pad: fails the box test)
             if (ka >= a.box[ax]) ina = false;
             if (ka != 0) firsta = false;
-            aoff += (size_t)ka * a.stride[ax];
+            aoff += (IDX)ka * (IDX)a.stride[ax];
             if (TWO) {
                 const unsigned kb = kk - (unsigned)b.pad[ax];
                 if (kb >= b.box[ax]) inb = false;
                 if (kb != 0) firstb = false;
-                boff += (size_t)kb * b.stride[ax];
+                boff += (IDX)kb * (IDX)b.stride[ax];
             }
         }
         V v;
         if (!TWO) {
-            v = ina ? chain_eval<E>(a, aoff, k, firsta) : E::zero();
+            v = ina ? chain_eval<E>(a, (size_t)aoff, k, firsta) : E::zero();
         } else {
             v = E::zero();
-            if (ina) v = E::add(v, chain_eval<E>(a, aoff, k, firsta));
+            if (ina) v = E::add(v, chain_eval<E>(a, (size_t)aoff, k, firsta));
             if (inb) {
-                V w = chain_eval<E>(b, boff, k, firstb);
+                V w = chain_eval<E>(b, (size_t)boff, k, firstb);
                 v = subtract ? E::sub(v, w) : E::add(v, w);
             }
         }
         E::st(out, out_plane, lin, v);
     }
+}
+// (offsets of lanes outside an operand's box may wrap in 32 bits: they are never dereferenced)
+static bool chain_fits_u32(const ChainSrc& c, const Shape& sh, size_t total) {
+    if (total >= 0x7fffffffull) return false;
+    unsigned long long span = 1;
+    for (int ax = 0; ax < sh.nd; ++ax) span += (unsigned long long)(c.box[ax] ? c.box[ax] - 1 : 0) * c.stride[ax];
+    return span < 0x7fffffffull;
 }
 // The same when every operand is its whole base tensor in the output's own layout (no sub-box, no pad, no table stage): the
 // element index IS the offset — no per-element odometer (64-bit divisions per axis: the general kernel reached 33 % of the
@@ -617,13 +628,13 @@ static bool chain_is_flat(const ChainSrc& c, const Shape& sh) {
 // k_chain<E, false> and k_linear_scan in one launch: the accumulator of a Horner step is a deferred chain whose FIRST
 // consumer is Mul's `extract_linear` (mt:1014-1072 asks `self` first) — materialise it and settle the question in the same
 // pass (one launch and its gap less per subst_var of a `--bounds` program).  Verdict and mailbox as in k_linear_scan.
-template <class E>
+template <class E, typename IDX>
 __global__ void __launch_bounds__(256) k_chain_scan(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, unsigned axes_mask,
                                                     unsigned* state, Mailbox mb, size_t total) {
     typedef typename E::V V;
     unsigned local = axes_mask;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
-        size_t r = lin, aoff = 0;
+        IDX r = (IDX)lin, aoff = 0;
         bool ina = true, firsta = true;
         unsigned k[MAXD];
         int nonzero_axes = 0, which = -1;
@@ -642,9 +653,9 @@ __global__ void __launch_bounds__(256) k_chain_scan(double* __restrict__ out, si
             const unsigned ka = kk - (unsigned)a.pad[ax];
             if (ka >= a.box[ax]) ina = false;
             if (ka != 0) firsta = false;
-            aoff += (size_t)ka * a.stride[ax];
+            aoff += (IDX)ka * (IDX)a.stride[ax];
         }
-        const V v = ina ? chain_eval<E>(a, aoff, k, firsta) : E::zero();
+        const V v = ina ? chain_eval<E>(a, (size_t)aoff, k, firsta) : E::zero();
         E::st(out, out_plane, lin, v);
         if (local != 0 && nonzero_axes != 0 && !E::is_zero(v)) {
             if (nonzero_axes == 1 && unit) local &= (1u << which);
@@ -694,7 +705,8 @@ void K<E>::chain_copy_scan(hipStream_t st, double* out, size_t out_plane, const 
     size_t total = 1;
     for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
     if (total == 0) return;
-    GFT_LAUNCH(k_chain_scan<E>, dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, axes_mask, state, mb, total);
+    if (chain_fits_u32(a, sh, total)) GFT_LAUNCH((k_chain_scan<E, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, axes_mask, state, mb, total);
+    else GFT_LAUNCH((k_chain_scan<E, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, axes_mask, state, mb, total);
 }
 template <class E>
 void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a) {
@@ -705,7 +717,8 @@ void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape
         GFT_LAUNCH((k_chain_flat<E, false>), dim3(grid_for((total + 1) / 2)), dim3(256), 0, st, out, out_plane, a, a, 0, total);
         return;
     }
-    GFT_LAUNCH((k_chain<E, false>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
+    if (chain_fits_u32(a, sh, total)) GFT_LAUNCH((k_chain<E, false, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
+    else GFT_LAUNCH((k_chain<E, false, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
 }
 template <class E>
 void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b,
@@ -717,7 +730,9 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
         GFT_LAUNCH((k_chain_flat<E, true>), dim3(grid_for((total + 1) / 2)), dim3(256), 0, st, out, out_plane, a, b, subtract, total);
         return;
     }
-    GFT_LAUNCH((k_chain<E, true>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
+    if (chain_fits_u32(a, sh, total) && chain_fits_u32(b, sh, total))
+        GFT_LAUNCH((k_chain<E, true, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
+    else GFT_LAUNCH((k_chain<E, true, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -849,14 +864,15 @@ __device__ __forceinline__ typename E::V obs_mul_tab(typename E::V x, typename E
     }
 }
 
-template <class E>
+template <class E, typename IDX>  // IDX: the odometer's type (see k_chain)
 __global__ void __launch_bounds__(256) k_observe_step(const double* __restrict__ a, size_t ap, double* __restrict__ out,
                                                       size_t op, ObserveArgs g, size_t total) {
     typedef typename E::V V;
     const V xv = E::from(g.x), cv = E::from(g.c);
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total;
          lin += (size_t)gridDim.x * blockDim.x) {
-        size_t r = lin, off = 0;
+        IDX r = (IDX)lin;
+        size_t off = 0;
         unsigned kv = 0;
         bool in_d = true;  // inside D' on every axis other than v
 #pragma unroll 1
@@ -896,8 +912,8 @@ void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double*
     size_t total = 1;
     for (int i = 0; i < args.out.nd; ++i) total *= args.out.d[i];
     if (total == 0) return;
-    GFT_LAUNCH(k_observe_step<E>, dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args,
-                       total);
+    if (total < 0x7fffffffull) GFT_LAUNCH((k_observe_step<E, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args, total);
+    else GFT_LAUNCH((k_observe_step<E, size_t>), dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args, total);
 }
 
 template <class E>
