@@ -1037,8 +1037,373 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_div_wavefront(const doub
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_div_wavefront, four source rows per wave (round 4; f64, rows of 33 .. 64 coefficients)
+// ------------------------------------------------------------------------------------------
+// The row product above costs two 8-byte LDS reads per multiply-add (the broadcast coefficient and the sliding one): with
+// four SIMDs sharing one LDS pipe the kernel is LDS-bound four times over (64^3 div: 1.9 TMAC/s).  Here a wave works on FOUR
+// source rows of a batch at once, one per 16-lane group, and a lane owns FOUR consecutive coefficients c = 4 l .. 4 l + 3 of
+// its group's row product: the broadcast coefficient a[j] is read once per step for four multiply-adds, and the sliding
+// operand is a register window — step j + 1 needs b[4 l - j - 1], ONE new value, the other three move up — so a step is two
+// LDS reads for four multiply-adds instead of eight.  Each output still receives its terms from zero in ascending j
+// (mul_1d, mt:971-982), the batch's products are still added in source order by wave 0: the same bits.  Everything else —
+// tasks, claim order, levels, publication, the lock-step division — is k_div_wavefront's.
+constexpr unsigned QNW = 8;             // waves per task
+// GL lanes per group (16: rows of 33 .. 64 coefficients, four groups = four source rows per wave; 8: rows <= 32, eight per wave)
+template <int GL>
+struct QCfg {
+    static constexpr unsigned NG = 64 / GL;          // groups (source rows) per wave
+    static constexpr unsigned RC = 4 * GL;           // coefficients a group holds
+    static constexpr unsigned QS = NG * QNW;         // source rows per batch
+    static constexpr unsigned QSTG = GL == 16 ? 198 : 101;  // doubles per group: {a: RC}{zeros + b: 2 RC + pads}, see qphys
+};
+
+// Bank layout of a group's sliding operand.  Lane l reads b[4 l - 1 - j]: neighbouring lanes are 4 doubles = 8 banks apart, so
+// lanes l and l + 8 (32 doubles apart) would meet in one bank — one pad double per 32 moves them two banks apart — and the
+// group pitch (198 doubles = 12 banks mod 64, i.e. 4 mod 8, for 16-lane groups; 101 = 10 banks, i.e. 2 mod 8, for 8-lane groups)
+// puts a half-wave's groups on disjoint banks: its 32 lanes read conflict-free, and the groups' broadcast reads of a[j] hit
+// different banks.
+__device__ inline unsigned qphys(unsigned i) { return i + (i >> 5); }
+
+// inner[r] = sum_{j < nr} a[j] * b[4 l + r - j]  (b = 0 below index 0), ascending j, for r = 0 .. 3.  `stage`: this group's region.
+template <int GL>
+__device__ inline void row_product4(double (&inner)[4], const double (&a4)[4], const double (&b4)[4], unsigned l, unsigned nr, unsigned mr,
+                                    double* stage) {
+    constexpr unsigned RC = QCfg<GL>::RC;
+    double* const zb = stage + RC;  // [zeros: RC][b: RC] through qphys
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        stage[4 * l + r] = a4[r];
+        zb[qphys(4 * l + r)] = 0.0;
+        zb[qphys(RC + 4 * l + r)] = b4[r];
+        inner[r] = 0.0;
+    }
+    // w[r] = b[4 l + r - j] at step j; the value that enters at r = 0 in step j + 1 is b[4 l - j - 1] = zb[qphys(RC + 4 l - 1 - j)]
+    double w0 = b4[0], w1 = b4[1], w2 = b4[2], w3 = b4[3];
+    const unsigned nbi = RC + 4 * l - 1;
+    auto nb = [&](unsigned j) { return zb[qphys(nbi - j)]; };
+    bool fin = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fin = fin && finite_d(a4[r]) && finite_d(b4[r]);
+    if (!any_lane(!fin)) {
+        // four steps per iteration: the window rotates through its registers without moves
+        unsigned j = 0;
+        for (; j + 4 <= nr; j += 4) {
+            const double a0 = stage[j], a1 = stage[j + 1], a2 = stage[j + 2], a3 = stage[j + 3];
+            const double n0 = nb(j), n1 = nb(j + 1), n2 = nb(j + 2), n3 = nb(j + 3);
+            inner[0] = inner[0] + a0 * w0; inner[1] = inner[1] + a0 * w1; inner[2] = inner[2] + a0 * w2; inner[3] = inner[3] + a0 * w3;
+            inner[0] = inner[0] + a1 * n0; inner[1] = inner[1] + a1 * w0; inner[2] = inner[2] + a1 * w1; inner[3] = inner[3] + a1 * w2;
+            inner[0] = inner[0] + a2 * n1; inner[1] = inner[1] + a2 * n0; inner[2] = inner[2] + a2 * w0; inner[3] = inner[3] + a2 * w1;
+            inner[0] = inner[0] + a3 * n2; inner[1] = inner[1] + a3 * n1; inner[2] = inner[2] + a3 * n0; inner[3] = inner[3] + a3 * w0;
+            w3 = n0; w2 = n1; w1 = n2; w0 = n3;
+        }
+        for (; j < nr; ++j) {
+            const double a0 = stage[j], n0 = nb(j);
+            inner[0] = inner[0] + a0 * w0; inner[1] = inner[1] + a0 * w1; inner[2] = inner[2] + a0 * w2; inner[3] = inner[3] + a0 * w3;
+            w3 = w2; w2 = w1; w1 = w0; w0 = n0;
+        }
+    } else {
+        for (unsigned j = 0; j < nr; ++j) {
+            const double a0 = stage[j], n0 = nb(j);
+            const double wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned c = 4 * l + r;
+                const double t = inner[r] + a0 * wv[r];
+                if (c >= j && c - j < mr) inner[r] = t;
+            }
+            w3 = w2; w2 = w1; w1 = w0; w0 = n0;
+        }
+    }
+}
+
+template <int L, int GL>
+__global__ void __launch_bounds__(64 * QNW) k_div_wavefront_q(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
+                                                         double* res, size_t rp, DivWfArgs g) {
+    typedef EF64 E;
+    typedef double V;
+    extern __shared__ double q_lds[];
+    constexpr unsigned NG = QCfg<GL>::NG, QS = QCfg<GL>::QS, QSTG = QCfg<GL>::QSTG;
+    double* const part = q_lds;                                  // [2][QS][64]
+    double* const stage_all = q_lds + 2 * QS * 64;               // [QNW][NG][QSTG]
+    __shared__ unsigned s_task;
+    const unsigned lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned g4 = lane / GL, l = lane % GL, c0 = 4u * l;
+    double* const my_stage = stage_all + ((size_t)wave * NG + g4) * QSTG;
+    const bool lg = g.log_mode == 1, ex = g.log_mode == 2;
+    unsigned slab_rows = 1;
+#pragma unroll
+    for (int a = 1; a < L; ++a) slab_rows *= g.n[a];
+    const V y0row = lane < g.mr ? E::ld(ys, yp, lane) : E::zero();
+    const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
+    for (;;) {
+        if (threadIdx.x == 0) s_task = atomicAdd(g.counter, 1u);
+        __syncthreads();
+        const unsigned t = s_task;
+        __syncthreads();
+        if (t >= g.ntasks) break;
+        unsigned k[3] = {0, 0, 0};
+        unsigned row_id = 0;
+        {
+            unsigned r = g.order ? g.order[t] : t;
+#pragma unroll
+            for (int a = L - 1; a >= 1; --a) {
+                k[a] = r % g.n[a];
+                r /= g.n[a];
+            }
+            k[0] = r + ((lg || ex) ? 1u : 0u);
+#pragma unroll
+            for (int a = 0; a < L; ++a) row_id = row_id * g.n[a] + k[a];
+        }
+        V r_prev = E::zero();
+        unsigned buf = 0;
+        auto level = [&](auto lev_c) {
+            constexpr int lev = decltype(lev_c)::value;
+            V S = E::zero();
+            const bool lg0 = (lg && lev == 0) || ex;
+            unsigned lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
+            unsigned total = 1;
+#pragma unroll
+            for (int a = lev; a < L; ++a) {
+                if (lg0 && a > 0) {
+                    lo[a] = 0;
+                    cnt[a] = (k[a] < g.xn[a] ? k[a] : g.xn[a] - 1) + 1;
+                } else {
+                    const unsigned mm = lg0 ? g.xn[a] : g.m[a];
+                    lo[a] = k[a] + 1 > mm ? k[a] + 1 - mm : 0;
+                    if (lg0 && lo[a] < 1) lo[a] = 1;
+                    unsigned hi = a == lev ? k[a] : k[a] + 1;
+                    if (ex) {
+                        lo[a] = 1;
+                        hi = (k[0] < g.xn[0] ? k[0] : g.xn[0] - 1) + 1;
+                    }
+                    cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
+                }
+                total *= cnt[a];
+            }
+            const double* const coh_base = (lg && lev > 0) ? g.qb : res;
+            size_t roff_n = 0;
+            unsigned src_n = 0, j0_n = 0;
+            V coh_n[4] = {0, 0, 0, 0}, oth_n[4] = {0, 0, 0, 0};
+            auto request = [&](unsigned i0) {  // i0: the wave's first source row of the batch; this lane's group takes row i0 + g4
+                if (i0 + g4 >= total) return;
+                unsigned rem = i0 + g4, j[3] = {0, 0, 0};
+#pragma unroll
+                for (int a = L - 1; a >= lev; --a) {
+                    j[a] = rem % cnt[a];
+                    rem /= cnt[a];
+                }
+                if (ex && g.rev) j[0] = cnt[0] - 1u - j[0];
+#pragma unroll
+                for (int a = lev; a < L; ++a) j[a] += lo[a];
+                size_t roff = 0, ooff = 0;
+                unsigned src = 0;
+#pragma unroll
+                for (int a = 0; a < L; ++a) {
+                    unsigned ra;
+                    if (a < lev) ra = k[a];
+                    else if (ex || (lg0 && a > 0)) ra = k[a] - j[a];
+                    else ra = j[a];
+                    roff += (size_t)ra * g.rstr[a];
+                    src = src * g.n[a] + ra;
+                    if (a >= lev) {
+                        if (ex) ooff += (size_t)j[a] * g.xstr[a];
+                        else if (lg0) ooff += (size_t)(a == 0 ? k[0] - j[0] : j[a]) * g.xstr[a];
+                        else ooff += (size_t)(k[a] - j[a]) * g.ystr[a];
+                    }
+                }
+                roff_n = roff;
+                src_n = src;
+                j0_n = j[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned c = c0 + r;
+                    if (lg0) oth_n[r] = c < g.xnr ? xs[ooff + c] : 0.0;
+                    else oth_n[r] = c < g.mr ? ys[ooff + c] : 0.0;
+                    coh_n[r] = c < g.nr ? ld_coherent<E>(coh_base, 0, roff + c) : 0.0;
+                }
+            };
+            request(wave * NG);
+            for (unsigned base = 0; base < total; base += QS) {
+                const unsigned i0 = base + wave * NG;
+                const bool live = i0 + g4 < total;
+                V coh[4], oth[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    coh[r] = live ? coh_n[r] : 0.0;
+                    oth[r] = live ? oth_n[r] : 0.0;
+                }
+                const size_t roff = roff_n;
+                const unsigned src = src_n, j0 = j0_n;
+                request(i0 + QS);
+                if (i0 < total) {
+                    bool confirmed = ex && src < slab_rows;
+                    auto empty_any = [&]() {
+                        bool e = false;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e = e || (c0 + r < g.nr && is_empty_bits(coh[r]));
+                        return e;
+                    };
+                    for (unsigned spins = 1; any_lane(live && !confirmed && empty_any()); ++spins) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (live && (spins & 31u) == 0u && __hip_atomic_load(g.flags + src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                            confirmed = true;
+                        if (live) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) coh[r] = c0 + r < g.nr ? ld_coherent<E>(coh_base, 0, roff + c0 + r) : 0.0;
+                        }
+                    }
+                    V prod[4];
+                    if (ex) {  // mul_1d(j0 * xs row, res row)
+                        V sc[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[r] = c0 + r < g.xnr ? oth[r] * (double)j0 : 0.0;
+                        row_product4<GL>(prod, sc, coh, l, g.xnr, g.nr, my_stage);
+                    } else if (lg0) {  // mul_1d(xs row, j0 * res row)
+                        V sc[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[r] = c0 + r < g.nr ? coh[r] * (double)j0 : 0.0;
+                        row_product4<GL>(prod, oth, sc, l, g.xnr, g.nr, my_stage);
+                    } else {
+                        row_product4<GL>(prod, coh, oth, l, g.nr, g.mr, my_stage);
+                    }
+                    double* pd = part + ((size_t)buf * QS + (wave * NG + g4)) * 64 + c0;  // = [source row of the batch][c]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pd[r] = prod[r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned nbt = total - base < QS ? total - base : QS;
+                    const double* pb = part + (size_t)buf * QS * 64 + lane;
+                    if (nbt == QS) {
+                        // (32 products' reads issued together ahead of their chain of adds)
+#pragma unroll
+                        for (unsigned w0 = 0; w0 < QS; w0 += 32) {
+                            V pv[32];
+#pragma unroll
+                            for (unsigned w = 0; w < 32; ++w) pv[w] = pb[(size_t)(w0 + w) * 64];
+#pragma unroll
+                            for (unsigned w = 0; w < 32; ++w) S = S + pv[w];
+                        }
+                    } else {
+                        for (unsigned w = 0; w < nbt; ++w) S = S + pb[(size_t)w * 64];
+                    }
+                }
+                buf ^= 1u;
+            }
+            if (ex) {
+                if (wave == 0) r_prev = S;
+                __syncthreads();
+                return;
+            }
+            if (wave == 0) {
+                V r = E::neg(S);
+                if (lev == 0) {
+                    bool in_x = lane < g.xnr;
+                    size_t xoff = 0;
+#pragma unroll
+                    for (int a = 0; a < L; ++a) {
+                        if (k[a] >= g.xn[a]) in_x = false;
+                        xoff += (size_t)k[a] * g.xstr[a];
+                    }
+                    if (in_x) {
+                        const V xin = xs[xoff + lane];
+                        r = E::add(r, lg ? E::mul(E::from_u32(k[0]), xin) : xin);
+                    }
+                } else {
+                    r = E::add(r, r_prev);
+                }
+                r_prev = r;
+            }
+            __syncthreads();
+        };
+        level(std::integral_constant<int, 0>{});
+        if (!ex) {
+            if constexpr (L > 1) level(std::integral_constant<int, 1>{});
+            if constexpr (L > 2) level(std::integral_constant<int, 2>{});
+        }
+        if (ex) {
+            if (wave == 0) {
+                size_t qoff = 0;
+#pragma unroll
+                for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
+                if (lane < g.nr) st_coherent(res, rp, qoff + lane, E::div(r_prev, E::from_u32(k[0])));
+                __threadfence();
+                if (lane == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (wave == 0) {
+            if (lane >= g.nr) r_prev = E::zero();
+            V cur1 = E::zero(), mine = E::zero(), ysl = y0row;
+            const bool fin = !any_lane(!elem_finite<E>(r_prev)) && !any_lane(!elem_finite<E>(y0row));
+            for (unsigned jj = 0; jj < g.nr; ++jj) {
+                const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r_prev), jj));
+                if (lane == jj) mine = q;
+                const V tnew = E::add(cur1, E::mul(q, ysl));
+                if (fin && elem_finite<E>(q)) {
+                    cur1 = tnew;
+                } else if (lane > jj && lane - jj < g.mr) {
+                    cur1 = tnew;
+                }
+                ysl = wave_shr1<E>(ysl);
+            }
+            size_t qoff = 0;
+#pragma unroll
+            for (int a = 0; a < L; ++a) qoff += (size_t)k[a] * g.rstr[a];
+            if (lane < g.nr) {
+                if (lg) {
+                    st_coherent(g.qb, g.qbp, qoff + lane, mine);
+                    st_coherent(res, rp, qoff + lane, E::div(mine, E::from_u32(k[0])));
+                } else {
+                    st_coherent(res, rp, qoff + lane, mine);
+                }
+            }
+            __threadfence();
+            if (lane == 0) __hip_atomic_store(g.flags + row_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <class E>
 static void launch_dwf(hipStream_t st, unsigned blocks, const double* xs, size_t xp, const double* ys, size_t yp, double* res, size_t rp, const DivWfArgs& g) {
+    // f64 rows of 33 .. 64 coefficients: four source rows per wave, four coefficients per lane (k_div_wavefront_q)
+    static const bool quad_on = [] {
+        const char* e = getenv("GFT_DWF_QUAD");  // A/B knob
+        return e ? atoi(e) != 0 : true;
+    }();
+    // (where a row has thousands of source rows — 64^3 div 4.8 -> 4.0 ms, 24^4 7.7 -> 6.2; thin or small quotients, whose time is the
+    // chain of rows, lose to its larger batches: 1000 x 32 6.2 -> 8.0 ms, 32^3 0.53 -> 0.62 — they keep one or two rows per wave)
+    size_t max_sources = 1;
+    for (int a = 0; a < g.L; ++a) max_sources *= g.n[a];
+    if constexpr (E::W == 1) {
+        if (quad_on && g.nr >= 8 && g.nr <= 64 && max_sources >= 2048) {
+            const bool wide = g.nr > 32;
+            const size_t lds = wide ? sizeof(double) * (2 * QCfg<16>::QS * 64 + (size_t)QNW * QCfg<16>::NG * QCfg<16>::QSTG)
+                                    : sizeof(double) * (2 * QCfg<8>::QS * 64 + (size_t)QNW * QCfg<8>::NG * QCfg<8>::QSTG);
+            static bool attr_set = false;
+            bool ok = true;
+            if (!attr_set) {
+                auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess; };
+                ok = set((const void*)k_div_wavefront_q<1, 16>) && set((const void*)k_div_wavefront_q<2, 16>) && set((const void*)k_div_wavefront_q<3, 16>) &&
+                     set((const void*)k_div_wavefront_q<1, 8>) && set((const void*)k_div_wavefront_q<2, 8>) && set((const void*)k_div_wavefront_q<3, 8>);
+                if (!ok) (void)hipGetLastError();
+                attr_set = ok;
+            }
+            if (ok) {
+                const dim3 qgrid(blocks), qblock(64 * QNW);
+                if (wide) {
+                    if (g.L == 1) GFT_LAUNCH((k_div_wavefront_q<1, 16>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                    else if (g.L == 2) GFT_LAUNCH((k_div_wavefront_q<2, 16>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                    else GFT_LAUNCH((k_div_wavefront_q<3, 16>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                } else {
+                    if (g.L == 1) GFT_LAUNCH((k_div_wavefront_q<1, 8>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                    else if (g.L == 2) GFT_LAUNCH((k_div_wavefront_q<2, 8>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                    else GFT_LAUNCH((k_div_wavefront_q<3, 8>), qgrid, qblock, lds, st, xs, xp, ys, yp, res, rp, g);
+                }
+                return;
+            }
+        }
+    }
     const dim3 grid(blocks), block(64 * DwfCfg<E>::NW);
     if (g.L == 1) GFT_LAUNCH((k_div_wavefront<E, 1>), grid, block, 0, st, xs, xp, ys, yp, res, rp, g);
     else if (g.L == 2) GFT_LAUNCH((k_div_wavefront<E, 2>), grid, block, 0, st, xs, xp, ys, yp, res, rp, g);
