@@ -1367,16 +1367,16 @@ __global__ void __launch_bounds__(64 * QNW) k_div_wavefront_q(const double* __re
 template <class E>
 static void launch_dwf(hipStream_t st, unsigned blocks, const double* xs, size_t xp, const double* ys, size_t yp, double* res, size_t rp, const DivWfArgs& g) {
     // f64 rows of 33 .. 64 coefficients: four source rows per wave, four coefficients per lane (k_div_wavefront_q)
-    static const bool quad_on = [] {
-        const char* e = getenv("GFT_DWF_QUAD");  // A/B knob
-        return e ? atoi(e) != 0 : true;
+    static const int quad_on = [] {
+        const char* e = getenv("GFT_DWF_QUAD");  // A/B knob: 0 = never, 2 = whenever the rows allow (tests)
+        return e ? atoi(e) : 1;
     }();
     // (where a row has thousands of source rows — 64^3 div 4.8 -> 4.0 ms, 24^4 7.7 -> 6.2; thin or small quotients, whose time is the
     // chain of rows, lose to its larger batches: 1000 x 32 6.2 -> 8.0 ms, 32^3 0.53 -> 0.62 — they keep one or two rows per wave)
     size_t max_sources = 1;
     for (int a = 0; a < g.L; ++a) max_sources *= g.n[a];
     if constexpr (E::W == 1) {
-        if (quad_on && g.nr >= 8 && g.nr <= 64 && max_sources >= 2048) {
+        if (quad_on && g.nr >= 8 && g.nr <= 64 && (max_sources >= 2048 || quad_on == 2)) {
             const bool wide = g.nr > 32;
             const size_t lds = wide ? sizeof(double) * (2 * QCfg<16>::QS * 64 + (size_t)QNW * QCfg<16>::NG * QCfg<16>::QSTG)
                                     : sizeof(double) * (2 * QCfg<8>::QS * 64 + (size_t)QNW * QCfg<8>::NG * QCfg<8>::QSTG);

@@ -1147,6 +1147,10 @@ WAVEFRONT_SHAPES = [
     ((21, 19, 31), (5, 19, 31), (21, 7, 9)),         # rows <= 32: two source rows per wave, odd row counts
     ((9, 11, 32), (9, 11, 32), (9, 11, 32)),         # rows of exactly 32
     ((13, 5, 7, 24), (13, 2, 7, 24), (4, 5, 7, 24)),  # rank 4, packed rows
+    # thousands of source rows per quotient row: four / eight source rows per wave, four coefficients per lane (round 4)
+    ((48, 48, 40), (48, 48, 40), (48, 48, 40)),      # rows of 33 .. 64: 16-lane groups
+    ((17, 13, 11, 24), (17, 5, 11, 24), (9, 13, 11, 20)),  # rank 4, rows <= 32: 8-lane groups, compact operands
+    ((2100, 9), (2100, 9), (2100, 9)),               # rank 2, short rows, a long chain
     # rank 2 with rows > 64: the coefficient-level wavefront (tasks are 64-coefficient segments of rows; round 4)
     ((24, 130), (24, 130), (24, 130)),               # three segments, the last one partial
     ((60, 200), (7, 70), (45, 150)),                 # compact divisor (its rows end inside segment 1) and dividend
