@@ -702,7 +702,7 @@ static std::map<hipStream_t, RbScratch>& rb_scratch() {
 // measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
 static double rb_min_macs = [] {
     const char* e = getenv("GFT_CONV_RB_MIN_MACS");
-    return e ? atof(e) : 2.0e10;
+    return e ? atof(e) : 1.5e10;  // (72^3 = 1.8e10: 29.4 -> 24.5 ms on this kernel; 64^3 = 9e9 stays on k_conv_staged: 10.6 vs 14.1 ms — profiles/r04/interval_rb_crossover.txt)
 }();
 void staged_set_rb_min_macs(double v) { rb_min_macs = v; }  // "conv_rb_min_macs" (tests; negative = never)
 void staged_release_scratch() {
