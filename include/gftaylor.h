@@ -93,7 +93,13 @@ int gft_set_conv_mode(int mode);
  * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div_wavefront" (0: the slab-by-slab blocked division instead of the one-launch row wavefront), "div2d" (0: host-driven division
  * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "async_launch" (0: kernels are launched by the
  * calling thread instead of the library's launch thread), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
- * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init). */
+ * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init),
+ * "shallow_max_terms" (plain products whose outputs receive at most this many terms each — one operand a stencil of a few
+ * coefficients — run on the fused reference-order kernel, general Horner steps res * subst + slab in one launch; 0: never;
+ * negative: the default, 256), "rows_wavefront" (0: rank-2 div / log / exp with rows longer than 64 coefficients row by row
+ * instead of the one-launch coefficient-level wavefront), "exp_right" (0: exp's terms in the reference's order everywhere),
+ * "recur_tiled_min_macs", "dist_event_slot", and the test knob "debug_fail_next_launch" (1: the next kernel launch requests
+ * 1 MB of LDS and fails — on the launch thread; the failure is reported by the next gft_synchronize / value inspection). */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);
