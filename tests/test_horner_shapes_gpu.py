@@ -5,6 +5,8 @@ round — compacting the stored shape).  The device path speculates "not linear"
 non-linear and verifies the speculation with per-step witnesses (gft_api.hip horner_speculative); these tests
 CONSTRUCT the cancellation, so the verification must fail and the exact loop must take over.  Shapes and values are
 compared with the oracle bit for bit, on the device tier and under the default size-threshold dispatch."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,7 +174,8 @@ def test_general_horner_fused_runs_on_the_device_tier(OTP, GTP):
     after = genfer_amd.op_stats()
     _check(OTP.new(a, deg).subst_var(0, OTP.new(s, deg)), g)
     # (under the default dispatch the first ~18 accumulators are host-resident: those steps run on the host tier)
-    assert after["fused_horner_steps"] - before["fused_horner_steps"] >= 15, (before, after)
+    if os.environ.get("GFT_SHALLOW_MAX_TERMS") != "0":  # (tools/verification_matrix.sh switches the path off: values only then)
+        assert after["fused_horner_steps"] - before["fused_horner_steps"] >= 15, (before, after)
 
 
 @pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
@@ -192,5 +195,5 @@ def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI,
     before = genfer_amd.op_stats()["shallow_products"]
     _check(O.new(x, deg) * O.new(y, deg), G.new(x, deg) * G.new(y, deg))
     _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
-    if tier == "device":
+    if tier == "device" and os.environ.get("GFT_SHALLOW_MAX_TERMS") is None:
         assert genfer_amd.op_stats()["shallow_products"] == before + 2, "the products did not take the shallow kernel"

@@ -4,6 +4,7 @@ queries) bit-exact; values within 1e-10 relative — and bit-exact wherever the 
 reference's operation order (everything except libm seeds, wave-shuffle axis sums and the
 tiled FMA convolution)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -573,7 +574,7 @@ def test_conv_tiled_in_place_operands_vs_oracle(xs, ys, deg, OTP, GTP, tier):
         check(want, got, exact=False)
         if tier == "device":
             assert after["tiled"] - before["tiled"] == 1
-            if xs[-1] == deg[-1] and ys[-1] == deg[-1]:  # (rows that stop short of the result's are packed: their blocks meet zero windows)
+            if xs[-1] == deg[-1] and ys[-1] == deg[-1] and os.environ.get("GFT_TILED_INPLACE") != "0":  # (rows that stop short of the result's are packed)
                 assert after["launches"] - before["launches"] <= 2, "in-place operands: the main kernel and the reduce, nothing else"
         xi, yi = x.copy(), y.copy()
         xi[tuple(min(2, s - 1) for s in xs)] = np.inf
@@ -1188,7 +1189,7 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier):
                 before = genfer_amd.op_stats()["launches"]
                 got[wf] = G.new(a, deg) / G.new(b, deg)
                 check(want, got[wf])
-                if wf and len(zs) == 2 and zs[1] > 64 and tier == "device":
+                if wf and len(zs) == 2 and zs[1] > 64 and tier == "device" and os.environ.get("GFT_ROWS_WAVEFRONT") != "0":
                     # one launch (+ the fill of the result with the EMPTY pattern, + the flags' memset): not one per row
                     assert genfer_amd.op_stats()["launches"] - before <= 8, "the long-row quotient did not take the one-launch wavefront"
             finally:

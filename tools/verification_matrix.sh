@@ -1,7 +1,15 @@
+# The parity / fuzz / KAT / Horner-shape tests under every A/B switch of the library (one process per configuration): a
+# result must not depend on which of two equivalent paths computed it.  Run on an MI355X box from the repo root; the record
+# lands in gpurun_out/verification_matrix.txt (copy it to profiles/rNN/).
 export HIP_FORCE_DEV_KERNARG=1
-mkdir -p gpurun_out/r03
-: > gpurun_out/r03/verification_matrix.txt
-for cfg in "GFT_DEFER=0" "GFT_ASYNC_LAUNCH=0" "GFT_HORNER_PIPE=0" "GFT_HORNER_LEAN=0" "GFT_DIV_WAVEFRONT=0" "GFT_DWF_DIAG=0" "GFT_DWF_PACK=0" "GFT_CONV_RB_MIN_MACS=0" "GFT_CONV_RB=0" "GFT_TILED_WG_MULT=1" "GFT_DEFER=0 GFT_ASYNC_LAUNCH=0 GFT_HORNER_PIPE=0 GFT_DIV_WAVEFRONT=0 GFT_CONV_RB=0"; do
+mkdir -p gpurun_out
+OUT=gpurun_out/verification_matrix.txt
+: > $OUT
+for cfg in "GFT_BASELINE=1" "GFT_DEFER=0" "GFT_ASYNC_LAUNCH=0" "GFT_HORNER_PIPE=0" "GFT_HORNER_LEAN=0" "GFT_DIV_WAVEFRONT=0" "GFT_DWF_DIAG=0" "GFT_DWF_PACK=0" \
+           "GFT_CONV_RB_MIN_MACS=0" "GFT_CONV_RB=0" "GFT_TILED_WG_MULT=1" \
+           "GFT_SHALLOW_MAX_TERMS=0" "GFT_SHALLOW_MAX_TERMS=64" "GFT_ROWS_WAVEFRONT=0" "GFT_HORNER_AHEAD=0" "GFT_HORNER_HOST_PHASE=0" "GFT_TILED_INPLACE=0" \
+           "GFT_DWF_QUAD=0" "GFT_DWF_QUAD=2" \
+           "GFT_DEFER=0 GFT_ASYNC_LAUNCH=0 GFT_HORNER_PIPE=0 GFT_DIV_WAVEFRONT=0 GFT_CONV_RB=0 GFT_SHALLOW_MAX_TERMS=0 GFT_ROWS_WAVEFRONT=0 GFT_HORNER_AHEAD=0 GFT_HORNER_HOST_PHASE=0 GFT_TILED_INPLACE=0 GFT_DWF_QUAD=0"; do
   res=$(env $cfg timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_exact_kats.py tests/test_horner_shapes_gpu.py tests/test_reference_unit_vectors.py tests/test_interval_pins.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -1)
-  echo "$cfg : $res" | tee -a gpurun_out/r03/verification_matrix.txt
+  echo "$cfg : $res" | tee -a $OUT
 done
