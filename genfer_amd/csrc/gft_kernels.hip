@@ -1270,10 +1270,13 @@ void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const doub
 // multiply and add => bit-identical to the CPU algorithm for f64.  Used for small tensors, for
 // interval tensors, for rank > 4 and as the on-device cross-check of the tiled kernel.
 // ------------------------------------------------------------------------------------------
-template <class E, int AX, int ND, bool INNER0>
+// OFF: the type of the operand offsets — `unsigned` where both operands have fewer than 2^31 elements (k_conv_shallow: the
+// 64-bit multiply-adds of the address arithmetic were most of its ~800 VALU instructions per output, and the kernel is
+// instruction-bound: profiles/r04/pmc_k_conv_shallow.txt)
+template <class E, int AX, int ND, bool INNER0, typename OFF = size_t>
 struct ConvLoop {
     __device__ static inline void run(const ConvArgs& a, const unsigned* k, const double* x, size_t xp,
-                                      const double* y, size_t yp, size_t xoff, size_t yoff,
+                                      const double* y, size_t yp, OFF xoff, OFF yoff,
                                       typename E::V& acc) {
         typedef typename E::V V;
         const unsigned kk = k[AX];
@@ -1290,23 +1293,23 @@ struct ConvLoop {
             if (INNER0) {
                 V inner = E::zero();
                 for (unsigned j = lo; j < hi; ++j)
-                    inner = E::add(inner, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[AX]),
-                                                 E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[AX])));
+                    inner = E::add(inner, E::mul(E::ld(x, xp, xoff + (OFF)j * (OFF)a.xstr[AX]),
+                                                 E::ld(y, yp, yoff + (OFF)(kk - j) * (OFF)a.ystr[AX])));
                 acc = E::add(acc, inner);
             } else {
                 const unsigned cnt = hi - lo;
                 for (unsigned t = 0; t < cnt; ++t) {
                     unsigned j = desc ? (hi - 1 - t) : (lo + t);
-                    acc = E::add(acc, E::mul(E::ld(x, xp, xoff + (size_t)j * a.xstr[AX]),
-                                             E::ld(y, yp, yoff + (size_t)(kk - j) * a.ystr[AX])));
+                    acc = E::add(acc, E::mul(E::ld(x, xp, xoff + (OFF)j * (OFF)a.xstr[AX]),
+                                             E::ld(y, yp, yoff + (OFF)(kk - j) * (OFF)a.ystr[AX])));
                 }
             }
         } else {
             const unsigned cnt = hi - lo;
             for (unsigned t = 0; t < cnt; ++t) {
                 unsigned j = desc ? (hi - 1 - t) : (lo + t);
-                ConvLoop<E, (AX + 1 < ND ? AX + 1 : AX), ND, INNER0>::run(
-                    a, k, x, xp, y, yp, xoff + (size_t)j * a.xstr[AX], yoff + (size_t)(kk - j) * a.ystr[AX], acc);
+                ConvLoop<E, (AX + 1 < ND ? AX + 1 : AX), ND, INNER0, OFF>::run(
+                    a, k, x, xp, y, yp, xoff + (OFF)j * (OFF)a.xstr[AX], yoff + (OFF)(kk - j) * (OFF)a.ystr[AX], acc);
             }
         }
     }
@@ -1391,7 +1394,7 @@ __device__ inline void wit_raise_once(unsigned* w) {
 //   mode 0   out = prod
 // and, optionally, the speculative Horner loop's witness of non-linearity on the result (k_witness).
 // ------------------------------------------------------------------------------------------
-template <class E, int ND, bool INNER0>
+template <class E, int ND, bool INNER0, typename OFF>
 __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__ x, size_t xp, const double* __restrict__ y,
                                                       size_t yp, double* __restrict__ out, size_t op, ConvArgs a, ConvEpi e,
                                                       unsigned total) {
@@ -1402,7 +1405,7 @@ __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__
         unsigned r = lin;
         bool inz = true, ina = e.mode == 1, big = false;
         int nz = 0;
-        size_t aoff = 0;
+        OFF aoff = 0;  // (the slab's source tensor has fewer than 2^31 elements whenever OFF is 32 bits: the host checks)
 #pragma unroll
         for (int ax = ND - 1; ax >= 0; --ax) {
             const unsigned d = e.os[ax];
@@ -1411,18 +1414,18 @@ __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__
             k[ax] = kk;
             if (kk >= a.zs[ax]) inz = false;
             if (kk >= e.abox[ax]) ina = false;
-            aoff += (size_t)kk * e.astr[ax];
+            aoff += (OFF)kk * (OFF)e.astr[ax];
             if (kk) nz++;
             if (kk >= 2) big = true;
         }
         V v = E::zero();
         if (inz) {
             V acc = E::zero();
-            ConvLoop<E, 0, ND, INNER0>::run(a, k, x, xp, y, yp, 0, 0, acc);
+            ConvLoop<E, 0, ND, INNER0, OFF>::run(a, k, x, xp, y, yp, (OFF)0, (OFF)0, acc);
             v = e.mode == 1 ? E::add(v, acc) : acc;
         }
         if (e.mode == 1) {
-            if (ina) v = E::add(v, E::ld(e.ap, e.aplane, aoff));
+            if (ina) v = E::add(v, E::ld(e.ap, e.aplane, (size_t)aoff));
         } else if (e.mode == 2 && lin == 0) {
             v = E::add(v, E::ld(e.ap, e.aplane, 0));
         }
@@ -1444,10 +1447,23 @@ bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const d
     for (int i = 0; i < a.nd; ++i) total *= e.os[i];
     if (total == 0 || total > 0x7fffffffull) return false;
     dim3 g(grid_for((size_t)total)), b(256);
+    unsigned long long nx = 1, ny = 1;
+    for (int i = 0; i < a.nd; ++i) {
+        nx *= a.xs[i];
+        ny *= a.ys[i];
+    }
+    unsigned long long aspan = 1;  // largest slab offset + 1
+    for (int i = 0; i < a.nd; ++i) aspan += (unsigned long long)(e.abox[i] ? e.abox[i] - 1 : 0) * e.astr[i];
+    const bool u32 = nx < 0x7fffffffull && ny < 0x7fffffffull && aspan < 0x7fffffffull;
 #define GFT_CASE(N)                                                                                                        \
     case N:                                                                                                                \
-        if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
-        else GFT_LAUNCH((k_conv_shallow<E, N, false>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
+        if (u32) {                                                                                                         \
+            if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
+            else GFT_LAUNCH((k_conv_shallow<E, N, false, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
+        } else {                                                                                                           \
+            if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true, size_t>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
+            else GFT_LAUNCH((k_conv_shallow<E, N, false, size_t>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
+        }                                                                                                                  \
         break;
     switch (a.nd) {
         GFT_CASE(1) GFT_CASE(2) GFT_CASE(3) GFT_CASE(4) GFT_CASE(5) GFT_CASE(6)
