@@ -775,9 +775,10 @@ template <class E>
 __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask, unsigned* state, Mailbox mb, size_t total) {
     double* out = mb.payload;
     unsigned local = axes_mask;
-    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total && local != 0;
-         lin += (size_t)gridDim.x * blockDim.x) {
-        if (E::is_zero(E::ld(t.p, t.plane, lin))) continue;
+    // (four loads in flight per thread: the loop's exit condition depends on what was loaded, so one load per iteration is one
+    // memory latency per element — a tensor that IS linear, the case in which every element is read, ran at 7 % of the HBM roof)
+    auto look = [&](typename E::V v, size_t lin) {
+        if (E::is_zero(v)) return;
         size_t r = lin;
         int nonzero_axes = 0, which = -1;
         bool unit = true;
@@ -792,9 +793,21 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
                 if (k != 1) unit = false;
             }
         }
-        if (nonzero_axes == 0) continue;
+        if (nonzero_axes == 0) return;
         if (nonzero_axes == 1 && unit) local &= (1u << which);
         else local = 0;  // nothing more to learn: the loop ends
+    };
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total && local != 0; lin += 4 * step) {
+        const size_t l1 = lin + step, l2 = lin + 2 * step, l3 = lin + 3 * step;
+        const typename E::V v0 = E::ld(t.p, t.plane, lin);
+        const typename E::V v1 = l1 < total ? E::ld(t.p, t.plane, l1) : E::zero();
+        const typename E::V v2 = l2 < total ? E::ld(t.p, t.plane, l2) : E::zero();
+        const typename E::V v3 = l3 < total ? E::ld(t.p, t.plane, l3) : E::zero();
+        look(v0, lin);
+        look(v1, l1);
+        look(v2, l2);
+        look(v3, l3);
     }
     // block-level AND, then at most one device atomic per block — and none if the global verdict already
     // implies ours (a dense tensor is settled by the first block; ~1400 same-address atomics cost 20 us)
