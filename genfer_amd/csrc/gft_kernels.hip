@@ -851,7 +851,9 @@ void K<E>::linear_scan(hipStream_t st, const DView& t, unsigned axes_mask, unsig
     size_t total = 1;
     for (int i = 0; i < t.sh.nd; ++i) total *= t.sh.d[i];
     if (total == 0) return;
-    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 128);  // few tickets; dense tensors exit at once
+    // few tickets (same-address atomics serialise at ~26 ns each; dense tensors exit at once) — but a tensor of hundreds of MB
+    // that IS linear is read in full, and 128 blocks keep only 1 MB of loads in flight
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, total > ((size_t)1 << 22) ? 1024 : 128);
     GFT_LAUNCH(k_linear_scan<E>, dim3(blocks), dim3(256), 0, st, t, axes_mask, state, mb, total);
 }
 
