@@ -3689,6 +3689,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
     else if (n == "conv_rb_spill") staged_set_rb_spill(value);
+    else if (n == "conv_rb_pairs") staged_set_rb_pairs(value);
     else if (n == "conv_rb_spill_cap") staged_set_rb_spill_cap(value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);

@@ -951,6 +951,302 @@ __global__ void __launch_bounds__(1024) k_rb_collect(const double* __restrict__ 
     if (has1) E::st(z, zp, B.zoff + (size_t)(k1 + 1) * B.zstrP + c, acc1);
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-pair sums (round 4): every row sum of the product as an independent task
+// ------------------------------------------------------------------------------------------
+// The reference orders only the ADDITIONS of the row sums; a row sum  S[a][b][c] = sum_j x[a][j] * y[b][c - j]  (formed from
+// zero in ascending j, mt:971-982) depends on one x row a and one y row b, and goes to the single output row a + b.  So
+// phase 1 is a batch of independent 1-d products, all (a, b) with a + b inside the result's box, and can take the layout
+// of the fast f64 kernel (gft_conv_tiled.hip) that the fused kernels above cannot — there the x value of a step comes
+// from LDS for every multiply-add because a wave spans four output rows:
+//   lanes       64 y rows b (a T0 x T1 tile of the last two outer axes), staged in LDS once per workgroup and reused by
+//               every x row the workgroup walks; a lane keeps 8 consecutive outputs c of ITS row sum in registers and
+//               slides an 8-wide window of its y row (one LDS read per 8 multiply-adds instead of three per two);
+//   x           one row per wave group at a time, wave-uniform: scalar loads, SGPR operands — no LDS, no VGPRs;
+//   waves       wave w of a group owns the column blocks w and nb - 1 - w (c + 1 chunk products for block c: equal work);
+//   order       chunks q ascending, s ascending inside: ascending j for every output, first term a plain product —
+//               the same operations on the same values as rb_sums / inner_sum => the same bits;
+//   regimes     positive / finite / general from the row flags (x row | the tile's y rows), validated on the finished
+//               sums and recomputed with the general multiply-add when a lane fails, as rb_row.
+// Phase 2 (k_pair_collect) is one workgroup per output row, a thread per column: it adds the row's terms in the
+// reference's order (outer axes lexicographic ascending, mt:984-1012) with sixteen loads in flight.
+// Workspace: the slots are ordered by OUTPUT row (row-major), and inside a row by the reference's term order — phase 2 reads
+// one contiguous stream per output row; phase 1 computes a lane's slot from closed-form per-axis prefix sums of the term
+// counts.  A slot is the row sum's n2 intervals, (lo, hi) interleaved.
+struct PairArgs {
+    unsigned xU, x0, x1, yU, y0, y1, zU, z0, z1;  // canonical outer extents (rank 2: U = axis 0 = 1; rank 3: U = 1)
+    unsigned n2, nx2, n8, nb, nxc;                // row lengths, padded row length, column blocks, x chunks
+    unsigned tsh;                                 // lane tile: T1 = 1 << tsh rows along axis 1, T0 = 64 >> tsh along axis 0
+    unsigned NW, XG, xch;                         // waves of a group, groups (x rows in flight), x rows per workgroup
+    unsigned tiles0, tiles1;                      // y tiles along the two lane axes
+    unsigned pitch;                               // LDS row pitch in doubles ((lo, hi) interleaved; pitch / 2 odd)
+    unsigned long long S0, S1;                    // terms summed over all k0 / all k1
+    const unsigned char* xflags;
+    const unsigned char* yflags;
+    unsigned dbg_nostore;                         // timing experiments only (GFT_RB_PAIRS_NOSTORE): phase 1 without its stores
+};
+// terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
+__host__ __device__ inline unsigned pair_lo(unsigned k, unsigned ny) { return k + 1 > ny ? k + 1 - ny : 0u; }
+__host__ __device__ inline unsigned pair_cnt(unsigned k, unsigned nx, unsigned ny) {
+    const unsigned lo = pair_lo(k, ny), hi = k + 1 < nx ? k + 1 : nx;
+    return hi > lo ? hi - lo : 0u;
+}
+__host__ __device__ inline unsigned long long pair_pre(unsigned k, unsigned nx, unsigned ny) {  // sum_{i < k} pair_cnt(i) (for x, y <= z: no empty k)
+    const unsigned long long kk = k;
+    const unsigned long long A = k <= nx ? kk * (kk + 1) / 2 : (unsigned long long)nx * (nx + 1) / 2 + (kk - nx) * nx;  // sum min(i + 1, nx)
+    const unsigned long long B = k > ny ? (kk - ny) * (kk - ny + 1) / 2 : 0ull;                                   // sum max(0, i + 1 - ny)
+    return A - B;
+}
+// slot of the row sum x row (ju, j0, j1) (*) y row (k - j): output rows in row-major order, each row's terms in the reference's
+// order (outer axes lexicographic ascending j) — phase 2 reads every output row's slots as ONE contiguous stream
+__device__ __forceinline__ unsigned long long pair_slot(const PairArgs& g, unsigned ju, unsigned j0, unsigned j1, unsigned ku, unsigned k0,
+                                                        unsigned k1) {
+    const unsigned cU = pair_cnt(ku, g.xU, g.yU), c0 = pair_cnt(k0, g.x0, g.y0), c1 = pair_cnt(k1, g.x1, g.y1);
+    const unsigned long long base = pair_pre(ku, g.xU, g.yU) * g.S0 * g.S1 + (unsigned long long)cU * (pair_pre(k0, g.x0, g.y0) * g.S1 + (unsigned long long)c0 * pair_pre(k1, g.x1, g.y1));
+    return base + ((unsigned long long)(ju - pair_lo(ku, g.yU)) * c0 + (j0 - pair_lo(k0, g.y0))) * c1 + (j1 - pair_lo(k1, g.y1));
+}
+
+typedef const double __attribute__((address_space(4))) * pair_cptr_t;  // wave-uniform, read-only: scalar loads
+
+// One CW x CW chunk product: x[CW q + s] (lo / hi from SGPRs) against the window (cur: y chunk cb - q, prev: the chunk below).
+// FIRST: chunk 0, whose s = 0 term starts every sum; TRI: the diagonal chunk (terms with s <= r only); PART: the x row may end
+// inside this chunk (slim = elements left; uniform tests per s).  REG 1: positive regime, 2: finite regime (gft_elem.hpp).
+// CW = 4: a lane holds 4 outputs and two 4-wide windows — ~60 VGPRs, so that 16 waves fit a CU: a single wave issues a 64-bit
+// VALU operation only every 8 cycles, two waves per SIMD reach 5.6, four 4.9 (profiles/r03/microbench_int64.txt), and the
+// 8-wide form of this kernel (168 VGPRs, 2 waves per SIMD) stood at 23-38 % of the issue roof.
+template <class E, int REG, int CW, bool FIRST, bool TRI, bool PART>
+__device__ __forceinline__ void pair_chunk(typename E::V (&acc)[CW], const double (&xlo)[CW], const double (&xhi)[CW], const typename E::V (&cur)[CW],
+                                           const typename E::V (&prev)[CW], unsigned slim) {
+    typedef typename E::V V;
+#pragma unroll
+    for (int s = 0; s < CW; ++s) {
+        if (!PART || (unsigned)s < slim) {
+            const V xv = Iv{xlo[s], xhi[s]};
+#pragma unroll
+            for (int r = 0; r < CW; ++r) {
+                if (TRI && r < s) continue;
+                const V yv = (r - s >= 0) ? cur[(r - s) % CW] : prev[(CW + r - s) % CW];
+                if (FIRST && s == 0) acc[r] = REG == 1 ? E::mul_pos(xv, yv) : E::mul_fin(xv, yv);
+                else acc[r] = REG == 1 ? E::mac_pos_unchecked(acc[r], xv, yv) : E::mac_fin(acc[r], xv, yv);
+            }
+        }
+    }
+}
+template <int CW>
+__device__ __forceinline__ void pair_ldx(double (&lo)[CW], double (&hi)[CW], pair_cptr_t xl, pair_cptr_t xh, unsigned q) {
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        lo[i] = xl[CW * q + i];
+        hi[i] = xh[CW * q + i];
+    }
+}
+template <class E, int CW>
+__device__ __forceinline__ void pair_ldw(typename E::V (&w)[CW], const double* yrow, unsigned chunk) {  // CW intervals, 16-byte reads
+    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(yrow + 2 * CW * chunk, 16));
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const double2 v = q[i];
+        w[i] = Iv{v.x, v.y};
+    }
+}
+// the CW outputs of column block cb of one row sum: x chunks q = 0 .. min(cb, nxc) - 1 against full windows (the window
+// alternates between (A, B) and (B, A): it slides without register moves), then the diagonal chunk if x reaches it
+template <class E, int REG, int CW>
+__device__ __forceinline__ void pair_block(typename E::V (&acc)[CW], unsigned cb, pair_cptr_t xl, pair_cptr_t xh, const double* yrow, unsigned nxc,
+                                           unsigned nx2) {
+    typedef typename E::V V;
+    V A[CW], B[CW];
+    double xlo[CW], xhi[CW];
+    pair_ldw<E, CW>(A, yrow, cb);
+    const unsigned qfull = cb < nxc ? cb : nxc;
+    const unsigned qwhole = nx2 / CW < qfull ? nx2 / CW : qfull;  // chunks x spans completely
+    if (qfull == 0) {  // cb == 0: the diagonal chunk is chunk 0
+        pair_ldx<CW>(xlo, xhi, xl, xh, 0);
+        pair_chunk<E, REG, CW, true, true, true>(acc, xlo, xhi, A, A, nx2);
+        return;
+    }
+    pair_ldw<E, CW>(B, yrow, cb - 1);
+    pair_ldx<CW>(xlo, xhi, xl, xh, 0);
+    pair_chunk<E, REG, CW, true, false, true>(acc, xlo, xhi, A, B, nx2);
+    unsigned q = 1;
+    for (; q + 2 <= qwhole; q += 2) {  // (the current window is in B here)
+        pair_ldw<E, CW>(A, yrow, cb - q - 1);
+        pair_ldx<CW>(xlo, xhi, xl, xh, q);
+        pair_chunk<E, REG, CW, false, false, false>(acc, xlo, xhi, B, A, CW);
+        pair_ldw<E, CW>(B, yrow, cb - q - 2);
+        pair_ldx<CW>(xlo, xhi, xl, xh, q + 1);
+        pair_chunk<E, REG, CW, false, false, false>(acc, xlo, xhi, A, B, CW);
+    }
+    for (; q < qfull; ++q) {  // at most one whole chunk and x's partial one: the window moves by copies here
+#pragma unroll
+        for (int i = 0; i < CW; ++i) A[i] = B[i];
+        pair_ldw<E, CW>(B, yrow, cb - q - 1);
+        pair_ldx<CW>(xlo, xhi, xl, xh, q);
+        pair_chunk<E, REG, CW, false, false, true>(acc, xlo, xhi, A, B, nx2 - CW * q);
+    }
+    if (cb < nxc) {  // the diagonal chunk: the current window is y chunk 0, in B
+        pair_ldx<CW>(xlo, xhi, xl, xh, cb);
+        pair_chunk<E, REG, CW, false, true, true>(acc, xlo, xhi, B, B, nx2 - CW * cb);
+    }
+}
+// the same CW outputs with the general multiply-add, as a plain loop per output (rare: operands with exact 0 / 1 / inf / NaN,
+// sums that left their regime — and the general multiply-add unrolled would be most of the kernel's code)
+template <class E, int CW>
+__device__ __forceinline__ void pair_block_general(typename E::V (&acc)[CW], unsigned cb, pair_cptr_t xl, pair_cptr_t xh, const double* yrow, unsigned nx2) {
+    typedef typename E::V V;
+#pragma unroll
+    for (int r = 0; r < CW; ++r) {
+        const unsigned c = CW * cb + r;
+        V s = E::mac(E::zero(), Iv{xl[0], xh[0]}, Iv{yrow[2 * c], yrow[2 * c + 1]});
+        const unsigned jend = c + 1 < nx2 ? c + 1 : nx2;
+#pragma unroll 1
+        for (unsigned j = 1; j < jend; ++j) s = E::mac(s, Iv{xl[j], xh[j]}, Iv{yrow[2 * (c - j)], yrow[2 * (c - j) + 1]});
+        acc[r] = s;
+    }
+}
+
+constexpr int PAIR_CW = 4;
+
+template <class E>
+__global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+                                                   double* __restrict__ ws, PairArgs g) {
+    typedef typename E::V V;
+    constexpr int CW = PAIR_CW;
+    extern __shared__ __align__(16) double smem[];
+    __shared__ unsigned s_tileflag;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned nwaves = blockDim.x >> 6;
+    const unsigned T1 = 1u << g.tsh, T0 = 64u >> g.tsh;
+    // the y tile (blockIdx.y) and the chunk of its x rows (blockIdx.x: consecutive workgroups go to consecutive XCDs, so a
+    // tile's chunks spread over all eight — with the tile as the fastest index and 8 tiles along an axis an XCD only ever
+    // saw ONE bt, and a tile's work falls with bt: XCD 0 had 8x the work of XCD 7 at 64^3)
+    unsigned tb = blockIdx.y;
+    const unsigned bt = tb % g.tiles1;
+    tb /= g.tiles1;
+    const unsigned at = tb % g.tiles0, ud = tb / g.tiles0;
+    const unsigned d0b = T0 * at, d1b = T1 * bt;
+    const unsigned nU = g.zU - ud < g.xU ? g.zU - ud : g.xU;  // x rows (ju, j0, j1) some lane of the tile pairs with
+    const unsigned n0 = g.z0 - d0b < g.x0 ? g.z0 - d0b : g.x0;
+    const unsigned n1 = g.z1 - d1b < g.x1 ? g.z1 - d1b : g.x1;
+    const unsigned long long count = (unsigned long long)nU * n0 * n1;
+    const unsigned long long xi_lo = (unsigned long long)blockIdx.x * g.xch;
+    if (xi_lo >= count) return;
+    const unsigned rows_here = (unsigned)(xi_lo + g.xch < count ? g.xch : count - xi_lo);
+    // ---- stage the tile's 64 y rows, (lo, hi) interleaved, zero beyond the row / for rows outside y
+    if (tid == 0) s_tileflag = 0;
+    __syncthreads();
+    {
+        unsigned fl = 0;
+        for (unsigned i = tid; i < 64u * g.n8; i += blockDim.x) {
+            const unsigned r = i / g.n8, cc = i - r * g.n8;
+            const unsigned d0 = d0b + (r >> g.tsh), d1 = d1b + (r & (T1 - 1u));
+            double2 v = double2{0.0, 0.0};
+            if (d0 < g.y0 && d1 < g.y1 && cc < g.n2) {
+                const size_t row = ((size_t)ud * g.y0 + d0) * g.y1 + d1;
+                v = double2{y[row * g.n2 + cc], y[yp + row * g.n2 + cc]};
+                if (cc == 0) fl |= g.yflags[row];
+            }
+            reinterpret_cast<double2*>(smem + (size_t)r * g.pitch)[cc] = v;
+        }
+        if (fl) atomicOr(&s_tileflag, fl);
+    }
+    __syncthreads();
+    const unsigned tileflag = s_tileflag;
+    const unsigned l0 = lane >> g.tsh, l1 = lane & (T1 - 1u);
+    const unsigned d0 = d0b + l0, d1 = d1b + l1;
+    const bool row_ok = d0 < g.y0 && d1 < g.y1;
+    const double* yrow = smem + (size_t)lane * g.pitch;
+    // ---- tasks (x row, pair of column blocks p and nbw - 1 - p: p + 1 and nbw - p chunk products, the same sum for every p),
+    // dealt round-robin to the waves
+    const unsigned nbw = g.n8 / CW, nxc = (g.nx2 + CW - 1) / CW, npairs = (nbw + 1) / 2;
+    const unsigned ntasks = rows_here * npairs;
+    for (unsigned t = wave; t < ntasks; t += nwaves) {
+        const unsigned long long xi = xi_lo + t / npairs;
+        const unsigned pr = t % npairs;
+        const unsigned j1 = (unsigned)(xi % n1);
+        const unsigned long long tt = xi / n1;
+        const unsigned j0 = (unsigned)(tt % n0), ju = (unsigned)(tt / n0);
+        const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
+        pair_cptr_t xl = (pair_cptr_t)(x + arow * g.nx2), xh = (pair_cptr_t)(x + xp + arow * g.nx2);
+        const bool lane_ok = row_ok && j0 + d0 < g.z0 && j1 + d1 < g.z1;
+        const unsigned f = tileflag | g.xflags[arow];
+        const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
+        double* const dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * 2;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const unsigned cb = half == 0 ? pr : nbw - 1 - pr;
+            if (half == 1 && cb <= pr) continue;  // (uniform: the middle block of an odd count is its own pair)
+            V acc[CW];
+#pragma unroll
+            for (int r = 0; r < CW; ++r) acc[r] = E::zero();
+            bool redo = true;
+            if (regime == 1) {
+                pair_block<E, 1, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && (!E::pos_first_ok(acc[r]) || !E::pos_result_ok(acc[r])));
+                redo = any_lane(lane_ok && bad);
+            } else if (regime == 2) {
+                pair_block<E, 2, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && !E::fin_result_ok(acc[r]));
+                redo = any_lane(lane_ok && bad);
+            }
+            if (redo) pair_block_general<E, CW>(acc, cb, xl, xh, yrow, g.nx2);
+            if (lane_ok && !g.dbg_nostore) {
+                double2* d = reinterpret_cast<double2*>(dst) + CW * cb;
+#pragma unroll
+                for (int r = 0; r < CW; ++r)
+                    if (CW * cb + r < g.n2) d[r] = double2{acc[r].lo, acc[r].hi};
+            }
+        }
+    }
+}
+
+// phase 2: the terms of one output row are one contiguous stream in the reference's order; thread = column, sixteen terms in
+// flight (the heaviest row of 64^3 has 4096 terms of 1 KB: its chain of loads is what the launch waits for)
+template <class E>
+__global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__ ws, double* __restrict__ z, size_t zp, PairArgs g) {
+    typedef typename E::V V;
+    const unsigned c = blockIdx.y * blockDim.x + threadIdx.x;
+    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest rows first
+    const unsigned k1 = (unsigned)(rr % g.z1);
+    rr /= g.z1;
+    const unsigned k0 = (unsigned)(rr % g.z0), ku = (unsigned)(rr / g.z0);
+    const unsigned long long n = (unsigned long long)pair_cnt(ku, g.xU, g.yU) * pair_cnt(k0, g.x0, g.y0) * pair_cnt(k1, g.x1, g.y1);
+    V acc = E::zero();
+    if (n > 0 && c < g.n2) {
+        const double2* p = reinterpret_cast<const double2*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 * 2) + c;
+        const size_t pitch = g.n2;  // double2 per term
+        constexpr int D = 16;
+        double2 buf[D];
+        // (no conditional loads in the steady state: hipcc waits for vmcnt(0) at every basic-block boundary, and a load
+        // under `if` is a block of its own — one load in flight instead of D)
+#pragma unroll
+        for (int u = 0; u < D; ++u) buf[u] = p[(size_t)((unsigned long long)u < n ? u : n - 1) * pitch];
+        unsigned long long i0 = 0;
+        for (; i0 + 2 * D <= n; i0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                acc = E::add(acc, Iv{buf[u].x, buf[u].y});
+                buf[u] = p[(size_t)(i0 + u + D) * pitch];
+            }
+        }
+        // the last D .. 2 D - 1 terms: D in the buffers, the rest loaded with clamped indices
+        double2 last[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) last[u] = p[(size_t)(i0 + D + u < n ? i0 + D + u : n - 1) * pitch];
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (i0 + u < n) acc = E::add(acc, Iv{buf[u].x, buf[u].y});
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (i0 + D + u < n) acc = E::add(acc, Iv{last[u].x, last[u].y});
+    }
+    if (c < g.n2) E::st(z, zp, (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c, acc);
+}
+
 // per-stream scratch for the row flags (grow-only; a stream's launches are ordered, so one buffer per stream is enough)
 struct RbScratch {
     unsigned char* p = nullptr;
@@ -986,6 +1282,18 @@ static size_t rb_spill_cap = [] {  // bytes of row sums per chunk of the leading
     const char* e = getenv("GFT_RB_SPILL_CAP_MB");
     return (size_t)(e ? std::max(1, atoi(e)) : 24576) << 20;
 }();
+// row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 products of [rb_pairs_min, ..) multiply-adds whose row sums fit the
+// workspace cap, 2 whenever it applies (tests)
+static int rb_pairs_default() {
+    const char* e = getenv("GFT_RB_PAIRS");
+    return e ? atoi(e) : 1;
+}
+static int rb_pairs_mode = rb_pairs_default();
+static double rb_pairs_min = [] {
+    const char* e = getenv("GFT_RB_PAIRS_MIN_MACS");
+    return e ? atof(e) : 1.0e8;
+}();
+void staged_set_rb_pairs(double v) { rb_pairs_mode = v < 0.0 ? rb_pairs_default() : (int)v; }  // "conv_rb_pairs" (negative: back to the default)
 void staged_set_rb_spill(double v) { rb_spill_mode = v < 0.0 ? rb_spill_default() : (int)v; }  // "conv_rb_spill" (negative: back to the default)
 void staged_set_rb_spill_cap(double bytes) { rb_spill_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)24576 << 20); }  // "conv_rb_spill_cap" (tests: chunking)
 // measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
@@ -1030,6 +1338,113 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     // worth it from a few 10^7 multiply-adds (two passes over the operands, a block per output row pair)
     double macs = 1.0;
     for (int ax = 0; ax < nd; ++ax) macs *= 0.5 * (double)a.zs[ax] * (double)std::min(a.xs[ax], a.ys[ax]);
+    // ---- row-pair form
+    if ((rb_pairs_mode == 2 || (rb_pairs_mode == 1 && macs >= rb_pairs_min)) && n2 <= 128 && a.slab_lo == 0 && a.slab_hi == a.zs[0]) {
+        PairArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.xU = g.x0 = g.x1 = g.yU = g.y0 = g.y1 = g.zU = g.z0 = g.z1 = 1;
+        const int no = nd - 1;
+        if (no == 1) {
+            g.x1 = a.xs[0]; g.y1 = a.ys[0]; g.z1 = a.zs[0];
+        } else if (no == 2) {
+            g.x0 = a.xs[0]; g.y0 = a.ys[0]; g.z0 = a.zs[0];
+            g.x1 = a.xs[1]; g.y1 = a.ys[1]; g.z1 = a.zs[1];
+        } else {
+            g.xU = a.xs[0]; g.yU = a.ys[0]; g.zU = a.zs[0];
+            g.x0 = a.xs[1]; g.y0 = a.ys[1]; g.z0 = a.zs[1];
+            g.x1 = a.xs[2]; g.y1 = a.ys[2]; g.z1 = a.zs[2];
+        }
+        g.n2 = n2;
+        g.nx2 = nx2;
+        g.n8 = (n2 + 7) / 8 * 8;
+        g.nb = g.n8 / 8;
+        g.nxc = (nx2 + 7) / 8;
+        {   // lane tile: the shape with the fewest lanes outside y's rows (ties: the squarest)
+            double best = -1.0;
+            for (unsigned tsh = 0; tsh <= 6; ++tsh) {
+                const unsigned T1 = 1u << tsh, T0 = 64u >> tsh;
+                const double e = (double)g.y0 / ((g.y0 + T0 - 1) / T0 * T0) * (double)g.y1 / ((g.y1 + T1 - 1) / T1 * T1);
+                const double pref = e - 1e-6 * (tsh > 3 ? tsh - 3 : 3 - tsh);
+                if (pref > best) {
+                    best = pref;
+                    g.tsh = tsh;
+                }
+            }
+        }
+        const unsigned T1 = 1u << g.tsh, T0 = 64u >> g.tsh;
+        g.tiles0 = (g.y0 + T0 - 1) / T0;
+        g.tiles1 = (g.y1 + T1 - 1) / T1;
+        g.pitch = 2 * g.n8 + 2;
+        // 16 waves per CU (the kernel holds <= 128 VGPRs): two workgroups of 8 where two tiles fit the LDS, else one of 16
+        g.NW = (size_t)64 * g.pitch * sizeof(double) * 2 + 1024 <= 160 * 1024 ? 8u : 16u;
+        g.XG = 1;
+        static const unsigned nw_env = [] {
+            const char* e = getenv("GFT_RB_PAIRS_WAVES");  // tuning knob: waves of a phase-1 workgroup
+            return (unsigned)(e ? std::max(0, std::min(16, atoi(e))) : 0);
+        }();
+        if (nw_env) g.NW = nw_env;
+        static const unsigned xch_env = [] {
+            const char* e = getenv("GFT_RB_PAIRS_XCH");  // tuning knob: x rows per phase-1 workgroup
+            return (unsigned)(e ? std::max(1, atoi(e)) : 32);
+        }();
+        g.xch = xch_env;
+        static const unsigned nostore_env = getenv("GFT_RB_PAIRS_NOSTORE") ? 1u : 0u;
+        g.dbg_nostore = nostore_env;
+        g.S0 = pair_pre(g.z0, g.x0, g.y0);  // terms over all k0 / all k1
+        g.S1 = pair_pre(g.z1, g.x1, g.y1);
+        const unsigned long long slots = pair_pre(g.zU, g.xU, g.yU) * g.S0 * g.S1;
+        const unsigned long long need = slots * n2 * 2 * sizeof(double);
+        const unsigned long long chunks_y = (xrows + g.xch - 1) / g.xch, tiles = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
+        if (slots > 0 && need <= rb_spill_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
+            RbScratch& sc = rb_scratch()[st];
+            RbSpillWs& w = rb_spill_ws()[st];
+            bool ok = true;
+            if (sc.bytes < xrows + yrows) {
+                if (sc.p) (void)hipFree(sc.p);
+                sc.p = nullptr;
+                sc.bytes = 0;
+                const size_t want = std::max<size_t>((xrows + yrows) * 2, 1 << 16);
+                if (hipMalloc(&sc.p, want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sc.p = nullptr;
+                    ok = false;
+                } else {
+                    sc.bytes = want;
+                }
+            }
+            if (ok && w.bytes < need) {
+                if (w.p) (void)hipFree(w.p);
+                w.p = nullptr;
+                w.bytes = 0;
+                if (hipMalloc((void**)&w.p, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    w.p = nullptr;
+                    ok = false;
+                } else {
+                    w.bytes = need;
+                }
+            }
+            if (ok) {
+                g.xflags = sc.p;
+                g.yflags = sc.p + xrows;
+                const size_t lds = (size_t)64 * g.pitch * sizeof(double);
+                static bool attr = false;
+                if (!attr) {
+                    (void)hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr = true;
+                }
+                GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
+                GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
+                GFT_LAUNCH(k_pair_sums<E>, dim3((unsigned)chunks_y, (unsigned)tiles), dim3(g.NW * 64), lds, st, x, xp, y, yp, w.p, g);
+                static const unsigned cw_env = [] {
+                    const char* e = getenv("GFT_RB_PAIRS_COLS");  // tuning knob: columns per phase-2 workgroup
+                    return (unsigned)(e ? std::max(1, std::min(128, atoi(e))) : 64);
+                }();
+                GFT_LAUNCH(k_pair_collect<E>, dim3((unsigned)(zs_ / n2), (n2 + cw_env - 1) / cw_env), dim3(cw_env), 0, st, (const double*)w.p, z, zp, g);
+                return true;
+            }
+        }
+    }
     bool spill = rb_spill_mode == 2 || (rb_spill_mode == 1 && macs >= rb_spill_min && macs <= rb_spill_max);
     if (!spill && (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64)) return false;  // (rows shorter than 64: the two-phase form only)
     RbArgs g;
