@@ -3688,9 +3688,8 @@ int gft_set_option(const char* name, double value) {
     else if (n == "debug_fail_next_launch") g_fail_next_launch.store(value != 0 ? 1 : 0);  // test knob (gft_launch.hpp)
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
-    else if (n == "conv_rb_spill") staged_set_rb_spill(value);
     else if (n == "conv_rb_pairs") staged_set_rb_pairs(value);
-    else if (n == "conv_rb_spill_cap") staged_set_rb_spill_cap(value);
+    else if (n == "conv_rb_pairs_cap") staged_set_rb_pairs_cap(value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default

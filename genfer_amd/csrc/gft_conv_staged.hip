@@ -414,7 +414,6 @@ struct RbArgs {
     size_t xrs[MAXO], yrs[MAXO];  // strides of the outer axes in ROWS
     const unsigned char* xflags;  // per row: bit 0 = some element is not pos_ok, bit 1 = some element is not fin_ok
     const unsigned char* yflags;
-    unsigned long long nt_total, c1_total;  // two-phase form: y rows over all row groups; lead steps over the last lead axis (rank 4)
 };
 constexpr unsigned RB_ROWS = 8;  // output rows of a workgroup (4 lane groups x 2 outputs per lane)
 
@@ -692,266 +691,6 @@ __global__ void __launch_bounds__(1024) k_conv_rows_rb(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Two phases for the mid sizes (round 4): row sums to a workspace, then the ordered additions
-// ------------------------------------------------------------------------------------------
-// k_conv_rows_rb's workgroup owns 8 output rows and walks ALL their (lead step, y row) pairs one batch after the other: at
-// 64^3 the heaviest of its 512 workgroups has 4096 row sums per output in a chain while most of the chip has long finished
-// (10.5 ms on either kernel, 17 % of the issue roof).  But the reference only orders the ADDITIONS of the row sums — every
-// row sum is formed from zero (mt:971-982) and does not depend on the others.  So:
-//   phase 1  k_rb_spill: one workgroup per (8 output rows, lead step, batch of y rows) — the batch body of k_conv_rows_rb,
-//            same staging, same rb_row — stores the finished row sums to a workspace slot; every workgroup has the same
-//            few microseconds of work and there are 10^5 of them;
-//   phase 2  k_rb_collect: one workgroup per 8 output rows streams its slots, which lie in the order of the reference's
-//            additions (lead steps ascending, then ascending j on the paired axis), and adds them: E::add on the same
-//            values in the same order => the same bits.
-// The workspace is (pairs of x and y rows that meet) x row length x 16 bytes — 4.4 GB at 64^3, written and read once
-// (~2 ms of HBM time against the 8 ms saved); the leading axis is cut into chunks of <= RB_SPILL_CAP bytes, and a product
-// whose single leading index exceeds that (>= ~100^3) stays on k_conv_rows_rb.
-// Slot order: blocks (K0 [, K1], row group pg) K0-major; inside a block (lead step, t_hi - t); a slot is [wave][4 sums][2
-// planes][64 lanes] like sums_l.  A block's base is a product of per-axis prefix counts, recomputed by short scalar loops.
-__device__ __forceinline__ unsigned rb_axis_cnt(unsigned k, unsigned nx, unsigned ny) {
-    const unsigned lo = k + 1 > ny ? k + 1 - ny : 0, hi = k + 1 < nx ? k + 1 : nx;
-    return hi > lo ? hi - lo : 0;
-}
-__host__ __device__ inline unsigned rb_group_rows(unsigned pg, unsigned nP, unsigned nxP, unsigned nyP) {  // y rows of row group pg
-    const unsigned k1g = RB_ROWS * pg;
-    const unsigned ktop = k1g + RB_ROWS - 1 < nP - 1 ? k1g + RB_ROWS - 1 : nP - 1;
-    const int t_hi = (int)(ktop < nyP - 1 ? ktop : nyP - 1);
-    const int t_lo = k1g + 1 > nxP ? (int)(k1g + 1 - nxP) : 0;
-    return t_hi >= t_lo ? (unsigned)(t_hi - t_lo + 1) : 0u;
-}
-
-struct RbBlock {  // what both phases derive from blockIdx.x
-    unsigned pg, k1g, ktop, nP, nxP, nyP, nt;
-    int t_hi, t_lo;
-    unsigned K[MAXO], lo[MAXO], cnt[MAXO];
-    unsigned long long lead_steps;
-    unsigned long long slot_base;  // first slot of the block
-    size_t zoff, zstrP;
-};
-template <bool WITH_BASE>
-__device__ __forceinline__ RbBlock rb_block(const ConvArgs& a, const RbArgs& g, unsigned long long b) {
-    RbBlock B;
-    const int P = g.no - 1;
-    B.pg = (unsigned)((b % g.n_pg + b / g.n_pg) % g.n_pg);
-    b /= g.n_pg;
-    B.k1g = RB_ROWS * B.pg;
-    B.lead_steps = 1;
-    B.zoff = 0;
-#pragma unroll
-    for (int ax = MAXO - 1; ax >= 0; --ax) {
-        B.K[ax] = B.lo[ax] = 0;
-        B.cnt[ax] = 1;
-        if (ax < P) {
-            unsigned d = a.zs[ax], base = 0;
-            if (ax == 0) {
-                d = a.slab_hi - a.slab_lo;
-                base = a.slab_lo;
-            }
-            B.K[ax] = base + (unsigned)(b % d);
-            b /= d;
-            B.zoff += (size_t)B.K[ax] * a.zstr[ax];
-            B.lo[ax] = B.K[ax] + 1 > a.ys[ax] ? B.K[ax] + 1 - a.ys[ax] : 0;
-            B.cnt[ax] = rb_axis_cnt(B.K[ax], a.xs[ax], a.ys[ax]);
-            B.lead_steps *= B.cnt[ax];
-        }
-    }
-    B.nP = B.nxP = B.nyP = 1;
-    B.zstrP = 0;
-#pragma unroll
-    for (int ax = 0; ax < MAXO; ++ax)
-        if (ax == P) {
-            B.nP = a.zs[ax];
-            B.nxP = a.xs[ax];
-            B.nyP = a.ys[ax];
-            B.zstrP = a.zstr[ax];
-        }
-    B.ktop = B.k1g + RB_ROWS - 1 < B.nP - 1 ? B.k1g + RB_ROWS - 1 : B.nP - 1;
-    B.t_hi = (int)(B.ktop < B.nyP - 1 ? B.ktop : B.nyP - 1);
-    B.t_lo = B.k1g + 1 > B.nxP ? (int)(B.k1g + 1 - B.nxP) : 0;
-    B.nt = B.t_hi >= B.t_lo ? (unsigned)(B.t_hi - B.t_lo + 1) : 0u;
-    B.slot_base = 0;
-    if (WITH_BASE) {
-        // slots before this block = sum over earlier (K0, K1, pg) of cnt0 cnt1 nt(pg): the three factors separate
-        // (static indices only: a dynamically indexed member array would live in scratch)
-        unsigned long long ntpre = 0;
-        for (unsigned p = 0; p < B.pg; ++p) ntpre += rb_group_rows(p, B.nP, B.nxP, B.nyP);
-        if (P == 0) {
-            B.slot_base = ntpre;  // rank 2: the row groups are all there is
-        } else {
-            unsigned long long pre0 = 0;
-            for (unsigned k = a.slab_lo; k < B.K[0]; ++k) pre0 += rb_axis_cnt(k, a.xs[0], a.ys[0]);
-            if (P == 1) {
-                B.slot_base = pre0 * g.nt_total + (unsigned long long)B.cnt[0] * ntpre;
-            } else {
-                unsigned long long pre1 = 0;
-                for (unsigned k = 0; k < B.K[1]; ++k) pre1 += rb_axis_cnt(k, a.xs[1], a.ys[1]);
-                B.slot_base = pre0 * g.c1_total * g.nt_total + (unsigned long long)B.cnt[0] * (pre1 * g.nt_total + (unsigned long long)B.cnt[1] * ntpre);
-            }
-        }
-    }
-    return B;
-}
-
-template <class E>
-__global__ void __launch_bounds__(1024) k_rb_spill(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
-                                                  double* __restrict__ ws, ConvArgs a, RbArgs g) {
-    typedef typename E::V V;
-    extern __shared__ __align__(16) double smem[];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned grp = wave_all / g.ntw, wave = wave_all - grp * g.ntw;
-    const unsigned q = lane >> 4, cl = lane & 15u;
-    const int P = g.no - 1;
-    RbBlock B = rb_block<false>(a, g, (unsigned long long)(gridDim.x - 1 - blockIdx.x));
-    unsigned long long step = blockIdx.y;
-    if (step >= B.lead_steps) return;  // (the grid is the bounding box of a triangle: most empty workgroups leave here)
-    const int tt = B.t_hi - (int)(blockIdx.z * g.tb);  // the batch: y rows tt, tt - 1, ..
-    if (tt < B.t_lo) return;
-    double* const ys_l = smem;
-    double* const xs_l = smem + (size_t)g.tb * 2 * g.n2 + 16;
-    const unsigned xpitch = 2 * g.nx2 + 2;
-    unsigned char* const fl_l = reinterpret_cast<unsigned char*>(xs_l + (size_t)(g.tb + RB_ROWS - 1) * xpitch);
-    const unsigned ctA = wave, ctB = g.ntiles - 1 - wave;
-    const bool twoB = ctB != ctA;
-    const unsigned c0A = ctA * 16, c0B = ctB * 16, cA = c0A + cl, cB = c0B + cl;
-    // the lead step's operand rows (last lead axis fastest, as k_conv_rows_rb's odometer)
-    size_t xrow_lead = 0, yrow_lead = 0;
-    {
-        unsigned long long s = step;
-#pragma unroll
-        for (int ax = MAXO - 1; ax >= 0; --ax)
-            if (ax < P) {
-                const unsigned j = B.lo[ax] + (unsigned)(s % B.cnt[ax]);
-                s /= B.cnt[ax];
-                xrow_lead += (size_t)j * g.xrs[ax];
-                yrow_lead += (size_t)(B.K[ax] - j) * g.yrs[ax];
-            }
-    }
-    const unsigned k1g = B.k1g, ktop = B.ktop, nxP = B.nxP;
-    const unsigned k1 = k1g + 2 * q;
-    const bool has0 = k1 < B.nP, has1 = k1 + 1 < B.nP;
-    const unsigned ypl = g.n2;
-    const int rows = tt - B.t_lo + 1 < (int)g.tb ? tt - B.t_lo + 1 : (int)g.tb;
-    const int tbot = tt - rows + 1;
-    const int jlo = (int)k1g - tt > 0 ? (int)k1g - tt : 0;
-    int jhi = (int)ktop - tbot;
-    if (jhi > (int)nxP - 1) jhi = (int)nxP - 1;
-    const int xrows = jhi >= jlo ? jhi - jlo + 1 : 0;
-    if (xrows <= 0) return;  // (uniform; phase 2 finds no valid term in these rows either)
-    for (unsigned i = tid; i < (unsigned)rows * g.n2; i += blockDim.x) {
-        const unsigned rr = i / g.n2, cc = i - rr * g.n2;
-        const size_t src = (yrow_lead + (size_t)(tbot + (int)rr)) * g.n2 + cc;
-        double* dst = ys_l + (size_t)((unsigned)rows - 1 - rr) * 2 * g.n2 + cc;
-        dst[0] = y[src];
-        dst[g.n2] = y[yp + src];
-    }
-    for (unsigned i = tid; i < (unsigned)xrows * g.nx2; i += blockDim.x) {
-        const size_t src = (xrow_lead + (size_t)jlo) * g.nx2 + i;
-        const unsigned xr = i / g.nx2, xc = i - xr * g.nx2;
-        reinterpret_cast<double2*>(xs_l + (size_t)xr * xpitch)[xc] = double2{x[src], x[xp + src]};
-    }
-    if (tid < (unsigned)rows) fl_l[tid] = g.yflags[yrow_lead + (size_t)(tt - (int)tid)];
-    for (unsigned i = tid; i < (unsigned)xrows; i += blockDim.x) fl_l[g.tb + i] = g.xflags[xrow_lead + (size_t)jlo + i];
-    __syncthreads();
-    if ((int)grp >= rows) return;
-    const int r = (int)grp, t = tt - r;
-    int ja = (int)k1g - t, jb = (int)ktop - t;
-    if (ja < 0) ja = 0;
-    if (jb > (int)nxP - 1) jb = (int)nxP - 1;
-    if (jb < ja) return;  // (uniform)
-    const bool v0 = has0 && t <= (int)k1 && k1 - (unsigned)t < nxP;
-    const bool v1 = has1 && t <= (int)k1 + 1 && k1 + 1 - (unsigned)t < nxP;
-    unsigned f = fl_l[r];
-    for (int jj = ja; jj <= jb; ++jj) f |= fl_l[g.tb + (unsigned)(jj - jlo)];
-    const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
-    int j10 = (int)k1 - t, j11 = (int)k1 + 1 - t;
-    j10 = j10 < ja ? ja : (j10 > jb ? jb : j10);
-    j11 = j11 < ja ? ja : (j11 > jb ? jb : j11);
-    const double* x0 = xs_l + (size_t)(j10 - jlo) * xpitch;
-    const double* x1 = xs_l + (size_t)(j11 - jlo) * xpitch;
-    const double* yrow = ys_l + (size_t)r * 2 * g.n2;
-    V sA0 = E::zero(), sA1 = E::zero(), sB0 = E::zero(), sB1 = E::zero();
-    if (cA < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cA, ypl, cA, c0A, g.nx2, sA0, sA1);
-    if (twoB && cB < g.n2) rb_row<E>(regime, v0, v1, x0, x1, yrow + cB, ypl, cB, c0B, g.nx2, sB0, sB1);
-    const unsigned long long slot = rb_block<true>(a, g, (unsigned long long)(gridDim.x - 1 - blockIdx.x)).slot_base + step * B.nt + (unsigned)(B.t_hi - t);
-    double* sl = ws + ((size_t)slot * g.ntw + wave) * 512 + lane;
-    E::st(sl, 64, 0, sA0);
-    E::st(sl + 128, 64, 0, sA1);
-    if (twoB) {
-        E::st(sl + 256, 64, 0, sB0);
-        E::st(sl + 384, 64, 0, sB1);
-    }
-}
-
-// phase 2: wave (tile pair `wave`, half h) adds the sums of its tile A (h = 0) or B (h = 1) in slot order
-template <class E>
-__global__ void __launch_bounds__(1024) k_rb_collect(const double* __restrict__ ws, double* __restrict__ z, size_t zp, ConvArgs a, RbArgs g) {
-    typedef typename E::V V;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned h = wave_all / g.ntw, wave = wave_all - h * g.ntw;
-    const unsigned q = lane >> 4, cl = lane & 15u;
-    const RbBlock B = rb_block<true>(a, g, (unsigned long long)(gridDim.x - 1 - blockIdx.x));
-    const unsigned ctA = wave, ctB = g.ntiles - 1 - wave;
-    if (h == 1 && ctB == ctA) return;
-    const unsigned c = (h == 0 ? ctA : ctB) * 16 + cl;
-    const unsigned k1 = B.k1g + 2 * q;
-    const bool has0 = k1 < B.nP, has1 = k1 + 1 < B.nP;
-    V acc0 = E::zero(), acc1 = E::zero();
-    const double* base = ws + ((size_t)B.slot_base * g.ntw + wave) * 512 + (h ? 256 : 0) + lane;
-    const size_t pitch = (size_t)g.ntw * 512;
-    // which of the lane's two outputs take the row of slot index ti (t = t_hi - ti): as k_conv_rows_rb's row_terms
-    auto valid = [&](unsigned ti, bool& v0, bool& v1) {
-        const int t = B.t_hi - (int)ti;
-        int ja = (int)B.k1g - t, jb = (int)B.ktop - t;
-        if (ja < 0) ja = 0;
-        if (jb > (int)B.nxP - 1) jb = (int)B.nxP - 1;
-        v0 = jb >= ja && has0 && t <= (int)k1 && k1 - (unsigned)t < B.nxP;
-        v1 = jb >= ja && has1 && t <= (int)k1 + 1 && k1 + 1 - (unsigned)t < B.nxP;
-    };
-    // the slots of the block are one linear stream (lead step major, then t descending); D of them are in flight per wave
-    // while the additions go on in order (a slot is 2 KB per wave; the heaviest block of 64^3 has 4096 of them)
-    constexpr int D = 8;
-    const unsigned long long n = B.lead_steps * B.nt;
-    V b0[D], b1[D];
-    bool w0[D], w1[D];
-    unsigned tis[D];  // slot index within its lead step, per buffer
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-        tis[u] = B.nt ? (unsigned)(u % B.nt) : 0u;
-        w0[u] = w1[u] = false;
-        b0[u] = b1[u] = E::zero();
-        if ((unsigned long long)u < n) {
-            valid(tis[u], w0[u], w1[u]);
-            if (w0[u]) b0[u] = E::ld(base + (size_t)u * pitch, 64, 0);
-            if (w1[u]) b1[u] = E::ld(base + (size_t)u * pitch + 128, 64, 0);
-        }
-    }
-    const unsigned dstep = B.nt ? (unsigned)(D % B.nt) : 0u;
-    for (unsigned long long i0 = 0; i0 < n; i0 += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const unsigned long long i = i0 + u;
-            if (i < n) {
-                if (w0[u]) acc0 = E::add(acc0, b0[u]);
-                if (w1[u]) acc1 = E::add(acc1, b1[u]);
-                const unsigned long long nx = i + D;
-                tis[u] += dstep;
-                if (tis[u] >= B.nt) tis[u] -= B.nt;
-                w0[u] = w1[u] = false;
-                if (nx < n) {
-                    valid(tis[u], w0[u], w1[u]);
-                    if (w0[u]) b0[u] = E::ld(base + (size_t)nx * pitch, 64, 0);
-                    if (w1[u]) b1[u] = E::ld(base + (size_t)nx * pitch + 128, 64, 0);
-                }
-            }
-        }
-    }
-    if (c >= g.n2) return;
-    if (has0) E::st(z, zp, B.zoff + (size_t)k1 * B.zstrP + c, acc0);
-    if (has1) E::st(z, zp, B.zoff + (size_t)(k1 + 1) * B.zstrP + c, acc1);
-}
-
-// ------------------------------------------------------------------------------------------
 // Row-pair sums (round 4): every row sum of the product as an independent task
 // ------------------------------------------------------------------------------------------
 // The reference orders only the ADDITIONS of the row sums; a row sum  S[a][b][c] = sum_j x[a][j] * y[b][c - j]  (formed from
@@ -960,24 +699,31 @@ __global__ void __launch_bounds__(1024) k_rb_collect(const double* __restrict__ 
 // of the fast f64 kernel (gft_conv_tiled.hip) that the fused kernels above cannot — there the x value of a step comes
 // from LDS for every multiply-add because a wave spans four output rows:
 //   lanes       64 y rows b (a T0 x T1 tile of the last two outer axes), staged in LDS once per workgroup and reused by
-//               every x row the workgroup walks; a lane keeps 8 consecutive outputs c of ITS row sum in registers and
-//               slides an 8-wide window of its y row (one LDS read per 8 multiply-adds instead of three per two);
-//   x           one row per wave group at a time, wave-uniform: scalar loads, SGPR operands — no LDS, no VGPRs;
-//   waves       wave w of a group owns the column blocks w and nb - 1 - w (c + 1 chunk products for block c: equal work);
+//               every x row the workgroup walks; a lane keeps 4 consecutive outputs c of ITS row sum in registers and
+//               slides a 4-wide window of its y row (one 16-byte LDS read per 4 multiply-adds instead of three per two);
+//   x           one row per task, wave-uniform: scalar loads, SGPR operands — no LDS, no VGPRs;
+//   tasks       (x row, pair of column blocks p and nbw - 1 - p: nbw + 1 chunk products whatever p), dealt round-robin to
+//               the workgroup's waves; 8 x rows per workgroup (a tile's x rows are cut into chunks: blockIdx.x, so that
+//               a tile's chunks spread over the XCDs);
+//   registers   <= 128 VGPRs, 16 waves per CU: one wave issues a 64-bit VALU operation every 8 cycles, four per SIMD
+//               every 4.9 (profiles/r03/microbench_int64.txt) — the first, 8-wide version of this kernel (168 VGPRs, two
+//               waves per SIMD) stood at 23-38 % of the issue roof;
 //   order       chunks q ascending, s ascending inside: ascending j for every output, first term a plain product —
 //               the same operations on the same values as rb_sums / inner_sum => the same bits;
 //   regimes     positive / finite / general from the row flags (x row | the tile's y rows), validated on the finished
 //               sums and recomputed with the general multiply-add when a lane fails, as rb_row.
 // Phase 2 (k_pair_collect) is one workgroup per output row, a thread per column: it adds the row's terms in the
-// reference's order (outer axes lexicographic ascending, mt:984-1012) with sixteen loads in flight.
-// Workspace: the slots are ordered by OUTPUT row (row-major), and inside a row by the reference's term order — phase 2 reads
-// one contiguous stream per output row; phase 1 computes a lane's slot from closed-form per-axis prefix sums of the term
-// counts.  A slot is the row sum's n2 intervals, (lo, hi) interleaved.
+// reference's order (outer axes lexicographic ascending, mt:984-1012) with sixteen loads in flight — a contiguous stream:
+// the slots are ordered by OUTPUT row (row-major) and inside a row by the reference's term order; phase 1 computes a lane's
+// slot from closed-form per-axis prefix sums of the term counts.  A slot is the row sum's n2 intervals, (lo, hi)
+// interleaved: 4.4 GB at 64^3, written and read once (1 ms each way against the 5 ms saved).
+// MI355X, positive / mixed-sign data (profiles/r04/interval_product.txt): 32^3 1.23 / 2.24 -> 0.22 / 0.39 ms, 48^3 3.03 / 5.44
+// -> 1.19 / 2.50, 64^3 10.5 / 19.3 -> 5.0 / 10.6, 72^3 24.6 / 49.1 -> 9.0 / 19.6, 80^3 28.5 / 59.3 -> 15.7 / 36.3.
 struct PairArgs {
     unsigned xU, x0, x1, yU, y0, y1, zU, z0, z1;  // canonical outer extents (rank 2: U = axis 0 = 1; rank 3: U = 1)
     unsigned n2, nx2, n8, nb, nxc;                // row lengths, padded row length, column blocks, x chunks
     unsigned tsh;                                 // lane tile: T1 = 1 << tsh rows along axis 1, T0 = 64 >> tsh along axis 0
-    unsigned NW, XG, xch;                         // waves of a group, groups (x rows in flight), x rows per workgroup
+    unsigned NW, xch;                             // waves and x rows of a phase-1 workgroup
     unsigned tiles0, tiles1;                      // y tiles along the two lane axes
     unsigned pitch;                               // LDS row pitch in doubles ((lo, hi) interleaved; pitch / 2 odd)
     unsigned long long S0, S1;                    // terms summed over all k0 / all k1
@@ -1256,32 +1002,21 @@ static std::map<hipStream_t, RbScratch>& rb_scratch() {
     static std::map<hipStream_t, RbScratch> m;
     return m;
 }
-struct RbSpillWs {
+struct PairWs {  // per-stream workspace of the row-pair form (grow-only up to the cap)
     double* p = nullptr;
     size_t bytes = 0;
 };
-static std::map<hipStream_t, RbSpillWs>& rb_spill_ws() {
-    static std::map<hipStream_t, RbSpillWs> m;
+static std::map<hipStream_t, PairWs>& pair_ws() {
+    static std::map<hipStream_t, PairWs> m;
     return m;
 }
-// two-phase form: 0 never, 1 products of [rb_spill_min, rb_spill_max] multiply-adds, 2 whenever the rows kernel applies (tests)
-static int rb_spill_default() {
-    const char* e = getenv("GFT_RB_SPILL");
-    return e ? atoi(e) : 1;
-}
-static int rb_spill_mode = rb_spill_default();
-static double rb_spill_min = [] {
-    const char* e = getenv("GFT_RB_SPILL_MIN_MACS");
-    return e ? atof(e) : 1.0e8;
-}();
-static double rb_spill_max = [] {
-    const char* e = getenv("GFT_RB_SPILL_MAX_MACS");
-    return e ? atof(e) : 1.0e9;  // (profiles/r04/interval_two_phase.txt: 32^3 1.23 -> 0.68 ms; from 48^3 on phase 1's batches are no faster than the fused kernels)
-}();
-static size_t rb_spill_cap = [] {  // bytes of row sums per chunk of the leading axis
-    const char* e = getenv("GFT_RB_SPILL_CAP_MB");
+// bytes of row sums the row-pair form may hold (24 GiB: 88^3; first-time hipMalloc of up to 28 GB takes 0.3 ms on this image,
+// of 33 GB 1.7 s).  Larger products stay on k_conv_rows_rb.
+static size_t rb_pairs_cap = [] {
+    const char* e = getenv("GFT_RB_PAIRS_CAP_MB");
     return (size_t)(e ? std::max(1, atoi(e)) : 24576) << 20;
 }();
+void staged_set_rb_pairs_cap(double bytes) { rb_pairs_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)24576 << 20); }  // "conv_rb_pairs_cap"
 // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 products of [rb_pairs_min, ..) multiply-adds whose row sums fit the
 // workspace cap, 2 whenever it applies (tests)
 static int rb_pairs_default() {
@@ -1289,13 +1024,15 @@ static int rb_pairs_default() {
     return e ? atoi(e) : 1;
 }
 static int rb_pairs_mode = rb_pairs_default();
-static double rb_pairs_min = [] {
+static double rb_pairs_min = [] {  // rank >= 3 (profiles/r04/interval_shapes.txt: 12^3 = 5e5 multiply-adds 0.098 -> 0.036 ms, 16^3 0.20 -> 0.05)
     const char* e = getenv("GFT_RB_PAIRS_MIN_MACS");
+    return e ? atof(e) : 3.0e5;
+}();
+static double rb_pairs_min_rank2 = [] {  // one lane axis, and the chains k_conv_staged has there are short anyway: break-even at 128^2
+    const char* e = getenv("GFT_RB_PAIRS_MIN_MACS_RANK2");
     return e ? atof(e) : 1.0e8;
 }();
 void staged_set_rb_pairs(double v) { rb_pairs_mode = v < 0.0 ? rb_pairs_default() : (int)v; }  // "conv_rb_pairs" (negative: back to the default)
-void staged_set_rb_spill(double v) { rb_spill_mode = v < 0.0 ? rb_spill_default() : (int)v; }  // "conv_rb_spill" (negative: back to the default)
-void staged_set_rb_spill_cap(double bytes) { rb_spill_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)24576 << 20); }  // "conv_rb_spill_cap" (tests: chunking)
 // measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
 static double rb_min_macs = [] {
     const char* e = getenv("GFT_CONV_RB_MIN_MACS");
@@ -1306,9 +1043,9 @@ void staged_release_scratch() {
     for (auto& kv : rb_scratch())
         if (kv.second.p) (void)hipFree(kv.second.p);
     rb_scratch().clear();
-    for (auto& kv : rb_spill_ws())
+    for (auto& kv : pair_ws())
         if (kv.second.p) (void)hipFree(kv.second.p);
-    rb_spill_ws().clear();
+    pair_ws().clear();
 }
 
 // The plain full product of large contiguous interval tensors; false = not this kernel's case (nothing launched).
@@ -1323,7 +1060,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     if (a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || !a.inner_from_zero || a.guard) return false;
     const int P = nd - 2;
     const unsigned n2 = a.zs[nd - 1], nx2 = a.xs[nd - 1];
-    if (a.ys[nd - 1] != n2 || n2 < 32 || n2 > 256 || nx2 == 0) return false;
+    if (a.ys[nd - 1] != n2 || n2 < 8 || n2 > 256 || nx2 == 0) return false;
     if (P == 0 && (a.slab_lo != 0 || a.slab_hi != a.zs[0])) return false;
     // contiguous operands and result
     size_t xs_ = 1, ys_ = 1, zs_ = 1;
@@ -1339,7 +1076,10 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     double macs = 1.0;
     for (int ax = 0; ax < nd; ++ax) macs *= 0.5 * (double)a.zs[ax] * (double)std::min(a.xs[ax], a.ys[ax]);
     // ---- row-pair form
-    if ((rb_pairs_mode == 2 || (rb_pairs_mode == 1 && macs >= rb_pairs_min)) && n2 <= 128 && a.slab_lo == 0 && a.slab_hi == a.zs[0]) {
+    bool pairs_ok = (rb_pairs_mode == 2 || (rb_pairs_mode == 1 && macs >= (nd == 2 ? rb_pairs_min_rank2 : rb_pairs_min))) && n2 <= 128 && a.slab_lo == 0 && a.slab_hi == a.zs[0];
+    for (int ax = 0; ax + 1 < nd; ++ax)
+        if (a.zs[ax] > a.xs[ax] + a.ys[ax] - 1) pairs_ok = false;  // (an output row without terms: the slot prefix sums assume none)
+    if (pairs_ok) {
         PairArgs g;
         std::memset(&g, 0, sizeof(g));
         g.xU = g.x0 = g.x1 = g.yU = g.y0 = g.y1 = g.zU = g.z0 = g.z1 = 1;
@@ -1377,7 +1117,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.pitch = 2 * g.n8 + 2;
         // 16 waves per CU (the kernel holds <= 128 VGPRs): two workgroups of 8 where two tiles fit the LDS, else one of 16
         g.NW = (size_t)64 * g.pitch * sizeof(double) * 2 + 1024 <= 160 * 1024 ? 8u : 16u;
-        g.XG = 1;
         static const unsigned nw_env = [] {
             const char* e = getenv("GFT_RB_PAIRS_WAVES");  // tuning knob: waves of a phase-1 workgroup
             return (unsigned)(e ? std::max(0, std::min(16, atoi(e))) : 0);
@@ -1385,7 +1124,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         if (nw_env) g.NW = nw_env;
         static const unsigned xch_env = [] {
             const char* e = getenv("GFT_RB_PAIRS_XCH");  // tuning knob: x rows per phase-1 workgroup
-            return (unsigned)(e ? std::max(1, atoi(e)) : 32);
+            return (unsigned)(e ? std::max(1, atoi(e)) : 8);  // (sweep in profiles/r04/interval_pairs_sweep.txt: 4 .. 12 equal, 32 loses 10 % to the last round of workgroups)
         }();
         g.xch = xch_env;
         static const unsigned nostore_env = getenv("GFT_RB_PAIRS_NOSTORE") ? 1u : 0u;
@@ -1395,9 +1134,9 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         const unsigned long long slots = pair_pre(g.zU, g.xU, g.yU) * g.S0 * g.S1;
         const unsigned long long need = slots * n2 * 2 * sizeof(double);
         const unsigned long long chunks_y = (xrows + g.xch - 1) / g.xch, tiles = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
-        if (slots > 0 && need <= rb_spill_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
+        if (slots > 0 && need <= rb_pairs_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
             RbScratch& sc = rb_scratch()[st];
-            RbSpillWs& w = rb_spill_ws()[st];
+            PairWs& w = pair_ws()[st];
             bool ok = true;
             if (sc.bytes < xrows + yrows) {
                 if (sc.p) (void)hipFree(sc.p);
@@ -1430,7 +1169,9 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                 const size_t lds = (size_t)64 * g.pitch * sizeof(double);
                 static bool attr = false;
                 if (!attr) {
-                    (void)hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    // (the kernel also has 4 bytes of static LDS: the full 160 KB is refused — and a refused call leaves its error
+                    // in this thread's HIP state, where the CALLER's next HIP call finds it)
+                    if (hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) (void)hipGetLastError();
                     attr = true;
                 }
                 GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
@@ -1445,8 +1186,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
             }
         }
     }
-    bool spill = rb_spill_mode == 2 || (rb_spill_mode == 1 && macs >= rb_spill_min && macs <= rb_spill_max);
-    if (!spill && (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64)) return false;  // (rows shorter than 64: the two-phase form only)
+    if (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64) return false;  // (rows shorter than 64: the row-pair form only)
     RbArgs g;
     std::memset(&g, 0, sizeof(g));
     g.no = nd - 1;
@@ -1476,73 +1216,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.xrs[ax] = a.xstr[ax] / nx2;
         g.yrs[ax] = a.ystr[ax] / n2;
     }
-    // ---- two-phase form: chunks of the leading axis whose row sums fit the workspace cap
-    struct SpillChunk { unsigned lo, hi, max_steps; };
-    std::vector<SpillChunk> chunks;
-    unsigned sp_tb = 1, sp_zdim = 1;
-    size_t sp_bytes = 0;
-    if (spill) {
-        const size_t cap = rb_spill_cap;
-        static const unsigned tb_env = [] {
-            const char* e = getenv("GFT_RB_SPILL_TB");  // tuning knob: y rows (= wave groups) of a phase-1 workgroup
-            return (unsigned)(e ? std::max(1, atoi(e)) : 0);
-        }();
-        auto cnt_of = [&](int ax, unsigned k) {
-            const unsigned l = k + 1 > a.ys[ax] ? k + 1 - a.ys[ax] : 0, h = k + 1 < a.xs[ax] ? k + 1 : a.xs[ax];
-            return h > l ? h - l : 0u;
-        };
-        unsigned max_nt = 0;
-        g.nt_total = 0;
-        for (unsigned pg = 0; pg < g.n_pg; ++pg) {
-            const unsigned nt = rb_group_rows(pg, a.zs[P], a.xs[P], a.ys[P]);
-            g.nt_total += nt;
-            max_nt = std::max(max_nt, nt);
-        }
-        g.c1_total = 1;
-        unsigned max_c1 = 1;
-        if (P >= 2) {
-            g.c1_total = 0;
-            max_c1 = 0;
-            for (unsigned k = 0; k < a.zs[1]; ++k) {
-                g.c1_total += cnt_of(1, k);
-                max_c1 = std::max(max_c1, cnt_of(1, k));
-            }
-        }
-        const size_t slot_bytes = (size_t)g.ntw * 512 * sizeof(double);
-        sp_tb = std::max(1u, std::min(tb_env ? tb_env : 4u, 16u / g.ntw));
-        sp_zdim = (max_nt + sp_tb - 1) / sp_tb;
-        if (g.nt_total == 0 || sp_zdim == 0 || sp_zdim > 65535u) spill = false;
-        if (spill && P == 0) {
-            const size_t need = (size_t)g.nt_total * slot_bytes;
-            if (need > cap) spill = false;
-            else {
-                chunks.push_back({0u, 0u, 1u});
-                sp_bytes = need;
-            }
-        } else if (spill) {
-            size_t cur = 0;
-            unsigned lo = a.slab_lo, ms = 0;
-            for (unsigned k = a.slab_lo; k < a.slab_hi && spill; ++k) {
-                const unsigned c0 = cnt_of(0, k);
-                const size_t need = (size_t)c0 * g.c1_total * g.nt_total * slot_bytes;
-                if (need > cap || (unsigned long long)c0 * max_c1 > 65535ull) spill = false;  // one leading index alone is too much
-                if (cur + need > cap && k > lo) {
-                    chunks.push_back({lo, k, ms});
-                    sp_bytes = std::max(sp_bytes, cur);
-                    lo = k;
-                    cur = 0;
-                    ms = 0;
-                }
-                cur += need;
-                ms = std::max(ms, c0 * max_c1);
-            }
-            if (spill) {
-                chunks.push_back({lo, a.slab_hi, ms});
-                sp_bytes = std::max(sp_bytes, cur);
-            }
-        }
-        if (!spill && (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64)) return false;
-    }
     // (every "not this kernel" exit comes before the first launch: a false return promises that nothing was launched)
     unsigned long long blocks = g.n_pg;
     for (int ax = 0; ax < P; ++ax) blocks *= ax == 0 ? (a.slab_hi - a.slab_lo) : a.zs[ax];
@@ -1561,49 +1234,10 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         }
         sc.bytes = want;
     }
-    if (spill) {
-        RbSpillWs& w = rb_spill_ws()[st];
-        if (w.bytes < sp_bytes) {
-            if (w.p) (void)hipFree(w.p);
-            w.p = nullptr;
-            w.bytes = 0;
-            if (hipMalloc((void**)&w.p, sp_bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                w.p = nullptr;
-                spill = false;
-                if (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64) return false;
-            } else {
-                w.bytes = sp_bytes;
-            }
-        }
-    }
     g.xflags = sc.p;
     g.yflags = sc.p + xrows;
     GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
     GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
-    if (spill) {
-        double* const wsp = rb_spill_ws()[st].p;
-        g.tb = sp_tb;
-        const size_t lds1 = ((size_t)g.tb * 2 * n2 + 16 + (size_t)(g.tb + RB_ROWS - 1) * (2 * nx2 + 2) + (2 * g.tb + RB_ROWS + 8 + 7) / 8) * sizeof(double);
-        static bool attr1 = false;
-        if (lds1 > 64 * 1024 && !attr1) {
-            (void)hipFuncSetAttribute((const void*)k_rb_spill<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr1 = true;  // (a refusal shows as a failed launch, latched by the launch thread)
-        }
-        for (const SpillChunk& ch : chunks) {
-            ConvArgs ac = a;
-            if (P >= 1) {
-                ac.slab_lo = ch.lo;
-                ac.slab_hi = ch.hi;
-            }
-            unsigned long long nb = g.n_pg;
-            for (int ax = 0; ax < P; ++ax) nb *= ax == 0 ? (ac.slab_hi - ac.slab_lo) : a.zs[ax];
-            if (nb == 0) continue;
-            GFT_LAUNCH(k_rb_spill<E>, dim3((unsigned)nb, ch.max_steps, sp_zdim), dim3(g.ntw * g.tb * 64), lds1, st, x, xp, y, yp, wsp, ac, g);
-            GFT_LAUNCH(k_rb_collect<E>, dim3((unsigned)nb), dim3(2 * g.ntw * 64), 0, st, (const double*)wsp, z, zp, ac, g);
-        }
-        return true;
-    }
     const unsigned threads = g.ntw * g.tb * 64;
     const size_t lds = lds_of(g.tb);
     static bool attr_set = false;

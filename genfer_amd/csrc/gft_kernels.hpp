@@ -354,9 +354,8 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 // Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
 void staged_set_rb_min_macs(double v);  // threshold of the register-blocked interval product (negative: never)
-void staged_set_rb_spill_cap(double bytes);  // its workspace cap per chunk of the leading axis (< 1: the default, 24 GiB)
 void staged_set_rb_pairs(double v);    // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 by size, 2 always, negative: the default
-void staged_set_rb_spill(double v);    // two-phase form of it (row sums to a workspace, ordered additions after): 0 never, 1 by size, 2 always
+void staged_set_rb_pairs_cap(double bytes);  // bytes of row sums it may hold (< 1: the default, 24 GiB)
 void staged_release_scratch();  // frees the register-blocked interval product's row-flag scratch (gft_shutdown)
 void dwf_release_orders();  // frees the row wavefront's cached claim-order tables (gft_shutdown)
 void tiled_set_lane_tile(int tsh);  // 0 = planner's choice, 3..6 = force T1 = 1 << tsh lanes along k1 (tests, A/B)

@@ -1238,10 +1238,12 @@ RB_SHAPES = [
     ((3, 1, 129), (3, 6, 129), (3, 6, 129)),       # one x row per slab; three waves, the last one almost empty
     ((3, 3, 5, 64), (2, 3, 5, 64), (3, 3, 5, 64)),  # rank 4
     ((2, 6, 256), (2, 1, 256), (2, 6, 256)),       # one y row per slab, the longest rows
-    ((9, 11, 40), (9, 11, 40), (9, 11, 40)),       # rows shorter than 64: the two-phase form only (else k_conv_staged)
-    ((20, 19, 48), (20, 19, 48), (20, 19, 48)),    # more than one batch of y rows per row group, three row groups
+    ((9, 11, 40), (9, 11, 40), (9, 11, 40)),       # rows shorter than 64: the row-pair form only (else k_conv_staged)
+    ((20, 19, 48), (20, 19, 48), (20, 19, 48)),    # nine y tiles, the last ones partly outside y
     ((70, 3, 33), (70, 2, 40), (70, 3, 40)),       # row-pair form: a tall thin lane tile, x rows end inside a chunk of 8
     ((2, 11, 13, 72), (3, 9, 13, 72), (3, 11, 13, 72)),  # rank 4 with compact x / y on the outer axes
+    ((13, 13, 13), (13, 13, 13), (13, 13, 13)),    # short rows (row-pair form only): four column blocks of 4, the last one partial
+    ((5, 6, 7, 9), (5, 6, 7, 9), (5, 6, 7, 9)),
 ]
 
 
@@ -1283,22 +1285,18 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
             want = OTPI.new(a, deg) * OTPI.new(b, deg)
             # (threshold, two-phase mode, workspace cap): the fused rows kernel, k_conv_staged, the two-phase form in one
             # chunk and cut into chunks of the leading axis (a cap of 256 KB holds a leading index or two of these shapes)
-            # (threshold, two-phase mode, workspace cap, row-pair mode): the fused rows kernel, k_conv_staged, the two-phase
-            # form in one chunk and cut into chunks of the leading axis (a cap of 256 KB holds a leading index or two of
-            # these shapes), the row-pair form (rows of <= 128; longer ones fall through to k_conv_staged)
-            for thr, spill, cap, pairs in ((0.0, 0.0, 0.0, 0.0), (-1.0, 0.0, 0.0, 0.0), (-1.0, 2.0, 0.0, 0.0), (-1.0, 2.0, 262144.0, 0.0),
-                                           (-1.0, 0.0, 0.0, 2.0)):
+            # (threshold, row-pair mode, its workspace cap): the fused rows kernel, k_conv_staged, the row-pair form (rows of
+            # <= 128; longer ones fall through to k_conv_staged), and a cap too small for it (back to k_conv_staged)
+            for thr, pairs, cap in ((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (-1.0, 2.0, 4096.0)):
                 assert L.gft_set_option(b"conv_rb_min_macs", thr) == 0
-                assert L.gft_set_option(b"conv_rb_spill", spill) == 0
-                assert L.gft_set_option(b"conv_rb_spill_cap", cap) == 0
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
+                assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
                 try:
                     check(want, GTPI.new(a, deg) * GTPI.new(b, deg))
                 finally:
                     L.gft_set_option(b"conv_rb_min_macs", 1.5e10)
-                    L.gft_set_option(b"conv_rb_spill", -1.0)
-                    L.gft_set_option(b"conv_rb_spill_cap", 0.0)
                     L.gft_set_option(b"conv_rb_pairs", -1.0)
+                    L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
     finally:
         L.gft_set_option(b"host_max_elems", -1.0)
 

@@ -49,6 +49,7 @@ python3 bench.py --steps 20 --warmup 3 > "$OUT/summary/bench_c2_n1.json" 2> "$OU
 python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock > "$OUT/summary/bench_c4_n1.json" 2> "$OUT/bench_c4.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench_fp64.hip -o /tmp/microbench_fp64 2> "$OUT/mb.err" && /tmp/microbench_fp64 > "$OUT/summary/microbench_fp64.txt" 2>&1
 python3 tools/bench_interval.py > "$OUT/summary/interval_product.txt" 2> "$OUT/iv.err"
+python3 tools/bench_interval_shapes.py > "$OUT/summary/interval_shapes.txt" 2> "$OUT/ivs.err"
 python3 tools/xover_host.py > "$OUT/summary/xover_host.txt" 2> "$OUT/xover.err"
 python3 tools/bench_e2e.py --limit 100 --runs 2 --bounds --only approx --gpu-only > "$OUT/e2e_bounds.log" 2>&1; tail -1 "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.json"
 python3 tools/bench_streaming.py 384 > "$OUT/summary/streaming_384.json" 2> "$OUT/streaming.err"
