@@ -799,15 +799,17 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
     };
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total && local != 0; lin += 4 * step) {
-        const size_t l1 = lin + step, l2 = lin + 2 * step, l3 = lin + 3 * step;
+        // (unconditional loads on clamped indices: a load under a condition is a basic block of its own, and hipcc waits for
+        // vmcnt(0) at every block boundary — the four loads would go out one after the other)
+        const size_t l1 = lin + step, l2 = lin + 2 * step, l3 = lin + 3 * step, last = total - 1;
         const typename E::V v0 = E::ld(t.p, t.plane, lin);
-        const typename E::V v1 = l1 < total ? E::ld(t.p, t.plane, l1) : E::zero();
-        const typename E::V v2 = l2 < total ? E::ld(t.p, t.plane, l2) : E::zero();
-        const typename E::V v3 = l3 < total ? E::ld(t.p, t.plane, l3) : E::zero();
+        const typename E::V v1 = E::ld(t.p, t.plane, l1 < total ? l1 : last);
+        const typename E::V v2 = E::ld(t.p, t.plane, l2 < total ? l2 : last);
+        const typename E::V v3 = E::ld(t.p, t.plane, l3 < total ? l3 : last);
         look(v0, lin);
-        look(v1, l1);
-        look(v2, l2);
-        look(v3, l3);
+        look(v1, l1 < total ? l1 : last);
+        look(v2, l2 < total ? l2 : last);
+        look(v3, l3 < total ? l3 : last);
     }
     // block-level AND, then at most one device atomic per block — and none if the global verdict already
     // implies ours (a dense tensor is settled by the first block; ~1400 same-address atomics cost 20 us)
