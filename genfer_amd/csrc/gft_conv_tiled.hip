@@ -379,6 +379,10 @@ k_conv_tiled(TiledArgs A) {
             const double* ybase = A.yp + (size_t)(u - ju) * A.y0 * A.y1 * y_row_stride;
             if (!NO_WINDOW) {
                 // (re)load the whole T0 x T1 window of y rows for (ju, j0, j1)
+                // (round 4: the <= 8 pieces of a thread are loaded one after the other — each load sits under its range test, a
+                // block of its own, and hipcc waits for vmcnt(0) at block boundaries.  Issuing all eight unconditionally first
+                // was measured: 16 hoisted per-piece invariants spill, 64^3 410 -> 429 us, 24^4 636 -> 704 us, 128^3 -2 %: the
+                // other workgroups of the CU already cover a row start)
                 __syncthreads();
                 for (unsigned p = tid; p < 64 * half_row; p += NT) {
                     unsigned row = (p * hr_magic) >> 24, col = p - row * half_row;
