@@ -1028,9 +1028,9 @@ static double rb_pairs_min = [] {  // rank >= 3 (profiles/r04/interval_shapes.tx
     const char* e = getenv("GFT_RB_PAIRS_MIN_MACS");
     return e ? atof(e) : 3.0e5;
 }();
-static double rb_pairs_min_rank2 = [] {  // one lane axis, and the chains k_conv_staged has there are short anyway: break-even at 128^2
+static double rb_pairs_min_rank2 = [] {  // (64^2 = 4e6 multiply-adds 0.064 -> 0.033 ms, 128^2 0.31 -> 0.07)
     const char* e = getenv("GFT_RB_PAIRS_MIN_MACS_RANK2");
-    return e ? atof(e) : 1.0e8;
+    return e ? atof(e) : 1.0e6;
 }();
 void staged_set_rb_pairs(double v) { rb_pairs_mode = v < 0.0 ? rb_pairs_default() : (int)v; }  // "conv_rb_pairs" (negative: back to the default)
 // measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
@@ -1127,6 +1127,9 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
             return (unsigned)(e ? std::max(1, atoi(e)) : 8);  // (sweep in profiles/r04/interval_pairs_sweep.txt: 4 .. 12 equal, 32 loses 10 % to the last round of workgroups)
         }();
         g.xch = xch_env;
+        // (small products: fewer x rows per workgroup until there are ~1000 workgroups — half of the (tile, chunk) grid is
+        // outside the triangle)
+        while (g.xch > 1 && (unsigned long long)g.yU * g.tiles0 * g.tiles1 * ((xrows + g.xch - 1) / g.xch) < 2048ull) g.xch /= 2;
         static const unsigned nostore_env = getenv("GFT_RB_PAIRS_NOSTORE") ? 1u : 0u;
         g.dbg_nostore = nostore_env;
         g.S0 = pair_pre(g.z0, g.x0, g.y0);  // terms over all k0 / all k1

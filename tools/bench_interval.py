@@ -6,7 +6,7 @@ SIMD-cycle ⇒ 256 CU x 4 SIMD x 2 x 2.4 GHz = 4.9 interval-TMAC/s.  Mixed-sign 
 operand can short-circuit, unguarded outward steps validated on the finished sum): 4 v_mul_f64 + 6 min / max + 2 v_add_f64 +
 4 outward steps of 4 instructions = 28 wave-instructions ⇒ 64 / 112 MACs per SIMD-cycle ⇒ 1.40 interval-TMAC/s.
 (4 cycles per wave-instruction is what tools/microbench_int64.hip measures for v_lshl_add_u64, v_mul_f64 and v_add_f64 at 8 waves
-per SIMD: 4.4-4.6 cycles at the nominal 2.4 GHz; profiles/r03/microbench_int64.txt.)  Rank >= 3 products of 3e5 multiply-adds and more
+per SIMD: 4.4-4.6 cycles at the nominal 2.4 GHz; profiles/r03/microbench_int64.txt.)  Products of 3e5 multiply-adds and more (rank 2: 1e6; rows of at most 128)
 run as row-pair sums (k_pair_sums + k_pair_collect, gft_conv_staged.hip) while their row sums fit 24 GiB (88^3); beyond, from 1.5e10
 multiply-adds, on k_conv_rows_rb, else on k_conv_staged; GFT_RB_PAIRS=0 / GFT_CONV_RB=0 switch the first / second off.
 Usage: bench_interval.py [n ...]"""
