@@ -417,10 +417,18 @@ struct RbArgs {
 };
 constexpr unsigned RB_ROWS = 8;  // output rows of a workgroup (4 lane groups x 2 outputs per lane)
 
+// (both operands in one launch: the x rows first, then the y rows, flags likewise)
 template <class E>
-__global__ void __launch_bounds__(256) k_row_flags(const double* p, size_t plane, size_t rows, unsigned len, unsigned char* flags) {
-    const size_t row = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
+__global__ void __launch_bounds__(256) k_row_flags(const double* x, size_t xplane, size_t xrows, unsigned xlen, const double* y, size_t yplane,
+                                                  size_t yrows, unsigned ylen, unsigned char* flags) {
+    size_t row = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= xrows + yrows) return;
+    flags += row;
+    const bool isy = row >= xrows;  // (wave-uniform: a wave is one row)
+    const double* p = isy ? y : x;
+    const size_t plane = isy ? yplane : xplane;
+    const unsigned len = isy ? ylen : xlen;
+    if (isy) row -= xrows;
     const unsigned lane = threadIdx.x & 63u;
     bool np = false, nf = false;
     for (unsigned i = lane; i < len; i += 64) {
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(256) k_row_flags(const double* p, size_t plane
         nf = nf || !E::fin_ok(v);
     }
     const bool anp = any_lane(np), anf = any_lane(nf);
-    if (lane == 0) flags[row] = (unsigned char)((anp ? 1 : 0) | (anf ? 2 : 0));
+    if (lane == 0) *flags = (unsigned char)((anp ? 1 : 0) | (anf ? 2 : 0));
 }
 
 // the finished row sums of one y row against the lane's two x rows, for the 16-column tile at c0; REG 1 positive, 2
@@ -710,8 +718,8 @@ __global__ void __launch_bounds__(1024) k_conv_rows_rb(const double* __restrict_
 //               waves per SIMD) stood at 23-38 % of the issue roof;
 //   order       chunks q ascending, s ascending inside: ascending j for every output, first term a plain product —
 //               the same operations on the same values as rb_sums / inner_sum => the same bits;
-//   regimes     positive / finite / general from the row flags (x row | the tile's y rows), validated on the finished
-//               sums and recomputed with the general multiply-add when a lane fails, as rb_row.
+//   regimes     positive / finite / general from the operands (the x row | the tile's y rows, tested while they are read),
+//               validated on the finished sums and recomputed with the general multiply-add when a lane fails, as rb_row.
 // Phase 2 (k_pair_collect) is one workgroup per output row, a thread per column: it adds the row's terms in the
 // reference's order (outer axes lexicographic ascending, mt:984-1012) with sixteen loads in flight — a contiguous stream:
 // the slots are ordered by OUTPUT row (row-major) and inside a row by the reference's term order; phase 1 computes a lane's
@@ -727,8 +735,6 @@ struct PairArgs {
     unsigned tiles0, tiles1;                      // y tiles along the two lane axes
     unsigned pitch;                               // LDS row pitch in doubles ((lo, hi) interleaved; pitch / 2 odd)
     unsigned long long S0, S1;                    // terms summed over all k0 / all k1
-    const unsigned char* xflags;
-    const unsigned char* yflags;
     unsigned dbg_nostore;                         // timing experiments only (GFT_RB_PAIRS_NOSTORE): phase 1 without its stores
 };
 // terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
@@ -890,7 +896,8 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
             if (d0 < g.y0 && d1 < g.y1 && cc < g.n2) {
                 const size_t row = ((size_t)ud * g.y0 + d0) * g.y1 + d1;
                 v = double2{y[row * g.n2 + cc], y[yp + row * g.n2 + cc]};
-                if (cc == 0) fl |= g.yflags[row];
+                const Iv e = Iv{v.x, v.y};  // the tile's regime: the worst of its elements (as k_row_flags would say)
+                fl |= (E::pos_ok(e) ? 0u : 1u) | (E::fin_ok(e) ? 0u : 2u);
             }
             reinterpret_cast<double2*>(smem + (size_t)r * g.pitch)[cc] = v;
         }
@@ -915,7 +922,16 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
         pair_cptr_t xl = (pair_cptr_t)(x + arow * g.nx2), xh = (pair_cptr_t)(x + xp + arow * g.nx2);
         const bool lane_ok = row_ok && j0 + d0 < g.z0 && j1 + d1 < g.z1;
-        const unsigned f = tileflag | g.xflags[arow];
+        unsigned f = tileflag;
+        {   // the x row's regime, from vector loads of the row (it is read through the scalar cache below)
+            bool np = false, nf = false;
+            for (unsigned i = lane; i < g.nx2; i += 64) {
+                const Iv e = Iv{x[arow * g.nx2 + i], x[xp + arow * g.nx2 + i]};
+                np = np || !E::pos_ok(e);
+                nf = nf || !E::fin_ok(e);
+            }
+            f |= (any_lane(np) ? 1u : 0u) | (any_lane(nf) ? 2u : 0u);
+        }
         const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
         double* const dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * 2;
 #pragma unroll 1
@@ -1138,22 +1154,8 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         const unsigned long long need = slots * n2 * 2 * sizeof(double);
         const unsigned long long chunks_y = (xrows + g.xch - 1) / g.xch, tiles = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
         if (slots > 0 && need <= rb_pairs_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
-            RbScratch& sc = rb_scratch()[st];
             PairWs& w = pair_ws()[st];
             bool ok = true;
-            if (sc.bytes < xrows + yrows) {
-                if (sc.p) (void)hipFree(sc.p);
-                sc.p = nullptr;
-                sc.bytes = 0;
-                const size_t want = std::max<size_t>((xrows + yrows) * 2, 1 << 16);
-                if (hipMalloc(&sc.p, want) != hipSuccess) {
-                    (void)hipGetLastError();
-                    sc.p = nullptr;
-                    ok = false;
-                } else {
-                    sc.bytes = want;
-                }
-            }
             if (ok && w.bytes < need) {
                 if (w.p) (void)hipFree(w.p);
                 w.p = nullptr;
@@ -1167,8 +1169,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                 }
             }
             if (ok) {
-                g.xflags = sc.p;
-                g.yflags = sc.p + xrows;
                 const size_t lds = (size_t)64 * g.pitch * sizeof(double);
                 static bool attr = false;
                 if (!attr) {
@@ -1177,8 +1177,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                     if (hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) (void)hipGetLastError();
                     attr = true;
                 }
-                GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
-                GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
                 GFT_LAUNCH(k_pair_sums<E>, dim3((unsigned)chunks_y, (unsigned)tiles), dim3(g.NW * 64), lds, st, x, xp, y, yp, w.p, g);
                 static const unsigned cw_env = [] {
                     const char* e = getenv("GFT_RB_PAIRS_COLS");  // tuning knob: columns per phase-2 workgroup
@@ -1239,8 +1237,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     }
     g.xflags = sc.p;
     g.yflags = sc.p + xrows;
-    GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, sc.p);
-    GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((yrows + 3) / 4)), dim3(256), 0, st, y, yp, yrows, n2, sc.p + xrows);
+    GFT_LAUNCH(k_row_flags<E>, dim3((unsigned)((xrows + yrows + 3) / 4)), dim3(256), 0, st, x, xp, xrows, nx2, y, yp, yrows, n2, sc.p);
     const unsigned threads = g.ntw * g.tb * 64;
     const size_t lds = lds_of(g.tb);
     static bool attr_set = false;
