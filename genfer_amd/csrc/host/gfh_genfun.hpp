@@ -37,26 +37,26 @@ struct GenFun {
     std::shared_ptr<const Node> p;
 
     static GenFun mk(Node n) { GenFun g; g.p = std::make_shared<const Node>(std::move(n)); return g; }
-    static GenFun var(size_t v) { Node n; n.kind = Var; n.var = v; return mk(n); }
-    static GenFun constant(const T& x) { Node n; n.kind = Const; n.c = x; return mk(n); }
+    static GenFun var(size_t v) { Node n; n.kind = Var; n.var = v; return mk(std::move(n)); }
+    static GenFun constant(const T& x) { Node n; n.kind = Const; n.c = x; return mk(std::move(n)); }
     static GenFun zero() { return constant(T::zero()); }
     static GenFun one() { return constant(T::one()); }
     static GenFun from_u32(uint32_t u) { return constant(T::from_u32(u)); }
     static GenFun from_ratio(const PosRatio& r) { return constant(T::from_ratio(r.numer, r.denom)); }
-    static GenFun polynomial(std::vector<T> coeffs, Dims shape) { Node n; n.kind = Polynomial; n.coeffs = std::move(coeffs); n.shape = std::move(shape); return mk(n); }
-    static GenFun un(Kind k, const GenFun& a) { Node n; n.kind = k; n.a = a; return mk(n); }
-    static GenFun bin(Kind k, const GenFun& a, const GenFun& b) { Node n; n.kind = k; n.a = a; n.b = b; return mk(n); }
+    static GenFun polynomial(std::vector<T> coeffs, Dims shape) { Node n; n.kind = Polynomial; n.coeffs = std::move(coeffs); n.shape = std::move(shape); return mk(std::move(n)); }
+    static GenFun un(Kind k, const GenFun& a) { Node n; n.kind = k; n.a = a; return mk(std::move(n)); }
+    static GenFun bin(Kind k, const GenFun& a, const GenFun& b) { Node n; n.kind = k; n.a = a; n.b = b; return mk(std::move(n)); }
     GenFun exp() const { return un(Exp, *this); }
     GenFun log() const { return un(Log, *this); }
-    GenFun pow(uint32_t e) const { Node n; n.kind = Pow; n.a = *this; n.n = e; return mk(n); }
+    GenFun pow(uint32_t e) const { Node n; n.kind = Pow; n.a = *this; n.n = e; return mk(std::move(n)); }
     GenFun max(const GenFun& g) const { return bin(Max, *this, g); }
     static GenFun uniform_mgf(const GenFun& g) { return un(UniformMgf, g); }
-    GenFun derive(size_t v, size_t order) const { Node n; n.kind = Derivative; n.a = *this; n.var = v; n.order = order; return mk(n); }
-    GenFun taylor_polynomial_at_zero(size_t v, Dims orders) const { Node n; n.kind = TaylorPolynomial; n.a = *this; n.var = v; n.orders = std::move(orders); return mk(n); }
-    GenFun taylor_coeff_at_zero(size_t v, size_t order) const { Node n; n.kind = TaylorCoeffAtZero; n.a = *this; n.var = v; n.order = order; return mk(n); }
-    GenFun taylor_coeff(size_t v, size_t order) const { Node n; n.kind = TaylorCoeff; n.a = *this; n.var = v; n.order = order; return mk(n); }
-    GenFun shift_down_taylor_at_zero(size_t v, size_t order) const { Node n; n.kind = ShiftTaylorAtZero; n.a = *this; n.var = v; n.order = order; return mk(n); }
-    GenFun substitute_var(size_t v, const GenFun& val) const { Node n; n.kind = Subst; n.a = *this; n.var = v; n.b = val; return mk(n); }
+    GenFun derive(size_t v, size_t order) const { Node n; n.kind = Derivative; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
+    GenFun taylor_polynomial_at_zero(size_t v, Dims orders) const { Node n; n.kind = TaylorPolynomial; n.a = *this; n.var = v; n.orders = std::move(orders); return mk(std::move(n)); }
+    GenFun taylor_coeff_at_zero(size_t v, size_t order) const { Node n; n.kind = TaylorCoeffAtZero; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
+    GenFun taylor_coeff(size_t v, size_t order) const { Node n; n.kind = TaylorCoeff; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
+    GenFun shift_down_taylor_at_zero(size_t v, size_t order) const { Node n; n.kind = ShiftTaylorAtZero; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
+    GenFun substitute_var(size_t v, const GenFun& val) const { Node n; n.kind = Subst; n.a = *this; n.var = v; n.b = val; return mk(std::move(n)); }
     friend GenFun operator+(const GenFun& a, const GenFun& b) { return bin(Add, a, b); }
     friend GenFun operator-(const GenFun& a) { return un(Neg, a); }
     friend GenFun operator-(const GenFun& a, const GenFun& b) { return a + (-b); }
@@ -184,6 +184,7 @@ struct GenFun {
     struct MaybeTP { bool some = false; TP v; };
     GenFun simplify() const {
         std::unordered_map<const Node*, MaybeTP> cache;
+        cache.reserve(1u << 18);  // (switchpoint: 2e5 nodes — growing the table by rehashing was a tenth of its run time)
         MaybeTP r = simplify_with(cache);
         if (!r.some) return *this;
         Dims shape;
@@ -239,6 +240,7 @@ struct GenFun {
 
     TP eval(const std::vector<T>& inputs, size_t degree_p1) const {
         EvalCache cache;
+        cache.reserve(1u << 18);
         return eval_with(inputs, degree_p1, cache);
     }
     TP eval_with(const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) const {
