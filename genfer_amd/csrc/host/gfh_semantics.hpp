@@ -77,7 +77,7 @@ struct GfTransformer {
     }
     Tr semantics(const Program& p) { return transform_statements(p.stmts, init(p)); }
     Tr transform_statements(const std::vector<Statement>& stmts, Tr cur) {
-        for (auto& s : stmts) cur = transform_statement(s, cur);
+        for (auto& s : stmts) cur = transform_statement(s, std::move(cur));
         return cur;
     }
 
