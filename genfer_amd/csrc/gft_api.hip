@@ -138,6 +138,8 @@ struct Runtime {
     unsigned long long mail_seq = 0;
     hipEvent_t events[64] = {};
     int conv_mode = 0;
+    int pairs_first = 1;                 // small plain f64 products ask the row-pair form before the tiled kernel ("pairs_first", GFT_PAIRS_FIRST)
+    double pairs_first_max = 1.0e7, pairs_first_max_rank2 = 2.0e8;  // ... up to this many multiply-adds (rank >= 3 / rank 2)
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     double tiled_min_override = -1;  // >= 0 while a div / log recurrence issues its accumulation products (recur_tiled_min_macs)
     // div / log: accumulation steps of at least this many multiply-adds may take the tiled kernel.  Off by default: the
@@ -1480,7 +1482,7 @@ struct Ops {
         a.j0_excl = j0_excl;
         a.j0_desc = j0_desc;
         a.variant = R.conv_variant;
-        a.operands_slack = (x.slack && W == 1) ? 1 : 0;
+        a.operands_slack = x.slack ? 1 : 0;
         // number of non-unit axes that take part in the reference's "1-d like" inner product
         int first_inner_axis = slab_mode ? 1 : 0;
         int nonunit = 0;
@@ -1510,6 +1512,15 @@ struct Ops {
                     R.stats_shallow[0]++;
                     return;
                 }
+            }
+        }
+        // Small plain f64 products: the row-pair form of the reference-order product (gft_conv_staged.hip) is bit-exact AND
+        // faster than the tiled kernel there (two launches, no planning: 12^3 38 -> 14 us, 16^3 27 -> 20, 64^2 27 -> 18,
+        // 100^2 42 -> 27 us; crossover at ~20^3 resp. ~200^2, profiles/r04/f64_pairs_vs_tiled.txt)
+        if (W == 1 && R.conv_mode == 0 && R.pairs_first && !slab_mode && !accumulate && a.slab_lo == 0 && a.slab_hi == a.zs[0] && a.nd >= 2) {
+            if (conv_pairs<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, a.nd == 2 ? R.pairs_first_max_rank2 : R.pairs_first_max)) {
+                R.stats[4]++;
+                return;
             }
         }
         bool want_tiled = (W == 1) && (R.conv_mode == 0 || R.conv_mode == 2);
@@ -3575,6 +3586,7 @@ int gft_init(int device) {
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
         if (const char* sm = getenv("GFT_SHALLOW_MAX_TERMS")) R.shallow_max_terms = (size_t)atoll(sm);
+        if (const char* pf = getenv("GFT_PAIRS_FIRST")) R.pairs_first = atoi(pf) != 0;  // A/B: 0 = small f64 products on the tiled kernel as before
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;
@@ -3689,6 +3701,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
     else if (n == "conv_rb_pairs") staged_set_rb_pairs(value);
+    else if (n == "pairs_first") R.pairs_first = value != 0.0;
     else if (n == "conv_rb_pairs_cap") staged_set_rb_pairs_cap(value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);

@@ -766,6 +766,13 @@ typedef const double __attribute__((address_space(4))) * pair_cptr_t;  // wave-u
 // CW = 4: a lane holds 4 outputs and two 4-wide windows — ~60 VGPRs, so that 16 waves fit a CU: a single wave issues a 64-bit
 // VALU operation only every 8 cycles, two waves per SIMD reach 5.6, four 4.9 (profiles/r03/microbench_int64.txt), and the
 // 8-wide form of this kernel (168 VGPRs, 2 waves per SIMD) stood at 23-38 % of the issue roof.
+template <class E>
+__device__ __forceinline__ typename E::V pair_mk(double lo, double hi) {  // an element from its plane values (f64: one plane)
+    if constexpr (E::W == 2) return Iv{lo, hi};
+    else return lo;
+}
+// REG 1: positive regime, 2: finite regime (gft_elem.hpp), 3: plain separate multiply and add (f64: E::mac; the first term is
+// 0 + x y as the reference's sum starts from zero, which turns a -0 product into +0)
 template <class E, int REG, int CW, bool FIRST, bool TRI, bool PART>
 __device__ __forceinline__ void pair_chunk(typename E::V (&acc)[CW], const double (&xlo)[CW], const double (&xhi)[CW], const typename E::V (&cur)[CW],
                                            const typename E::V (&prev)[CW], unsigned slim) {
@@ -773,32 +780,42 @@ __device__ __forceinline__ void pair_chunk(typename E::V (&acc)[CW], const doubl
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
         if (!PART || (unsigned)s < slim) {
-            const V xv = Iv{xlo[s], xhi[s]};
+            const V xv = pair_mk<E>(xlo[s], xhi[s]);
 #pragma unroll
             for (int r = 0; r < CW; ++r) {
                 if (TRI && r < s) continue;
                 const V yv = (r - s >= 0) ? cur[(r - s) % CW] : prev[(CW + r - s) % CW];
-                if (FIRST && s == 0) acc[r] = REG == 1 ? E::mul_pos(xv, yv) : E::mul_fin(xv, yv);
-                else acc[r] = REG == 1 ? E::mac_pos_unchecked(acc[r], xv, yv) : E::mac_fin(acc[r], xv, yv);
+                if constexpr (REG == 1) acc[r] = (FIRST && s == 0) ? E::mul_pos(xv, yv) : E::mac_pos_unchecked(acc[r], xv, yv);
+                else if constexpr (REG == 2) acc[r] = (FIRST && s == 0) ? E::mul_fin(xv, yv) : E::mac_fin(acc[r], xv, yv);
+                else acc[r] = E::mac((FIRST && s == 0) ? E::zero() : acc[r], xv, yv);
             }
         }
     }
 }
-template <int CW>
+template <class E, int CW>
 __device__ __forceinline__ void pair_ldx(double (&lo)[CW], double (&hi)[CW], pair_cptr_t xl, pair_cptr_t xh, unsigned q) {
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
         lo[i] = xl[CW * q + i];
-        hi[i] = xh[CW * q + i];
+        hi[i] = E::W == 2 ? xh[CW * q + i] : 0.0;
     }
 }
 template <class E, int CW>
-__device__ __forceinline__ void pair_ldw(typename E::V (&w)[CW], const double* yrow, unsigned chunk) {  // CW intervals, 16-byte reads
-    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(yrow + 2 * CW * chunk, 16));
+__device__ __forceinline__ void pair_ldw(typename E::V (&w)[CW], const double* yrow, unsigned chunk) {  // CW elements, 16-byte reads
+    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(yrow + E::W * CW * chunk, 16));
+    if constexpr (E::W == 2) {
 #pragma unroll
-    for (int i = 0; i < CW; ++i) {
-        const double2 v = q[i];
-        w[i] = Iv{v.x, v.y};
+        for (int i = 0; i < CW; ++i) {
+            const double2 v = q[i];
+            w[i] = Iv{v.x, v.y};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CW / 2; ++i) {
+            const double2 v = q[i];
+            w[2 * i] = v.x;
+            w[2 * i + 1] = v.y;
+        }
     }
 }
 // the CW outputs of column block cb of one row sum: x chunks q = 0 .. min(cb, nxc) - 1 against full windows (the window
@@ -813,31 +830,31 @@ __device__ __forceinline__ void pair_block(typename E::V (&acc)[CW], unsigned cb
     const unsigned qfull = cb < nxc ? cb : nxc;
     const unsigned qwhole = nx2 / CW < qfull ? nx2 / CW : qfull;  // chunks x spans completely
     if (qfull == 0) {  // cb == 0: the diagonal chunk is chunk 0
-        pair_ldx<CW>(xlo, xhi, xl, xh, 0);
+        pair_ldx<E, CW>(xlo, xhi, xl, xh, 0);
         pair_chunk<E, REG, CW, true, true, true>(acc, xlo, xhi, A, A, nx2);
         return;
     }
     pair_ldw<E, CW>(B, yrow, cb - 1);
-    pair_ldx<CW>(xlo, xhi, xl, xh, 0);
+    pair_ldx<E, CW>(xlo, xhi, xl, xh, 0);
     pair_chunk<E, REG, CW, true, false, true>(acc, xlo, xhi, A, B, nx2);
     unsigned q = 1;
     for (; q + 2 <= qwhole; q += 2) {  // (the current window is in B here)
         pair_ldw<E, CW>(A, yrow, cb - q - 1);
-        pair_ldx<CW>(xlo, xhi, xl, xh, q);
+        pair_ldx<E, CW>(xlo, xhi, xl, xh, q);
         pair_chunk<E, REG, CW, false, false, false>(acc, xlo, xhi, B, A, CW);
         pair_ldw<E, CW>(B, yrow, cb - q - 2);
-        pair_ldx<CW>(xlo, xhi, xl, xh, q + 1);
+        pair_ldx<E, CW>(xlo, xhi, xl, xh, q + 1);
         pair_chunk<E, REG, CW, false, false, false>(acc, xlo, xhi, A, B, CW);
     }
     for (; q < qfull; ++q) {  // at most one whole chunk and x's partial one: the window moves by copies here
 #pragma unroll
         for (int i = 0; i < CW; ++i) A[i] = B[i];
         pair_ldw<E, CW>(B, yrow, cb - q - 1);
-        pair_ldx<CW>(xlo, xhi, xl, xh, q);
+        pair_ldx<E, CW>(xlo, xhi, xl, xh, q);
         pair_chunk<E, REG, CW, false, false, true>(acc, xlo, xhi, A, B, nx2 - CW * q);
     }
     if (cb < nxc) {  // the diagonal chunk: the current window is y chunk 0, in B
-        pair_ldx<CW>(xlo, xhi, xl, xh, cb);
+        pair_ldx<E, CW>(xlo, xhi, xl, xh, cb);
         pair_chunk<E, REG, CW, false, true, true>(acc, xlo, xhi, B, B, nx2 - CW * cb);
     }
 }
@@ -857,13 +874,16 @@ __device__ __forceinline__ void pair_block_general(typename E::V (&acc)[CW], uns
     }
 }
 
-constexpr int PAIR_CW = 4;
+// column block width: intervals 4 (see pair_chunk), f64 8 (half the registers per element: fewer window / x loads per multiply-add)
+template <class E>
+struct PairCW { static constexpr int value = E::W == 2 ? 4 : 8; };
 
 template <class E>
 __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
                                                    double* __restrict__ ws, PairArgs g) {
     typedef typename E::V V;
-    constexpr int CW = PAIR_CW;
+    constexpr int CW = PairCW<E>::value;
+    constexpr unsigned W = E::W;
     extern __shared__ __align__(16) double smem[];
     __shared__ unsigned s_tileflag;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -892,14 +912,18 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         for (unsigned i = tid; i < 64u * g.n8; i += blockDim.x) {
             const unsigned r = i / g.n8, cc = i - r * g.n8;
             const unsigned d0 = d0b + (r >> g.tsh), d1 = d1b + (r & (T1 - 1u));
-            double2 v = double2{0.0, 0.0};
+            double lo = 0.0, hi = 0.0;
             if (d0 < g.y0 && d1 < g.y1 && cc < g.n2) {
                 const size_t row = ((size_t)ud * g.y0 + d0) * g.y1 + d1;
-                v = double2{y[row * g.n2 + cc], y[yp + row * g.n2 + cc]};
-                const Iv e = Iv{v.x, v.y};  // the tile's regime: the worst of its elements (as k_row_flags would say)
-                fl |= (E::pos_ok(e) ? 0u : 1u) | (E::fin_ok(e) ? 0u : 2u);
+                lo = y[row * g.n2 + cc];
+                if constexpr (W == 2) {
+                    hi = y[yp + row * g.n2 + cc];
+                    const Iv e = Iv{lo, hi};  // the tile's regime: the worst of its elements (as k_row_flags would say)
+                    fl |= (E::pos_ok(e) ? 0u : 1u) | (E::fin_ok(e) ? 0u : 2u);
+                }
             }
-            reinterpret_cast<double2*>(smem + (size_t)r * g.pitch)[cc] = v;
+            if constexpr (W == 2) reinterpret_cast<double2*>(smem + (size_t)r * g.pitch)[cc] = double2{lo, hi};
+            else smem[(size_t)r * g.pitch + cc] = lo;
         }
         if (fl) atomicOr(&s_tileflag, fl);
     }
@@ -923,7 +947,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         pair_cptr_t xl = (pair_cptr_t)(x + arow * g.nx2), xh = (pair_cptr_t)(x + xp + arow * g.nx2);
         const bool lane_ok = row_ok && j0 + d0 < g.z0 && j1 + d1 < g.z1;
         unsigned f = tileflag;
-        {   // the x row's regime, from vector loads of the row (it is read through the scalar cache below)
+        if constexpr (E::HAS_POS) {  // the x row's regime, from vector loads of the row (it is read through the scalar cache below)
             bool np = false, nf = false;
             for (unsigned i = lane; i < g.nx2; i += 64) {
                 const Iv e = Iv{x[arow * g.nx2 + i], x[xp + arow * g.nx2 + i]};
@@ -933,7 +957,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
             f |= (any_lane(np) ? 1u : 0u) | (any_lane(nf) ? 2u : 0u);
         }
         const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
-        double* const dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * 2;
+        double* const dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * W;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const unsigned cb = half == 0 ? pr : nbw - 1 - pr;
@@ -941,26 +965,37 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
             V acc[CW];
 #pragma unroll
             for (int r = 0; r < CW; ++r) acc[r] = E::zero();
-            bool redo = true;
-            if (regime == 1) {
-                pair_block<E, 1, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
-                bool bad = false;
+            if constexpr (E::HAS_POS) {
+                bool redo = true;
+                if (regime == 1) {
+                    pair_block<E, 1, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
+                    bool bad = false;
 #pragma unroll
-                for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && (!E::pos_first_ok(acc[r]) || !E::pos_result_ok(acc[r])));
-                redo = any_lane(lane_ok && bad);
-            } else if (regime == 2) {
-                pair_block<E, 2, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
-                bool bad = false;
+                    for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && (!E::pos_first_ok(acc[r]) || !E::pos_result_ok(acc[r])));
+                    redo = any_lane(lane_ok && bad);
+                } else if (regime == 2) {
+                    pair_block<E, 2, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
+                    bool bad = false;
 #pragma unroll
-                for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && !E::fin_result_ok(acc[r]));
-                redo = any_lane(lane_ok && bad);
+                    for (int r = 0; r < CW; ++r) bad = bad || (CW * cb + r < g.n2 && !E::fin_result_ok(acc[r]));
+                    redo = any_lane(lane_ok && bad);
+                }
+                if (redo) pair_block_general<E, CW>(acc, cb, xl, xh, yrow, g.nx2);
+            } else {
+                pair_block<E, 3, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
             }
-            if (redo) pair_block_general<E, CW>(acc, cb, xl, xh, yrow, g.nx2);
             if (lane_ok && !g.dbg_nostore) {
-                double2* d = reinterpret_cast<double2*>(dst) + CW * cb;
+                if constexpr (W == 2) {
+                    double2* d = reinterpret_cast<double2*>(dst) + CW * cb;
 #pragma unroll
-                for (int r = 0; r < CW; ++r)
-                    if (CW * cb + r < g.n2) d[r] = double2{acc[r].lo, acc[r].hi};
+                    for (int r = 0; r < CW; ++r)
+                        if (CW * cb + r < g.n2) d[r] = double2{acc[r].lo, acc[r].hi};
+                } else {
+                    double* d = dst + CW * cb;
+#pragma unroll
+                    for (int r = 0; r < CW; ++r)
+                        if (CW * cb + r < g.n2) d[r] = acc[r];
+                }
             }
         }
     }
@@ -971,6 +1006,11 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
 template <class E>
 __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__ ws, double* __restrict__ z, size_t zp, PairArgs g) {
     typedef typename E::V V;
+    typedef typename std::conditional<E::W == 2, double2, double>::type Raw;  // a stored element
+    auto val = [](const Raw& r) -> V {
+        if constexpr (E::W == 2) return Iv{r.x, r.y};
+        else return r;
+    };
     const unsigned c = blockIdx.y * blockDim.x + threadIdx.x;
     unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest rows first
     const unsigned k1 = (unsigned)(rr % g.z1);
@@ -979,10 +1019,10 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
     const unsigned long long n = (unsigned long long)pair_cnt(ku, g.xU, g.yU) * pair_cnt(k0, g.x0, g.y0) * pair_cnt(k1, g.x1, g.y1);
     V acc = E::zero();
     if (n > 0 && c < g.n2) {
-        const double2* p = reinterpret_cast<const double2*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 * 2) + c;
-        const size_t pitch = g.n2;  // double2 per term
+        const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 * E::W) + c;
+        const size_t pitch = g.n2;  // elements per term
         constexpr int D = 16;
-        double2 buf[D];
+        Raw buf[D];
         // (no conditional loads in the steady state: hipcc waits for vmcnt(0) at every basic-block boundary, and a load
         // under `if` is a block of its own — one load in flight instead of D)
 #pragma unroll
@@ -991,20 +1031,20 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
         for (; i0 + 2 * D <= n; i0 += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                acc = E::add(acc, Iv{buf[u].x, buf[u].y});
+                acc = E::add(acc, val(buf[u]));
                 buf[u] = p[(size_t)(i0 + u + D) * pitch];
             }
         }
         // the last D .. 2 D - 1 terms: D in the buffers, the rest loaded with clamped indices
-        double2 last[D];
+        Raw last[D];
 #pragma unroll
         for (int u = 0; u < D; ++u) last[u] = p[(size_t)(i0 + D + u < n ? i0 + D + u : n - 1) * pitch];
 #pragma unroll
         for (int u = 0; u < D; ++u)
-            if (i0 + u < n) acc = E::add(acc, Iv{buf[u].x, buf[u].y});
+            if (i0 + u < n) acc = E::add(acc, val(buf[u]));
 #pragma unroll
         for (int u = 0; u < D; ++u)
-            if (i0 + D + u < n) acc = E::add(acc, Iv{last[u].x, last[u].y});
+            if (i0 + D + u < n) acc = E::add(acc, val(last[u]));
     }
     if (c < g.n2) E::st(z, zp, (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c, acc);
 }
@@ -1066,13 +1106,14 @@ void staged_release_scratch() {
 
 // The plain full product of large contiguous interval tensors; false = not this kernel's case (nothing launched).
 template <class E>
-static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a) {
+static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a,
+                         bool pairs_only = false, double pairs_max_macs = 1e300) {
     static const int on = [] {
         const char* e = getenv("GFT_CONV_RB");  // A/B knob (0 = k_conv_staged for these products too)
         return e ? atoi(e) : 1;
     }();
     const int nd = a.nd;
-    if (!on || !E::HAS_POS || nd < 2 || nd > 4) return false;
+    if (nd < 2 || nd > 4) return false;
     if (a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || !a.inner_from_zero || a.guard) return false;
     const int P = nd - 2;
     const unsigned n2 = a.zs[nd - 1], nx2 = a.xs[nd - 1];
@@ -1092,9 +1133,10 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     double macs = 1.0;
     for (int ax = 0; ax < nd; ++ax) macs *= 0.5 * (double)a.zs[ax] * (double)std::min(a.xs[ax], a.ys[ax]);
     // ---- row-pair form
-    bool pairs_ok = (rb_pairs_mode == 2 || (rb_pairs_mode == 1 && macs >= (nd == 2 ? rb_pairs_min_rank2 : rb_pairs_min))) && n2 <= 128 && a.slab_lo == 0 && a.slab_hi == a.zs[0];
+    bool pairs_ok = (rb_pairs_mode == 2 || (rb_pairs_mode == 1 && macs >= (nd == 2 ? rb_pairs_min_rank2 : rb_pairs_min))) && macs <= pairs_max_macs && n2 <= (E::W == 2 ? 128u : 256u) && a.slab_lo == 0 && a.slab_hi == a.zs[0];
     for (int ax = 0; ax + 1 < nd; ++ax)
         if (a.zs[ax] > a.xs[ax] + a.ys[ax] - 1) pairs_ok = false;  // (an output row without terms: the slot prefix sums assume none)
+    if (!a.operands_slack && nx2 % PairCW<E>::value != 0) pairs_ok = false;  // (the scalar loads of x's last chunk read to the chunk's end: a caller's raw buffer may end with the row)
     if (pairs_ok) {
         PairArgs g;
         std::memset(&g, 0, sizeof(g));
@@ -1130,7 +1172,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         const unsigned T1 = 1u << g.tsh, T0 = 64u >> g.tsh;
         g.tiles0 = (g.y0 + T0 - 1) / T0;
         g.tiles1 = (g.y1 + T1 - 1) / T1;
-        g.pitch = 2 * g.n8 + 2;
+        g.pitch = E::W * g.n8 + 2;
         // 16 waves per CU (the kernel holds <= 128 VGPRs): two workgroups of 8 where two tiles fit the LDS, else one of 16
         g.NW = (size_t)64 * g.pitch * sizeof(double) * 2 + 1024 <= 160 * 1024 ? 8u : 16u;
         static const unsigned nw_env = [] {
@@ -1151,7 +1193,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.S0 = pair_pre(g.z0, g.x0, g.y0);  // terms over all k0 / all k1
         g.S1 = pair_pre(g.z1, g.x1, g.y1);
         const unsigned long long slots = pair_pre(g.zU, g.xU, g.yU) * g.S0 * g.S1;
-        const unsigned long long need = slots * n2 * 2 * sizeof(double);
+        const unsigned long long need = slots * n2 * E::W * sizeof(double);
         const unsigned long long chunks_y = (xrows + g.xch - 1) / g.xch, tiles = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
         if (slots > 0 && need <= rb_pairs_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
             PairWs& w = pair_ws()[st];
@@ -1187,7 +1229,11 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
             }
         }
     }
-    if (rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64) return false;  // (rows shorter than 64: the row-pair form only)
+    if (pairs_only) return false;
+    if constexpr (!E::HAS_POS) {
+        return false;  // (f64: the row-pair form only)
+    } else {
+    if (!on || rb_min_macs < 0.0 || macs < rb_min_macs || n2 < 64) return false;  // (rows shorter than 64: the row-pair form only)
     RbArgs g;
     std::memset(&g, 0, sizeof(g));
     g.no = nd - 1;
@@ -1250,7 +1296,18 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     }
     GFT_LAUNCH(k_conv_rows_rb<E>, dim3((unsigned)blocks), dim3(threads), lds, st, x, xp, y, yp, z, zp, a, g);
     return true;
+    }
 }
+
+// The row-pair form alone (k_pair_sums + k_pair_collect) for plain products of at most max_macs multiply-adds; false: not its
+// case, nothing launched.  (gft_api.hip asks it first for small f64 products: bit-exact AND faster than the tiled kernel there.)
+template <class E>
+bool conv_pairs(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a, double max_macs) {
+    if (a.slab_hi <= a.slab_lo) return false;
+    return conv_rows_rb<E>(st, x, xp, y, yp, z, zp, a, true, max_macs);
+}
+template bool conv_pairs<EF64>(hipStream_t, const double*, size_t, const double*, size_t, double*, size_t, const ConvArgs&, double);
+template bool conv_pairs<EIv>(hipStream_t, const double*, size_t, const double*, size_t, double*, size_t, const ConvArgs&, double);
 
 // Returns false (nothing launched) when the shape does not suit the staged kernel; the caller then
 // uses conv_naive.  `force`: ignore the "worth it" thresholds (tests).
@@ -1260,9 +1317,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     const int nd = a.nd;
     if (nd < 1) return false;
     if (a.slab_hi <= a.slab_lo) return true;  // nothing to do
-    if constexpr (E::HAS_POS) {
-        if (conv_rows_rb<E>(st, x, xp, y, yp, z, zp, a)) return true;
-    }
+    if (conv_rows_rb<E>(st, x, xp, y, yp, z, zp, a)) return true;  // (the row-pair form, f64 and interval; the fused rows kernel, interval)
     constexpr size_t LDS_MAX = 160 * 1024;
     const size_t W = E::W;
     StagedArgs g;

@@ -210,7 +210,7 @@ struct ConvArgs {
     int j0_desc;                // iterate j0 downwards (log's summation order)
     int inner_from_zero;        // last axis' partial sum is formed from zero, then added (mul_1d, mt:971-982)
     int variant;                // tiled-kernel variant (gft_set_conv_variant; -1 = library default)
-    int operands_slack;         // tiled kernel: 64 bytes after x's last element are readable (the library's own buffers)
+    int operands_slack;         // 64 bytes after x's last element are readable (the library's own buffers): the tiled kernel's in-place operands, the row-pair kernel's last partial x chunk
     const unsigned* guard;      // optional device word: the reference-order kernels run only if *guard == guard_epoch
     unsigned guard_epoch;       // (fallback for non-finite operands of the tiled kernel, decided on the device)
 };
@@ -353,6 +353,8 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
 
 // Inner-axis splitting helpers for the tiled kernel (see gft_conv_tiled.hip): zero-pad rows to `plen`, and the
 // overlap-add that folds the (Pz, 2B-1) pieces of every row back into a row of zI coefficients.
+template <class E>
+bool conv_pairs(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a, double max_macs);
 void staged_set_rb_min_macs(double v);  // threshold of the register-blocked interval product (negative: never)
 void staged_set_rb_pairs(double v);    // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 by size, 2 always, negative: the default
 void staged_set_rb_pairs_cap(double bytes);  // bytes of row sums it may hold (< 1: the default, 24 GiB)

@@ -87,7 +87,7 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
  * to each other and to the CPU algorithm.  Test/bench knob. */
 int gft_set_conv_mode(int mode);
 /* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
- * tiled product), "conv_rb_min_macs" (smallest interval product, in multiply-adds, that takes the register-blocked rows kernel; negative: never), "conv_rb_pairs" (interval product as independent row-pair sums with the ordered additions in a second pass: 0 never, 1 from 3e5 multiply-adds (rank 2: 1e6; rows of 8 .. 128) while the row sums fit "conv_rb_pairs_cap" bytes [default 24 GiB], 2 whenever it applies, negative: the default), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
+ * tiled product), "conv_rb_min_macs" (smallest interval product, in multiply-adds, that takes the register-blocked rows kernel; negative: never), "conv_rb_pairs" (reference-order product, interval and f64, as independent row-pair sums with the ordered additions in a second pass: 0 never, 1 from 3e5 multiply-adds (rank 2: 1e6; rows of 8 .. 128) while the row sums fit "conv_rb_pairs_cap" bytes [default 24 GiB], 2 whenever it applies, negative: the default), "pairs_first" (0: small plain f64 products go to the tiled kernel as before round 4 instead of asking the bit-exact row-pair form first), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
  * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div_wavefront" (0: the slab-by-slab blocked division instead of the one-launch row wavefront), "div2d" (0: host-driven division

@@ -1301,6 +1301,45 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
         L.gft_set_option(b"host_max_elems", -1.0)
 
 
+@pytest.mark.parametrize("xs,ys,zs", RB_SHAPES + [((3, 5, 200), (3, 5, 200), (3, 5, 200)), ((40, 40, 24), (40, 40, 24), (40, 40, 24))])
+def test_f64_reference_order_product_as_row_pair_sums_bit_exact(xs, ys, zs, OTP, GTP):
+    """The f64 reference-order product (conv mode 3: what the interpreter takes where the tiled kernel does not apply, and
+    what a caller who wants the reference's bits sets) as row-pair sums: every row sum formed from zero in ascending j
+    with separate multiply and add, the row sums added in the reference's order (mt:971-1012) => the oracle's bits,
+    including the sign of zeros (the reference's sums start from +0: a -0 product becomes +0) and non-finite values;
+    against the LDS-staged kernel (row-pair form off) as well."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    deg = list(zs)
+    x, y = rand(xs, 191, -1.0, 1.0), rand(ys, 192, -1.0, 1.0)
+    xz, yz = x.copy(), y.copy()
+    xz.flat[::7] = 0.0   # exact zeros against negative partners: -0 products inside the sums
+    yz.flat[::5] = -0.0
+    xz[tuple(0 for _ in xs)] = -1.0
+    yz[tuple(0 for _ in ys)] = 0.0  # the constant coefficient: a single -0 term
+    xi = x.copy()
+    xi[tuple(min(1, n - 1) for n in xs)] = np.inf
+    yn = y.copy()
+    yn[tuple(n - 1 for n in ys)] = np.nan
+    L.gft_set_option(b"host_max_elems", 0.0)
+    assert L.gft_set_conv_mode(3) == 0
+    try:
+        for a, b in ((x, y), (xz, yz), (xi, yn), (x * 1e-200, y * 1e-200), (x * 1e200, y * 1e160)):
+            want = (OTP.new(a, deg) * OTP.new(b, deg)).array()
+            for pairs in (2.0, 0.0):
+                assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
+                try:
+                    got = (GTP.new(a, deg) * GTP.new(b, deg)).array()
+                finally:
+                    L.gft_set_option(b"conv_rb_pairs", -1.0)
+                ok = (np.asarray(want).view(np.uint64) == np.asarray(got).view(np.uint64)) | (np.isnan(want) & np.isnan(got))
+                assert np.all(ok), (pairs, np.asarray(want)[~ok][:4], np.asarray(got)[~ok][:4])
+    finally:
+        L.gft_set_conv_mode(0)
+        L.gft_set_option(b"host_max_elems", -1.0)
+
+
 @pytest.mark.parametrize("async_launch", [1, 0])
 def test_failed_kernel_launch_is_reported_not_swallowed(OTP, GTP, async_launch):
     """Launches are issued by the library's worker thread (gft_launch.hpp) and HIP's last-error state is per thread: the

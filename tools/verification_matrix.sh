@@ -8,8 +8,8 @@ OUT=gpurun_out/verification_matrix.txt
 for cfg in "GFT_BASELINE=1" "GFT_DEFER=0" "GFT_ASYNC_LAUNCH=0" "GFT_HORNER_PIPE=0" "GFT_HORNER_LEAN=0" "GFT_DIV_WAVEFRONT=0" "GFT_DWF_DIAG=0" "GFT_DWF_PACK=0" \
            "GFT_CONV_RB_MIN_MACS=0" "GFT_CONV_RB=0" "GFT_TILED_WG_MULT=1" \
            "GFT_SHALLOW_MAX_TERMS=0" "GFT_SHALLOW_MAX_TERMS=64" "GFT_ROWS_WAVEFRONT=0" "GFT_HORNER_AHEAD=0" "GFT_HORNER_HOST_PHASE=0" "GFT_TILED_INPLACE=0" \
-           "GFT_DWF_QUAD=0" "GFT_DWF_QUAD=2" "GFT_RB_PAIRS=0" "GFT_RB_PAIRS=2" \
-           "GFT_DEFER=0 GFT_ASYNC_LAUNCH=0 GFT_HORNER_PIPE=0 GFT_DIV_WAVEFRONT=0 GFT_CONV_RB=0 GFT_SHALLOW_MAX_TERMS=0 GFT_ROWS_WAVEFRONT=0 GFT_HORNER_AHEAD=0 GFT_HORNER_HOST_PHASE=0 GFT_TILED_INPLACE=0 GFT_DWF_QUAD=0 GFT_RB_PAIRS=0"; do
+           "GFT_DWF_QUAD=0" "GFT_DWF_QUAD=2" "GFT_RB_PAIRS=0" "GFT_RB_PAIRS=2" "GFT_PAIRS_FIRST=0" \
+           "GFT_DEFER=0 GFT_ASYNC_LAUNCH=0 GFT_HORNER_PIPE=0 GFT_DIV_WAVEFRONT=0 GFT_CONV_RB=0 GFT_SHALLOW_MAX_TERMS=0 GFT_ROWS_WAVEFRONT=0 GFT_HORNER_AHEAD=0 GFT_HORNER_HOST_PHASE=0 GFT_TILED_INPLACE=0 GFT_DWF_QUAD=0 GFT_RB_PAIRS=0 GFT_PAIRS_FIRST=0"; do
   res=$(env $cfg timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_exact_kats.py tests/test_horner_shapes_gpu.py tests/test_reference_unit_vectors.py tests/test_interval_pins.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -1)
   echo "$cfg : $res" | tee -a $OUT
 done
