@@ -1518,7 +1518,7 @@ struct Ops {
         // faster than the tiled kernel there (two launches, no planning: 12^3 38 -> 14 us, 16^3 27 -> 20, 64^2 27 -> 18,
         // 100^2 42 -> 27 us; crossover at ~20^3 resp. ~200^2, profiles/r04/f64_pairs_vs_tiled.txt)
         if (W == 1 && R.conv_mode == 0 && R.pairs_first && !slab_mode && !accumulate && a.slab_lo == 0 && a.slab_hi == a.zs[0] && a.nd >= 2) {
-            if (conv_pairs<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, a.nd == 2 ? R.pairs_first_max_rank2 : R.pairs_first_max)) {
+            if (conv_pairs<E>(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a, a.nd == 2 ? R.pairs_first_max_rank2 : (a.nd == 3 ? R.pairs_first_max : 0.1 * R.pairs_first_max))) {  // (rank 4: 8^4 27 vs 22 us already)
                 R.stats[4]++;
                 return;
             }

@@ -518,10 +518,26 @@ __global__ void __launch_bounds__(256) k_conv_reduce(TiledArgs A, unsigned n_red
             }
         }
         const unsigned lo = (unsigned)((unsigned long long)rt.count * q / 4), hi = (unsigned)((unsigned long long)rt.count * (q + 1) / 4);
-        for (unsigned p = lo; p < hi; ++p) {
-            // (a tile's partial slabs are consecutive workspace slots — the plan's ranges are contiguous in tile order — so
-            // the slab address follows from the tile's entry alone: one dependent load less in a launch that is nothing
-            // but a few memory latencies)
+        // (a tile's partial slabs are consecutive workspace slots — the plan's ranges are contiguous in tile order — so
+        // the slab address follows from the tile's entry alone: one dependent load less in a launch that is nothing
+        // but a few memory latencies; and four slabs' loads go out before the first is added — in the same order as before)
+        unsigned p = lo;
+        if (!A.red_slots) {
+            const size_t stride = (size_t)A.nb * 512;
+            const double* w = A.ws + (size_t)(rt.slot0 + lo) * stride + ((size_t)c * 64 + lane) * 8;
+            for (; p + 4 <= hi; p += 4, w += 4 * stride) {
+                double t[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t[u][r] = w[(size_t)u * stride + r];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += t[u][r];
+            }
+        }
+        for (; p < hi; ++p) {
             const unsigned slot = A.red_slots ? A.red_slots[rt.first + p] : rt.slot0 + p;
             const double* w = A.ws + (size_t)slot * A.nb * 512 + ((size_t)c * 64 + lane) * 8;
 #pragma unroll
