@@ -1,5 +1,7 @@
-"""Reference-order product: one-thread-per-output kernel (conv mode 1) vs the LDS-staged kernel
-(mode 3) on the GPU — time per product and a bit-exactness check of the two results.
+"""Reference-order product: one-thread-per-output kernel (conv mode 1) vs conv mode 3 — the row-pair form (k_pair_sums +
+k_pair_collect, round 4) where it applies (rank 2-4, rows of 8 .. 256 / 128 for intervals, row sums within the workspace cap),
+else the LDS-staged kernel; GFT_RB_PAIRS=0 times the LDS-staged kernel alone — on the GPU: time per product and a
+bit-exactness check of the two results (`staged_ms` is the mode-3 time).
     python tools/bench_staged.py            (needs a gfx950 device)"""
 import json
 import os
