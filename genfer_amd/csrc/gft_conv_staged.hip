@@ -735,7 +735,6 @@ struct PairArgs {
     unsigned tiles0, tiles1;                      // y tiles along the two lane axes
     unsigned pitch;                               // LDS row pitch in doubles ((lo, hi) interleaved; pitch / 2 odd)
     unsigned long long S0, S1;                    // terms summed over all k0 / all k1
-    unsigned dbg_nostore;                         // timing experiments only (GFT_RB_PAIRS_NOSTORE): phase 1 without its stores
 };
 // terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
 __host__ __device__ inline unsigned pair_lo(unsigned k, unsigned ny) { return k + 1 > ny ? k + 1 - ny : 0u; }
@@ -984,7 +983,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
             } else {
                 pair_block<E, 3, CW>(acc, cb, xl, xh, yrow, nxc, g.nx2);
             }
-            if (lane_ok && !g.dbg_nostore) {
+            if (lane_ok) {
                 if constexpr (W == 2) {
                     double2* d = reinterpret_cast<double2*>(dst) + CW * cb;
 #pragma unroll
@@ -1188,8 +1187,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         // (small products: fewer x rows per workgroup until there are ~1000 workgroups — half of the (tile, chunk) grid is
         // outside the triangle)
         while (g.xch > 1 && (unsigned long long)g.yU * g.tiles0 * g.tiles1 * ((xrows + g.xch - 1) / g.xch) < 2048ull) g.xch /= 2;
-        static const unsigned nostore_env = getenv("GFT_RB_PAIRS_NOSTORE") ? 1u : 0u;
-        g.dbg_nostore = nostore_env;
         g.S0 = pair_pre(g.z0, g.x0, g.y0);  // terms over all k0 / all k1
         g.S1 = pair_pre(g.z1, g.x1, g.y1);
         const unsigned long long slots = pair_pre(g.zU, g.xU, g.yU) * g.S0 * g.S1;
