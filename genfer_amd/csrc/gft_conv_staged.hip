@@ -710,8 +710,8 @@ __global__ void __launch_bounds__(1024) k_conv_rows_rb(const double* __restrict_
 //               every x row the workgroup walks; a lane keeps 4 consecutive outputs c of ITS row sum in registers and
 //               slides a 4-wide window of its y row (one 16-byte LDS read per 4 multiply-adds instead of three per two);
 //   x           one row per task, wave-uniform: scalar loads, SGPR operands — no LDS, no VGPRs;
-//   tasks       (x row, pair of column blocks p and nbw - 1 - p: nbw + 1 chunk products whatever p), dealt round-robin to
-//               the workgroup's waves; 8 x rows per workgroup (a tile's x rows are cut into chunks: blockIdx.x, so that
+//   tasks       (x row, pair of column blocks p and nbw - 1 - p: nbw + 1 chunk products whatever p), a contiguous share per
+//               wave (the row's regime and slots once per row); 8 x rows per workgroup (a tile's x rows are cut into chunks: blockIdx.x, so that
 //               a tile's chunks spread over the XCDs);
 //   registers   <= 128 VGPRs, 16 waves per CU: one wave issues a 64-bit VALU operation every 8 cycles, four per SIMD
 //               every 4.9 (profiles/r03/microbench_int64.txt) — the first, 8-wide version of this kernel (168 VGPRs, two
@@ -932,31 +932,42 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     const unsigned d0 = d0b + l0, d1 = d1b + l1;
     const bool row_ok = d0 < g.y0 && d1 < g.y1;
     const double* yrow = smem + (size_t)lane * g.pitch;
-    // ---- tasks (x row, pair of column blocks p and nbw - 1 - p: p + 1 and nbw - p chunk products, the same sum for every p),
-    // dealt round-robin to the waves
+    // ---- tasks (x row, pair of column blocks p and nbw - 1 - p: p + 1 and nbw - p chunk products, the same sum for every p):
+    // every wave takes a contiguous share of them, so what belongs to the x row — its regime, the lanes' slots — is worked
+    // out once per row and wave (with 8 rows and 8 waves: once per row), not once per task
     const unsigned nbw = g.n8 / CW, nxc = (g.nx2 + CW - 1) / CW, npairs = (nbw + 1) / 2;
     const unsigned ntasks = rows_here * npairs;
-    for (unsigned t = wave; t < ntasks; t += nwaves) {
-        const unsigned long long xi = xi_lo + t / npairs;
-        const unsigned pr = t % npairs;
-        const unsigned j1 = (unsigned)(xi % n1);
-        const unsigned long long tt = xi / n1;
-        const unsigned j0 = (unsigned)(tt % n0), ju = (unsigned)(tt / n0);
-        const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
-        pair_cptr_t xl = (pair_cptr_t)(x + arow * g.nx2), xh = (pair_cptr_t)(x + xp + arow * g.nx2);
-        const bool lane_ok = row_ok && j0 + d0 < g.z0 && j1 + d1 < g.z1;
-        unsigned f = tileflag;
-        if constexpr (E::HAS_POS) {  // the x row's regime, from vector loads of the row (it is read through the scalar cache below)
-            bool np = false, nf = false;
-            for (unsigned i = lane; i < g.nx2; i += 64) {
-                const Iv e = Iv{x[arow * g.nx2 + i], x[xp + arow * g.nx2 + i]};
-                np = np || !E::pos_ok(e);
-                nf = nf || !E::fin_ok(e);
+    const unsigned t_lo = (unsigned)((unsigned long long)ntasks * wave / nwaves), t_hi = (unsigned)((unsigned long long)ntasks * (wave + 1) / nwaves);
+    unsigned cur_row = 0xffffffffu;
+    pair_cptr_t xl = nullptr, xh = nullptr;
+    bool lane_ok = false;
+    int regime = 0;
+    double* dst = ws;
+    for (unsigned t = t_lo; t < t_hi; ++t) {
+        const unsigned row = t / npairs, pr = t - row * npairs;
+        if (row != cur_row) {  // (uniform)
+            cur_row = row;
+            const unsigned long long xi = xi_lo + row;
+            const unsigned j1 = (unsigned)(xi % n1);
+            const unsigned long long tt = xi / n1;
+            const unsigned j0 = (unsigned)(tt % n0), ju = (unsigned)(tt / n0);
+            const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
+            xl = (pair_cptr_t)(x + arow * g.nx2);
+            xh = (pair_cptr_t)(x + xp + arow * g.nx2);
+            lane_ok = row_ok && j0 + d0 < g.z0 && j1 + d1 < g.z1;
+            unsigned f = tileflag;
+            if constexpr (E::HAS_POS) {  // the x row's regime, from vector loads of the row (it is read through the scalar cache below)
+                bool np = false, nf = false;
+                for (unsigned i = lane; i < g.nx2; i += 64) {
+                    const Iv e = Iv{x[arow * g.nx2 + i], x[xp + arow * g.nx2 + i]};
+                    np = np || !E::pos_ok(e);
+                    nf = nf || !E::fin_ok(e);
+                }
+                f |= (any_lane(np) ? 1u : 0u) | (any_lane(nf) ? 2u : 0u);
             }
-            f |= (any_lane(np) ? 1u : 0u) | (any_lane(nf) ? 2u : 0u);
+            regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
+            dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * W;
         }
-        const int regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
-        double* const dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * W;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const unsigned cb = half == 0 ? pr : nbw - 1 - pr;
