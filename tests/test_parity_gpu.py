@@ -1249,7 +1249,9 @@ RB_SHAPES = [
 
 @pytest.mark.parametrize("xs,ys,zs", RB_SHAPES)
 def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
-    """Large interval products run on k_conv_rows_rb (two outputs per lane sharing each y read, x through scalar loads,
+    """The interval product's three reference-order kernels against the oracle: k_conv_staged, the row-pair form (k_pair_sums
+    + k_pair_collect: every row sum an independent task, ordered additions in a second pass) and k_conv_rows_rb.
+    Large interval products run on k_conv_rows_rb (two outputs per lane sharing each y read, x through scalar loads,
     regimes from per-row flags): every output still receives its row sums in the reference's order (mt:971-1012) =>
     bit-exact against the oracle and identical to k_conv_staged, for positive data (positive regime), mixed-sign data
     (finite regime), data with exact zeros / ones / infinities (general regime) and sums that leave their regime
@@ -1283,8 +1285,6 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
     try:
         for a, b in cases:
             want = OTPI.new(a, deg) * OTPI.new(b, deg)
-            # (threshold, two-phase mode, workspace cap): the fused rows kernel, k_conv_staged, the two-phase form in one
-            # chunk and cut into chunks of the leading axis (a cap of 256 KB holds a leading index or two of these shapes)
             # (threshold, row-pair mode, its workspace cap): the fused rows kernel, k_conv_staged, the row-pair form (rows of
             # <= 128; longer ones fall through to k_conv_staged), and a cap too small for it (back to k_conv_staged)
             for thr, pairs, cap in ((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (-1.0, 2.0, 4096.0)):
