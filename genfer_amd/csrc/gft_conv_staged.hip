@@ -1059,6 +1059,53 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
     if (c < g.n2) E::st(z, zp, (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c, acc);
 }
 
+// f64 rows of even length: two columns per thread (16-byte loads, as the interval form has anyway)
+__global__ void __launch_bounds__(128) k_pair_collect2_f64(const double* __restrict__ ws, double* __restrict__ z, PairArgs g) {
+    const unsigned c = 2 * (blockIdx.y * blockDim.x + threadIdx.x);
+    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest rows first
+    const unsigned k1 = (unsigned)(rr % g.z1);
+    rr /= g.z1;
+    const unsigned k0 = (unsigned)(rr % g.z0), ku = (unsigned)(rr / g.z0);
+    const unsigned long long n = (unsigned long long)pair_cnt(ku, g.xU, g.yU) * pair_cnt(k0, g.x0, g.y0) * pair_cnt(k1, g.x1, g.y1);
+    double a0 = 0.0, a1 = 0.0;
+    if (c >= g.n2) return;
+    if (n > 0) {
+        const double2* p = reinterpret_cast<const double2*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 + c);
+        const size_t pitch = g.n2 / 2;  // double2 per term
+        constexpr int D = 16;
+        double2 buf[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) buf[u] = p[(size_t)((unsigned long long)u < n ? u : n - 1) * pitch];
+        unsigned long long i0 = 0;
+        for (; i0 + 2 * D <= n; i0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                a0 = a0 + buf[u].x;
+                a1 = a1 + buf[u].y;
+                buf[u] = p[(size_t)(i0 + u + D) * pitch];
+            }
+        }
+        double2 last[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) last[u] = p[(size_t)(i0 + D + u < n ? i0 + D + u : n - 1) * pitch];
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (i0 + u < n) {
+                a0 = a0 + buf[u].x;
+                a1 = a1 + buf[u].y;
+            }
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (i0 + D + u < n) {
+                a0 = a0 + last[u].x;
+                a1 = a1 + last[u].y;
+            }
+    }
+    double* zr = z + (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c;
+    zr[0] = a0;
+    zr[1] = a1;
+}
+
 // per-stream scratch for the row flags (grow-only; a stream's launches are ordered, so one buffer per stream is enough)
 struct RbScratch {
     unsigned char* p = nullptr;
@@ -1232,7 +1279,10 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                     const char* e = getenv("GFT_RB_PAIRS_COLS");  // tuning knob: columns per phase-2 workgroup
                     return (unsigned)(e ? std::max(1, std::min(128, atoi(e))) : 64);
                 }();
-                GFT_LAUNCH(k_pair_collect<E>, dim3((unsigned)(zs_ / n2), (n2 + cw_env - 1) / cw_env), dim3(cw_env), 0, st, (const double*)w.p, z, zp, g);
+                if (E::W == 1 && n2 >= 64 && n2 % 2 == 0 && !((uintptr_t)z & 15))  // (shorter rows: too few threads per row — 32^3 0.104 -> 0.113 ms; 80^3 7.7 -> 7.1)
+                    GFT_LAUNCH(k_pair_collect2_f64, dim3((unsigned)(zs_ / n2), (n2 / 2 + 63) / 64), dim3(64), 0, st, (const double*)w.p, z, g);
+                else
+                    GFT_LAUNCH(k_pair_collect<E>, dim3((unsigned)(zs_ / n2), (n2 + cw_env - 1) / cw_env), dim3(cw_env), 0, st, (const double*)w.p, z, zp, g);
                 return true;
             }
         }
