@@ -3553,7 +3553,10 @@ int gft_init(int device) {
         HIP_OK(hipStreamCreateWithFlags(&R.side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&R.ev_main, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&R.ev_bulk, hipEventDisableTiming));
-        HIP_OK(hipMalloc((void**)&R.d_flag, 256));
+        // (words 0 .. 63: predicates and counters; from byte 1024 on: the scans' group arrival counters, one per 128 bytes —
+        // gft_kernels.hip scan_arrive)
+        HIP_OK(hipMalloc((void**)&R.d_flag, 1024 + 128 * 64));
+        HIP_OK(hipMemset(R.d_flag, 0, 1024 + 128 * 64));
         {
             unsigned init[64] = {0};
             init[8] = 0xffffffffu;  // linear_scan state: mask word, arrival counter

@@ -625,6 +625,22 @@ static bool chain_is_flat(const ChainSrc& c, const Shape& sh) {
     return true;
 }
 
+// Arrival of a scan's workgroup (thread 0, after its verdict is in state[0]): true for the LAST workgroup of the launch.
+// Two levels — groups of 32 workgroups count on their own word (128 bytes apart, behind the state words: state + 248 +
+// 32 g), a group's last arriver counts on state[1] — because same-address atomics serialise at ~26 ns each: one counter for
+// the 329 workgroups of a 290^2 tensor was 8 us of a 6 us kernel's tail, for the 2048 of a 100^3 tensor 50 us.
+__device__ __forceinline__ bool scan_arrive(unsigned* state) {
+    constexpr unsigned G = 32;
+    const unsigned group = blockIdx.x / G, ngroups = (gridDim.x + G - 1) / G;
+    const unsigned gsize = group + 1 < ngroups ? G : gridDim.x - group * G;
+    unsigned* gc = state + 248 + 32 * (group & 63u);  // (at most 2048 workgroups = 64 groups per launch)
+    __threadfence();
+    if (atomicAdd(gc, 1u) != gsize - 1) return false;
+    atomicExch(gc, 0u);  // everyone of the group has arrived: ready for the next launch on this stream
+    __threadfence();
+    return atomicAdd(&state[1], 1u) == ngroups - 1;
+}
+
 // k_chain<E, false> and k_linear_scan in one launch: the accumulator of a Horner step is a deferred chain whose FIRST
 // consumer is Mul's `extract_linear` (mt:1014-1072 asks `self` first) — materialise it and settle the question in the same
 // pass (one launch and its gap less per subst_var of a `--bounds` program).  Verdict and mailbox as in k_linear_scan.
@@ -657,24 +673,24 @@ __global__ void __launch_bounds__(256) k_chain_scan(double* __restrict__ out, si
         }
         const V v = ina ? chain_eval<E>(a, (size_t)aoff, k, firsta) : E::zero();
         E::st(out, out_plane, lin, v);
+        // the last workgroup reads back element 0 and the element at 1 along the linear axis: only THEIR writers make
+        // their store visible device-wide (a fence is a write-back of the XCD's whole L2 — every thread paid one)
+        if (nonzero_axes == 0 || (nonzero_axes == 1 && unit)) __threadfence();
         if (local != 0 && nonzero_axes != 0 && !E::is_zero(v)) {
             if (nonzero_axes == 1 && unit) local &= (1u << which);
             else local = 0;
         }
     }
-    __threadfence();  // this thread's elements are visible device-wide before the block takes its ticket
     for (int off = 32; off > 0; off >>= 1) local &= __shfl_xor(local, off, 64);
     __shared__ unsigned s_and[4];
     __shared__ unsigned s_last;
     if ((threadIdx.x & 63) == 0) s_and[threadIdx.x >> 6] = local;
-    __syncthreads();
+    __syncthreads();  // (also: the fenced stores of this workgroup's threads precede its arrival)
     if (threadIdx.x == 0) {
         unsigned blk = s_and[0] & s_and[1] & s_and[2] & s_and[3];
         unsigned cur = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur & ~blk) atomicAnd(&state[0], blk);
-        __threadfence();
-        unsigned ticket = atomicAdd(&state[1], 1u);
-        s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
+        s_last = scan_arrive(state) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
@@ -822,9 +838,7 @@ __global__ void __launch_bounds__(256) k_linear_scan(DView t, unsigned axes_mask
         unsigned blk = s_and[0] & s_and[1] & s_and[2] & s_and[3];
         unsigned cur = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur & ~blk) atomicAnd(&state[0], blk);
-        __threadfence();
-        unsigned ticket = atomicAdd(&state[1], 1u);
-        s_last = (ticket == gridDim.x - 1) ? 1u : 0u;
+        s_last = scan_arrive(state) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
