@@ -397,7 +397,9 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
     }();
     // (only where bandwidth is the issue: on a 180 x 180 tensor one wave per row is 180 waves walking their rows serially
     // where the per-element kernel has 32 000 threads in flight — mixture --bounds 3.0 -> 3.7 s when it was unconditional)
-    if (rows_on && a.out.nd >= 2 && a.out.d[a.out.nd - 1] >= 48 && total >= ((size_t)1 << 20)) {
+    // (and only with rows enough to fill the chip: four_populations gathers 1e6 elements in a few dozen rows of tens of
+    // thousands — 8 workgroups walking them took 337 us where the per-element kernel takes 19)
+    if (rows_on && a.out.nd >= 2 && a.out.d[a.out.nd - 1] >= 48 && total >= ((size_t)1 << 20) && total / a.out.d[a.out.nd - 1] >= 4096) {
         const size_t rows = total / a.out.d[a.out.nd - 1];
         const size_t blocks = std::min<size_t>((rows + 3) / 4, 256 * 16);
         GFT_LAUNCH(k_gather_rows<E>, dim3((unsigned)blocks), dim3(256), 0, st, src, src_plane, out, out_plane, a, rows);
