@@ -3476,6 +3476,8 @@ struct ApiTrace {
         if (!on) return;
         for (auto& kv : counts) fprintf(stderr, "[gft api] %-40s %10zu calls %10.4f s\n", kv.first.c_str(), kv.second, secs[kv.first]);
         for (auto& kv : tiny) fprintf(stderr, "[gft api] tiny device result from %-22s %zu\n", kv.first.c_str(), kv.second);
+        fprintf(stderr, "[gft api] host-tier Horner steps: positive constants %llu, sign-known c %llu, other %llu; elements of a sign-known step that left its fast path %llu\n",
+                gft::g_host_horner_stats[0], gft::g_host_horner_stats[1], gft::g_host_horner_stats[2], gft::g_host_horner_stats[3]);
         for (auto& kv : settles) fprintf(stderr, "[gft api] chains materialised for %-24s %zu\n", kv.first.c_str(), kv.second);
     }
 };

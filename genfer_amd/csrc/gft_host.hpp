@@ -14,7 +14,11 @@
 
 #include "gft_kernels.hpp"
 
+#include <cstdio>
 namespace gft {
+// GFT_TRACE_API: host-tier Horner steps by regime {positive constants, sign-known c, general} and elements that fell back
+extern unsigned long long g_host_horner_stats[4];
+
 
 template <class E>
 struct HK {
@@ -327,12 +331,35 @@ struct HK {
     static void horner_linear(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g) {
         const int nd = g.out.nd;
         if (nd == 0) {
-            horner_linear_elem(res, rp, a, ap, out, op, g, 0, 0, g.a_base, 0, true, true, true, false);
+            horner_linear_elem(res, rp, a, ap, out, op, g, 0, 0, g.a_base, 0, true, true, true, false, 0, 0);
             return;
         }
         const V cv = E::from(g.c), mv = E::from(g.m);
         bool pos_consts = false;
         if constexpr (E::HAS_POS) pos_consts = E::pos_ok(mv) && (g.c_zero || g.c_one || E::pos_ok(cv));
+        // The `--bounds` runs of v -> c + m v have a c that is a few ulps AROUND zero (an interval with a negative and a
+        // positive bound): not the positive regime, but the signs of c's bounds are known, so against a positive x the
+        // reference's product (iv:164-190) is [c.lo * x.hi, c.hi * x.hi] (or the analogous pair) and its outward steps are
+        // the integer steps `bits +- 1` in the direction those signs dictate — the device's lean Horner step
+        // (gft_kernels.hip LeanConsts<EIv>), here for the host tier: switchpoint `--bounds` spends 2.5 of its 2.8 s in this loop.
+        int semi = 0;  // bit 0: usable, bit 1: lo uses x.hi, bit 2: hi uses x.lo, bit 3: dlo = +1, bit 4: dhi = +1, bit 5: m = [1,1]
+        if constexpr (E::HAS_POS) {
+            // (m = [1,1], a pure shift v -> c + v: the reference's product with it returns the other operand, iv:164-190)
+            if (!pos_consts && !g.c_zero && !g.c_one && (E::pos_ok(mv) || E::is_one(mv)) && E::is_finite(cv) && cv.lo <= cv.hi && !E::maybe_special(cv) &&
+                cv.lo != 0.0 && cv.hi != 0.0)
+                semi = 1 | (!(cv.lo >= 0.0) ? 2 : 0) | (!(cv.hi >= 0.0) ? 4 : 0) | (cv.lo < 0.0 ? 8 : 0) | (cv.hi > 0.0 ? 16 : 0) | (E::is_one(mv) ? 32 : 0);
+        }
+        if (semi) pos_consts = false;
+        // ... and where the DATA are not positive either (switchpoint's accumulators are error intervals [-t, +t] around zero)
+        // the finite regime of the device kernels (gft_elem.hpp mul_fin / widen_fin): operands that are finite and no exact
+        // 0 / +-1 point take no short-circuit, the outward steps need no NaN / inf guard, and ONE test of the result (not NaN)
+        // validates every term.  bit 0: usable, bit 5: m = [1,1]
+        int fin = 0;
+        if constexpr (E::HAS_POS) {
+            if (!g.c_zero && !g.c_one && E::fin_ok(cv) && cv.lo <= cv.hi && (E::fin_ok(mv) || E::is_one(mv)) && mv.lo <= mv.hi)
+                fin = 1 | (E::is_one(mv) ? 32 : 0);
+        }
+        g_host_horner_stats[semi ? 1 : (pos_consts ? 0 : 2)]++;
         const int last = nd - 1;
         const unsigned nlast = g.out.d[last];
         size_t outer = 1;
@@ -356,7 +383,7 @@ struct HK {
                 const bool in_p = in_p0 && k < g.sh[last], in_r = in_r0 && k < g.rs[last], in_c = in_c0 && k < g.oc[last];
                 const unsigned kw = g.w == last ? k : kw0;
                 const size_t roff = roff0 + (size_t)k * g.rstr[last], aoff = aoff0 + (size_t)k * g.astr[last];
-                horner_linear_elem(res, rp, a, ap, out, op, g, lin, roff, aoff, kw, in_p, in_r, in_c, pos_consts);
+                horner_linear_elem(res, rp, a, ap, out, op, g, lin, roff, aoff, kw, in_p, in_r, in_c, pos_consts, semi, fin);
             }
             for (int ax = last - 1; ax >= 0; --ax) {
                 if (++idx[ax] < g.out.d[ax]) break;
@@ -365,12 +392,70 @@ struct HK {
         }
     }
     static inline void horner_linear_elem(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g,
-                                          size_t lin, size_t roff, size_t aoff, unsigned kw, bool in_p, bool in_r, bool in_c, bool pos_consts) {
+                                          size_t lin, size_t roff, size_t aoff, unsigned kw, bool in_p, bool in_r, bool in_c, bool pos_consts,
+                                          int semi, int fin) {
         const V cv = E::from(g.c), mv = E::from(g.m);
         const bool t1 = in_p && kw >= 1 && kw - 1 < g.upper;  // res[k - 1] * m exists
         const bool t2 = in_p && !g.c_zero && in_r;            // c * res[k] exists
         const bool t3 = g.coeff_scalar ? lin == 0 : in_c;     // the coefficient slab reaches this position
         if constexpr (E::HAS_POS) {
+            if (semi) {
+                const V xm1 = t1 ? E::ld(res, rp, roff - g.rstr[g.w]) : E::one(), x = t2 ? E::ld(res, rp, roff) : E::one();
+                const V cf = t3 ? E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff) : E::one();
+                if ((!t1 || E::pos_ok(xm1)) && (!t2 || E::pos_ok(x)) && (!t3 || E::pos_ok(cf))) {
+                    // every SUM below is formed with add_pos, which is the reference's sum iff its lower bound comes out
+                    // positive (and its upper bound finite): `lo > 0` is false for the NaN patterns the integer steps make of
+                    // a zero, a negative or an infinite sum, so one test per sum validates it
+                    const V p1 = (semi & 32) ? xm1 : E::mul_pos(xm1, mv);
+                    V p2;
+                    p2.lo = bits_f64(f64_bits(cv.lo * ((semi & 2) ? x.hi : x.lo)) + ((semi & 8) ? 1 : -1));
+                    p2.hi = bits_f64(f64_bits(cv.hi * ((semi & 4) ? x.lo : x.hi)) + ((semi & 16) ? 1 : -1));
+                    const double inf = bits_f64(0x7ff0000000000000LL);
+                    bool bad = (t1 && !(p1.lo > 0.0 && p1.hi < inf)) || (t2 && !(p2.lo > -inf && p2.hi < inf));  // (NaN fails every compare)
+                    V p = E::zero();
+                    if (t1 && t2) {
+                        p = E::add_pos(p1, p2);
+                        bad = bad || !(p.lo > 0.0 && p.hi < inf);
+                    } else if (t1) {
+                        p = p1;
+                    } else if (t2) {
+                        p = p2;
+                    }
+                    V v = p;
+                    if (t3) {
+                        if (t1 || t2) {
+                            v = E::add_pos(p, cf);
+                            bad = bad || !(v.lo > 0.0 && v.hi < inf);
+                        } else {
+                            v = cf;
+                        }
+                    }
+                    if (!bad) {
+                        E::st(out, op, lin, v);
+                        return;
+                    }
+                }
+                g_host_horner_stats[3]++;
+            }
+            if (fin) {
+                const V two = Iv{2.0, 3.0};  // (a finite, unremarkable stand-in for operands a position does not have)
+                const V xm1 = t1 ? E::ld(res, rp, roff - g.rstr[g.w]) : two, x = t2 ? E::ld(res, rp, roff) : two;
+                const V cf = t3 ? E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff) : two;
+                if (E::fin_ok(xm1) && E::fin_ok(x) && E::fin_ok(cf)) {
+                    const V p1 = (fin & 32) ? xm1 : E::mul_fin(xm1, mv);
+                    const V p2 = E::mul_fin(cv, x);
+                    V p = E::zero();
+                    if (t1 && t2) p = E::widen_fin(p1.lo + p2.lo, p1.hi + p2.hi);
+                    else if (t1) p = p1;
+                    else if (t2) p = p2;
+                    V v = p;
+                    if (t3) v = (t1 || t2) ? E::widen_fin(p.lo + cf.lo, p.hi + cf.hi) : cf;
+                    if (!E::is_nan(v)) {
+                        E::st(out, op, lin, v);
+                        return;
+                    }
+                }
+            }
             if (pos_consts) {
                 const V xm1 = t1 ? E::ld(res, rp, roff - g.rstr[g.w]) : E::one(), x = t2 ? E::ld(res, rp, roff) : E::one();
                 const V cf = t3 ? E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff) : E::one();

@@ -15,6 +15,7 @@
 namespace gft {
 
 unsigned long long g_launches = 0;
+unsigned long long g_host_horner_stats[4] = {0, 0, 0, 0};  // gft_host.hpp (GFT_TRACE_API)
 unsigned long long g_launches_in_place = 0;
 
 // ------------------------------------------------------------------------------------------
