@@ -252,15 +252,95 @@ def e2e_seconds(gpu_runs=5, oracle_available=True):
 
 
 _CLOCK_HELPER = r"""
-import shutil, subprocess, sys
-exe = shutil.which("rocm-smi")
-line = sys.stdin.readline()
-if line.strip() == "go" and exe:
+import glob, json, select, shutil, subprocess, sys, time
+# Two services for a parent that must not fork after it has initialised the GPU:
+#   "start" ... "stop": poll the amdgpu sysfs nodes (shader clock, socket power) every ~10 ms while the parent's TIMED
+#                       loop runs -> one JSON line of samples per card (no exec, no GPU access: plain file reads);
+#   "go":               one `rocm-smi --showclocks --showpower` (the round-3 sampler, run under a separate untimed load).
+def cards():
+    out = []
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(dev + "/vendor").read().strip() != "0x1002":
+                continue
+        except OSError:
+            continue
+        hw = sorted(glob.glob(dev + "/hwmon/hwmon*"))
+        f = [h + "/freq1_input" for h in hw if glob.glob(h + "/freq1_input")]
+        p = [h + "/" + n for h in hw for n in ("power1_average", "power1_input") if glob.glob(h + "/" + n)]
+        out.append({"dev": dev, "freq": f[0] if f else None, "power": p[0] if p else None, "dpm": dev + "/pp_dpm_sclk"})
+    return out
+def read_num(path):
     try:
-        sys.stdout.write(subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout)
+        return float(open(path).read().split()[0])
+    except Exception:
+        return None
+def read_dpm(path):
+    try:
+        for ln in open(path).read().splitlines():
+            if ln.rstrip().endswith("*"):
+                return float("".join(ch for ch in ln.split(":")[1] if ch.isdigit() or ch == "."))
     except Exception:
         pass
+    return None
+exe = shutil.which("rocm-smi")
+cs = cards()
+while True:
+    line = sys.stdin.readline()
+    if not line:
+        break
+    cmd = line.strip()
+    if cmd == "start":
+        samples = [{"mhz": [], "w": []} for _ in cs]
+        t0 = time.time()
+        while True:
+            for c, s in zip(cs, samples):
+                hz = read_num(c["freq"]) if c["freq"] else None
+                mhz = hz / 1e6 if hz else read_dpm(c["dpm"])
+                uw = read_num(c["power"]) if c["power"] else None
+                if mhz is not None: s["mhz"].append(mhz)
+                if uw is not None: s["w"].append(uw / 1e6)
+            r, _, _ = select.select([sys.stdin], [], [], 0.01)
+            if r:
+                sys.stdin.readline()
+                break
+            if time.time() - t0 > 120:
+                break
+        sys.stdout.write(json.dumps({"seconds": time.time() - t0, "cards": samples}) + "\n")
+        sys.stdout.flush()
+    elif cmd == "go":
+        if exe:
+            try:
+                sys.stdout.write(subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout)
+            except Exception:
+                pass
+        break
 """
+
+
+def timed_loop_samples(helper, text):
+    """The sysfs samples the helper took between "start" and "stop" (i.e. DURING the timed loop), reduced to the card that
+    drew the most power (the one under load when the box exposes several)."""
+    try:
+        rec = json.loads(text)
+        best = None
+        for c in rec["cards"]:
+            if not c["mhz"] and not c["w"]:
+                continue
+            key = float(np.mean(c["w"])) if c["w"] else 0.0
+            if best is None or key > best[0]:
+                best = (key, c)
+        if best is None:
+            return None
+        c = best[1]
+        out = {"samples": max(len(c["mhz"]), len(c["w"])), "window_s": rec["seconds"], "source": "amdgpu sysfs (hwmon freq1_input / power1_average), polled by a child forked before GPU initialisation"}
+        if c["mhz"]:
+            out["sclk_mhz"] = {"min": float(np.min(c["mhz"])), "median": float(np.median(c["mhz"])), "max": float(np.max(c["mhz"]))}
+        if c["w"]:
+            out["socket_power_w"] = {"min": float(np.min(c["w"])), "median": float(np.median(c["w"])), "max": float(np.max(c["w"]))}
+        return out
+    except Exception:  # noqa: BLE001 - informational only
+        return None
 
 
 def ensure_oracle():
@@ -453,6 +533,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    sampling = False
+    if clock_helper is not None and clock_helper.poll() is None:
+        try:  # (a pipe write: the child polls sysfs while the timed loop runs; nothing is spawned)
+            clock_helper.stdin.write("start\n")
+            clock_helper.stdin.flush()
+            sampling = True
+        except Exception:  # noqa: BLE001
+            sampling = False
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -461,6 +549,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    during = None
+    if sampling:
+        try:
+            clock_helper.stdin.write("stop\n")
+            clock_helper.stdin.flush()
+            during = timed_loop_samples(clock_helper, clock_helper.stdout.readline())
+        except Exception:  # noqa: BLE001
+            during = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -509,6 +605,11 @@ def main():
             "note": "FP64 FMA roof (vector == matrix FP64 peak on gfx950, 78.6 TFLOP/s); flops = 2*MACs of the "
                     "slabs this rank computes / mean HIP-event duration of the product launch(es) on its stream",
             "kernel_ms": k_ms,
+            # the per-step HIP-event durations of the timed steps: a slow line explains itself (first steps at a cold clock,
+            # a box whose clock sits lower, one outlier)
+            "kernel_ms_steps": {"min": float(np.min(kern_ms)), "median": float(np.median(kern_ms)), "max": float(np.max(kern_ms)),
+                                "first": float(kern_ms[0]), "n": len(kern_ms)},
+            "during_timed_loop": during,
             "hbm_algorithmic": {
                 "achieved": alg_bytes * (local_macs / total_macs) / (k_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBPS,
@@ -526,6 +627,8 @@ def main():
             if clk.get("sclk_mhz_under_load"):
                 peak_at = FP64_PEAK_TFLOPS * clk["sclk_mhz_under_load"] / 2400.0
                 out["roofline"]["frac_at_observed_clock"] = achieved_tflops / peak_at
+        if during and during.get("sclk_mhz"):  # the clock of the timed loop itself, when sysfs gives it
+            out["roofline"]["frac_at_timed_loop_clock"] = achieved_tflops / (FP64_PEAK_TFLOPS * during["sclk_mhz"]["median"] / 2400.0)
     if clock_helper is not None and clock_helper.poll() is None:
         try:
             clock_helper.stdin.close()  # never told to sample: let it go

@@ -369,6 +369,39 @@ double orc_mul_slabs_timed(const double* xs, const size_t* xshape, const double*
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// The rows (k0, k1) for k1 in [k1_lo, k1_hi) of the same product — a slab cut along its second axis, so that the heaviest
+// slabs of a 64^4 product can be spread over host threads by the tests.  Per output element the terms arrive exactly as
+// in mt:984-1012: j0 ascending, inside it j1 ascending, each a recursive product of the remaining axes into z[k0][k1].
+// Requires rank >= 3 and at least two non-unit result axes after the first (otherwise the reference's 1-d shortcut,
+// mt:996-1000, applies to the whole slab and a row cut is not the same computation).  Returns 0, or -1 with orc_last_error.
+int orc_mul_rows(const double* xs, const size_t* xshape, const double* ys, const size_t* yshape, double* res,
+                 const size_t* rshape, size_t ndim, size_t k0, size_t k1_lo, size_t k1_hi) {
+    try {
+        if (ndim < 3) panic("orc_mul_rows: rank >= 3 required");
+        usize nonunit = 0;
+        for (usize a = 1; a < ndim; ++a) nonunit += rshape[a] != 1;
+        if (nonunit < 2) panic("orc_mul_rows: the slab would take the 1-d shortcut");
+        View<const F64> xv{reinterpret_cast<const F64*>(xs), vec(xshape, ndim), c_strides(vec(xshape, ndim))};
+        View<const F64> yv{reinterpret_cast<const F64*>(ys), vec(yshape, ndim), c_strides(vec(yshape, ndim))};
+        View<F64> rv{reinterpret_cast<F64*>(res), vec(rshape, ndim), c_strides(vec(rshape, ndim))};
+        if (k0 >= rshape[0]) return 0;
+        View<F64> slab = rv.index0(k0);
+        usize lo0 = sat_sub(k0 + 1, yv.len_of(0)), hi0 = std::min(k0 + 1, xv.len_of(0));
+        for (usize j0 = lo0; j0 < hi0; ++j0) {
+            View<const F64> xj = xv.index0(j0), yj = yv.index0(k0 - j0);
+            for (usize k1 = k1_lo; k1 < k1_hi && k1 < rshape[1]; ++k1) {
+                View<F64> z = slab.index0(k1);
+                usize lo1 = sat_sub(k1 + 1, yj.len_of(0)), hi1 = std::min(k1 + 1, xj.len_of(0));
+                for (usize j1 = lo1; j1 < hi1; ++j1) mul_rec<F64>(xj.index0(j1), yj.index0(k1 - j1), z);
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // One raw Interval<F64> operation (iv:117-234, 264-276) on scalars, for the interval pin tests: op 0 add, 1 sub,
 // 2 mul, 3 div, 4 neg, 5 exp, 6 log.
 int orci_scalar_op(int op, const double* a, const double* b, double* out) {

@@ -55,6 +55,17 @@ def test_nothing_spawns_a_process_after_gpu_initialisation():
     assert "subprocess" not in after and "os.system" not in after and "Popen(" not in after
 
 
+def test_smoke_builds_the_oracle_before_it_initialises_the_gpu():
+    """__graft_entry__.smoke(): _oracle_cls() may spawn `make`; it must run before genfer_amd.init() (the same rule)."""
+    with open(os.path.join(ROOT, "__graft_entry__.py")) as f:
+        src = f.read()
+    smoke = src[src.index("def smoke()"):]
+    smoke = smoke[:smoke.index("\n\n\n")]
+    assert smoke.index("_oracle_cls()") < smoke.index("genfer_amd.init("), "build the oracle before the GPU is initialised"
+    after = smoke[smoke.index("genfer_amd.init("):]
+    assert "subprocess" not in after and "os.system" not in after and "_oracle_cls" not in after
+
+
 def test_e2e_rows_carry_a_parity_verdict():
     src = _bench_source()
     body = src[src.index("def e2e_seconds("):src.index("_CLOCK_HELPER")]

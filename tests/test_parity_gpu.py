@@ -685,6 +685,111 @@ def test_full_size_c4_properties():
     assert np.all(np.abs(got[0] - want0) <= 1e-10 * np.abs(want0))
 
 
+def _oracle_slabs_parallel(oracle_lib, x, y, zs, slabs, threads):
+    """Leading-axis output slabs of the reference-order product on the oracle, one slab per host thread (slabs are
+    independent, mt:1001-1011; the per-element operation order is the reference's).  Returns {k0: slab}."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_slabs_timed.restype = C.c_double
+    oracle_lib.orc_mul_slabs_timed.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t, C.c_size_t,
+                                               C.c_size_t, C.POINTER(C.c_double)]
+    nd = len(zs)
+    res = np.zeros(zs)
+    sx, sy, sz = (C.c_size_t * nd)(*x.shape), (C.c_size_t * nd)(*y.shape), (C.c_size_t * nd)(*zs)
+
+    def one(k):
+        m = C.c_double(0.0)
+        oracle_lib.orc_mul_slabs_timed(x.ctypes.data_as(C.c_void_p), sx, y.ctypes.data_as(C.c_void_p), sy,
+                                       res.ctypes.data_as(C.c_void_p), sz, nd, k, k + 1, C.byref(m))
+        return k
+
+    order = sorted(slabs, reverse=True)  # heaviest first
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        list(ex.map(one, order))
+    return {k: res[k] for k in slabs}
+
+
+def test_full_size_c2_whole_tensor_vs_oracle_directly(oracle_lib):
+    """BASELINE configs[1] (128^3), the headline tensor itself: EVERY coefficient of the tiled product against the CPU
+    oracle (not through the GPU reference-order kernel).  5.6e11 multiply-adds on the oracle: all host threads, one
+    leading slab each (about 16 s on the 256-core GPU box); skipped below 32 threads."""
+    threads = os.cpu_count() or 1
+    if threads < 32:
+        pytest.skip(f"the full 128^3 oracle product needs >= 32 host threads to finish in a test's time (have {threads})")
+    shape = (128, 128, 128)
+    x, y = rand(shape, 1), rand(shape, 2)
+    got = _conv_raw_gpu(2, x, y, shape)
+    want = _oracle_slabs_parallel(oracle_lib, x, y, shape, range(128), min(threads, 128))
+    worst = 0.0
+    for k in range(128):
+        err = np.abs(got[k] - want[k]) / np.abs(want[k])
+        worst = max(worst, float(err.max()))
+    assert worst <= 1e-10, worst
+
+
+def test_c4_slabs_vs_oracle_directly(oracle_lib):
+    """BASELINE configs[3] (64^4): the leading slabs {0, 31, 63} of the tiled result against the oracle directly (not the
+    GPU reference-order kernel).  Slab 63 alone is 5.8e11 multiply-adds, so the slabs are cut into their 64 rows along
+    the second axis (orc_mul_rows: the same terms in the same order per output) and spread over the host's threads;
+    with fewer than 32 threads only light slabs are checked."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = os.cpu_count() or 1
+    shape = (64, 64, 64, 64)
+    x, y = rand(shape, 3), rand(shape, 4)
+    slabs = [0, 31, 63] if threads >= 32 else ([0, 7] if threads >= 8 else [0, 1])
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_rows.restype = C.c_int
+    oracle_lib.orc_mul_rows.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    sz = (C.c_size_t * 4)(*shape)
+    want = np.zeros(shape)
+
+    def one(task):
+        k0, k1 = task
+        return oracle_lib.orc_mul_rows(x.ctypes.data_as(C.c_void_p), sz, y.ctypes.data_as(C.c_void_p), sz,
+                                       want.ctypes.data_as(C.c_void_p), sz, 4, k0, k1, k1 + 1)
+
+    tasks = sorted(((k0, k1) for k0 in slabs for k1 in range(64)), key=lambda t: -(t[0] + 1) * (t[1] + 1))
+    with ThreadPoolExecutor(min(threads, 128)) as ex:
+        assert all(rc == 0 for rc in ex.map(one, tasks))
+    for k in slabs:
+        got = _conv_raw_gpu(2, x, y, shape, slab=(k, k + 1), z0=np.zeros(shape))[k]
+        assert np.all(np.abs(got - want[k]) <= 1e-10 * np.abs(want[k])), (k, np.abs((got - want[k]) / want[k]).max())
+
+
+def test_conv_tiled_rank5_vs_oracle_directly(oracle_lib):
+    """A rank-5 general product on the tiled kernel (host loop over the leading axis, accumulate-mode rank-4 launches)
+    against the oracle's orc_mul_raw directly: 1e-10 on positive data, normwise on mixed-sign data."""
+    import ctypes as C
+
+    import genfer_amd
+
+    szp = C.POINTER(C.c_size_t)
+    oracle_lib.orc_mul_raw.restype = C.c_int
+    oracle_lib.orc_mul_raw.argtypes = [C.c_void_p, szp, C.c_void_p, szp, C.c_void_p, szp, C.c_size_t]
+    sz = lambda s: (C.c_size_t * len(s))(*s)
+
+    def oracle(x, y, zs):
+        ref = np.zeros(zs)
+        assert oracle_lib.orc_mul_raw(x.ctypes.data_as(C.c_void_p), sz(x.shape), y.ctypes.data_as(C.c_void_p), sz(y.shape),
+                                      ref.ctypes.data_as(C.c_void_p), sz(zs), len(zs)) == 0
+        return ref
+
+    for xs, ys, zs in (((4, 5, 6, 7, 8), (4, 5, 6, 7, 8), (4, 5, 6, 7, 8)), ((3, 6, 7, 8, 9), (2, 5, 7, 6, 9), (4, 8, 9, 10, 12))):
+        x, y = rand(xs, 171), rand(ys, 172)
+        before = genfer_amd.op_stats()["tiled"]
+        got = _conv_raw_gpu(2, x, y, zs)
+        assert genfer_amd.op_stats()["tiled"] > before, "the product did not take the tiled kernel"
+        want = oracle(x, y, zs)
+        assert np.all(np.abs(got - want) <= 1e-10 * np.abs(want)), np.abs((got - want) / np.where(want == 0, 1, want)).max()
+        xm, ym = 2 * x - 1, 2 * y - 1
+        bound = oracle(np.abs(xm), np.abs(ym), zs)
+        assert np.all(np.abs(_conv_raw_gpu(2, xm, ym, zs) - oracle(xm, ym, zs)) <= 1e-10 * bound)
+
+
 @pytest.mark.parametrize("interval", [False, True])
 def test_derivative_truncated_equals_two_step_form(interval, OTP, GTP, OTPI, GTPI):
     """gft_derivative_truncated == derivative(v, n).truncate_to_degree_p1(d) of the oracle (generating_function.rs
