@@ -16,7 +16,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <exception>
+#include <functional>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -113,11 +115,64 @@ thread_local std::string g_err;
             throw Error(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #call);           \
     } while (0)
 
+// ---- side streams (round 5) ----------------------------------------------------------------------------------------
+// A Genfer program is tens of thousands of dependent 5-50 us launches on ONE stream, but its dataflow is wider than that:
+// the first arm of an `if` reads a MEMOISED predecessor (generating_function.rs:186-222, 557-566) that was computed a whole
+// subtree ago, so its observation chain / Horner loop depends on nothing the main stream still has to do.  Such work runs
+// in a SIDE SCOPE: every launch of the operation goes to one of NSIDE side streams, and the buffers carry what orders
+// them against the other streams:
+//   * a scope starts with "side waits for everything issued on main so far" (one event; skipped when main has issued
+//     nothing since this side stream's last scope) — so a side operation may read any main-stream buffer;
+//   * a scope ends with an event on the side stream that every buffer written inside it keeps (`Buf::ready`); the first
+//     access from another stream (dp() / chain_src() / peek: `use_buf`) makes THAT stream wait for it, once;
+//   * each stream has its own pool, mailbox, scan state and witness words (`StreamCtx`, swapped into the Runtime's
+//     fields while the stream is current, so no kernel-issuing code knows about streams); a block returns to its home
+//     pool at once unless another stream has work on it in flight — then it waits in that pool's `limbo` behind events
+//     recorded on those streams and is taken out when they have completed (polled, never waited for).
+// Which operations take a side scope, and when: Ops::pick_stream.  "side_streams" / GFT_SIDE_STREAMS = 0: one stream.
+struct EvHolder;
+struct Buf;
+struct LimboBlock {
+    void* p;
+    size_t cls;
+    std::vector<std::shared_ptr<EvHolder>> after;
+};
+struct StreamCtx {
+    hipStream_t stream = nullptr;
+    std::map<size_t, std::vector<void*>> free_blocks;
+    std::deque<LimboBlock> limbo;
+    unsigned* d_flag = nullptr;
+    double* d_scratch = nullptr;
+    unsigned* d_wit = nullptr;
+    double* h_pinned = nullptr;
+    double* h_mail = nullptr;
+    double* d_mail = nullptr;
+    unsigned long long mail_seq = 0;
+    hipEvent_t ev_entry = nullptr;          // "main has got this far" for this side stream's scopes
+    unsigned long long entry_ops = ~0ull;   // main-stream operation count at the last such record
+};
+
 struct Runtime {
     bool ready = false;
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    static constexpr int NSIDE = 4;
+    int cur = 0;                   // stream context the Runtime's per-stream fields belong to right now (0: main)
+    int nside = 0;                 // side streams in use ("side_streams" / GFT_SIDE_STREAMS, at most NSIDE; 0 — the default, see below — everything on the main stream)
+    StreamCtx ctx[1 + NSIDE];      // the per-stream fields of the streams that are NOT current (ctx[cur] is stale)
+    unsigned next_side = 0;
+    unsigned long long side_ops = 0;        // stream operations issued inside side scopes (g_stream_ops - side_ops: main's)
+    unsigned long long scope_ops0 = 0;      // g_stream_ops when the open scope began
+    unsigned long long side_min_age = 2;    // main-stream operations since an input was produced for it to count as "old"
+    unsigned side_dirty = 0;                // side streams with work since the last gft_synchronize (bits)
+    std::vector<std::weak_ptr<Buf>> scope_bufs;  // device buffers written inside the open side scope
+    std::vector<hipEvent_t> ev_free;        // recycled events (disable-timing)
+    size_t stats_side[4] = {0, 0, 0, 0};    // {side scopes, cross-stream waits, observation chains that rode along with another launch, lazy observations fused}
+    bool obs_riders = true;                 // "obs_riders" / GFT_OBS_RIDERS: recorded chains ride along with other observation launches
+    bool lazy_horner = true;                // "lazy_horner" / GFT_LAZY_HORNER: proven Horner loops on old operands are recorded (Ops::horner_linear_rest)
+    bool horner_riders = true;              // "horner_riders" / GFT_HORNER_RIDERS: ... and ride along with other loops' launches
+    bool lazy_observe = true;               // "lazy_observe" / GFT_LAZY_OBSERVE: observation chains are recorded, not launched (Ops::observe_chain)
     // Side stream of the blocked recurrences (div / log): the bulk of a right-looking update runs here while the main
     // stream already divides the next slab.  Joined before the recurrence returns, so the pool's "one stream" rule holds
     // for every buffer that outlives it.
@@ -178,7 +233,7 @@ struct Runtime {
     double host_max_macs = HOST_MAX_MACS_DEFAULT;
     std::map<size_t, std::vector<void*>> host_blocks;  // free host-tier blocks by size class
 };
-Runtime R;
+Runtime& R = *new Runtime;  // (never destroyed: handles and cached tables released during static destruction still find their pool)
 
 static size_t size_class(size_t bytes) {
     if (bytes < 256) return 256;
@@ -191,22 +246,87 @@ static size_t size_class(size_t bytes) {
     return (bytes + g - 1) / g * g;
 }
 
+static void release_kernel_scratch() { staged_release_scratch(); }  // (the device is idle when this is called)
+
+struct EvHolder {
+    hipEvent_t ev = nullptr;
+    // set by the launch thread once the record has really been issued: hipEventQuery of an event whose record is still in
+    // the launch queue would say "complete"
+    std::shared_ptr<std::atomic<int>> issued = std::make_shared<std::atomic<int>>(0);
+    ~EvHolder() {
+        if (ev) R.ev_free.push_back(ev);  // (holders die on the API thread: handles, limbo entries)
+    }
+};
+static inline hipStream_t stream_of(int sid) { return sid == R.cur ? R.stream : R.ctx[sid].stream; }
+static inline std::map<size_t, std::vector<void*>>& blocks_of(int sid) { return sid == R.cur ? R.free_blocks : R.ctx[sid].free_blocks; }
+static inline unsigned long long main_ops_now() { return gft::g_stream_ops - R.side_ops - (R.cur ? gft::g_stream_ops - R.scope_ops0 : 0); }
+// an event on stream `sid` behind everything issued to it so far (queued like a launch: program order)
+static std::shared_ptr<EvHolder> record_event(int sid) {
+    auto h = std::make_shared<EvHolder>();
+    if (!R.ev_free.empty()) {
+        h->ev = R.ev_free.back();
+        R.ev_free.pop_back();
+    } else {
+        launch_drain();
+        HIP_OK(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    }
+    hipEvent_t ev = h->ev;
+    hipStream_t st = stream_of(sid);
+    std::shared_ptr<std::atomic<int>> flag = h->issued;
+    enqueue_task([ev, st, flag] {
+        lq_note((hipEventRecord)(ev, st), nullptr, "hipEventRecord (stream hand-over)");
+        flag->store(1, std::memory_order_release);
+    });
+    return h;
+}
+static bool event_done(const EvHolder& h) {
+    return h.issued->load(std::memory_order_acquire) && (hipEventQuery)(h.ev) == hipSuccess;
+}
+static bool limbo_done(const LimboBlock& l) {
+    for (const auto& e : l.after)
+        if (!event_done(*e)) return false;
+    return true;
+}
+
 static void* pool_alloc(size_t bytes, size_t* cls_out) {
     size_t cls = size_class(bytes);
     *cls_out = cls;
     std::vector<void*>& fl = R.free_blocks[cls];
-    void* p;
+    void* p = nullptr;
+    std::deque<LimboBlock>& limbo = R.ctx[R.cur].limbo;
+    // blocks whose last foreign reader has finished come home (a few per allocation: the queue stays short)
+    for (int k = 0; k < 4 && !limbo.empty() && limbo_done(limbo.front()); ++k) {
+        R.free_blocks[limbo.front().cls].push_back(limbo.front().p);
+        limbo.pop_front();
+    }
     if (!fl.empty()) {
         p = fl.back();
         fl.pop_back();
         R.cached -= cls;
     } else {
+        size_t looked = 0;
+        for (auto it = limbo.begin(); it != limbo.end() && looked < 32; ++it, ++looked)
+            if (it->cls == cls && limbo_done(*it)) {
+                p = it->p;
+                limbo.erase(it);
+                R.cached -= cls;
+                break;
+            }
+    }
+    if (!p) {
         hipError_t e = hipMalloc(&p, cls);
-        if (e != hipSuccess) {  // release the cache and retry once
-            for (auto& kv : R.free_blocks)
-                for (void* q : kv.second) (void)hipFree(q);
-            R.free_blocks.clear();
+        if (e != hipSuccess) {  // release every cache (all streams idle first: limbo blocks are then free too) and retry once
+            launch_drain();
+            (void)(hipDeviceSynchronize)();
+            for (int sid = 0; sid <= Runtime::NSIDE; ++sid) {
+                for (auto& kv : blocks_of(sid))
+                    for (void* q : kv.second) (void)hipFree(q);
+                blocks_of(sid).clear();
+                for (auto& l : R.ctx[sid].limbo) (void)hipFree(l.p);
+                R.ctx[sid].limbo.clear();
+            }
             R.cached = 0;
+            release_kernel_scratch();  // the row-pair workspace and the register-blocked kernel's scratch (gft_conv_staged.hip)
             HIP_OK(hipMalloc(&p, cls));
         }
     }
@@ -215,10 +335,25 @@ static void* pool_alloc(size_t bytes, size_t* cls_out) {
     return p;
 }
 
-static void pool_free(void* p, size_t cls) {
+// `touched`: bits of the streams OTHER than `home` that have issued work on the block.  Nobody else: the block is
+// reusable at once by its home stream (stream order).  Otherwise it waits in limbo behind an event on each of them.
+static void pool_free(void* p, size_t cls, int home = 0, unsigned touched = 0) {
     R.in_use -= cls;
     R.cached += cls;
-    R.free_blocks[cls].push_back(p);
+    touched &= ~(1u << home);
+    if (!touched) {
+        blocks_of(home)[cls].push_back(p);
+        return;
+    }
+    LimboBlock l{p, cls, {}};
+    try {
+        for (int sid = 0; sid <= Runtime::NSIDE; ++sid)
+            if (touched & (1u << sid)) l.after.push_back(record_event(sid));
+    } catch (...) {  // (a destructor must not throw: without the events the block is simply never reused)
+        R.cached -= cls;
+        return;
+    }
+    R.ctx[home].limbo.push_back(std::move(l));
 }
 
 static void* host_alloc(size_t bytes, size_t* cls_out) {
@@ -236,11 +371,19 @@ static void* host_alloc(size_t bytes, size_t* cls_out) {
 }
 static void host_free(void* p, size_t cls) { R.host_blocks[cls].push_back(p); }
 
-struct Buf {
+struct LazyOp;
+struct Buf : std::enable_shared_from_this<Buf> {
     double* p = nullptr;
     size_t cls = 0;
     bool borrowed = false;
     bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
+    // streams (see StreamCtx): the pool the block returns to, the stream that wrote the contents, the event recorded behind
+    // that write (side-stream producers only), who has waited for it, and which streams besides `home` have work on the block
+    unsigned char home = 0, prod = 0, seen = 0, touched = 0;
+    std::shared_ptr<EvHolder> ready;
+    unsigned long long birth = 0;   // main-stream operations issued when the buffer was created (Ops::pick_stream)
+    // the contents have not been launched yet (a recorded observation chain): use_buf() launches, or the consumer fuses
+    std::shared_ptr<LazyOp> lazy;
     std::shared_ptr<Buf> dev;
     // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
     // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
@@ -255,15 +398,28 @@ struct Buf {
     ~Buf() {
         if (!p || borrowed) return;
         if (host) host_free(p, cls);
-        else if (R.ready) pool_free(p, cls);
+        else if (R.ready) pool_free(p, cls, home, touched);
     }
 };
+// What a lazy buffer needs to become real: `run(b)` launches the producer into b->p on the current stream; `fuse` (optional)
+// launches it with a consumer's Add folded into its epilogue, writing somewhere else (Ops::observe_chain).
+struct LazyOp {
+    std::function<void(Buf*)> run;
+    std::shared_ptr<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
+    std::shared_ptr<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
+    unsigned long long input_birth = 0;  // when the recording's inputs were there (main-stream operation count): the buffer's age once launched
+};
+// When the values of a buffer were (or, for a recording, could have been) there, in main-stream operations.
+static unsigned long long birth_of(const Buf* b) { return b->lazy ? b->lazy->input_birth : b->birth; }
 
 // (+ 8 doubles of slack: the tiled product reads operands in place and its pipelined x loads request one 64-byte chunk
 // beyond the last one they use — gft_conv_tiled.hip, ConvArgs::operands_slack)
 static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     auto b = std::make_shared<Buf>();
     b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
+    b->home = b->prod = (unsigned char)R.cur;
+    b->birth = main_ops_now();
+    if (R.cur) R.scope_bufs.push_back(b);
     return b;
 }
 static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
@@ -273,6 +429,121 @@ static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
     return b;
 }
 static std::shared_ptr<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
+
+// ---- stream contexts -------------------------------------------------------------------------------------------------------
+static void ctx_swap(StreamCtx& c) {  // the Runtime's per-stream fields <-> a saved context
+    std::swap(c.stream, R.stream);
+    c.free_blocks.swap(R.free_blocks);
+    std::swap(c.d_flag, R.d_flag);
+    std::swap(c.d_scratch, R.d_scratch);
+    std::swap(c.d_wit, R.d_wit);
+    std::swap(c.h_pinned, R.h_pinned);
+    std::swap(c.h_mail, R.h_mail);
+    std::swap(c.d_mail, R.d_mail);
+    std::swap(c.mail_seq, R.mail_seq);
+}
+static void switch_ctx(int to) {
+    if (to == R.cur) return;
+    ctx_swap(R.ctx[R.cur]);  // park the current fields
+    ctx_swap(R.ctx[to]);     // bring in the target's
+    R.cur = to;
+}
+static void stream_wait(const EvHolder& h) {  // the CURRENT stream waits for the event
+    hipEvent_t ev = h.ev;
+    hipStream_t st = R.stream;
+    enqueue_task([ev, st] { lq_note((hipStreamWaitEvent)(st, ev, 0), nullptr, "hipStreamWaitEvent (stream hand-over)"); });
+    R.stats_side[1]++;
+}
+static void force_buf(Buf* b);
+// Every access to a device buffer's contents on behalf of work about to be issued on the current stream.
+static inline void use_buf(Buf* b) {
+    if (b->host) return;
+    if (b->lazy) force_buf(b);
+    const unsigned bit = 1u << R.cur;
+    if (b->prod != R.cur && b->ready && !(b->seen & bit)) {
+        stream_wait(*b->ready);
+        b->seen |= (unsigned char)bit;
+    }
+    if (b->home != R.cur) b->touched |= (unsigned char)bit;
+}
+// Side scope: the launches between enter and leave go to side stream `sid` (see StreamCtx).
+static void side_enter(int sid) {
+    if (R.cur != 0) throw Error("internal: nested side scope");
+    StreamCtx& c = R.ctx[sid];
+    const unsigned long long mo = main_ops_now();
+    if (c.entry_ops != mo) {  // main has issued something since this stream last synchronised with it
+        hipEvent_t ev = c.ev_entry;
+        hipStream_t ms = R.stream, ss = c.stream;
+        enqueue_task([ev, ms, ss] {
+            lq_note((hipEventRecord)(ev, ms), nullptr, "hipEventRecord (main stream, side scope)");
+            lq_note((hipStreamWaitEvent)(ss, ev, 0), nullptr, "hipStreamWaitEvent (side scope)");
+        });
+        c.entry_ops = main_ops_now();  // (the task itself counted as a main-stream operation)
+    }
+    switch_ctx(sid);
+    R.scope_bufs.clear();
+    R.scope_ops0 = gft::g_stream_ops;
+    R.stats_side[0]++;
+}
+// Ends the scope; the buffers written inside it keep the event that marks their completion.  `join`: the main stream waits
+// for it at once (an operation that found out in mid-flight that it needs main-stream state: ensure_main).
+static void side_leave(bool join) {
+    if (R.cur == 0) return;
+    const int sid = R.cur;
+    std::shared_ptr<EvHolder> ev;
+    if (gft::g_stream_ops != R.scope_ops0) {
+        ev = record_event(sid);
+        for (auto& w : R.scope_bufs)
+            if (auto b = w.lock()) {
+                b->ready = ev;
+                b->seen = (unsigned char)(1u << sid);
+            }
+        R.side_dirty |= 1u << sid;
+    }
+    R.scope_bufs.clear();
+    R.side_ops += gft::g_stream_ops - R.scope_ops0;
+    switch_ctx(0);
+    if (join && ev) {
+        stream_wait(*ev);
+        // (every buffer of the scope is now ordered before main's next operation; they find out one by one in use_buf)
+    }
+}
+struct SideScope {
+    bool on = false;
+    explicit SideScope(int sid) {
+        if (sid > 0 && R.cur == 0) {
+            side_enter(sid);
+            on = true;
+        }
+    }
+    ~SideScope() {
+        if (on && R.cur != 0) {
+            try {
+                side_leave(std::uncaught_exceptions() > 0);
+            } catch (...) {
+                switch_ctx(0);
+            }
+        }
+    }
+};
+// Operations that own main-stream state (the product workspace, the recurrences' side stream) call this first.
+static inline void ensure_main() {
+    if (R.cur != 0) side_leave(true);
+}
+static void force_buf(Buf* b) {
+    std::shared_ptr<LazyOp> op = b->lazy;
+    b->lazy = nullptr;  // (first: run() reaches dp() of OTHER buffers only)
+    b->prod = (unsigned char)R.cur;
+    b->birth = op->input_birth;  // (its inputs' age, not the launch's: what reads it may still be "old news" to the main chain)
+    if (R.cur != 0) R.scope_bufs.push_back(b->shared_from_this());  // written inside the open side scope: gets its event
+    op->run(b);
+}
+static void sync_all_streams() {
+    HIP_OK(hipStreamSynchronize(R.stream));
+    for (int sid = 1; sid <= Runtime::NSIDE; ++sid)
+        if ((R.side_dirty >> sid) & 1u) HIP_OK(hipStreamSynchronize(stream_of(sid)));
+    R.side_dirty = 0;
+}
 
 static void require_ready() {
     if (!R.ready) {
@@ -425,6 +696,7 @@ static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
     const Dims& bs = p.pend ? p.pend->base_shape : p.shape;
     Dims st(bs.size(), 1);
     for (size_t i = bs.size(); i-- > 1;) st[i - 1] = st[i] * bs[i];
+    use_buf(p.buf.get());
     c.p = p.buf->p + (p.pend ? p.pend->base_off : 0);
     c.plane = p.pend ? p.pend->base_numel : p.numel;
     for (size_t j = 0; j < keep.size(); ++j) {
@@ -453,6 +725,7 @@ static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
                         found = true;
                     }
                 if (!found) throw Error("internal: table axis of a deferred chain was collapsed");
+                use_buf(g.tab->dev.get());
                 o.tab = g.tab->dev->p;
                 o.tab_plane = g.tab->len;
             }
@@ -524,8 +797,10 @@ static double* dp(const gft_poly& p) {
             R.stats[7]++;
             trace_mirror(p.numel);
         }
+        use_buf(b->dev.get());
         return b->dev->p;
     }
+    use_buf(b);
     return b->p;
 }
 // true iff every value of the polynomial is host-resident (host-tier buffer, or a lazy handle without a buffer)
@@ -838,6 +1113,7 @@ struct Ops {
         if (p.pend) {  // element 0 of the base, then the chain's stages on the host (same functors)
             double v[2] = {0, 0};
             R.stats[1]++;
+            use_buf(p.buf.get());
             peek(v, p.buf->p + p.pend->base_off, p.pend->base_numel, W);
             for (int i = 0; i < p.pend->n; ++i) stage_apply_first(p.pend->st[i], v);
             out[0] = v[0];
@@ -1213,11 +1489,14 @@ struct Ops {
         }
         Dims shape = max_shape(self, other);
         const bool host = tier_host(prod(shape), self, other);
-        if (!host && (self.pend || other.pend)) {
+        auto recorded = [](const P& p) { return p.buf && !p.buf->host && p.buf->lazy; };
+        if (!host && (self.pend || other.pend || recorded(self) || recorded(other))) {
             // deferred operands: their chains are evaluated inside the add itself (one launch for the whole run of
             // operations that led here)
             Dims ckeep = chain_keep(shape, {&self, &other});
             if (ckeep.size() <= (size_t)MAXD) {
+                P fused;
+                if (fuse_lazy_observe(self, other, subtract, shape, rd, &fused)) return fused;
                 P out = make(shape, rd);
                 if (!self.pend) (void)dp<E>(self);   // plain operands: lazy handles / host-tier tensors get their device buffer
                 if (!other.pend) (void)dp<E>(other);
@@ -1450,6 +1729,7 @@ struct Ops {
     // recurrence step (axis 0 is always an "outer" axis, see gft_kernels.hip).
     static void conv(const HV& x, const HV& y, const HV& z, size_t slab_lo, size_t slab_hi, bool accumulate,
                      bool slab_mode, int j0_min, int j0_excl, int j0_desc) {
+        ensure_main();  // the product workspace, plan arena and non-finite epoch are the main stream's
         Dims keep = collapse_mask({&z.shape}, slab_mode);
         Dims xs = pick(x.shape, keep), ys = pick(y.shape, keep), zs = pick(z.shape, keep);
         if (zs.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
@@ -2390,7 +2670,10 @@ struct Ops {
         auto& cache = caches[host ? 1 : 0];
         auto key = std::make_tuple(table_op, n, len);
         auto it = cache.find(key);
-        if (it != cache.end()) return it->second;
+        if (it != cache.end()) {
+            use_buf(it->second.get());  // (a table another stream uploaded: ordered before this stream's next launch)
+            return it->second;
+        }
         if (cache.size() > 4096) cache.clear();
         std::shared_ptr<Buf> tab = alloc_tier(host, len * W);
         if (host) HK<E>::factor_table(table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
@@ -2543,7 +2826,9 @@ struct Ops {
             return r;
         };
         if (n == 0) return a;
-        if (n == 1 || tier_host(a.numel, a) || n > 4096) return stepwise();
+        // (a single step takes the chain kernel too when chains are recorded: as the epilogue-carrying launch of the Add that
+        // follows, or as a rider, it costs no launch of its own — k_observe_step is the one-launch form)
+        if ((n == 1 && !(R.lazy_observe && R.cur == 0)) || tier_host(a.numel, a) || n > 4096) return stepwise();
         if (n > (size_t)OC_MAX) {  // long chains: OC_MAX steps per launch
             P r = a;
             for (size_t i = 0; i < n; i += OC_MAX) {
@@ -2585,9 +2870,8 @@ struct Ops {
             if (val_is_one(c)) g.c_one |= 1ull << i;
         }
         if (longest > K<E>::OBSERVE_LINE_MAX || prod(S) / S[v] > 0x7fffffffu) return stepwise();
-        P out = make(S, G);
         std::shared_ptr<Buf> tab = cached_table(TAB_DERIV, 1, a.shape[v] - 1);
-        Dims ast = c_strides(a.shape), ost = c_strides(S);
+        Dims ast = c_strides(a.shape), ost = c_strides(S), okeep;
         int nd = 0;
         g.axis = -1;
         for (size_t ax = 0; ax < S.size(); ++ax) {
@@ -2597,6 +2881,7 @@ struct Ops {
             g.a_stride[nd] = ast[ax];
             g.o_stride[nd] = ost[ax];
             if (ax == v) g.axis = nd;
+            okeep.push_back(ax);
             nd++;
         }
         g.nd = nd;
@@ -2607,8 +2892,178 @@ struct Ops {
         g.tab = tab->p;
         g.tab_plane = a.shape[v] - 1;
         g.lw_pad = (longest + 8) / 8 * 8;
-        K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, (unsigned)(prod(S) / S[v]), longest);
+        const unsigned lines = (unsigned)(prod(S) / S[v]);
+        // Where and when (round 5).  An input that is old news to the main stream — the memoised predecessor the first arm of
+        // an `if` reads — starts a chain of its own on a side stream (pick_stream): launched now, beside whatever the main
+        // stream is doing.  Otherwise the chain is RECORDED, not launched: what usually follows is a scaling or two (deferred
+        // stages) and the Add of the two arms, and then the observation kernel runs with that Add as its epilogue (addsub ->
+        // fuse_lazy_observe) — one launch instead of two on the critical path of every `if`.  Anything else that wants the
+        // values launches the plain kernel through use_buf().
+        const int sid = pick_stream(a);
+        if (sid == 0 && R.lazy_observe && R.cur == 0 && a.buf && !a.buf->host) {
+            P out = make(S, G);
+            auto lo = std::make_shared<LazyObs>();
+            lo->a = a;
+            lo->tab = tab;
+            lo->g = g;
+            lo->lines = lines;
+            lo->longest = longest;
+            lo->S = S;
+            lo->okeep = okeep;
+            lo->out_numel = out.numel;
+            auto op = std::make_shared<LazyOp>();
+            op->obs = lo;
+            op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr, b); };
+            op->input_birth = birth_of(a.buf.get());
+            out.buf->lazy = op;
+            pending_obs().push_back(out.buf);
+            return out;
+        }
+        SideScope scope(sid);
+        P out = make(S, G);
+        K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, lines, longest);
         return out;
+    }
+    // A recorded observation chain (observe_chain above): everything its launch needs.
+    struct LazyObs {
+        P a;                        // the input (keeps its buffer alive)
+        std::shared_ptr<Buf> tab;   // derivative factors (the cache may drop its own reference)
+        ObserveChainArgs g;
+        unsigned lines = 0, longest = 0;
+        Dims S, okeep;              // result shape; the result's axes the kernel indexes (its non-unit axes and v)
+        size_t out_numel = 0;
+        bool fused = false;         // a consumer has launched it with its Add folded in: the plain values are (so far) nobody's business
+    };
+    // Recorded chains that nobody has needed yet, most recent last.  The next observation launch of this element type takes
+    // the most recent one whose input is in memory along as its second chain (K<E>::observe_chain_multi): on the way back up
+    // a chain of `if`s every launch of the critical path carries the independent arm of a statement further up.
+    static std::vector<std::weak_ptr<Buf>>& pending_obs() {
+        static std::vector<std::weak_ptr<Buf>> v;
+        return v;
+    }
+    // Launches a recorded chain into `outp` (its own buffer `self`, or a consumer's output with the epilogue `epi`).
+    static void launch_obs(LazyObs& lo, double* outp, size_t out_numel, const ObsEpi* epi, Buf* self) {
+        const double* ap = dp<E>(lo.a);  // (a recorded input is launched first, on its own)
+        std::shared_ptr<Buf> ride;
+        std::shared_ptr<LazyOp> rop;
+        LazyObs* ro = nullptr;
+        auto& pend = pending_obs();
+        if (R.obs_riders)
+            for (size_t i = pend.size(); i-- > 0;) {
+                std::shared_ptr<Buf> b = pend[i].lock();
+                if (!b || !b->lazy || !b->lazy->obs) {
+                    pend.erase(pend.begin() + (long)i);
+                    continue;
+                }
+                LazyObs* c = static_cast<LazyObs*>(b->lazy->obs.get());
+                if (c->fused) {
+                    pend.erase(pend.begin() + (long)i);
+                    continue;
+                }
+                if (b.get() == self || c == &lo) continue;
+                const Buf* ib = c->a.buf.get();
+                if (!ib || ib->host || ib->lazy || c->a.pend) continue;  // its input is not in device memory (yet)
+                ride = b;
+                rop = b->lazy;
+                ro = c;
+                pend.erase(pend.begin() + (long)i);
+                break;
+            }
+        if (!ro) {
+            K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, nullptr, 0, nullptr, 0, nullptr, 0, 0);
+            return;
+        }
+        const double* rap = dp<E>(ro->a);  // (in memory: no launch; another stream's event if need be)
+        ride->lazy = nullptr;
+        ride->prod = (unsigned char)R.cur;
+        ride->birth = rop->input_birth;
+        if (R.cur != 0) R.scope_bufs.push_back(ride);
+        K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, rap, ro->a.numel, ride->p,
+                                  ro->out_numel, &ro->g, ro->lines, ro->longest);
+        R.stats_side[2]++;
+    }
+    // Which stream an operation whose (large) input is `in` is issued to — 0: main.  (i) The input was written on a side
+    // stream and the main stream has not caught up with it yet: stay on that stream (a chain of operations on one arm of an
+    // `if` needs no event at all).  (ii) The input is OLD — at least side_min_age operations have been issued on the main
+    // stream since it was produced, i.e. the main stream has other things to do: the operation starts a chain on the next
+    // side stream.  (iii) Otherwise it is probably the next link of the main stream's own chain: main.
+    static int pick_stream(const P& in, size_t min_numel = 1024) {
+        if (!R.nside || R.cur != 0) return 0;
+        Buf* b = in.buf.get();
+        if (!b || b->host || b->borrowed || b->lazy || in.numel < min_numel) return 0;
+        if (b->prod != 0 && b->ready && !(b->seen & 1u)) return b->prod <= R.nside ? b->prod : 0;
+        if (main_ops_now() - birth_of(b) >= R.side_min_age) {
+            R.next_side = R.next_side % (unsigned)R.nside + 1;
+            return (int)R.next_side;
+        }
+        return 0;
+    }
+    // addsub(self, other) where one operand is a chain on top of a recorded observation whose result is the whole output:
+    // the observation kernel runs with the other operand's chain and the Add as its epilogue (ObsEpi).  false = not this
+    // case (nothing launched).
+    static bool fuse_lazy_observe(const P& self, const P& other, bool subtract, const Dims& shape, const Dims& rd, P* result) {
+        if (!R.lazy_observe || R.cur != 0) return false;
+        auto lazy_of = [&](const P& p) -> LazyObs* {
+            if (!p.buf || p.buf->host || !p.buf->lazy || !p.buf->lazy->obs) return nullptr;
+            LazyObs* lo = static_cast<LazyObs*>(p.buf->lazy->obs.get());
+            if (!same_dims_mod_trailing_ones(lo->S, shape) || !same_dims_mod_trailing_ones(p.shape, shape)) return nullptr;
+            if (p.pend) {
+                const Pend& q = *p.pend;
+                if (q.padded || q.base_off != 0 || q.mat || !same_dims_mod_trailing_ones(q.base_shape, lo->S)) return nullptr;
+            }
+            return lo;
+        };
+        // prefer the RIGHT operand (when both are recorded, the left one is launched plain by chain_src below — or has been,
+        // on a side stream)
+        LazyObs* lo = lazy_of(other);
+        const bool x_is_other = lo != nullptr;
+        if (!lo) lo = lazy_of(self);
+        if (!lo) return false;
+        const P& X = x_is_other ? other : self;
+        const P& Y = x_is_other ? self : other;
+        if (Y.buf && Y.buf.get() == X.buf.get()) return false;  // (both read the same recording: launch it)
+        // every axis the other operand's chain indexes must be one of the kernel's axes
+        Dims ckeep = chain_keep(shape, {&self, &other});
+        auto pos = [&](size_t ax) -> int {
+            for (size_t j = 0; j < lo->okeep.size(); ++j)
+                if (lo->okeep[j] == ax) return (int)j;
+            return -1;
+        };
+        for (size_t ax : ckeep)
+            if (pos(ax) < 0) return false;
+        ObsEpi e;
+        std::memset(&e, 0, sizeof(e));
+        e.mode = x_is_other ? 1 : 2;
+        e.subtract = subtract ? 1 : 0;
+        if (X.pend) {
+            e.npost = X.pend->n;
+            for (int i = 0; i < X.pend->n; ++i) {
+                const PendStage& s = X.pend->st[i];
+                e.post[i].kind = s.kind;
+                e.post[i].s = Scalar2{s.s[0], s.s[1]};
+                e.post[i].axis = 0;
+                if (s.kind == CH_MUL_TAB) {
+                    const int j = pos((size_t)s.axis);
+                    if (j < 0) return false;
+                    e.post[i].axis = j;
+                    use_buf(s.tab->dev.get());
+                    e.post[i].tab = s.tab->dev->p;
+                    e.post[i].tab_plane = s.tab->len;
+                }
+            }
+        }
+        // From here on the recording is spoken for: bringing Y into memory may launch OTHER recorded chains (Y's own base, with
+        // a rider) and must not pick this one as its rider — its LazyOp would be released under our feet.
+        std::shared_ptr<LazyOp> keep = X.buf->lazy;
+        lo->fused = true;
+        if (!Y.pend) (void)dp<E>(Y);  // a lazy handle / host-tier tensor gets its device buffer
+        e.y = chain_src_dev(Y, lo->okeep);
+        P out = make(shape, rd);
+        launch_obs(*lo, dp<E>(out), out.numel, &e, X.buf.get());
+        R.stats_side[3]++;
+        R.stats_ex[2]++;
+        *result = out;
+        return true;
     }
     static size_t v_deg(size_t d, size_t n, size_t i) { return d + (n - 1 - i); }  // truncation degree of step i of n
 
@@ -2673,6 +3128,10 @@ struct Ops {
     // ---- subst_var (mt:540-580) -----------------------------------------------------------------------------------------
     static P subst_var(const P& a, size_t v, const P& subst) {
         if (v >= a.shape.size()) return a;
+        // (before anything below launches a recorded input) is the operand old news to the main chain?  Then its Horner loop,
+        // if it comes to one, is recorded and rides along with a later loop's launch (horner_linear_rest, LazyHorner)
+        const bool old_input = R.lazy_horner && R.cur == 0 && a.buf && !a.buf->host && !a.buf->borrowed &&
+                               main_ops_now() - birth_of(a.buf.get()) >= R.side_min_age;
         Dims deg = min_degrees(a, subst);
         if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
         double c[2], m[2];
@@ -2749,8 +3208,12 @@ struct Ops {
         P ca = with_meta_unchecked(a, cshape);
         // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
         const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2;
+        // A Horner loop with a linear substitution (the `--bounds` form of a scaling: subst - constant_term(subst) is a few
+        // ulps around zero) is tens of microseconds of one wave per line — and in the first arm of an `if` it reads a memoised
+        // predecessor: it runs beside the main stream (pick_stream; scans, mailbox and witness words are the side stream's own)
+        SideScope scope(lin_known && (subst.numel <= 2 || on_host(subst)) ? pick_stream(ca) : 0);
         P res;
-        if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res)) return res;
+        if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res, old_input)) return res;
         return horner_exact(ca, v, subst, deg);
     }
     // One Horner coefficient: a[.., i, ..] clipped to deg (mt:571-576)
@@ -2790,7 +3253,7 @@ struct Ops {
     }
     static constexpr size_t WIT_SLOTS = 8192;
     static bool horner_speculative(const P& ca, size_t v, const P& subst, const Dims& deg, bool lin_known, const double c[2],
-                                   const double m[2], size_t w, P* result) {
+                                   const double m[2], size_t w, P* result, bool old_input = false) {
         ScanCtx sc_hs("subst_var.horner_speculative");
         P res = zero_with(deg);
         bool res_nonlinear_seen = false;
@@ -2865,7 +3328,9 @@ struct Ops {
                     if (ahead_on && !tok.done && R.fuse_horner && lin_known && res.shape.size() == deg.size()) {
                         if (i >= 1 && (proven || ahead_wit)) {
                             if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
-                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16);
+                            // a proven loop on an operand the main chain has long passed: RECORDED (its launch needs no guard —
+                            // nobody looks at the handle before the verdict below is in — and is dropped if the verdict is "linear")
+                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16, proven && old_input);
                         }
                         // ... or the single fused step where the whole-loop launch does not apply: the last step (nothing is
                         // speculated about its result), or any step of a proven loop (no witness to raise)
@@ -3088,8 +3553,61 @@ struct Ops {
     // (horner_speculative), so a step where the speculation fails is redone by the exact loop.
     // Steps i, i-1, .., 0 in one launch (k_horner_linear_loop) when the final tensor is small enough for a single
     // workgroup to be the faster machine (a launch per step costs ~4 us of host time + ~4 us on the device).
+    // A recorded linear Horner loop (horner_linear_rest with `defer`): everything its launch needs.
+    struct LazyHorner {
+        P res, ca;                  // incoming accumulator and coefficient tensor (keep their buffers alive)
+        HornerLoopArgs g;
+        unsigned lines = 0;
+        size_t fn = 0;
+    };
+    static std::vector<std::weak_ptr<Buf>>& pending_horner() {  // recorded loops nobody has needed yet, most recent last
+        static std::vector<std::weak_ptr<Buf>> v;
+        return v;
+    }
+    // Launches a loop — a recorded one into its own buffer `self`, or a fresh one — and takes up to two recorded loops along
+    // (K<E>::horner_linear_loop's riders) where the kernel the launch resolves to can carry them.
+    static void launch_horner(const P& res, const P& ca, double* outp, size_t fn, const HornerLoopArgs& g, unsigned lines, unsigned* wit, Buf* self) {
+        const double* rp = dp<E>(res);
+        const double* cp = dp<E>(ca);
+        HornerRider riders[2];
+        std::shared_ptr<Buf> rbuf[2];
+        std::shared_ptr<LazyOp> rop[2];
+        int nr = 0;
+        auto& pend = pending_horner();
+        if (R.horner_riders && !pend.empty() && K<E>::horner_can_carry(g))
+            for (size_t k = pend.size(); k-- > 0 && nr < 2;) {
+                std::shared_ptr<Buf> b = pend[k].lock();
+                if (!b || !b->lazy || !b->lazy->horner) {
+                    pend.erase(pend.begin() + (long)k);
+                    continue;
+                }
+                if (b.get() == self) continue;
+                LazyHorner* h = static_cast<LazyHorner*>(b->lazy->horner.get());
+                auto in_memory = [](const P& p) { return p.buf && !p.buf->lazy && !p.pend; };
+                if (!in_memory(h->res) || !in_memory(h->ca) || !K<E>::horner_can_ride(h->g)) continue;
+                rbuf[nr] = b;
+                rop[nr] = b->lazy;
+                HornerRider& r = riders[nr];
+                r.res0 = dp<E>(h->res);  // (in memory: no launch)
+                r.rp0 = h->res.numel;
+                r.a = dp<E>(h->ca);
+                r.ap = h->ca.numel;
+                r.out = b->p;
+                r.plane = h->fn;
+                r.g = h->g;
+                r.lines = h->lines;
+                b->lazy = nullptr;
+                b->prod = (unsigned char)R.cur;
+                b->birth = rop[nr]->input_birth;
+                if (R.cur != 0) R.scope_bufs.push_back(b);
+                pend.erase(pend.begin() + (long)k);
+                ++nr;
+                R.stats_side[2]++;
+            }
+        K<E>::horner_linear_loop(R.stream, rp, res.numel, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
+    }
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
-                                   const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr) {
+                                   const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr, bool defer = false) {
         const size_t nd = deg.size();
         Dims oc = ca.shape;
         oc[v] = 1;
@@ -3155,7 +3673,30 @@ struct Ops {
             g.stat = d_stat;
         }
         g.guard = guard;
-        K<E>::horner_linear_loop(R.stream, dp<E>(res), res.numel, dp<E>(ca), ca.numel, dp<E>(out), fn, g, (unsigned)(fn / fs[w]), wit);
+        const unsigned lines = (unsigned)(fn / fs[w]);
+        if (defer && !wit && !(hdiag & 64) && res.buf && ca.buf) {
+            g.guard = nullptr;
+            if (K<E>::horner_can_ride(g)) {
+                (void)dp<E>(res);  // (both are in memory already — the scan read them —; a chain would be settled here, once)
+                (void)dp<E>(ca);
+                auto lh = std::make_shared<LazyHorner>();
+                lh->res = res;
+                lh->ca = ca;
+                lh->g = g;
+                lh->lines = lines;
+                lh->fn = fn;
+                auto op = std::make_shared<LazyOp>();
+                op->horner = lh;
+                op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr, b); };
+                op->input_birth = std::max(birth_of(res.buf.get()), birth_of(ca.buf.get()));
+                out.buf->lazy = op;
+                pending_horner().push_back(out.buf);
+                *result = out;
+                return true;
+            }
+            g.guard = guard;
+        }
+        launch_horner(res, ca, dp<E>(out), fn, g, lines, wit, out.buf.get());
         *result = out;
         return true;
     }
@@ -3571,6 +4112,34 @@ int gft_init(int device) {
         std::memset(R.h_mail, 0, 4096);
         HIP_OK(hipHostGetDevicePointer((void**)&R.d_mail, R.h_mail, 0));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
+        // side streams: each with the per-stream scratch the main stream has (scan state, witness words, mailbox, staging)
+        for (int sid = 1; sid <= Runtime::NSIDE; ++sid) {
+            StreamCtx& c = R.ctx[sid];
+            HIP_OK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&c.ev_entry, hipEventDisableTiming));
+            HIP_OK(hipMalloc((void**)&c.d_flag, 1024 + 128 * 64));
+            HIP_OK(hipMemset(c.d_flag, 0, 1024 + 128 * 64));
+            unsigned init[64] = {0};
+            init[8] = 0xffffffffu;
+            HIP_OK(hipMemcpy(c.d_flag, init, sizeof(init), hipMemcpyHostToDevice));
+            HIP_OK(hipMalloc((void**)&c.d_scratch, 256));
+            HIP_OK(hipMalloc((void**)&c.d_wit, sizeof(unsigned) * 8192));
+            HIP_OK(hipHostMalloc((void**)&c.h_pinned, 4096, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&c.h_mail, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(c.h_mail, 0, 4096);
+            HIP_OK(hipHostGetDevicePointer((void**)&c.d_mail, c.h_mail, 0));
+            c.mail_seq = 0;
+            c.entry_ops = ~0ull;
+        }
+        R.cur = 0;
+        R.side_ops = 0;
+        R.side_dirty = 0;
+        if (const char* ss = getenv("GFT_SIDE_STREAMS")) R.nside = std::max(0, std::min(Runtime::NSIDE, atoi(ss)));
+        if (const char* sa = getenv("GFT_SIDE_MIN_AGE")) R.side_min_age = (unsigned long long)std::max(0, atoi(sa));
+        if (const char* lo = getenv("GFT_LAZY_OBSERVE")) R.lazy_observe = atoi(lo) != 0;
+        if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
+        if (const char* lh = getenv("GFT_LAZY_HORNER")) R.lazy_horner = atoi(lh) != 0;
+        if (const char* hr = getenv("GFT_HORNER_RIDERS")) R.horner_riders = atoi(hr) != 0;
         R.device = device;
         if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
             double v = atof(tm);
@@ -3607,8 +4176,11 @@ int gft_init(int device) {
 void gft_shutdown(void) {
     if (!R.ready) return;
     lq_shutdown();
+    if (R.cur != 0) switch_ctx(0);
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
+    for (int sid = 1; sid <= Runtime::NSIDE; ++sid)
+        if (R.ctx[sid].stream) (void)hipStreamSynchronize(R.ctx[sid].stream);
     for (auto& c : g_pow_tabs) c.clear();  // device tables of this context: back into the pool before it is freed
     dwf_release_orders();
     staged_release_scratch();
@@ -3619,6 +4191,27 @@ void gft_shutdown(void) {
     for (auto& kv : R.free_blocks)
         for (void* q : kv.second) (void)hipFree(q);
     R.free_blocks.clear();
+    for (auto& l : R.ctx[0].limbo) (void)hipFree(l.p);
+    R.ctx[0].limbo.clear();
+    for (int sid = 1; sid <= Runtime::NSIDE; ++sid) {
+        StreamCtx& c = R.ctx[sid];
+        for (auto& kv : c.free_blocks)
+            for (void* q : kv.second) (void)hipFree(q);
+        c.free_blocks.clear();
+        for (auto& l : c.limbo) (void)hipFree(l.p);
+        c.limbo.clear();
+        if (c.d_flag) (void)hipFree(c.d_flag);
+        if (c.d_scratch) (void)hipFree(c.d_scratch);
+        if (c.d_wit) (void)hipFree(c.d_wit);
+        if (c.h_pinned) (void)hipHostFree(c.h_pinned);
+        if (c.h_mail) (void)hipHostFree(c.h_mail);
+        if (c.ev_entry) (void)hipEventDestroy(c.ev_entry);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c = StreamCtx();
+    }
+    R.scope_bufs.clear();
+    for (hipEvent_t ev : R.ev_free) (void)hipEventDestroy(ev);
+    R.ev_free.clear();
     R.cached = 0;
     if (R.conv_ws) (void)hipFree(R.conv_ws);
     R.conv_ws = nullptr;
@@ -3642,15 +4235,16 @@ void gft_shutdown(void) {
 
 int gft_set_stream(void* s) {
     return guard_int([&] {
-        HIP_OK(hipStreamSynchronize(R.stream));
+        sync_all_streams();
         R.stream = s ? (hipStream_t)s : R.own_stream;
+        for (int sid = 1; sid <= Runtime::NSIDE; ++sid) R.ctx[sid].entry_ops = ~0ull;  // (a new main stream: nothing is ordered against it yet)
         return 0;
     });
 }
 void* gft_get_stream(void) { return (void*)R.stream; }
 int gft_synchronize(void) {
     return guard_int([&] {
-        HIP_OK(hipStreamSynchronize(R.stream));
+        sync_all_streams();  // the main stream and every side stream that has had work since the last call
         return 0;
     });
 }
@@ -3660,10 +4254,10 @@ void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
 size_t gft_op_stats_ex(size_t* out, size_t cap) {
-    const size_t v[7] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
-                         R.stats_shallow[0], R.stats_shallow[1]};
-    for (size_t i = 0; i < 7 && i < cap; ++i) out[i] = v[i];
-    return 7;
+    const size_t v[11] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
+                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3]};
+    for (size_t i = 0; i < 11 && i < cap; ++i) out[i] = v[i];
+    return 11;
 }
 void gft_pool_stats(size_t out[3]) {
     out[0] = R.in_use;
@@ -3700,6 +4294,12 @@ int gft_set_option(const char* name, double value) {
     else if (n == "exp_right") R.exp_right = value != 0;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
+    else if (n == "side_streams") R.nside = value < 0 ? 0 : std::min<int>(Runtime::NSIDE, (int)value);  // < 0: default (off)
+    else if (n == "side_min_age") R.side_min_age = value < 0 ? 2 : (unsigned long long)value;
+    else if (n == "lazy_observe") R.lazy_observe = value != 0;
+    else if (n == "obs_riders") R.obs_riders = value != 0;
+    else if (n == "lazy_horner") R.lazy_horner = value != 0;
+    else if (n == "horner_riders") R.horner_riders = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default
     else if (n == "debug_fail_next_launch") g_fail_next_launch.store(value != 0 ? 1 : 0);  // test knob (gft_launch.hpp)
@@ -4173,7 +4773,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::derivative_truncated(*a, v, n, d); });                              \
     }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
-        return guard([&] { return Ops<E>::observe_step(*a, v, x, c, d); });                                   \
+        return guard([&] { return R.lazy_observe ? Ops<E>::observe_chain(*a, v, x, c, 1, d) : Ops<E>::observe_step(*a, v, x, c, d); }); \
     }                                                                                                         \
     gft_poly* PFX##observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
         return guard([&] { return Ops<E>::observe_chain(*a, v, x, cs, n, d); });                              \

@@ -17,6 +17,7 @@ namespace gft {
 unsigned long long g_launches = 0;
 unsigned long long g_host_horner_stats[4] = {0, 0, 0, 0};  // gft_host.hpp (GFT_TRACE_API)
 unsigned long long g_launches_in_place = 0;
+unsigned long long g_stream_ops = 0;
 
 // ------------------------------------------------------------------------------------------
 // the launch thread (gft_launch.hpp): single-producer / single-consumer ring of launch closures
@@ -508,12 +509,17 @@ void K<E>::addsub_padded(hipStream_t st, const DView& out, const DView& a, const
 // deferred elementwise chains (gft_kernels.hpp ChainSrc): materialise one, or add / subtract two on the fly
 // ------------------------------------------------------------------------------------------
 template <class E>
+__device__ __forceinline__ typename E::V chain_apply(const ChainStage* st, int nstages, const int* pad, typename E::V x, const unsigned* k, bool first);
+template <class E>
 __device__ __forceinline__ typename E::V chain_eval(const ChainSrc& c, size_t off, const unsigned* k, bool first) {
-    typedef typename E::V V;
-    V x = E::ld(c.p, c.plane, off);
+    return chain_apply<E>(c.st, c.nstages, c.pad, E::ld(c.p, c.plane, off), k, first);
+}
+// the recorded stages on a value that is already in a register (`pad`: the view's front pad per axis, or null)
+template <class E>
+__device__ __forceinline__ typename E::V chain_apply(const ChainStage* st, int nstages, const int* pad, typename E::V x, const unsigned* k, bool first) {
 #pragma unroll 1
-    for (int i = 0; i < c.nstages; ++i) {
-        const ChainStage& g = c.st[i];
+    for (int i = 0; i < nstages; ++i) {
+        const ChainStage& g = st[i];
         switch (g.kind) {
             case CH_LMUL_S: x = E::mul(E::from(g.s), x); break;
             case CH_MUL_S: x = E::mul(x, E::from(g.s)); break;
@@ -525,7 +531,7 @@ __device__ __forceinline__ typename E::V chain_eval(const ChainSrc& c, size_t of
                 if (first) x = E::sub(x, E::from(g.s));
                 x = E::neg(x);
                 break;
-            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab, g.tab_plane, k[g.axis] - (unsigned)c.pad[g.axis])); break;  // (the view's own coordinate)
+            case CH_MUL_TAB: x = E::mul(x, E::ld(g.tab, g.tab_plane, k[g.axis] - (pad ? (unsigned)pad[g.axis] : 0u))); break;  // (the view's own coordinate)
             default: break;
         }
     }
@@ -950,20 +956,23 @@ void K<E>::observe_step(hipStream_t st, const double* a, size_t a_plane, double*
     else GFT_LAUNCH((k_observe_step<E, size_t>), dim3(grid_for(total)), dim3(256), 0, st, a, a_plane, out, out_plane, args, total);
 }
 
-template <class E>
-__global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
-                                                        ObserveChainArgs g) {
+template <class E, bool EPI>
+__device__ __forceinline__ void observe_chain_line(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
+                                                   const ObserveChainArgs& g, const typename std::conditional<EPI, ObsEpi, int>::type& epi,
+                                                   unsigned line, double* oc_lds) {
     typedef typename E::V V;
-    extern __shared__ double oc_lds[];  // [buffer][plane][lw_pad]
     size_t aoff = 0, ooff = 0;
+    unsigned kk[MAXD];  // (EPI) the line's coordinates on the collapsed axes; kk[axis] is filled per element
     {
-        size_t r = blockIdx.x;
+        size_t r = line;
 #pragma unroll
         for (int ax = MAXD - 1; ax >= 0; --ax) {
+            kk[ax] = 0;
             if (ax < g.nd && ax != g.axis) {
                 const unsigned d = g.fs[ax];
                 const unsigned k = (unsigned)(r % d);
                 r /= d;
+                kk[ax] = k;
                 aoff += (size_t)k * g.a_stride[ax];
                 ooff += (size_t)k * g.o_stride[ax];
             }
@@ -977,6 +986,27 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
     const unsigned k0 = threadIdx.x, ntab = g.len0 ? g.len0 - 1 : 0;
     const V tab_lo = (k0 >= 1 && k0 - 1 < ntab) ? E::ld(g.tab, g.tab_plane, k0 - 1) : E::zero();
     const V tab_hi = k0 < ntab ? E::ld(g.tab, g.tab_plane, k0) : E::zero();
+    // (EPI) the other operand's element at this thread's first output position: requested NOW, so that its memory latency runs
+    // beside the chain's instead of behind it
+    bool y_in0 = false, y_first0 = false, line_first = true;
+    size_t y_off_line = 0;
+    V y_raw0 = E::zero();
+    if constexpr (EPI) {
+        y_in0 = true;
+        y_first0 = true;
+#pragma unroll
+        for (int ax = 0; ax < MAXD; ++ax)
+            if (ax < g.nd && ax != g.axis) {
+                const unsigned ka = kk[ax] - (unsigned)epi.y.pad[ax];  // (wraps below the pad: fails the box test)
+                if (ka >= epi.y.box[ax]) y_in0 = false;
+                if (ka != 0) y_first0 = false;
+                if (kk[ax] != 0) line_first = false;
+                y_off_line += (size_t)ka * epi.y.stride[ax];
+            }
+        const unsigned ka = k0 - (unsigned)epi.y.pad[g.axis];
+        const bool in0 = y_in0 && ka < epi.y.box[g.axis];
+        if (in0) y_raw0 = E::ld(epi.y.p, epi.y.plane, y_off_line + (size_t)ka * epi.y.stride[g.axis]);
+    }
     for (unsigned t = 0; t < g.nsteps; ++t) {
         const unsigned dlt = g.dl[t], lout = g.lo[t];
         const bool first = t == 0, last = t + 1 == g.nsteps;
@@ -1001,19 +1031,93 @@ __global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict
                 }
             }
             if (!c_one) res = E::mulw(cv, res);
-            if (last) E::st(out, op, ooff + (size_t)kv * svo, res);
-            else E::st(dst_l, g.lw_pad, kv, res);
+            if (!last) E::st(dst_l, g.lw_pad, kv, res);
+            else if constexpr (!EPI) E::st(out, op, ooff + (size_t)kv * svo, res);
+            else {
+                // the consumer's Add, element for element k_chain<E, true>'s operations
+                kk[g.axis] = kv;
+                const V X = chain_apply<E>(epi.post, epi.npost, nullptr, res, kk, line_first && kv == 0);
+                const unsigned ka = kv - (unsigned)epi.y.pad[g.axis];
+                const bool iny = y_in0 && ka < epi.y.box[g.axis];
+                V Y = E::zero();
+                if (iny) {
+                    const V raw = mine ? y_raw0 : E::ld(epi.y.p, epi.y.plane, y_off_line + (size_t)ka * epi.y.stride[g.axis]);
+                    Y = chain_apply<E>(epi.y.st, epi.y.nstages, epi.y.pad, raw, kk, y_first0 && ka == 0);
+                }
+                V v = E::zero();
+                if (epi.mode == 1) {
+                    if (iny) v = E::add(v, Y);
+                    v = epi.subtract ? E::sub(v, X) : E::add(v, X);
+                } else {
+                    v = E::add(v, X);
+                    if (iny) v = epi.subtract ? E::sub(v, Y) : E::add(v, Y);
+                }
+                E::st(out, op, ooff + (size_t)kv * svo, v);
+            }
         }
         lds_barrier();  // the line passes through LDS only
     }
 }
+template <class E, bool EPI>
+__global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
+                                                        ObserveChainArgs g, typename std::conditional<EPI, ObsEpi, int>::type epi) {
+    extern __shared__ double oc_lds[];  // [buffer][plane][lw_pad]
+    observe_chain_line<E, EPI>(a, ap, out, op, g, epi, blockIdx.x, oc_lds);
+}
+// Two independent observation chains in ONE launch (round 5: horizontal fusion).  A recorded chain whose input has been
+// there for a while — the first arm of an `if` reads a memoised predecessor — rides along with the next observation launch
+// of the main chain instead of costing a launch (and its ~5 us of dependent latencies) of its own: workgroups
+// [0, lines0) run the first chain (with its epilogue, if any), the rest the second.
+struct ObsRider {
+    const double* a;
+    size_t ap;
+    double* out;
+    size_t op;
+    ObserveChainArgs g;
+};
+template <class E, bool EPI>
+__global__ void __launch_bounds__(1024) k_observe_chain2(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
+                                                         ObserveChainArgs g, typename std::conditional<EPI, ObsEpi, int>::type epi,
+                                                         unsigned lines0, ObsRider r) {
+    extern __shared__ double oc_lds[];
+    if (blockIdx.x < lines0) observe_chain_line<E, EPI>(a, ap, out, op, g, epi, blockIdx.x, oc_lds);
+    else observe_chain_line<E, false>(r.a, r.ap, r.out, r.op, r.g, 0, blockIdx.x - lines0, oc_lds);
+}
 template <class E>
 void K<E>::observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                          const ObserveChainArgs& args, unsigned lines, unsigned longest) {
+    observe_chain_multi(st, a, a_plane, out, out_plane, args, lines, longest, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0);
+}
+template <class E>
+void K<E>::observe_chain_epi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                             const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi& epi) {
+    observe_chain_multi(st, a, a_plane, out, out_plane, args, lines, longest, &epi, nullptr, 0, nullptr, 0, nullptr, 0, 0);
+}
+// the general form: optional epilogue on the first chain, optional second chain (rider)
+template <class E>
+void K<E>::observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                               const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi,
+                               const double* ra, size_t ra_plane, double* rout, size_t rout_plane, const ObserveChainArgs* rargs,
+                               unsigned rlines, unsigned rlongest) {
     if (lines == 0 || args.nsteps == 0) return;
-    const unsigned threads = std::min<unsigned>(1024, (longest + 63) / 64 * 64);
-    const size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
-    GFT_LAUNCH(k_observe_chain<E>, dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args);
+    const bool two = rargs && rlines && rargs->nsteps;
+    const unsigned lg = two ? std::max(longest, rlongest) : longest;
+    const unsigned threads = std::min<unsigned>(1024, (lg + 63) / 64 * 64);
+    const unsigned pad = two ? std::max(args.lw_pad, rargs->lw_pad) : args.lw_pad;
+    const size_t lds = (size_t)2 * E::W * pad * sizeof(double);
+    if (!two) {
+        if (epi) GFT_LAUNCH((k_observe_chain<E, true>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi);
+        else GFT_LAUNCH((k_observe_chain<E, false>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0);
+        return;
+    }
+    ObsRider r;
+    r.a = ra;
+    r.ap = ra_plane;
+    r.out = rout;
+    r.op = rout_plane;
+    r.g = *rargs;
+    if (epi) GFT_LAUNCH((k_observe_chain2<E, true>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi, lines, r);
+    else GFT_LAUNCH((k_observe_chain2<E, false>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0, lines, r);
 }
 
 template <class E>
@@ -2088,28 +2192,34 @@ struct LeanConsts<EIv> {
     }
 };
 
+// One line of the loop: `line` = the line's index among the loop's lines, `nw` = the waves the line needs (the workgroup may
+// have more when two loops share a launch: the surplus waves only attend the one barrier).
 template <class E>
-__global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __restrict__ res0, size_t rp0,
-                                                            const double* __restrict__ a, size_t ap,
-                                                            double* __restrict__ out, size_t plane, HornerLoopArgs g,
-                                                            unsigned* __restrict__ wit) {
+__device__ __forceinline__ void horner_pipe_point_line(const double* __restrict__ res0, size_t rp0, const double* __restrict__ a, size_t ap,
+                                                       double* __restrict__ out, size_t plane, const HornerLoopArgs& g,
+                                                       unsigned* __restrict__ wit, const unsigned line, const unsigned nw, double* hp_lds) {
     typedef typename E::V V;
     typedef LeanConsts<E> LC;
-    extern __shared__ double hp_lds[];  // [boundary b][plane][nsteps] rings, [plane][nsteps] coefficients, counters, dummy area
+    // hp_lds: [boundary b][plane][nsteps] rings, [plane][nsteps] coefficients, counters, dummy area
     if (g.guard && *g.guard != 0u) return;  // the scan queued before this launch found the accumulator linear: the speculation failed
     const unsigned lw = g.fs[g.w];
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const unsigned nthreads = nw * 64u;
+    if (wave >= nw) {  // (a surplus wave of a shared launch)
+        (void)__syncthreads_and(1);
+        return;
+    }
     const unsigned nslots = g.nsteps;
     const double* ring_b = hp_lds + (size_t)(wave ? wave - 1 : 0) * E::W * nslots;
     double* ring_a = hp_lds + (size_t)wave * E::W * nslots;
     double* coef_l = hp_lds + (size_t)(nw - 1) * E::W * nslots;
     double* dummy = coef_l + (size_t)E::W * nslots;  // 64 x value planes nobody reads (where the non-publishing lanes write)
-    for (size_t i = threadIdx.x; i < (size_t)(nw - 1) * E::W * nslots; i += blockDim.x) ring_store_bits(hp_lds + i, RING_EMPTY);
+    for (size_t i = threadIdx.x; i < (size_t)(nw - 1) * E::W * nslots; i += nthreads) ring_store_bits(hp_lds + i, RING_EMPTY);
     size_t foff_b = 0, aoff_b = 0, roff0_b = 0;
     bool off_p0 = true, off_o0 = true, in_c_b = true;
     unsigned wit_from = 2;
     {
-        size_t r = blockIdx.x;
+        size_t r = line;
         unsigned nz_coords = 0;
         bool big = false;
 #pragma unroll
@@ -2136,11 +2246,11 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __rest
     const unsigned degw = g.deg[g.w], ocw = g.coeff_scalar ? 0u : g.oc[g.w];
     const unsigned kw = threadIdx.x, kwm1 = kw - 1u;  // position 0: kwm1 = 2^32 - 1, below no extent
     const bool have = kw < lw;
-    const bool line_takes = g.coeff_scalar ? blockIdx.x == 0 : in_c_b;
+    const bool line_takes = g.coeff_scalar ? line == 0 : in_c_b;
     const bool takes_c = have && kw == 0 && line_takes;
     // stage the line's coefficients; are they all usable as lean operands?
     int coefs_ok = 1;
-    for (unsigned i = threadIdx.x; i < g.nsteps; i += blockDim.x) {
+    for (unsigned i = threadIdx.x; i < g.nsteps; i += nthreads) {
         const V cf = line_takes ? E::ld(a, ap, (size_t)(g.first_i - i) * g.a_vstride + aoff_b) : E::zero();
         E::st(coef_l, nslots, i, cf);
         if (line_takes && !LC::operand_ok(cf)) coefs_ok = 0;
@@ -2276,27 +2386,100 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __rest
 }
 
 template <class E>
+__global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __restrict__ res0, size_t rp0,
+                                                            const double* __restrict__ a, size_t ap,
+                                                            double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                            unsigned* __restrict__ wit) {
+    extern __shared__ double hp_lds[];
+    horner_pipe_point_line<E>(res0, rp0, a, ap, out, plane, g, wit, blockIdx.x, blockDim.x >> 6, hp_lds);
+}
+// Two (three) independent loops in ONE launch (round 5: horizontal fusion).  A loop that was recorded instead of launched —
+// the first arm of an `if` substitutes into a memoised predecessor, nobody needs its result for a while — rides along with
+// the next loop the main chain launches: the lines of the riders are further workgroups of the same grid, each with its own
+// argument block; the carrier's guard word (a speculative launch queued behind its scan) only stops the carrier's lines.
+template <class E>
+__global__ void __launch_bounds__(1024) k_horner_pipe_point_multi(const double* __restrict__ res0, size_t rp0,
+                                                                  const double* __restrict__ a, size_t ap,
+                                                                  double* __restrict__ out, size_t plane, HornerLoopArgs g,
+                                                                  unsigned* __restrict__ wit, unsigned lines0, HornerRider r1, HornerRider r2) {
+    extern __shared__ double hp_lds[];
+    const unsigned b = blockIdx.x;
+    if (b < lines0) horner_pipe_point_line<E>(res0, rp0, a, ap, out, plane, g, wit, b, (g.fs[g.w] + 63u) >> 6, hp_lds);
+    else if (b - lines0 < r1.lines)
+        horner_pipe_point_line<E>(r1.res0, r1.rp0, r1.a, r1.ap, r1.out, r1.plane, r1.g, nullptr, b - lines0, (r1.g.fs[r1.g.w] + 63u) >> 6, hp_lds);
+    else
+        horner_pipe_point_line<E>(r2.res0, r2.rp0, r2.a, r2.ap, r2.out, r2.plane, r2.g, nullptr, b - lines0 - r1.lines, (r2.g.fs[r2.g.w] + 63u) >> 6, hp_lds);
+}
+
+// the LDS a loop needs on the POINT pipeline, or 0 if it does not run there (lines > 1024, non-point coefficient boxes, rings
+// beyond 60 KB, GFT_HORNER_PIPE / GFT_HORNER_LEAN = 0)
+template <class E>
+static size_t horner_pipe_point_lds(const HornerLoopArgs& args) {
+    static const bool pipe_on = [] {
+        const char* e = getenv("GFT_HORNER_PIPE");  // A/B knob (0 = the LDS ping-pong loop below)
+        return e ? atoi(e) != 0 : true;
+    }();
+    static const bool lean_on = [] {
+        const char* e = getenv("GFT_HORNER_LEAN");  // A/B knob (0 = the generic pipeline step for POINT lines too)
+        return e ? atoi(e) != 0 : true;
+    }();
+    const unsigned lw = args.fs[args.w];
+    if (!pipe_on || !lean_on || lw > 1024) return 0;
+    const bool point = args.coeff_scalar || args.oc[args.w] == 1;
+    if (!point) return 0;
+    const unsigned nwv = (lw + 63) / 64;
+    const size_t lds = (size_t)nwv * E::W * args.nsteps * sizeof(double) + (size_t)128 * 8 + 16;
+    return lds <= 60 * 1024 ? lds : 0;
+}
+template <class E>
+bool K<E>::horner_can_carry(const HornerLoopArgs& args) {
+    return args.nsteps != 0 && horner_pipe_point_lds<E>(args) != 0;
+}
+template <class E>
+bool K<E>::horner_can_ride(const HornerLoopArgs& args) {
+    return args.nsteps != 0 && horner_pipe_point_lds<E>(args) != 0 && args.guard == nullptr;
+}
+template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
-                              size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit) {
-    if (args.nsteps == 0 || lines == 0) return;
+                              size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit, const HornerRider* riders, int nriders) {
+    if (args.nsteps == 0 || lines == 0) {
+        if (nriders > 0) throw std::runtime_error("internal: Horner riders on an empty carrier");
+        return;
+    }
     const unsigned lw = args.fs[args.w];
     // wave pipeline (k_horner_linear_pipe): lines up to 1024 whose boundary rings fit LDS
     static const bool pipe_on = [] {
         const char* e = getenv("GFT_HORNER_PIPE");  // A/B knob (0 = the LDS ping-pong loop below)
         return e ? atoi(e) != 0 : true;
     }();
+    if (const size_t lds0 = horner_pipe_point_lds<E>(args)) {
+        if (nriders <= 0) {
+            GFT_LAUNCH((k_horner_pipe_point<E>), dim3(lines), dim3((lw + 63) / 64 * 64), lds0, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
+            return;
+        }
+        HornerRider r1 = riders[0], r2;
+        if (nriders > 1) r2 = riders[1];
+        else {
+            std::memset(&r2, 0, sizeof(r2));
+            r2.lines = 0;
+        }
+        size_t lds = std::max(lds0, horner_pipe_point_lds<E>(r1.g));
+        unsigned wmax = std::max(lw, r1.g.fs[r1.g.w]);
+        if (nriders > 1) {
+            lds = std::max(lds, horner_pipe_point_lds<E>(r2.g));
+            wmax = std::max(wmax, r2.g.fs[r2.g.w]);
+        }
+        GFT_LAUNCH((k_horner_pipe_point_multi<E>), dim3(lines + r1.lines + r2.lines), dim3((wmax + 63) / 64 * 64), lds, st, res0, res0_plane, a,
+                   a_plane, out, plane, args, wit, lines, r1, r2);
+        return;
+    }
+    if (nriders > 0) throw std::runtime_error("internal: Horner riders on a carrier that is not a POINT pipeline");
     if (pipe_on && lw <= 1024) {
         const unsigned nwv = (lw + 63) / 64;
         const bool point = args.coeff_scalar || args.oc[args.w] == 1;
         const size_t lds = (size_t)(nwv - 1 + (point ? 1 : 0)) * E::W * args.nsteps * sizeof(double) + (point ? (size_t)128 * 8 : 0) + 16;
         if (lds <= 60 * 1024) {
-            static const bool lean_on = [] {
-                const char* e = getenv("GFT_HORNER_LEAN");  // A/B knob (0 = the generic pipeline step for POINT lines too)
-                return e ? atoi(e) != 0 : true;
-            }();
-            if (point && lean_on)
-                GFT_LAUNCH((k_horner_pipe_point<E>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
-            else if (point)
+            if (point)
                 GFT_LAUNCH((k_horner_linear_pipe<E, 8, true>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
             else
                 GFT_LAUNCH((k_horner_linear_pipe<E, 8, false>), dim3(lines), dim3(nwv * 64), lds, st, res0, res0_plane, a, a_plane, out, plane, args, wit);

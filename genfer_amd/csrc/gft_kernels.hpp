@@ -129,6 +129,19 @@ struct ObserveChainArgs {
     unsigned lw_pad;           // LDS line pitch (>= the longest line)
 };
 
+// Epilogue of an observation chain that was recorded lazily and is consumed by an Add / Sub of two tensors (round 5): the
+// kernel applies the recorded elementwise stages `post` to each finished value X (the chain that sat on top of the
+// observation's result), evaluates the OTHER operand's chain Y at the same output index and stores the sum — per element
+// exactly k_chain<E, true>'s operations: mode 1 = (0 + Y) (+|-) X (the observation is the right operand), mode 2 =
+// (0 + X) (+|-) Y.  The output has the observation's own shape, so every element receives its X.
+struct ObsEpi {
+    int mode;                  // 0: none (plain store)
+    int subtract;
+    int npost;
+    ChainStage post[CHAIN_MAX];  // axis: index into the kernel's collapsed axes
+    ChainSrc y;                // over the kernel's collapsed axes
+};
+
 // One Horner step of subst_var with a LINEAR substitution s = c + m*eps_w (mt:566-579, 589-623, 873-880):
 //   out = res * s + coeff_i,   coeff_i = a[.., i, ..] along the substituted axis,
 // computed per element in exactly the order of the reference's op sequence
@@ -174,6 +187,18 @@ struct HornerLoopArgs {
     unsigned long long* stat;  // GFT_HORNER_DIAG & 64: {lean wave-steps, wave-steps} of the POINT pipeline are added here
     const unsigned* guard;     // optional: the launch does nothing if *guard != 0 — the verdict word of the linear scan queued just
                                // before it said "the accumulator IS linear", i.e. the speculation this launch embodies failed
+};
+
+// A whole linear Horner loop that shares another loop's launch (K<E>::horner_linear_loop's riders).
+struct HornerRider {
+    const double* res0;
+    size_t rp0;
+    const double* a;
+    size_t ap;
+    double* out;
+    size_t plane;
+    HornerLoopArgs g;
+    unsigned lines;
 };
 
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
@@ -262,14 +287,25 @@ struct K {
                               size_t out_plane, const HornerArgs& args);
     static constexpr unsigned HORNER_LINE_MAX = 2048;  // longest line along the substitution axis of horner_linear_loop
     // `wit` (optional): wit[t] = 1 if the accumulator after in-kernel step t < nsteps-1 has a non-linearity witness
+    // `riders` (optional, at most 2): further loops that share the launch — only where horner_can_ride() says so for the
+    // carrier and for every rider (the POINT pipeline, no guard)
     static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
-                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit);
+                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit,
+                                   const HornerRider* riders = nullptr, int nriders = 0);
+    static bool horner_can_ride(const HornerLoopArgs& args);
+    static bool horner_can_carry(const HornerLoopArgs& args);
     // *flag = 1 if `t` holds a non-zero coefficient at an index with two non-zero coordinates or a coordinate >= 2:
     // such a tensor is not of the form c + m*x_v (extract_linear, mt:275-294, would say None).  Sticky, no read-back.
     static void witness(hipStream_t st, const DView& t, unsigned* flag);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     static constexpr unsigned OBSERVE_LINE_MAX = 2048;  // longest line along v of observe_chain
+    static void observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                                    const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi,
+                                    const double* ra, size_t ra_plane, double* rout, size_t rout_plane, const ObserveChainArgs* rargs,
+                                    unsigned rlines, unsigned rlongest);
+    static void observe_chain_epi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
+                                  const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi& epi);
     static void observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                               const ObserveChainArgs& args, unsigned lines, unsigned longest);
     // in-place elementwise map over n contiguous elements

@@ -29,6 +29,9 @@
 namespace gft {
 
 extern unsigned long long g_launches;  // launches requested so far (gft_op_stats_ex)
+// every operation handed to a stream so far — launches, queued tasks, and the wrapped hip* calls the API thread makes itself
+// (the side-stream scopes of gft_api.hip tell "nothing was issued on the main stream since" by it)
+extern unsigned long long g_stream_ops;
 
 constexpr size_t LQ_SLOT_BYTES = 4096;  // (k_upload_small's 480 doubles by value are the largest block: 3.9 KB)
 extern unsigned long long g_launches_in_place;  // closures too large for a slot: launched on the calling thread after a full drain
@@ -57,6 +60,7 @@ extern std::atomic<int> g_fail_next_launch;
 template <class F>
 inline void enqueue(F&& f) {
     typedef typename std::decay<F>::type Fn;
+    ++g_stream_ops;
     if (!lq_enabled() || sizeof(Fn) > LQ_SLOT_BYTES) {
         if (lq_enabled()) ++g_launches_in_place;
         launch_drain();
@@ -77,6 +81,7 @@ inline void enqueue(F&& f) {
 template <class F>
 inline void enqueue_task(F&& f) {
     if (lq_debug() & 2) {
+        ++g_stream_ops;
         launch_drain();
         f();
         return;
@@ -107,6 +112,7 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
 #ifndef GFT_LAUNCH_NO_WRAP
 #define GFT_DRAINED(fn, ...)                              \
     ([&](auto&&... a_) {                                  \
+        ++::gft::g_stream_ops;                            \
         ::gft::launch_drain();                            \
         return (fn)(static_cast<decltype(a_)&&>(a_)...);  \
     }(__VA_ARGS__))
