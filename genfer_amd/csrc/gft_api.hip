@@ -170,6 +170,8 @@ struct Runtime {
     std::vector<hipEvent_t> ev_free;        // recycled events (disable-timing)
     size_t stats_side[4] = {0, 0, 0, 0};    // {side scopes, cross-stream waits, observation chains that rode along with another launch, lazy observations fused}
     bool obs_riders = true;                 // "obs_riders" / GFT_OBS_RIDERS: recorded chains ride along with other observation launches
+    size_t stats_nz = 0;                    // linearity scans answered by a "no exact zero" proof
+    bool nz_proofs = true;                  // "nz_proofs" / GFT_NZ_PROOFS: interval tensors proven free of exact zeros skip the Horner loops' linearity scans
     bool lazy_horner = true;                // "lazy_horner" / GFT_LAZY_HORNER: proven Horner loops on old operands are recorded (Ops::horner_linear_rest)
     bool horner_riders = true;              // "horner_riders" / GFT_HORNER_RIDERS: ... and ride along with other loops' launches
     bool lazy_observe = true;               // "lazy_observe" / GFT_LAZY_OBSERVE: observation chains are recorded, not launched (Ops::observe_chain)
@@ -384,6 +386,9 @@ struct Buf : std::enable_shared_from_this<Buf> {
     unsigned long long birth = 0;   // main-stream operations issued when the buffer was created (Ops::pick_stream)
     // the contents have not been launched yet (a recorded observation chain): use_buf() launches, or the consumer fuses
     std::shared_ptr<LazyOp> lazy;
+    // interval tensors: 2 = PROVEN to hold no coefficient that is exactly [0,0] (Ops::nz_of), 1 = holds one / descends from a
+    // tensor that does (nobody asks again), 0 = unknown
+    unsigned char nz = 0;
     std::shared_ptr<Buf> dev;
     // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
     // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
@@ -623,6 +628,7 @@ struct TabEntry {
     std::shared_ptr<Buf> dev;   // W planes of `len` doubles
     std::vector<double> host;   // the same values (element 0 of a chain is host-computable)
     size_t len = 0;
+    int nz = -1;                // (intervals) 1: no entry is exactly [0,0]; -1: not looked at yet
 };
 struct PendStage {
     int kind = 0, axis = 0;
@@ -748,6 +754,44 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
     }
     return keep;
 }
+// ---- "no exact zero anywhere" (round 5, Interval<F64> only) -----------------------------------------------------------------
+// Interval arithmetic does not cancel: a product of two intervals is [0,0] only if a factor is (iv:164-190: the zero and one
+// short-circuits return an operand, everything else is widened outwards, lo < hi), and a sum only if both terms are
+// (iv:126-155).  So "no coefficient of this tensor is exactly [0,0]" is INHERITED by the operations Genfer's observation
+// loops are made of — elementwise stages with non-zero constants, sub-box views, observation steps, linear Horner loops with
+// non-zero c and m, sums of equal shape — and such a tensor with >= 3 coefficients is never of the form c + m*x_v: the
+// per-subst_var linearity scan of the accumulator (a launch and a host round trip, 18 000 per mixture --bounds run) has a
+// known answer.  2 = proven, 1 = holds a zero (or descends from such a tensor: nobody asks again), 0 = unknown.
+template <class E>
+static int nz_of_poly(const gft_poly& p) {
+    if (E::W != 2 || !p.buf || p.buf->host) return 0;
+    const int base = p.buf->nz;
+    if (base != 2 || !p.pend) return base;
+    const Pend& q = *p.pend;
+    if (q.padded) return 1;  // zeros in front
+    for (int i = 0; i < q.n; ++i) {
+        const PendStage& g = q.st[i];
+        switch (g.kind) {
+            case gft::CH_LMUL_S:
+            case gft::CH_MUL_S:
+            case gft::CH_DIV_S:
+                if (g.s[0] == 0.0 && g.s[1] == 0.0) return 1;  // x * [0,0]
+                break;
+            case gft::CH_MUL_TAB: {
+                TabEntry& t = *g.tab;
+                if (t.nz < 0) {
+                    t.nz = 1;
+                    for (size_t k = 0; k < t.len; ++k)
+                        if (t.host[k] == 0.0 && t.host[t.len + k] == 0.0) t.nz = 0;
+                }
+                if (!t.nz) return 0;
+                break;
+            }
+            default: break;  // neg, element 0 +/- s: a sum is [0,0] only if both terms are
+        }
+    }
+    return 2;
+}
 static void trace_settle();  // GFT_TRACE_API: which entry point materialised a chain (below)
 static void trace_mirror(size_t numel);  // ... and which one mirrored a host-tier tensor to the device
 // Materialise a deferred chain (one launch; every copy of the handle shares the result).
@@ -764,6 +808,7 @@ static void settle(const gft_poly& p) {
         for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)p.shape[keep[j]];
         K<E>::chain_copy(R.stream, out->p, p.numel, sh, chain_src<E>(p, keep));
         trace_settle();
+        out->nz = (unsigned char)nz_of_poly<E>(p);
         q.mat = out;
         q.mat_shape = p.shape;
         R.stats_ex[1]++;
@@ -1420,6 +1465,15 @@ struct Ops {
         return true;
     }
 
+    // (intervals) a sum of two tensors of the result's own shape: [0,0] only where both are
+    static unsigned char sum_nz(const P& a, const P& b, const Dims& shape) {
+        if (W != 2) return 0;
+        const int x = nz_of(a), y = nz_of(b);
+        const bool whole = same_dims_mod_trailing_ones(a.shape, shape) && same_dims_mod_trailing_ones(b.shape, shape);
+        if (whole && (x == 2 || y == 2)) return 2;
+        if (x == 2 && y == 2) return 0;  // (an L-shaped union of two boxes has a corner neither covers)
+        return (unsigned char)((x == 1 || y == 1) ? 1 : 0);
+    }
     // ---- Add / Sub / Neg (mt:854-937) -----------------------------------------------------------------
     static P addsub(P self, P other, bool subtract) {
         Dims rd = min_degrees(self, other);
@@ -1498,6 +1552,7 @@ struct Ops {
                 P fused;
                 if (fuse_lazy_observe(self, other, subtract, shape, rd, &fused)) return fused;
                 P out = make(shape, rd);
+                out.buf->nz = sum_nz(self, other, shape);
                 if (!self.pend) (void)dp<E>(self);   // plain operands: lazy handles / host-tier tensors get their device buffer
                 if (!other.pend) (void)dp<E>(other);
                 Shape sh;
@@ -2899,9 +2954,14 @@ struct Ops {
         // stages) and the Add of the two arms, and then the observation kernel runs with that Add as its epilogue (addsub ->
         // fuse_lazy_observe) — one launch instead of two on the critical path of every `if`.  Anything else that wants the
         // values launches the plain kernel through use_buf().
+        // (intervals) no exact zero in, none out: every position of every step receives a term src * factor (* x), the
+        // derivative factors j + 1 and the constants c are non-zero (checked above), x is not [0,0]
+        const int in_nz = nz_of(a);
+        const unsigned char out_nz = (unsigned char)(in_nz == 2 ? (val_is_zero(x) ? 0 : 2) : in_nz);
         const int sid = pick_stream(a);
         if (sid == 0 && R.lazy_observe && R.cur == 0 && a.buf && !a.buf->host) {
             P out = make(S, G);
+            out.buf->nz = out_nz;
             auto lo = std::make_shared<LazyObs>();
             lo->a = a;
             lo->tab = tab;
@@ -2921,8 +2981,34 @@ struct Ops {
         }
         SideScope scope(sid);
         P out = make(S, G);
+        out.buf->nz = out_nz;
         K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, lines, longest);
         return out;
+    }
+    static int nz_of(const P& p) { return nz_of_poly<E>(p); }
+    // Asks the device once whether a (plain, interval) tensor holds an exact zero and remembers the answer on its buffer.
+    // Programs whose tensors do (triangular supports: hmm) would pay a round trip per tensor for nothing, so a "yes" makes
+    // the next candidates go unasked (doubling back-off); their descendants inherit the 1 anyway.
+    static int nz_query(const P& p) {
+        static unsigned skip = 0, backoff = 0;
+        if (W != 2 || !R.nz_proofs || !p.buf || p.buf->host || p.pend || p.numel < 64) return nz_of(p);
+        if (p.buf->nz) return p.buf->nz;
+        if (skip) {
+            --skip;
+            return 0;
+        }
+        Mailbox mb = next_mail();
+        K<E>::any_zero(R.stream, dp<E>(p), p.numel, p.numel, R.d_flag + 24, mb);
+        double has = 1.0;
+        wait_mail(mb, &has, 1);
+        R.stats[1]++;
+        p.buf->nz = has != 0.0 ? 1 : 2;
+        if (has != 0.0) {
+            backoff = backoff ? std::min(backoff * 2, 4096u) : 4;
+            skip = backoff;
+        } else
+            backoff = 0;
+        return p.buf->nz;
     }
     // A recorded observation chain (observe_chain above): everything its launch needs.
     struct LazyObs {
@@ -3059,6 +3145,7 @@ struct Ops {
         if (!Y.pend) (void)dp<E>(Y);  // a lazy handle / host-tier tensor gets its device buffer
         e.y = chain_src_dev(Y, lo->okeep);
         P out = make(shape, rd);
+        out.buf->nz = sum_nz(self, other, shape);
         launch_obs(*lo, dp<E>(out), out.numel, &e, X.buf.get());
         R.stats_side[3]++;
         R.stats_ex[2]++;
@@ -3300,6 +3387,17 @@ struct Ops {
         for (size_t i = ca.shape[v]; i-- > 0;) {
             bool speculate = false;
             if (!on_host(res) && res.numel > 1) {
+                // (round 5, intervals) a proven loop whose coefficient tensor holds no exact zero: the accumulator — a slab of it,
+                // at least 3 coefficients — cannot be linear (nz_of_poly): no scan, no round trip; the verdict is memoised as
+                // if the scan had delivered it
+                if (!res_nonlinear_seen && W == 2 && proven && R.nz_proofs && res.numel >= 3 && res.buf &&
+                    (nz_of(res) == 2 || (res.buf.get() == ca.buf.get() && nz_of(ca) == 0 && nz_query(ca) == 2 && nz_of(res) == 2))) {
+                    // (the loop reads the slab in place where it is a pure view — res_is_view —, from memory otherwise: dp() in
+                    // launch_horner materialises it then)
+                    if (!res.pend && res.buf && !res.buf->host && !res.buf->lin_state) res.buf->lin_state = 1;
+                    res_nonlinear_seen = true;
+                    R.stats_nz++;
+                }
                 if (!res_nonlinear_seen) {  // device accumulator: scan until the first "not linear" verdict
                     double c_[2], m_[2];
                     size_t u_;
@@ -3400,7 +3498,7 @@ struct Ops {
             bool witnessed = false;
             if (lin_known && res.shape.size() == deg.size()) {
                 // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
-                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots)) {
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots, nullptr, proven && old_input)) {
                     if (!proven) slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
                     break;
                 }
@@ -3553,6 +3651,21 @@ struct Ops {
     // (horner_speculative), so a step where the speculation fails is redone by the exact loop.
     // Steps i, i-1, .., 0 in one launch (k_horner_linear_loop) when the final tensor is small enough for a single
     // workgroup to be the faster machine (a launch per step costs ~4 us of host time + ~4 us on the device).
+    // The first accumulator of a Horner loop is the top coefficient slab: a sub-box VIEW of the coefficient tensor with the
+    // stage "element 0 + [0,0]" from the reference's first step (0 * subst + slab).  For intervals that stage returns its
+    // operand unchanged unless the operand is itself zero (iv:126-134), so where the tensor is proven free of exact zeros the
+    // view IS the sub-box, bit for bit, and the loop kernel reads it in place (base pointer + the tensor's strides) instead of
+    // from a materialised copy — one launch less per subst_var.
+    static bool res_is_view(const P& res, const P& ca) {
+        if (W != 2 || !R.nz_proofs || !res.pend || !res.buf || res.buf.get() != ca.buf.get() || ca.pend || res.buf->host) return false;
+        const Pend& q = *res.pend;
+        if (q.padded || q.mat || q.base_shape.size() != res.shape.size() || !(q.base_shape == ca.shape)) return false;
+        for (int i = 0; i < q.n; ++i) {
+            const PendStage& g = q.st[i];
+            if (!((g.kind == CH_FIRST_ADD || g.kind == CH_FIRST_SUB) && g.s[0] == 0.0 && g.s[1] == 0.0)) return false;
+        }
+        return nz_of(res) == 2;
+    }
     // A recorded linear Horner loop (horner_linear_rest with `defer`): everything its launch needs.
     struct LazyHorner {
         P res, ca;                  // incoming accumulator and coefficient tensor (keep their buffers alive)
@@ -3567,8 +3680,10 @@ struct Ops {
     // Launches a loop — a recorded one into its own buffer `self`, or a fresh one — and takes up to two recorded loops along
     // (K<E>::horner_linear_loop's riders) where the kernel the launch resolves to can carry them.
     static void launch_horner(const P& res, const P& ca, double* outp, size_t fn, const HornerLoopArgs& g, unsigned lines, unsigned* wit, Buf* self) {
-        const double* rp = dp<E>(res);
         const double* cp = dp<E>(ca);
+        const bool rview = res_is_view(res, ca);  // (as when the arguments were built: the handle keeps its own chain)
+        const double* rp = rview ? cp + res.pend->base_off : dp<E>(res);
+        const size_t rplane = rview ? res.pend->base_numel : res.numel;
         HornerRider riders[2];
         std::shared_ptr<Buf> rbuf[2];
         std::shared_ptr<LazyOp> rop[2];
@@ -3584,13 +3699,14 @@ struct Ops {
                 if (b.get() == self) continue;
                 LazyHorner* h = static_cast<LazyHorner*>(b->lazy->horner.get());
                 auto in_memory = [](const P& p) { return p.buf && !p.buf->lazy && !p.pend; };
-                if (!in_memory(h->res) || !in_memory(h->ca) || !K<E>::horner_can_ride(h->g)) continue;
+                const bool hview = res_is_view(h->res, h->ca);
+                if (!(hview || in_memory(h->res)) || !in_memory(h->ca) || !K<E>::horner_can_ride(h->g)) continue;
                 rbuf[nr] = b;
                 rop[nr] = b->lazy;
                 HornerRider& r = riders[nr];
-                r.res0 = dp<E>(h->res);  // (in memory: no launch)
-                r.rp0 = h->res.numel;
-                r.a = dp<E>(h->ca);
+                r.a = dp<E>(h->ca);  // (in memory: no launch)
+                r.res0 = hview ? r.a + h->res.pend->base_off : dp<E>(h->res);
+                r.rp0 = hview ? h->res.pend->base_numel : h->res.numel;
                 r.ap = h->ca.numel;
                 r.out = b->p;
                 r.plane = h->fn;
@@ -3604,7 +3720,7 @@ struct Ops {
                 ++nr;
                 R.stats_side[2]++;
             }
-        K<E>::horner_linear_loop(R.stream, rp, res.numel, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
+        K<E>::horner_linear_loop(R.stream, rp, rplane, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
     }
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
                                    const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr, bool defer = false) {
@@ -3627,7 +3743,8 @@ struct Ops {
         HornerLoopArgs g;
         std::memset(&g, 0, sizeof(g));
         g.nd = (int)keep.size();
-        Dims rst = c_strides(res.shape), fst = c_strides(fs), ast = c_strides(ca.shape);
+        const bool rview = res_is_view(res, ca);
+        Dims rst = c_strides(rview ? res.pend->base_shape : res.shape), fst = c_strides(fs), ast = c_strides(ca.shape);
         g.w = -1;
         for (size_t j = 0; j < keep.size(); ++j) {
             size_t ax = keep[j];
@@ -3673,12 +3790,18 @@ struct Ops {
             g.stat = d_stat;
         }
         g.guard = guard;
+        // (intervals, c and m not [0,0]) no exact zero among the coefficients, none in the result: position (o, k_w) of the final
+        // box receives coeff_i[o, k'] * C(i,j) c^(i-j) m^j for every k' + j = k_w — at least one such term exists, none cancels
+        if (W == 2) {
+            const int cn = nz_of(ca);
+            out.buf->nz = (unsigned char)((cn == 2 && !val_is_zero(c) && !val_is_zero(m)) ? 2 : (cn == 1 ? 1 : 0));
+        }
         const unsigned lines = (unsigned)(fn / fs[w]);
         if (defer && !wit && !(hdiag & 64) && res.buf && ca.buf) {
             g.guard = nullptr;
             if (K<E>::horner_can_ride(g)) {
-                (void)dp<E>(res);  // (both are in memory already — the scan read them —; a chain would be settled here, once)
-                (void)dp<E>(ca);
+                if (!rview) (void)dp<E>(res);  // (in memory already if a scan read it; a chain is settled here, once)
+                if (!ca.buf->lazy) (void)dp<E>(ca);  // (a recorded observation stays recorded: it rides first, then this loop)
                 auto lh = std::make_shared<LazyHorner>();
                 lh->res = res;
                 lh->ca = ca;
@@ -4139,6 +4262,7 @@ int gft_init(int device) {
         if (const char* lo = getenv("GFT_LAZY_OBSERVE")) R.lazy_observe = atoi(lo) != 0;
         if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
         if (const char* lh = getenv("GFT_LAZY_HORNER")) R.lazy_horner = atoi(lh) != 0;
+        if (const char* np = getenv("GFT_NZ_PROOFS")) R.nz_proofs = atoi(np) != 0;
         if (const char* hr = getenv("GFT_HORNER_RIDERS")) R.horner_riders = atoi(hr) != 0;
         R.device = device;
         if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
@@ -4254,10 +4378,10 @@ void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
 size_t gft_op_stats_ex(size_t* out, size_t cap) {
-    const size_t v[11] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
-                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3]};
-    for (size_t i = 0; i < 11 && i < cap; ++i) out[i] = v[i];
-    return 11;
+    const size_t v[12] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
+                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3], R.stats_nz};
+    for (size_t i = 0; i < 12 && i < cap; ++i) out[i] = v[i];
+    return 12;
 }
 void gft_pool_stats(size_t out[3]) {
     out[0] = R.in_use;
@@ -4299,6 +4423,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "lazy_observe") R.lazy_observe = value != 0;
     else if (n == "obs_riders") R.obs_riders = value != 0;
     else if (n == "lazy_horner") R.lazy_horner = value != 0;
+    else if (n == "nz_proofs") R.nz_proofs = value != 0;
     else if (n == "horner_riders") R.horner_riders = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default

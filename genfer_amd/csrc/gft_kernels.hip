@@ -1402,6 +1402,31 @@ void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const doub
     GFT_LAUNCH(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
 }
 
+// Does the tensor hold a coefficient that is exactly zero ([0,0] for intervals)?  One launch, the answer through the mailbox
+// (payload[0] = 1 if so): the premise of the "no exact zero anywhere" proofs of gft_api.hip (Ops::nz_of).  state[0] collects
+// the blocks' findings, state[1] counts their arrivals; the last block publishes and leaves both words zero.
+template <class E>
+__global__ void __launch_bounds__(256) k_any_zero(const double* __restrict__ p, size_t plane, size_t n, unsigned* state, Mailbox mb) {
+    int z = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n && !z; i += (size_t)gridDim.x * blockDim.x)
+        z = E::is_zero(E::ld(p, plane, i)) ? 1 : 0;
+    z = __syncthreads_or(z);
+    if (threadIdx.x != 0) return;
+    if (z) atomicOr(&state[0], 1u);
+    __threadfence();
+    if (atomicAdd(&state[1], 1u) != gridDim.x - 1) return;
+    __threadfence();
+    const unsigned v = atomicExch(&state[0], 0u);
+    atomicExch(&state[1], 0u);
+    mb.payload[0] = v ? 1.0 : 0.0;
+    mailbox_publish(mb);
+}
+template <class E>
+void K<E>::any_zero(hipStream_t st, const double* p, size_t plane, size_t n, unsigned* state, const Mailbox& mb) {
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 64));
+    GFT_LAUNCH(k_any_zero<E>, dim3(blocks), dim3(256), 0, st, p, plane, n, state, mb);
+}
+
 // ------------------------------------------------------------------------------------------
 // Reference-order convolution: one thread per output element, loops in exactly the reference's
 // order (outer axes lexicographic ascending, innermost partial sum from zero), separate

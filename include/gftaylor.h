@@ -76,8 +76,9 @@ void gft_op_stats(size_t out[8]);
  * memory, add/sub launches that evaluated deferred chains on the fly, launches whose argument block did not fit a
  * slot of the launch ring and were issued in place after a full drain, shallow (stencil) products on the fused
  * reference-order kernel, of which whole general Horner steps res * subst + slab in one launch, operations issued in a
- * side-stream scope, cross-stream event waits, recorded observation chains that rode along with another observation launch,
- * recorded observation chains launched with the consumer's Add as their epilogue}.  Diagnostics; bench.py's e2e rows. */
+ * side-stream scope, cross-stream event waits, recorded observation chains / Horner loops that rode along with another launch
+ * of their kind, recorded observation chains launched with the consumer's Add as their epilogue, linearity scans answered by
+ * a "no exact zero" proof (intervals)}.  Diagnostics; bench.py's e2e rows. */
 size_t gft_op_stats_ex(size_t* out, size_t cap);
 /* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
