@@ -160,6 +160,14 @@ OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_
                "fused_horner_steps", "side_scopes", "cross_stream_waits", "riders", "fused_observe_adds", "scans_proven")
 
 
+def pool_stats() -> dict:
+    """Device memory the library holds, in bytes: pool blocks in use / cached, and the peak (gft_pool_stats; the kernels'
+    grow-only workspaces are included in `in_use` and `peak`)."""
+    a = (ctypes.c_size_t * 3)()
+    lib().gft_pool_stats(a)
+    return {"in_use": int(a[0]), "cached": int(a[1]), "peak": int(a[2])}
+
+
 def op_stats() -> dict:
     """Cumulative counters of the library since gft_init (gft_op_stats + gft_op_stats_ex) by name."""
     L = lib()

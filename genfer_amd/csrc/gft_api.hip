@@ -186,6 +186,7 @@ struct Runtime {
     // copy of this library is ordered on the one stream.
     std::map<size_t, std::vector<void*>> free_blocks;  // size class -> free device blocks (vectors: no node churn)
     size_t in_use = 0, cached = 0, peak = 0;
+    size_t ws_peak = 0;          // largest total of the kernels' grow-only workspaces seen by gft_pool_stats
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
     double* d_scratch = nullptr; // small device scratch for packed read-backs
     unsigned* d_wit = nullptr;   // sticky non-linearity witnesses of a speculative Horner loop (Ops::WIT_SLOTS words)
@@ -3004,7 +3005,7 @@ struct Ops {
         R.stats[1]++;
         p.buf->nz = has != 0.0 ? 1 : 2;
         if (has != 0.0) {
-            backoff = backoff ? std::min(backoff * 2, 4096u) : 4;
+            backoff = backoff ? std::min(backoff * 2, 4096u) : 32;
             skip = backoff;
         } else
             backoff = 0;
@@ -4384,9 +4385,13 @@ size_t gft_op_stats_ex(size_t* out, size_t cap) {
     return 12;
 }
 void gft_pool_stats(size_t out[3]) {
-    out[0] = R.in_use;
+    // (the grow-only kernel workspaces — row-pair sums, row flags, the tiled product's — are not pool blocks: counted here so that
+    // a host sees what the library holds; pool_alloc's out-of-memory retry releases the staged kernels' ones)
+    const size_t ws = staged_scratch_bytes() + R.conv_ws_bytes;
+    out[0] = R.in_use + ws;
     out[1] = R.cached;
-    out[2] = R.peak;
+    out[2] = std::max(R.peak, R.in_use) + std::max(R.ws_peak, ws);
+    R.ws_peak = std::max(R.ws_peak, ws);
 }
 int gft_event_record(int slot) {
     return guard_int([&] {

@@ -735,6 +735,12 @@ struct PairArgs {
     unsigned tiles0, tiles1;                      // y tiles along the two lane axes
     unsigned pitch;                               // LDS row pitch in doubles ((lo, hi) interleaved; pitch / 2 odd)
     unsigned long long S0, S1;                    // terms summed over all k0 / all k1
+    // Bounded workspace (round 5): a launch covers the output slabs [klo, khi) of the LEADING outer axis only, and its slots
+    // start at slot_base.  band 2: the leading axis is U (rank 4) — the x rows' ju is restricted; band 1: it is axis 0 (rank 3),
+    // a lane axis — the y tile is the WINDOW d0 = klo - j0 + l0 of T0 = khi - klo rows under one j0 (every lane of it pairs with
+    // an output slab of the range), a workgroup's x rows share that j0.  band 0: the whole product (klo = 0).
+    unsigned band, klo, khi;
+    unsigned long long slot_base;
 };
 // terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
 __host__ __device__ inline unsigned pair_lo(unsigned k, unsigned ny) { return k + 1 > ny ? k + 1 - ny : 0u; }
@@ -755,6 +761,11 @@ __device__ __forceinline__ unsigned long long pair_slot(const PairArgs& g, unsig
     const unsigned cU = pair_cnt(ku, g.xU, g.yU), c0 = pair_cnt(k0, g.x0, g.y0), c1 = pair_cnt(k1, g.x1, g.y1);
     const unsigned long long base = pair_pre(ku, g.xU, g.yU) * g.S0 * g.S1 + (unsigned long long)cU * (pair_pre(k0, g.x0, g.y0) * g.S1 + (unsigned long long)c0 * pair_pre(k1, g.x1, g.y1));
     return base + ((unsigned long long)(ju - pair_lo(ku, g.yU)) * c0 + (j0 - pair_lo(k0, g.y0))) * c1 + (j1 - pair_lo(k1, g.y1));
+}
+
+// first output row (row-major over (ku, k0, k1)) of a launch's slab range
+__device__ __forceinline__ unsigned long long pair_row_base(const PairArgs& g) {
+    return g.band == 2 ? (unsigned long long)g.klo * g.z0 * g.z1 : (g.band == 1 ? (unsigned long long)g.klo * g.z1 : 0ull);
 }
 
 typedef const double __attribute__((address_space(4))) * pair_cptr_t;  // wave-uniform, read-only: scalar loads
@@ -894,14 +905,22 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     unsigned tb = blockIdx.y;
     const unsigned bt = tb % g.tiles1;
     tb /= g.tiles1;
-    const unsigned at = tb % g.tiles0, ud = tb / g.tiles0;
-    const unsigned d0b = T0 * at, d1b = T1 * bt;
-    const unsigned nU = g.zU - ud < g.xU ? g.zU - ud : g.xU;  // x rows (ju, j0, j1) some lane of the tile pairs with
-    const unsigned n0 = g.z0 - d0b < g.x0 ? g.z0 - d0b : g.x0;
+    const unsigned at = tb % g.tiles0, ud = tb / g.tiles0;  // (band 1: `at` is the x rows' j0, tiles0 = x0)
+    const int d0b = g.band == 1 ? (int)g.klo - (int)at : (int)(T0 * at);
+    const unsigned d1b = T1 * bt;
+    // x rows (ju, j0, j1) some lane of the tile pairs with
+    unsigned nU = g.zU - ud < g.xU ? g.zU - ud : g.xU, ju_lo = 0;
+    if (g.band == 2) {  // ju + ud in [klo, khi)
+        ju_lo = g.klo > ud ? g.klo - ud : 0u;
+        const unsigned hi = g.khi > ud ? (g.khi - ud < nU ? g.khi - ud : nU) : 0u;
+        nU = hi > ju_lo ? hi - ju_lo : 0u;
+    }
+    const unsigned n0 = g.band == 1 ? 1u : (g.z0 - (unsigned)d0b < g.x0 ? g.z0 - (unsigned)d0b : g.x0);
     const unsigned n1 = g.z1 - d1b < g.x1 ? g.z1 - d1b : g.x1;
     const unsigned long long count = (unsigned long long)nU * n0 * n1;
     const unsigned long long xi_lo = (unsigned long long)blockIdx.x * g.xch;
     if (xi_lo >= count) return;
+    if (g.band == 1 && d0b >= (int)g.y0) return;  // (a compact y: the window of this j0 lies above its last row)
     const unsigned rows_here = (unsigned)(xi_lo + g.xch < count ? g.xch : count - xi_lo);
     // ---- stage the tile's 64 y rows, (lo, hi) interleaved, zero beyond the row / for rows outside y
     if (tid == 0) s_tileflag = 0;
@@ -910,7 +929,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         unsigned fl = 0;
         for (unsigned i = tid; i < 64u * g.n8; i += blockDim.x) {
             const unsigned r = i / g.n8, cc = i - r * g.n8;
-            const unsigned d0 = d0b + (r >> g.tsh), d1 = d1b + (r & (T1 - 1u));
+            const unsigned d0 = (unsigned)(d0b + (int)(r >> g.tsh)), d1 = d1b + (r & (T1 - 1u));  // (a window row below 0 wraps: fails the test)
             double lo = 0.0, hi = 0.0;
             if (d0 < g.y0 && d1 < g.y1 && cc < g.n2) {
                 const size_t row = ((size_t)ud * g.y0 + d0) * g.y1 + d1;
@@ -929,8 +948,8 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     __syncthreads();
     const unsigned tileflag = s_tileflag;
     const unsigned l0 = lane >> g.tsh, l1 = lane & (T1 - 1u);
-    const unsigned d0 = d0b + l0, d1 = d1b + l1;
-    const bool row_ok = d0 < g.y0 && d1 < g.y1;
+    const unsigned d0 = (unsigned)(d0b + (int)l0), d1 = d1b + l1;
+    const bool row_ok = d0 < g.y0 && d1 < g.y1 && (g.band != 1 || l0 < g.khi - g.klo);
     const double* yrow = smem + (size_t)lane * g.pitch;
     // ---- tasks (x row, pair of column blocks p and nbw - 1 - p: p + 1 and nbw - p chunk products, the same sum for every p):
     // every wave takes a contiguous share of them, so what belongs to the x row — its regime, the lanes' slots — is worked
@@ -950,7 +969,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
             const unsigned long long xi = xi_lo + row;
             const unsigned j1 = (unsigned)(xi % n1);
             const unsigned long long tt = xi / n1;
-            const unsigned j0 = (unsigned)(tt % n0), ju = (unsigned)(tt / n0);
+            const unsigned j0 = g.band == 1 ? at : (unsigned)(tt % n0), ju = ju_lo + (unsigned)(tt / n0);
             const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
             xl = (pair_cptr_t)(x + arow * g.nx2);
             xh = (pair_cptr_t)(x + xp + arow * g.nx2);
@@ -966,7 +985,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
                 f |= (any_lane(np) ? 1u : 0u) | (any_lane(nf) ? 2u : 0u);
             }
             regime = (f & 1u) == 0u ? 1 : ((f & 2u) == 0u ? 2 : 0);
-            dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) : 0ull) * g.n2 * W;
+            dst = ws + (size_t)(lane_ok ? pair_slot(g, ju, j0, j1, ju + ud, j0 + d0, j1 + d1) - g.slot_base : 0ull) * g.n2 * W;
         }
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -1022,14 +1041,14 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
         else return r;
     };
     const unsigned c = blockIdx.y * blockDim.x + threadIdx.x;
-    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest rows first
+    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x) + pair_row_base(g);  // heaviest rows first; the launch's slab range
     const unsigned k1 = (unsigned)(rr % g.z1);
     rr /= g.z1;
     const unsigned k0 = (unsigned)(rr % g.z0), ku = (unsigned)(rr / g.z0);
     const unsigned long long n = (unsigned long long)pair_cnt(ku, g.xU, g.yU) * pair_cnt(k0, g.x0, g.y0) * pair_cnt(k1, g.x1, g.y1);
     V acc = E::zero();
     if (n > 0 && c < g.n2) {
-        const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 * E::W) + c;
+        const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)(pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) - g.slot_base) * g.n2 * E::W) + c;
         const size_t pitch = g.n2;  // elements per term
         constexpr int D = 16;
         Raw buf[D];
@@ -1062,7 +1081,7 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
 // f64 rows of even length: two columns per thread (16-byte loads, as the interval form has anyway)
 __global__ void __launch_bounds__(128) k_pair_collect2_f64(const double* __restrict__ ws, double* __restrict__ z, PairArgs g) {
     const unsigned c = 2 * (blockIdx.y * blockDim.x + threadIdx.x);
-    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x);  // heaviest rows first
+    unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x) + pair_row_base(g);  // heaviest rows first; the launch's slab range
     const unsigned k1 = (unsigned)(rr % g.z1);
     rr /= g.z1;
     const unsigned k0 = (unsigned)(rr % g.z0), ku = (unsigned)(rr / g.z0);
@@ -1070,7 +1089,7 @@ __global__ void __launch_bounds__(128) k_pair_collect2_f64(const double* __restr
     double a0 = 0.0, a1 = 0.0;
     if (c >= g.n2) return;
     if (n > 0) {
-        const double2* p = reinterpret_cast<const double2*>(ws + (size_t)pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) * g.n2 + c);
+        const double2* p = reinterpret_cast<const double2*>(ws + (size_t)(pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) - g.slot_base) * g.n2 + c);
         const size_t pitch = g.n2 / 2;  // double2 per term
         constexpr int D = 16;
         double2 buf[D];
@@ -1123,13 +1142,20 @@ static std::map<hipStream_t, PairWs>& pair_ws() {
     static std::map<hipStream_t, PairWs> m;
     return m;
 }
-// bytes of row sums the row-pair form may hold (24 GiB: 88^3; first-time hipMalloc of up to 28 GB takes 0.3 ms on this image,
-// of 33 GB 1.7 s).  Larger products stay on k_conv_rows_rb.
+// bytes of row sums the row-pair form may hold AT A TIME (2 GiB; round 4 held a whole product's: up to 24 GiB).  A product whose
+// row sums exceed it runs in slab ranges of its leading outer axis (PairArgs::band), each range through both phases from the
+// same workspace; per output the terms still arrive in the reference's order, so the bits do not depend on the cut.
 static size_t rb_pairs_cap = [] {
     const char* e = getenv("GFT_RB_PAIRS_CAP_MB");
-    return (size_t)(e ? std::max(1, atoi(e)) : 24576) << 20;
+    return (size_t)(e ? std::max(1, atoi(e)) : 2048) << 20;
 }();
-void staged_set_rb_pairs_cap(double bytes) { rb_pairs_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)24576 << 20); }  // "conv_rb_pairs_cap"
+void staged_set_rb_pairs_cap(double bytes) { rb_pairs_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)2048 << 20); }  // "conv_rb_pairs_cap"
+size_t staged_scratch_bytes() {  // what the grow-only workspaces hold right now (gft_pool_stats counts it)
+    size_t n = 0;
+    for (auto& kv : rb_scratch()) n += kv.second.bytes;
+    for (auto& kv : pair_ws()) n += kv.second.bytes;
+    return n;
+}
 // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 products of [rb_pairs_min, ..) multiply-adds whose row sums fit the
 // workspace cap, 2 whenever it applies (tests)
 static int rb_pairs_default() {
@@ -1159,6 +1185,29 @@ void staged_release_scratch() {
     for (auto& kv : pair_ws())
         if (kv.second.p) (void)hipFree(kv.second.p);
     pair_ws().clear();
+}
+
+// Two lanes for the slab ranges of a product whose row sums exceed the cap (PairArgs::band): each range is a phase-1 launch
+// (compute-bound, uneven workgroups) followed by a phase-2 launch (a latency-bound stream per output row) on the SAME
+// workspace — on one stream every launch waits for the slowest workgroup of the one before it, 2 x #ranges times per product
+// (64^3 in 8 ranges: 7.1 ms against 5.1 ms in one piece).  With the ranges dealt to two streams, each with half the cap as its
+// own workspace, one lane's tails and phase 2 run under the other lane's phase 1.  Fork and join are one event each way per
+// product (HIP events cost ~20 us a pair, tools/microbench_streams.hip: nothing at these sizes).
+struct PairLanes {
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    bool ok = false, tried = false;
+};
+static PairLanes& pair_lanes() {
+    static PairLanes l;
+    if (!l.tried) {
+        l.tried = true;
+        l.ok = hipStreamCreateWithFlags(&l.st[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&l.st[1], hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&l.join[0], hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&l.join[1], hipEventDisableTiming) == hipSuccess;
+        if (!l.ok) (void)hipGetLastError();
+    }
+    return l;
 }
 
 // The plain full product of large contiguous interval tensors; false = not this kernel's case (nothing launched).
@@ -1248,23 +1297,76 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.S0 = pair_pre(g.z0, g.x0, g.y0);  // terms over all k0 / all k1
         g.S1 = pair_pre(g.z1, g.x1, g.y1);
         const unsigned long long slots = pair_pre(g.zU, g.xU, g.yU) * g.S0 * g.S1;
-        const unsigned long long need = slots * n2 * E::W * sizeof(double);
-        const unsigned long long chunks_y = (xrows + g.xch - 1) / g.xch, tiles = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
-        if (slots > 0 && need <= rb_pairs_cap && tiles <= 65535ull && chunks_y <= 0x7fffffffull && zs_ / n2 <= 0x7fffffffull) {
-            PairWs& w = pair_ws()[st];
-            bool ok = true;
-            if (ok && w.bytes < need) {
-                if (w.p) (void)hipFree(w.p);
-                w.p = nullptr;
-                w.bytes = 0;
-                if (hipMalloc((void**)&w.p, need) != hipSuccess) {
-                    (void)hipGetLastError();
-                    w.p = nullptr;
-                    ok = false;
+        const unsigned long long row_bytes = (unsigned long long)n2 * E::W * sizeof(double);
+        const unsigned long long need = slots * row_bytes;
+        // ---- the plan: one launch pair for the whole product, or slab ranges of the leading outer axis that fit the cap
+        struct Range {
+            unsigned lo, hi;
+            unsigned long long base, slots;
+        };
+        std::vector<Range> plan;
+        bool plan_ok = slots > 0 && zs_ / n2 <= 0x7fffffffull, use_lanes = false;
+        unsigned band = 0;
+        if (plan_ok && need <= rb_pairs_cap) {
+            plan.push_back(Range{0, 0, 0, slots});
+        } else if (plan_ok && no >= 2) {
+            static const int lanes_on = [] {
+                const char* e = getenv("GFT_RB_PAIRS_LANES");  // A/B knob (0 = every range on the product's own stream)
+                return e ? atoi(e) : 0;  // (measured, profiles/r05/interval_pairs_bounded.txt: 64^3 7.0 -> 6.5 ms, but 88^3 34.9 -> 40.8, 96^3 55.9 -> 61.2:
+            }();                          // half the cap per lane means thinner ranges — narrower window tiles, more launches)
+            use_lanes = lanes_on && pair_lanes().ok;
+            const size_t range_cap = use_lanes ? rb_pairs_cap / 2 : rb_pairs_cap;
+            band = no == 3 ? 2u : 1u;  // leading axis: U (rank 4) or axis 0 (rank 3: a lane axis — ranges of 1, 2, 4 or 8 slabs, the window's height)
+            const unsigned nlead = band == 2 ? g.zU : g.z0, xl = band == 2 ? g.xU : g.x0, yl = band == 2 ? g.yU : g.y0;
+            const unsigned long long per = band == 2 ? g.S0 * g.S1 : g.S1;  // slots per term of the leading axis
+            auto slots_of = [&](unsigned lo, unsigned hi) { return (pair_pre(hi, xl, yl) - pair_pre(lo, xl, yl)) * per; };
+            for (unsigned lo = 0; lo < nlead && plan_ok;) {
+                unsigned h = 0;
+                if (band == 2) {
+                    while (lo + h < nlead && slots_of(lo, lo + h + 1) * row_bytes <= range_cap) ++h;
                 } else {
-                    w.bytes = need;
+                    for (unsigned c = 8; c >= 1; c /= 2)
+                        if (lo + c <= nlead && slots_of(lo, lo + c) * row_bytes <= range_cap) {
+                            h = c;
+                            break;
+                        }
                 }
+                if (h == 0) plan_ok = false;  // (one slab alone exceeds the cap: not this form's product)
+                else plan.push_back(Range{lo, lo + h, pair_pre(lo, xl, yl) * per, slots_of(lo, lo + h)});
+                lo += h;
             }
+            if (plan.size() > 4096) plan_ok = false;
+        } else
+            plan_ok = false;
+        if (plan_ok) {
+            unsigned long long most = 0;
+            for (const Range& r : plan) most = std::max(most, r.slots * row_bytes);
+            if (plan.size() < 2) use_lanes = false;
+            bool ok = true;
+            PairWs* wsv[2] = {nullptr, nullptr};
+            for (int l = 0; l < (use_lanes ? 2 : 1) && ok; ++l) {
+                PairWs& w = pair_ws()[use_lanes ? pair_lanes().st[l] : st];
+                if (w.bytes < most) {
+                    launch_drain();  // (nothing queued may still be using the old block)
+                    if (w.p) {
+                        (void)(hipStreamSynchronize)(use_lanes ? pair_lanes().st[l] : st);
+                        (void)(hipFree)(w.p);
+                    }
+                    w.p = nullptr;
+                    w.bytes = 0;
+                    if (hipMalloc((void**)&w.p, most) != hipSuccess) {
+                        (void)hipGetLastError();
+                        w.p = nullptr;
+                        ok = false;
+                    } else {
+                        w.bytes = most;
+                    }
+                }
+                wsv[l] = &w;
+            }
+            // grid limits (per launch)
+            const unsigned long long tiles_full = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
+            if (band == 0 && (tiles_full > 65535ull || (xrows + g.xch - 1) / g.xch > 0x7fffffffull)) ok = false;
             if (ok) {
                 const size_t lds = (size_t)64 * g.pitch * sizeof(double);
                 static bool attr = false;
@@ -1274,16 +1376,77 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                     if (hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) (void)hipGetLastError();
                     attr = true;
                 }
-                GFT_LAUNCH(k_pair_sums<E>, dim3((unsigned)chunks_y, (unsigned)tiles), dim3(g.NW * 64), lds, st, x, xp, y, yp, w.p, g);
                 static const unsigned cw_env = [] {
                     const char* e = getenv("GFT_RB_PAIRS_COLS");  // tuning knob: columns per phase-2 workgroup
                     return (unsigned)(e ? std::max(1, std::min(128, atoi(e))) : 64);
                 }();
-                if (E::W == 1 && n2 >= 64 && n2 % 2 == 0 && !((uintptr_t)z & 15))  // (shorter rows: too few threads per row — 32^3 0.104 -> 0.113 ms; 80^3 7.7 -> 7.1)
-                    GFT_LAUNCH(k_pair_collect2_f64, dim3((unsigned)(zs_ / n2), (n2 / 2 + 63) / 64), dim3(64), 0, st, (const double*)w.p, z, g);
-                else
-                    GFT_LAUNCH(k_pair_collect<E>, dim3((unsigned)(zs_ / n2), (n2 + cw_env - 1) / cw_env), dim3(cw_env), 0, st, (const double*)w.p, z, zp, g);
-                return true;
+                // (checked for every range BEFORE the first launch: a false return promises that nothing was launched)
+                std::vector<PairArgs> gs;
+                std::vector<dim3> grids;
+                std::vector<unsigned long long> rows;
+                for (const Range& r : plan) {
+                    PairArgs q = g;
+                    q.band = band;
+                    q.klo = r.lo;
+                    q.khi = r.hi;
+                    q.slot_base = r.base;
+                    unsigned long long cy = (xrows + q.xch - 1) / q.xch, ty = tiles_full, nrows = zs_ / n2;
+                    if (band == 1) {  // window tiles: T0 = the range's height, one tile row per j0; a workgroup's x rows share j0
+                        const unsigned h = r.hi - r.lo;
+                        unsigned tsh = 6;
+                        while ((64u >> tsh) < h) --tsh;
+                        q.tsh = tsh;
+                        const unsigned T1w = 1u << tsh;
+                        q.tiles1 = (q.y1 + T1w - 1) / T1w;
+                        q.tiles0 = std::min(q.x0, r.hi);  // j0 <= k0 < khi
+                        cy = (q.x1 + q.xch - 1) / q.xch;
+                        ty = (unsigned long long)q.tiles0 * q.tiles1;
+                        nrows = (unsigned long long)(r.hi - r.lo) * q.z1;
+                    } else if (band == 2) {
+                        cy = ((unsigned long long)std::min(q.xU, r.hi - r.lo) * q.x0 * q.x1 + q.xch - 1) / q.xch;
+                        nrows = (unsigned long long)(r.hi - r.lo) * q.z0 * q.z1;
+                    }
+                    if (ty > 65535ull || cy > 0x7fffffffull || nrows > 0x7fffffffull || ty == 0 || cy == 0) ok = false;
+                    gs.push_back(q);
+                    grids.push_back(dim3((unsigned)cy, (unsigned)ty));
+                    rows.push_back(nrows);
+                }
+                if (ok) {
+                    PairLanes& L = pair_lanes();
+                    if (use_lanes) {  // fork: the lanes wait for everything queued on the product's stream (the operands)
+                        hipEvent_t ev = L.fork;
+                        hipStream_t a0 = L.st[0], a1 = L.st[1];
+                        enqueue_task([=] {
+                            lq_note((hipEventRecord)(ev, st), nullptr, "hipEventRecord (row-pair lanes, fork)");
+                            lq_note((hipStreamWaitEvent)(a0, ev, 0), nullptr, "hipStreamWaitEvent (row-pair lane 0)");
+                            lq_note((hipStreamWaitEvent)(a1, ev, 0), nullptr, "hipStreamWaitEvent (row-pair lane 1)");
+                        });
+                    }
+                    // heaviest ranges first (the top slabs), alternating between the lanes
+                    for (size_t k = plan.size(); k-- > 0;) {
+                        const size_t i = k;
+                        const int l = use_lanes ? (int)((plan.size() - 1 - k) & 1u) : 0;
+                        hipStream_t ls = use_lanes ? L.st[l] : st;
+                        double* wp = wsv[l]->p;
+                        const PairArgs& q = gs[i];
+                        GFT_LAUNCH(k_pair_sums<E>, grids[i], dim3(q.NW * 64), lds, ls, x, xp, y, yp, wp, q);
+                        if (E::W == 1 && n2 >= 64 && n2 % 2 == 0 && !((uintptr_t)z & 15))  // (shorter rows: too few threads per row — 32^3 0.104 -> 0.113 ms; 80^3 7.7 -> 7.1)
+                            GFT_LAUNCH(k_pair_collect2_f64, dim3((unsigned)rows[i], (n2 / 2 + 63) / 64), dim3(64), 0, ls, (const double*)wp, z, q);
+                        else
+                            GFT_LAUNCH(k_pair_collect<E>, dim3((unsigned)rows[i], (n2 + cw_env - 1) / cw_env), dim3(cw_env), 0, ls, (const double*)wp, z, zp, q);
+                    }
+                    if (use_lanes) {  // join: the product's stream waits for both lanes
+                        hipEvent_t e0 = L.join[0], e1 = L.join[1];
+                        hipStream_t a0 = L.st[0], a1 = L.st[1];
+                        enqueue_task([=] {
+                            lq_note((hipEventRecord)(e0, a0), nullptr, "hipEventRecord (row-pair lane 0)");
+                            lq_note((hipEventRecord)(e1, a1), nullptr, "hipEventRecord (row-pair lane 1)");
+                            lq_note((hipStreamWaitEvent)(st, e0, 0), nullptr, "hipStreamWaitEvent (row-pair lanes, join)");
+                            lq_note((hipStreamWaitEvent)(st, e1, 0), nullptr, "hipStreamWaitEvent (row-pair lanes, join)");
+                        });
+                    }
+                    return true;
+                }
             }
         }
     }

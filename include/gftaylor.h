@@ -64,7 +64,9 @@ int gft_set_stream(void* hip_stream);
 void* gft_get_stream(void);
 int gft_synchronize(void);
 const char* gft_last_error(void);
-/* Device-memory pool statistics in bytes: {in_use, cached, peak_in_use}. */
+/* Device-memory statistics in bytes: {in_use, cached, peak_in_use}.  in_use and peak include the kernels' grow-only
+ * workspaces (the row-pair sums of the reference-order product, at most conv_rb_pairs_cap = 2 GiB per stream; the tiled
+ * product's plan workspace), which are not pool blocks. */
 void gft_pool_stats(size_t out[3]);
 /* Cumulative operation counters since gft_init: {extract_linear device scans (each a host round trip),
  * 1-element value read-backs, coefficient() read-backs, products on the tiled kernel, on the LDS-staged

@@ -1392,7 +1392,9 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
             want = OTPI.new(a, deg) * OTPI.new(b, deg)
             # (threshold, row-pair mode, its workspace cap): the fused rows kernel, k_conv_staged, the row-pair form (rows of
             # <= 128; longer ones fall through to k_conv_staged), and a cap too small for it (back to k_conv_staged)
-            for thr, pairs, cap in ((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (-1.0, 2.0, 4096.0)):
+            # ... and caps that cut it into slab ranges of the leading axis (round 5: the bounded workspace; ranges of 1 - 8
+            # slabs for rank 3, of any height for rank 4 — where one slab alone exceeds the cap the product falls back)
+            for thr, pairs, cap in ((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (-1.0, 2.0, 4096.0), (-1.0, 2.0, 4.0e6), (-1.0, 2.0, 6.0e5)):
                 assert L.gft_set_option(b"conv_rb_min_macs", thr) == 0
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
                 assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
@@ -1403,6 +1405,39 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
                     L.gft_set_option(b"conv_rb_pairs", -1.0)
                     L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
     finally:
+        L.gft_set_option(b"host_max_elems", -1.0)
+
+
+def test_interval_row_pair_workspace_is_bounded(OTPI, GTPI):
+    """The row-pair form of the interval product under a small cap: a 40^3 product whose row sums (0.44 GB) exceed a 32 MB cap
+    runs in slab ranges of its leading axis from one bounded workspace — the same bits as the oracle (per output the terms
+    arrive in the reference's order whatever the cut), and what the library holds stays bounded: gft_pool_stats' peak grows
+    by less than cap + the operands and the result."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    shape = (40, 40, 40)
+    lo_x, lo_y = rand(shape, 291, 0.1, 1.0), rand(shape, 292, 0.1, 1.0)
+    a, b = np.stack([lo_x, lo_x * (1 + 1e-15)]), np.stack([lo_y, lo_y * (1 + 1e-15)])
+    want = OTPI.new(a, list(shape)) * OTPI.new(b, list(shape))
+    cap = 32.0 * 2**20
+    L.gft_set_option(b"host_max_elems", 0.0)
+    assert L.gft_set_option(b"conv_rb_pairs", 2.0) == 0
+    assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
+    try:
+        gx, gy = GTPI.new(a, list(shape)), GTPI.new(b, list(shape))
+        before = genfer_amd.pool_stats()
+        staged0 = genfer_amd.op_stats()["staged"]
+        got = gx * gy
+        L.gft_synchronize()
+        after = genfer_amd.pool_stats()
+        check(want, got)
+        assert genfer_amd.op_stats()["staged"] > staged0
+        # (peak includes the kernels' workspaces; earlier tests of this process may have grown it: only its GROWTH is bounded here)
+        assert after["peak"] - max(before["peak"], before["in_use"]) <= cap + 4 * 2 * 8 * 40**3 + (8 << 20), (before, after)
+    finally:
+        L.gft_set_option(b"conv_rb_pairs", -1.0)
+        L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
         L.gft_set_option(b"host_max_elems", -1.0)
 
 
@@ -1432,14 +1467,16 @@ def test_f64_reference_order_product_as_row_pair_sums_bit_exact(xs, ys, zs, OTP,
     try:
         for a, b in ((x, y), (xz, yz), (xi, yn), (x * 1e-200, y * 1e-200), (x * 1e200, y * 1e160)):
             want = (OTP.new(a, deg) * OTP.new(b, deg)).array()
-            for pairs in (2.0, 0.0):
+            for pairs, cap in ((2.0, 0.0), (0.0, 0.0), (2.0, 2.0e6), (2.0, 3.0e5)):  # (the capped ones: slab ranges of the leading axis)
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
+                assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
                 try:
                     got = (GTP.new(a, deg) * GTP.new(b, deg)).array()
                 finally:
                     L.gft_set_option(b"conv_rb_pairs", -1.0)
+                    L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
                 ok = (np.asarray(want).view(np.uint64) == np.asarray(got).view(np.uint64)) | (np.isnan(want) & np.isnan(got))
-                assert np.all(ok), (pairs, np.asarray(want)[~ok][:4], np.asarray(got)[~ok][:4])
+                assert np.all(ok), (pairs, cap, np.asarray(want)[~ok][:4], np.asarray(got)[~ok][:4])
     finally:
         L.gft_set_conv_mode(0)
         L.gft_set_option(b"host_max_elems", -1.0)
