@@ -214,6 +214,15 @@ struct Runtime {
     bool div_wavefront = true;     // GFT_DIV_WAVEFRONT=0 / "div_wavefront": the blocked recurrence instead of the one-launch row wavefront
     bool rows_wavefront = true;    // GFT_ROWS_WAVEFRONT=0 / "rows_wavefront": rank-2 recurrences with rows > 64 row by row (A/B, bisecting)
     bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
+    // "div_right" / GFT_DIV_RIGHT=1: large f64 div / log as a blocked right-looking recurrence on the tiled kernel (Ops::div_right_blocked).
+    // OFF by default: measured (profiles/r05/recurrences_div_right.txt) the diagonal blocks are bound by their dependency DEPTH
+    // (B + n1 row steps of ~11 us each), not by their work, so four blocks of a 64^3 quotient cost what the whole wavefront
+    // costs (4.5 vs 4.0 ms; 3.6 ms with two blocks of 32; 24^4 with blocks of 8: 6.2 -> 3.6 ms) — and the form gives up the
+    // reference's bits for the tiled kernel's 1e-10 contract.
+    bool div_right = false;
+    double div_right_min_macs = 1.0e9;  // "div_right_min_macs": ... from this many multiply-adds
+    size_t div_right_block = 16;   // "div_right_block": leading slabs per diagonal block
+    size_t stats_right[2] = {0, 0};  // {blocked divisions, blocked logarithms}
     // Shallow products (round 4): a plain product whose outputs receive at most this many terms each (prod_i min(xs_i, ys_i):
     // one operand is a stencil — the substitutions of `+~ Binomial(other, p)` statements are 3-6 coefficients) runs on the
     // reference-order one-thread-per-output kernel with the Horner step's Add fused in (K<E>::conv_shallow) instead of the
@@ -2383,6 +2392,7 @@ struct Ops {
             if (rs[i] == UMAX) throw Error("div: untruncated result shape (degrees_p1 == usize::MAX)");
         const bool host = tier_host(prod(rs), self, other) && est_macs(rs, other.shape, rs) <= R.host_max_macs;
         P out = make(rs, deg, host);
+        if (!host && div_right_blocked(self, other, out)) return out;
         if (!host && div_wavefront(self, other, out)) return out;
         div_rec(view(self, host), view(other, host), view(out, host));
         return seal(out);
@@ -2394,28 +2404,142 @@ struct Ops {
         if (!R.div_wavefront || !R.div2d) return false;
         Dims keep = collapse_mask({&out.shape}, false);
         if (keep.size() < 2 || keep.size() > 4) return false;
+        // dropped axes have extent 1 in the result, hence in both operands (shapes never exceed the result's)
+        HV x{dp<E>(self), self.numel, pick(self.shape, keep), false}, y{dp<E>(other), other.numel, pick(other.shape, keep), false},
+            z{dp<E>(out), out.numel, pick(out.shape, keep), false};
+        return div_wavefront_hv(x, y, z);
+    }
+    // (contiguous views of rank 2-4, no unit axes to drop)
+    static bool div_wavefront_hv(const HV& x, const HV& y, const HV& z) {
+        if (!R.div_wavefront || !R.div2d) return false;
+        const size_t nd = z.shape.size();
+        if (nd < 2 || nd > 4) return false;
         unsigned xs[4], ys[4], zs[4];
         size_t rows = 1;
-        for (size_t i = 0; i < keep.size(); ++i) {
-            xs[i] = (unsigned)self.shape[keep[i]];
-            ys[i] = (unsigned)other.shape[keep[i]];
-            zs[i] = (unsigned)out.shape[keep[i]];
-            if (i + 1 < keep.size()) rows *= zs[i];
+        for (size_t i = 0; i < nd; ++i) {
+            xs[i] = (unsigned)x.shape[i];
+            ys[i] = (unsigned)y.shape[i];
+            zs[i] = (unsigned)z.shape[i];
+            if (i + 1 < nd) rows *= zs[i];
         }
-        // dropped axes have extent 1 in the result, hence in both operands (shapes never exceed the result's)
-        if (keep.size() == 2 && zs[1] > 64 && zs[1] <= 4096 && rows >= 8 && R.rows_wavefront) {
+        if (nd == 2 && zs[1] > 64 && zs[1] <= 4096 && rows >= 8 && R.rows_wavefront) {
             // long rows, rank 2: the coefficient-level wavefront (tasks are 64-coefficient segments of rows)
             const size_t words = rows * ((zs[1] + 63) / 64) + 1;
             std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
             zero_elems(false, fl->p, (words + 1) / 2 + 1);
-            return K<E>::rows_wavefront(R.stream, 0, dp<E>(self), self.numel, xs, dp<E>(other), other.numel, ys, dp<E>(out), out.numel, zs, nullptr, 0,
-                                        reinterpret_cast<unsigned*>(fl->p));
+            return K<E>::rows_wavefront(R.stream, 0, x.p, x.plane, xs, y.p, y.plane, ys, z.p, z.plane, zs, nullptr, 0, reinterpret_cast<unsigned*>(fl->p));
         }
-        if (zs[keep.size() - 1] > 64 || zs[keep.size() - 1] < 2 || rows < 64) return false;
+        if (zs[nd - 1] > 64 || zs[nd - 1] < 2 || rows < 64) return false;
         std::shared_ptr<Buf> fl = alloc_doubles((rows + 1 + 1) / 2 + 1);
         zero_elems(false, fl->p, (rows + 1 + 1) / 2 + 1);
-        return K<E>::div_wavefront(R.stream, dp<E>(self), self.numel, xs, dp<E>(other), other.numel, ys, dp<E>(out), out.numel, zs,
-                                   (int)keep.size(), reinterpret_cast<unsigned*>(fl->p));
+        return K<E>::div_wavefront(R.stream, x.p, x.plane, xs, y.p, y.plane, ys, z.p, z.plane, zs, (int)nd, reinterpret_cast<unsigned*>(fl->p));
+    }
+    // Large f64 quotients: the recurrence BLOCKED over the leading axis, right-looking (round 5).  The wavefronts keep the
+    // reference's order and pay for it with two 8-byte LDS reads per multiply-add on one workgroup per CU: 2-6 % of the FP64
+    // roof at every size, 8-10x the time of the product of the same multiply-adds.  But only the terms INSIDE a block of B
+    // leading slabs depend on each other slab by slab:
+    //   res[b0..b1) = (xs[b0..b1) - sum_{j < b0} res[j] (*) ys[k - j]) / ys[0..B)        -- a division of B slabs: the wavefront
+    //   acc[k] += sum_{j in block} res[j] (*) ys[k - j]   for k >= b1                       -- ONE slab-range product, accumulating:
+    // the tiled FMA kernel (gft_conv_raw's own accumulate mode).  The quotient's memory holds the running sums, as in div_rec.
+    // Contract: the tiled kernel's (explicit FMA, its own summation order) — 1e-10 against the oracle, normwise on data whose
+    // quotient cancels; non-finite operands reach the guarded reference-order product, so the non-finite pattern is the
+    // reference's.  "div_right" = 0 (GFT_DIV_RIGHT) keeps the reference order everywhere; below div_right_min_macs it is kept
+    // anyway (the wavefront alone is faster there).
+    static bool div_right_blocked(const P& self, const P& other, const P& out) {
+        if (W != 1 || !R.div_right) return false;
+        Dims keep = collapse_mask({&out.shape}, false);
+        if (keep.size() < 2 || keep.size() > 4) return false;
+        Dims xsh = pick(self.shape, keep), ysh = pick(other.shape, keep), zsh = pick(out.shape, keep);
+        if (!div_right_applies(xsh, ysh, zsh)) return false;  // (before dp(): nothing is launched for a product this form declines)
+        HV x{dp<E>(self), self.numel, xsh, false}, y{dp<E>(other), other.numel, ysh, false}, z{dp<E>(out), out.numel, zsh, false};
+        div_right_hv(x, y, z);
+        R.stats_right[0]++;
+        return true;
+    }
+    static size_t div_right_block_of(const Dims& zsh) {
+        const size_t nd = zsh.size(), n0 = zsh[0], last = zsh[nd - 1], rows_per_slab = prod(zsh) / n0 / last;
+        size_t B = std::max<size_t>(R.div_right_block, 1);
+        if (last <= 64) B = std::max(B, (64 + rows_per_slab - 1) / rows_per_slab);  // the block's row wavefront wants >= 64 rows
+        else B = std::max<size_t>(B, 8);                                               // ... the long-row one >= 8
+        return B;
+    }
+    static bool div_right_applies(const Dims& xsh, const Dims& ysh, const Dims& zsh) {
+        if (W != 1 || !R.div_right || !R.div_wavefront || !R.div2d || R.conv_mode == 1 || R.conv_mode == 3) return false;
+        const size_t nd = zsh.size();
+        if (nd < 2 || nd > 4 || xsh.size() != nd || ysh.size() != nd) return false;
+        const size_t last = zsh[nd - 1];
+        if (last < 2 || !(last <= 64 || (nd == 2 && last <= 4096 && R.rows_wavefront))) return false;
+        for (size_t i = 0; i < nd; ++i)
+            if (xsh[i] > zsh[i] || ysh[i] > zsh[i] || ysh[i] == 0 || zsh[i] < 2) return false;
+        if (est_macs(zsh, ysh, zsh) < R.div_right_min_macs) return false;
+        return zsh[0] >= 2 * div_right_block_of(zsh);
+    }
+    // z = x / y on contiguous views without unit axes (div_right_applies holds).  x may be shorter than z on any axis.
+    static void div_right_hv(const HV& x, const HV& y, const HV& z) {
+        const Dims &xsh = x.shape, &ysh = y.shape, &zsh = z.shape;
+        const size_t n0 = zsh[0], B = div_right_block_of(zsh);
+        const size_t slab = z.numel() / n0, xslab = xsh[0] ? x.numel() / xsh[0] : 0;
+        Dims rest(zsh.begin() + 1, zsh.end()), yrest(ysh.begin() + 1, ysh.end()), xrest(xsh.begin() + 1, xsh.end());
+        const bool x_full = xrest == rest;
+        zero_elems(false, z.p, z.numel());
+        for (size_t b0 = 0; b0 < n0;) {
+            const size_t b1 = n0 - (b0 + B) < B ? n0 : b0 + B, nb = b1 - b0;  // (a short remainder joins the last block)
+            // the block's dividend: xs[b0..b1) - (what the earlier blocks have accumulated into res[b0..b1))
+            std::shared_ptr<Buf> tmp = alloc_doubles(nb * slab);
+            Dims bsh{nb};
+            bsh.insert(bsh.end(), rest.begin(), rest.end());
+            HV tv{tmp->p, nb * slab, bsh, false}, zb{z.p + b0 * slab, z.plane, bsh, false};
+            if (b0 == 0) zero_elems(false, tmp->p, nb * slab);
+            else {
+                copy_elems(false, tmp->p, zb.p, nb * slab);
+                x_map_inplace(tv, MAP_NEG, 0);
+            }
+            if (b0 < xsh[0]) {
+                const size_t nx = std::min(b1, xsh[0]) - b0;
+                if (x_full) {
+                    Dims s{nx};
+                    s.insert(s.end(), rest.begin(), rest.end());
+                    x_block_op(HV{tmp->p, nb * slab, s, false}, HV{x.p + b0 * xslab, x.plane, s, false}, BLK_ADD, 0);
+                } else {
+                    for (size_t k = 0; k < nx; ++k) x_block_op(tv.index0(k), HV{x.p + (b0 + k) * xslab, x.plane, xrest, false}, BLK_ADD, 0);
+                }
+            }
+            Dims ybsh{std::min(nb, ysh[0])};
+            ybsh.insert(ybsh.end(), yrest.begin(), yrest.end());
+            if (!div_wavefront_hv(tv, HV{y.p, y.plane, ybsh, false}, zb)) throw Error("internal: blocked division: the block's wavefront declined");
+            if (b1 < n0 && ysh[0] >= 2) {  // trailing update: res[b0 + k'] += sum_{j' < nb} res[b0 + j'] (*) ys[k' - j'] for k' in [nb, ..)
+                const size_t hi = std::min(n0 - b0, nb + ysh[0] - 1);
+                Dims zt{n0 - b0};
+                zt.insert(zt.end(), rest.begin(), rest.end());
+                conv(zb, y, HV{z.p + b0 * slab, z.plane, zt, false}, nb, hi, true, false, 0, 0, 0);
+            }
+            b0 = b1;
+        }
+    }
+    // The slabs k0 >= 1 of log(xs) the same way (slab 0 — a logarithm one dimension down — is there already): with
+    // q_k = k * res[k] the recurrence mt:1362-1384 reads q_k = (k xs[k] - sum_{1 <= j < k} xs[k-j] (*) q_j) / xs[0], which is the
+    // division (k xs[k])_{k >= 1} / xs, and res[k] = q_k / k.  Same contract as div_right_blocked.
+    static bool log_right(const HV& xs, const HV& res) {
+        if (W != 1 || res.host || xs.host) return false;
+        const size_t nd = res.shape.size();
+        if (nd < 2 || nd > 4 || xs.shape.size() != nd || xs.shape[0] < 2) return false;
+        for (size_t i = 0; i < nd; ++i)
+            if (res.shape[i] < 2 || xs.shape[i] > res.shape[i]) return false;
+        Dims qsh = res.shape, xq = xs.shape;
+        qsh[0] -= 1;
+        xq[0] -= 1;
+        Dims yq = xs.shape;  // the divisor: the slabs of xs the quotient's q0 slabs can see
+        yq[0] = std::min(yq[0], qsh[0]);
+        if (qsh[0] < 2 || !div_right_applies(xq, yq, qsh)) return false;
+        HV scaled;
+        std::shared_ptr<Buf> sb = scaled_by_index(xs, &scaled);  // xs[j] * j
+        const size_t xslab = xs.numel() / xs.shape[0], slab = res.numel() / res.shape[0];
+        std::shared_ptr<Buf> qb = alloc_doubles(qsh[0] * slab);
+        HV q{qb->p, qsh[0] * slab, qsh, false};
+        div_right_hv(HV{scaled.p + xslab, scaled.plane, xq, false}, HV{xs.p, xs.plane, yq, false}, q);
+        K<E>::div_by_index(R.stream, q.p, q.plane, res.p + slab, res.plane, qsh[0], slab, 1u);
+        R.stats_right[1]++;
+        return true;
     }
 
     // ---- exp / log (mt:406-430, 1270-1386) ---------------------------------------------------------------------
@@ -2596,6 +2720,7 @@ struct Ops {
         log_rec(xs.index0(0), res.index0(0), seed);
         size_t n0 = res.shape[0];
         if (n0 <= 1) return;
+        if (!host && log_right(xs, res)) return;  // (large f64 logarithms: blocked right-looking, the tiled product's contract)
         if (!host && log_wavefront(xs, res)) return;
         // rs[j] = res[j] * j, filled slab by slab as res becomes known (mt:1362-1365)
         std::shared_ptr<Buf> rsbuf = alloc_tier(host, res.numel() * W);
@@ -4275,6 +4400,9 @@ int gft_init(int device) {
         if (const char* dw = getenv("GFT_DIV_WAVEFRONT")) R.div_wavefront = atoi(dw) != 0;
         if (const char* rw = getenv("GFT_ROWS_WAVEFRONT")) R.rows_wavefront = atoi(rw) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
+        if (const char* dr = getenv("GFT_DIV_RIGHT")) R.div_right = atoi(dr) != 0;
+        if (const char* db = getenv("GFT_DIV_RIGHT_BLOCK")) R.div_right_block = (size_t)std::max(1, atoi(db));
+        if (const char* dm = getenv("GFT_DIV_RIGHT_MIN_MACS")) R.div_right_min_macs = atof(dm);
         if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
         {
@@ -4421,6 +4549,9 @@ int gft_set_option(const char* name, double value) {
     else if (n == "div_wavefront") R.div_wavefront = value != 0;
     else if (n == "rows_wavefront") R.rows_wavefront = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
+    else if (n == "div_right") R.div_right = value != 0;
+    else if (n == "div_right_block") R.div_right_block = value < 1 ? 16 : (size_t)value;
+    else if (n == "div_right_min_macs") R.div_right_min_macs = value < 0 ? 1.0e9 : value;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
     else if (n == "side_streams") R.nside = value < 0 ? 0 : std::min<int>(Runtime::NSIDE, (int)value);  // < 0: default (off)

@@ -1402,6 +1402,21 @@ void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const doub
     GFT_LAUNCH(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
 }
 
+// dst[k][..] = src[k][..] / from(first + k) for nslabs leading slabs of `slab` elements: the "/ k0" of every slab of a
+// logarithm (mt:1384) in one launch (the blocked right-looking form, gft_api.hip Ops::log_right)
+template <class E>
+__global__ void __launch_bounds__(256) k_div_by_index(const double* __restrict__ src, size_t sp, double* __restrict__ dst, size_t dp, size_t slab,
+                                                      size_t total, unsigned first) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        E::st(dst, dp, i, E::div(E::ld(src, sp, i), E::from_u32(first + (unsigned)(i / slab))));
+}
+template <class E>
+void K<E>::div_by_index(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t nslabs, size_t slab, unsigned first) {
+    const size_t total = nslabs * slab;
+    if (total == 0) return;
+    GFT_LAUNCH(k_div_by_index<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, dst, dst_plane, slab, total, first);
+}
+
 // Does the tensor hold a coefficient that is exactly zero ([0,0] for intervals)?  One launch, the answer through the mailbox
 // (payload[0] = 1 if so): the premise of the "no exact zero anywhere" proofs of gft_api.hip (Ops::nz_of).  state[0] collects
 // the blocks' findings, state[1] counts their arrivals; the last block publishes and leaves both words zero.

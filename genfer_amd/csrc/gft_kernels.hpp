@@ -363,6 +363,7 @@ struct K {
     static void sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
                          unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode);
     // *count += number of positions where a != b  (n contiguous elements)
+    static void div_by_index(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t nslabs, size_t slab, unsigned first);
     static void any_zero(hipStream_t st, const double* p, size_t plane, size_t n, unsigned* state, const Mailbox& mb);
     static void count_neq(hipStream_t st, const double* a, size_t a_plane, const double* b, size_t b_plane,
                           size_t n, unsigned* count);
