@@ -157,7 +157,7 @@ def run_sgcl(source: str, flags: str = ""):
 OP_STATS = ("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops",
             "host_to_device_mirrors")
 OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_launches", "launches_in_place", "shallow_products",
-               "fused_horner_steps", "side_scopes", "cross_stream_waits", "riders", "fused_observe_adds", "scans_proven")
+               "fused_horner_steps", "side_scopes", "cross_stream_waits", "riders", "fused_observe_adds", "scans_proven", "nested_adds")
 
 
 def pool_stats() -> dict:

@@ -129,7 +129,8 @@ thread_local std::string g_err;
 //     fields while the stream is current, so no kernel-issuing code knows about streams); a block returns to its home
 //     pool at once unless another stream has work on it in flight — then it waits in that pool's `limbo` behind events
 //     recorded on those streams and is taken out when they have completed (polled, never waited for).
-// Which operations take a side scope, and when: Ops::pick_stream.  "side_streams" / GFT_SIDE_STREAMS = 0: one stream.
+// Which operations take a side scope, and when: Ops::pick_stream.  "side_streams" / GFT_SIDE_STREAMS = 0 (the default): one
+// stream.  Side streams and RECORDED operations (Buf::lazy) are alternatives: with side streams on nothing is recorded.
 struct EvHolder;
 struct Buf;
 struct LimboBlock {
@@ -171,6 +172,8 @@ struct Runtime {
     size_t stats_side[4] = {0, 0, 0, 0};    // {side scopes, cross-stream waits, observation chains that rode along with another launch, lazy observations fused}
     bool obs_riders = true;                 // "obs_riders" / GFT_OBS_RIDERS: recorded chains ride along with other observation launches
     size_t stats_nz = 0;                    // linearity scans answered by a "no exact zero" proof
+    size_t stats_sum = 0;                   // Adds that evaluated a recorded Add of two chains in their own launch (K<E>::chain_nest)
+    bool lazy_sum = true;                   // "lazy_sum" / GFT_LAZY_SUM: Adds of two chains are recorded, not launched (Ops::fuse_lazy_sums)
     bool nz_proofs = true;                  // "nz_proofs" / GFT_NZ_PROOFS: interval tensors proven free of exact zeros skip the Horner loops' linearity scans
     bool lazy_horner = true;                // "lazy_horner" / GFT_LAZY_HORNER: proven Horner loops on old operands are recorded (Ops::horner_linear_rest)
     bool horner_riders = true;              // "horner_riders" / GFT_HORNER_RIDERS: ... and ride along with other loops' launches
@@ -422,6 +425,7 @@ struct LazyOp {
     std::function<void(Buf*)> run;
     std::shared_ptr<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
     std::shared_ptr<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
+    std::shared_ptr<void> sum;     // Ops<E>::LazySum: a recorded Add / Sub of two chains (an Add that consumes it launches both: K<E>::chain_nest)
     unsigned long long input_birth = 0;  // when the recording's inputs were there (main-stream operation count): the buffer's age once launched
 };
 // When the values of a buffer were (or, for a recording, could have been) there, in main-stream operations.
@@ -598,7 +602,12 @@ struct ScanCtx {
     ~ScanCtx() { g_scan_trace.ctx = prev; }
 };
 
+// (All mails share ONE payload slot and the poll matches the sequence number exactly: a mail issued while a scan's mail is
+// still outstanding — between extract_linear_begin and _end, where the caller queues guarded launches — would overwrite the
+// payload and make the scan's wait miss its number.  Nothing does that today; this makes sure nothing starts to.)
+static int g_scan_mail_open = 0;
 static Mailbox next_mail() {
+    if (g_scan_mail_open) throw Error("internal: a mailbox round trip was started while a linearity scan's mail is outstanding");
     Mailbox mb;
     mb.payload = R.d_mail;
     mb.seq = (unsigned long long*)(R.d_mail + 8);
@@ -1475,6 +1484,120 @@ struct Ops {
         return true;
     }
 
+    // A recorded Add / Sub of two chains (addsub's chain path): the operands as they stood after broadcast and truncation.
+    struct LazySum {
+        P a, b;
+        bool subtract = false;
+        Dims shape;  // the sum's own shape
+    };
+    static void launch_sum(const LazySum& ls, double* outp) {
+        Dims ckeep = chain_keep(ls.shape, {&ls.a, &ls.b});
+        if (!ls.a.pend) (void)dp<E>(ls.a);
+        if (!ls.b.pend) (void)dp<E>(ls.b);
+        Shape sh;
+        sh.nd = (int)ckeep.size();
+        for (size_t j = 0; j < ckeep.size(); ++j) sh.d[j] = (unsigned)ls.shape[ckeep[j]];
+        K<E>::chain_addsub(R.stream, outp, prod(ls.shape), sh, chain_src_dev(ls.a, ckeep), chain_src_dev(ls.b, ckeep), ls.subtract ? 1 : 0);
+        R.stats_ex[2]++;
+    }
+    // addsub(self, other) where an operand is (a stage-carrying whole view of) a recorded sum: ONE launch evaluates the recorded
+    // sum(s) and this one, element for element the operations of the separate launches (K<E>::chain_nest).  false = not this
+    // case (nothing launched).
+    static bool fuse_lazy_sums(const P& self, const P& other, bool subtract, const Dims& shape, const Dims& rd, P* result) {
+        if (!R.lazy_sum || R.cur != 0) return false;
+        auto sum_of = [&](const P& p) -> LazySum* {
+            if (!p.buf || p.buf->host || !p.buf->lazy || !p.buf->lazy->sum) return nullptr;
+            LazySum* ls = static_cast<LazySum*>(p.buf->lazy->sum.get());
+            if (!same_dims_mod_trailing_ones(p.shape, ls->shape)) return nullptr;  // (a sub-box view: launch the sum)
+            if (p.pend) {
+                const Pend& q = *p.pend;
+                if (q.padded || q.base_off != 0 || q.mat || !same_dims_mod_trailing_ones(q.base_shape, ls->shape)) return nullptr;
+                for (int i = 0; i < q.n; ++i)
+                    if (q.st[i].kind == CH_MUL_TAB) return nullptr;  // (table stages index the view's axes: keep it simple)
+            }
+            return ls;
+        };
+        LazySum* la = sum_of(self);
+        LazySum* lb = sum_of(other);
+        if (!la && !lb) return false;
+        if (la && lb && self.buf.get() == other.buf.get()) return false;
+        // the kernel's axes: the output's non-unit axes and every table / pad axis of the four leaves
+        Dims keep;
+        {
+            std::vector<const P*> leaves;
+            auto add_leaves = [&](const P& p, LazySum* l) {
+                if (l) {
+                    leaves.push_back(&l->a);
+                    leaves.push_back(&l->b);
+                } else
+                    leaves.push_back(&p);
+            };
+            add_leaves(self, la);
+            add_leaves(other, lb);
+            for (size_t ax = 0; ax < shape.size(); ++ax) {
+                bool k = shape[ax] != 1;
+                for (const P* p : leaves)
+                    if (p->pend) {
+                        for (int i = 0; i < p->pend->n; ++i)
+                            if (p->pend->st[i].kind == CH_MUL_TAB && (size_t)p->pend->st[i].axis == ax) k = true;
+                        if (p->pend->padded && ax < p->pend->pad.size() && p->pend->pad[ax] > 0) k = true;
+                    }
+                if (k) keep.push_back(ax);
+            }
+            for (const P* p : leaves) {  // no leaf may index an axis beyond the output's rank
+                if (p->pend)
+                    for (int i = 0; i < p->pend->n; ++i)
+                        if (p->pend->st[i].kind == CH_MUL_TAB && (size_t)p->pend->st[i].axis >= shape.size()) return false;
+            }
+        }
+        if (keep.size() > (size_t)MAXD || prod(shape) >= 0x7fffffffull) return false;
+        // hold the recordings: bringing a leaf into memory may launch other recordings, never these (they are not in any rider list)
+        std::shared_ptr<LazyOp> keep_a = la ? self.buf->lazy : nullptr, keep_b = lb ? other.buf->lazy : nullptr;
+        auto leaf = [&](const P& p) {
+            if (!p.pend) (void)dp<E>(p);
+            return chain_src_dev(p, keep);
+        };
+        auto fits = [&](const ChainSrc& c) {
+            unsigned long long span = 1;
+            for (size_t j = 0; j < keep.size(); ++j) span += (unsigned long long)(c.box[j] ? c.box[j] - 1 : 0) * c.stride[j];
+            return span < 0x7fffffffull;
+        };
+        auto nest = [&](const P& p, LazySum* l, NestSrc& n) -> bool {
+            std::memset(&n, 0, sizeof(n));
+            if (!l) {
+                n.nested = 0;
+                n.a = leaf(p);
+                return fits(n.a);
+            }
+            n.nested = 1;
+            n.sub_inner = l->subtract ? 1 : 0;
+            n.a = leaf(l->a);
+            n.b = leaf(l->b);
+            for (size_t j = 0; j < keep.size(); ++j) n.box[j] = (unsigned)(keep[j] < l->shape.size() ? l->shape[keep[j]] : 1);
+            if (p.pend) {
+                n.npost = p.pend->n;
+                for (int i = 0; i < p.pend->n; ++i) {
+                    n.post[i].kind = p.pend->st[i].kind;
+                    n.post[i].s = Scalar2{p.pend->st[i].s[0], p.pend->st[i].s[1]};
+                }
+            }
+            return fits(n.a) && fits(n.b);
+        };
+        NestSrc na, nb;
+        if (!nest(self, la, na) || !nest(other, lb, nb)) return false;  // (leaves brought into memory stay there: no harm)
+        // (a leaf's dp() may have launched one of the recordings after all — as a leaf of itself it cannot, but be safe)
+        if ((la && !self.buf->lazy) || (lb && !other.buf->lazy)) return false;
+        P out = make(shape, rd);
+        out.buf->nz = sum_nz(self, other, shape);
+        Shape sh;
+        sh.nd = (int)keep.size();
+        for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)shape[keep[j]];
+        K<E>::chain_nest(R.stream, dp<E>(out), out.numel, sh, na, nb, subtract ? 1 : 0);
+        R.stats_ex[2]++;
+        R.stats_sum++;
+        *result = out;
+        return true;
+    }
     // (intervals) a sum of two tensors of the result's own shape: [0,0] only where both are
     static unsigned char sum_nz(const P& a, const P& b, const Dims& shape) {
         if (W != 2) return 0;
@@ -1561,8 +1684,31 @@ struct Ops {
             if (ckeep.size() <= (size_t)MAXD) {
                 P fused;
                 if (fuse_lazy_observe(self, other, subtract, shape, rd, &fused)) return fused;
+                if (fuse_lazy_sums(self, other, subtract, shape, rd, &fused)) return fused;
                 P out = make(shape, rd);
                 out.buf->nz = sum_nz(self, other, shape);
+                const bool shifted = (self.pend && self.pend->padded) || (other.pend && other.pend->padded);
+                if (R.lazy_sum && R.cur == 0 && !R.nside && prod(shape) >= 64 && shifted) {
+                    // The Add inside mul_linear (c * t + m * shift(t): one operand carries a front pad) is RECORDED, not launched:
+                    // if an Add consumes it (the merge of an `if` whose arms both end in `State ~ Bernoulli(p)`), both run as one
+                    // launch (fuse_lazy_sums); anybody else launches it through use_buf().  Other two-chain Adds are launched
+                    // where they stand: their consumers are observation chains, and a later launch is only less overlap
+                    // (mixture f64 0.129 -> 0.145 s with every Add recorded)
+                    auto ls = std::make_shared<LazySum>();
+                    ls->a = self;
+                    ls->b = other;
+                    ls->subtract = subtract;
+                    ls->shape = shape;
+                    auto op = std::make_shared<LazyOp>();
+                    op->sum = ls;
+                    op->run = [ls](Buf* b) { launch_sum(*ls, b->p); };
+                    unsigned long long ib = 0;
+                    if (self.buf && !self.buf->host) ib = std::max(ib, birth_of(self.buf.get()));
+                    if (other.buf && !other.buf->host) ib = std::max(ib, birth_of(other.buf.get()));
+                    op->input_birth = ib;
+                    out.buf->lazy = op;
+                    return out;
+                }
                 if (!self.pend) (void)dp<E>(self);   // plain operands: lazy handles / host-tier tensors get their device buffer
                 if (!other.pend) (void)dp<E>(other);
                 Shape sh;
@@ -1658,6 +1804,7 @@ struct Ops {
                     if (p.shape[ckeep[j]] >= 2) cm |= 1u << j;
                 }
                 t.mb = next_mail();
+                g_scan_mail_open = 1;
                 K<E>::chain_copy_scan(R.stream, outb->p, p.numel, sh, chain_src<E>(p, ckeep), cm, R.d_flag + 8, t.mb);
                 trace_settle();
                 R.stats_ex[1]++;
@@ -1701,6 +1848,7 @@ struct Ops {
         HV v = view(p);
         DView dv = dview(v, &keep);
         t.mb = next_mail();
+        g_scan_mail_open = 1;
         K<E>::linear_scan(R.stream, dv, cmask, R.d_flag + 8, t.mb);  // one launch (state words 8, 9), result by mailbox
         R.stats[0]++;
         g_scan_trace.hit(p.numel, keep.size());
@@ -1729,6 +1877,7 @@ struct Ops {
     static bool extract_linear_end(ScanToken& t, double c[2], double m[2], size_t* var) {
         if (!t.done) {
             double res[5];
+            g_scan_mail_open = 0;
             wait_mail(t.mb, res, 5);
             finish_scan(t, res);
             t.done = true;
@@ -3009,7 +3158,7 @@ struct Ops {
         if (n == 0) return a;
         // (a single step takes the chain kernel too when chains are recorded: as the epilogue-carrying launch of the Add that
         // follows, or as a rider, it costs no launch of its own — k_observe_step is the one-launch form)
-        if ((n == 1 && !(R.lazy_observe && R.cur == 0)) || tier_host(a.numel, a) || n > 4096) return stepwise();
+        if ((n == 1 && !(R.lazy_observe && R.cur == 0 && !R.nside)) || tier_host(a.numel, a) || n > 4096) return stepwise();
         if (n > (size_t)OC_MAX) {  // long chains: OC_MAX steps per launch
             P r = a;
             for (size_t i = 0; i < n; i += OC_MAX) {
@@ -3084,8 +3233,11 @@ struct Ops {
         // derivative factors j + 1 and the constants c are non-zero (checked above), x is not [0,0]
         const int in_nz = nz_of(a);
         const unsigned char out_nz = (unsigned char)(in_nz == 2 ? (val_is_zero(x) ? 0 : 2) : in_nz);
+        // (a recorded SUM as the input is launched now: only an Add could have launched it for free, and a chain whose input is
+        // not in memory can neither ride along with another launch nor let the Horner loop behind it do so)
+        if (a.buf && !a.buf->host && a.buf->lazy && a.buf->lazy->sum) use_buf(a.buf.get());
         const int sid = pick_stream(a);
-        if (sid == 0 && R.lazy_observe && R.cur == 0 && a.buf && !a.buf->host) {
+        if (sid == 0 && R.lazy_observe && R.cur == 0 && !R.nside && a.buf && !a.buf->host) {
             P out = make(S, G);
             out.buf->nz = out_nz;
             auto lo = std::make_shared<LazyObs>();
@@ -3230,7 +3382,9 @@ struct Ops {
         LazyObs* lo = lazy_of(other);
         const bool x_is_other = lo != nullptr;
         if (!lo) lo = lazy_of(self);
-        if (!lo) return false;
+        if (!lo) {
+            return false;
+        }
         const P& X = x_is_other ? other : self;
         const P& Y = x_is_other ? self : other;
         if (Y.buf && Y.buf.get() == X.buf.get()) return false;  // (both read the same recording: launch it)
@@ -3343,7 +3497,7 @@ struct Ops {
         if (v >= a.shape.size()) return a;
         // (before anything below launches a recorded input) is the operand old news to the main chain?  Then its Horner loop,
         // if it comes to one, is recorded and rides along with a later loop's launch (horner_linear_rest, LazyHorner)
-        const bool old_input = R.lazy_horner && R.cur == 0 && a.buf && !a.buf->host && !a.buf->borrowed &&
+        const bool old_input = R.lazy_horner && R.cur == 0 && !R.nside && a.buf && !a.buf->host && !a.buf->borrowed &&
                                main_ops_now() - birth_of(a.buf.get()) >= R.side_min_age;
         Dims deg = min_degrees(a, subst);
         if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
@@ -3597,7 +3751,9 @@ struct Ops {
                 if (in_block) {
                     double c_[2], m_[2];
                     size_t u_;
-                    if (res.numel > 1 && !extract_linear(res, c_, m_, &u_)) res_nonlinear_seen = true;  // (the device steps need not ask again)
+                    // (a PROVEN loop's device steps need not ask again; an unproven one scans the accumulator that arrives on the
+                    // device — this verdict is about the accumulator BEFORE the step, and only witnesses cover results of steps)
+                    if (res.numel > 1 && !extract_linear(res, c_, m_, &u_) && proven) res_nonlinear_seen = true;
                     res = addsub(mul(res, subst), horner_coeff(ca_h, v, i - ca_h_lo, deg), false);
                     continue;
                 }
@@ -3605,10 +3761,10 @@ struct Ops {
                     double c_[2], m_[2];
                     size_t u_;
                     if (!extract_linear(res, c_, m_, &u_)) {
-                        // (the host scan's verdict carries over when the accumulator outgrows the host tier: proven — it
-                        // stays non-linear; otherwise the speculation the device steps make anyway, verified by their witnesses.
-                        // Without this the first device accumulator was scanned again: a launch and a host round trip)
-                        res_nonlinear_seen = true;
+                        // (the host scan's verdict carries over when the accumulator outgrows the host tier ONLY for a proven loop
+                        // — it stays non-linear.  Otherwise the accumulator this step hands to the device is scanned there once:
+                        // the witnesses of the speculative steps cover their own results, not the one they start from)
+                        if (proven) res_nonlinear_seen = true;
                         // proven (interval, non-zero finite constant): the accumulator stays non-linear for the rest of the
                         // loop, so every remaining step runs in one host loop — two ping-pong buffers, no per-step scan,
                         // handle or shape vectors (they cost as much as the arithmetic on ~100-element tensors)
@@ -4302,6 +4458,8 @@ static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
         return r;
     } catch (const std::exception& e) {
         g_err = e.what();
+        g_scan_mail_open = 0;
+        if (R.cur != 0) switch_ctx(0);
         return nullptr;
     }
 }
@@ -4314,6 +4472,8 @@ static int guard_int(F&& f, const char* fn = __builtin_FUNCTION()) {
         return f();
     } catch (const std::exception& e) {
         g_err = e.what();
+        g_scan_mail_open = 0;
+        if (R.cur != 0) switch_ctx(0);
         return -1;
     }
 }
@@ -4389,6 +4549,7 @@ int gft_init(int device) {
         if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
         if (const char* lh = getenv("GFT_LAZY_HORNER")) R.lazy_horner = atoi(lh) != 0;
         if (const char* np = getenv("GFT_NZ_PROOFS")) R.nz_proofs = atoi(np) != 0;
+        if (const char* lsum = getenv("GFT_LAZY_SUM")) R.lazy_sum = atoi(lsum) != 0;
         if (const char* hr = getenv("GFT_HORNER_RIDERS")) R.horner_riders = atoi(hr) != 0;
         R.device = device;
         if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
@@ -4507,10 +4668,10 @@ void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
 size_t gft_op_stats_ex(size_t* out, size_t cap) {
-    const size_t v[12] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
-                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3], R.stats_nz};
-    for (size_t i = 0; i < 12 && i < cap; ++i) out[i] = v[i];
-    return 12;
+    const size_t v[13] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
+                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3], R.stats_nz, R.stats_sum};
+    for (size_t i = 0; i < 13 && i < cap; ++i) out[i] = v[i];
+    return 13;
 }
 void gft_pool_stats(size_t out[3]) {
     // (the grow-only kernel workspaces — row-pair sums, row flags, the tiled product's — are not pool blocks: counted here so that
@@ -4560,6 +4721,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "obs_riders") R.obs_riders = value != 0;
     else if (n == "lazy_horner") R.lazy_horner = value != 0;
     else if (n == "nz_proofs") R.nz_proofs = value != 0;
+    else if (n == "lazy_sum") R.lazy_sum = value != 0;
     else if (n == "horner_riders") R.horner_riders = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default
@@ -5034,7 +5196,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::derivative_truncated(*a, v, n, d); });                              \
     }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
-        return guard([&] { return R.lazy_observe ? Ops<E>::observe_chain(*a, v, x, c, 1, d) : Ops<E>::observe_step(*a, v, x, c, d); }); \
+        return guard([&] { return (R.lazy_observe && !R.nside) ? Ops<E>::observe_chain(*a, v, x, c, 1, d) : Ops<E>::observe_step(*a, v, x, c, d); }); \
     }                                                                                                         \
     gft_poly* PFX##observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
         return guard([&] { return Ops<E>::observe_chain(*a, v, x, cs, n, d); });                              \

@@ -638,6 +638,12 @@ static bool chain_is_flat(const ChainSrc& c, const Shape& sh) {
 // Two levels — groups of 32 workgroups count on their own word (128 bytes apart, behind the state words: state + 248 +
 // 32 g), a group's last arriver counts on state[1] — because same-address atomics serialise at ~26 ns each: one counter for
 // the 329 workgroups of a 290^2 tensor was 8 us of a 6 us kernel's tail, for the 2048 of a 100^3 tensor 50 us.
+// INVARIANT (what the last workgroup may read, and who fences it): after the last arrival the publishing workgroup reads back
+// ONLY state[0] (atomics: coherent by themselves) and, in k_chain_scan / k_linear_scan, element 0 and the unit positions of the
+// tensor — and exactly the WRITERS of those elements fence their stores (device scope) before their workgroup's barrier and
+// arrival.  The __threadfence() below orders thread 0's own view (its workgroup's atomics before its arrival); it is NOT a
+// licence to read other elements another XCD wrote: a read-back of anything else needs its writer to fence first
+// (__syncthreads alone does not wait for vmcnt outside tgsplit mode).
 __device__ __forceinline__ bool scan_arrive(unsigned* state) {
     constexpr unsigned G = 32;
     const unsigned group = blockIdx.x / G, ngroups = (gridDim.x + G - 1) / G;
@@ -758,6 +764,62 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
     if (chain_fits_u32(a, sh, total) && chain_fits_u32(b, sh, total))
         GFT_LAUNCH((k_chain<E, true, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
     else GFT_LAUNCH((k_chain<E, true, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
+}
+
+// Nested chain add (NestSrc): out = (0 + A) (+|-) B where A / B are chains or recorded two-chain sums.
+template <class E>
+__device__ __forceinline__ bool nest_chain_at(const ChainSrc& c, const unsigned* k, int nd, typename E::V& v) {
+    unsigned off = 0;
+    bool in = true, first = true;
+#pragma unroll 1
+    for (int ax = 0; ax < nd; ++ax) {
+        const unsigned ka = k[ax] - (unsigned)c.pad[ax];  // (wraps below the pad: fails the box test)
+        if (ka >= c.box[ax]) in = false;
+        if (ka != 0) first = false;
+        off += ka * (unsigned)c.stride[ax];
+    }
+    if (in) v = chain_eval<E>(c, (size_t)off, k, first);
+    return in;
+}
+template <class E>
+__device__ __forceinline__ bool nest_eval(const NestSrc& s, const unsigned* k, int nd, typename E::V& out) {
+    typedef typename E::V V;
+    if (!s.nested) return nest_chain_at<E>(s.a, k, nd, out);
+    bool all0 = true;
+#pragma unroll 1
+    for (int ax = 0; ax < nd; ++ax) {
+        if (k[ax] >= s.box[ax]) return false;
+        if (k[ax]) all0 = false;
+    }
+    V v = E::zero(), t;
+    if (nest_chain_at<E>(s.a, k, nd, t)) v = E::add(v, t);
+    if (nest_chain_at<E>(s.b, k, nd, t)) v = s.sub_inner ? E::sub(v, t) : E::add(v, t);
+    out = chain_apply<E>(s.post, s.npost, nullptr, v, k, all0);
+    return true;
+}
+template <class E>
+__global__ void __launch_bounds__(256) k_chain_nest(double* __restrict__ out, size_t out_plane, Shape sh, NestSrc a, NestSrc b, int subtract, unsigned total) {
+    typedef typename E::V V;
+    for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < total; lin += gridDim.x * 256u) {
+        unsigned k[MAXD], r = lin;
+#pragma unroll 1
+        for (int ax = sh.nd - 1; ax >= 0; --ax) {
+            const unsigned d = sh.d[ax];
+            k[ax] = r % d;
+            r /= d;
+        }
+        V v = E::zero(), t;
+        if (nest_eval<E>(a, k, sh.nd, t)) v = E::add(v, t);
+        if (nest_eval<E>(b, k, sh.nd, t)) v = subtract ? E::sub(v, t) : E::add(v, t);
+        E::st(out, out_plane, lin, v);
+    }
+}
+template <class E>
+void K<E>::chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const NestSrc& a, const NestSrc& b, int subtract) {
+    size_t total = 1;
+    for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
+    if (total == 0) return;
+    GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, (unsigned)total);
 }
 
 // ------------------------------------------------------------------------------------------

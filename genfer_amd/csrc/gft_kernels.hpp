@@ -92,6 +92,18 @@ struct ChainSrc {
     ChainStage st[CHAIN_MAX];
 };
 
+// An operand of a NESTED chain add (round 5): either a chain `a`, or a RECORDED sum (0 + a) (+|-) b of two chains over its own
+// box — what k_chain<E, true> would have written to memory — with the stages `post` a view of that sum carried.  An `if`
+// whose arms both end in mul_linear (State ~ Bernoulli(p) in hmm: c * t + m * shift(t), itself a two-chain add) and the Add of
+// the arms are then ONE launch of four sources instead of three launches; per element the operations of the three.
+struct NestSrc {
+    int nested, sub_inner;
+    ChainSrc a, b;
+    unsigned box[MAXD];
+    int npost;
+    ChainStage post[CHAIN_MAX];
+};
+
 // Fused observation step (generating_function.rs:678-700): out = c * ((D * 1)>>v + x * D) with
 // D = derivative(a, v, 1) truncated, i.e. the reference sequence derivative -> truncate -> * (x + eps_v)
 // (mul_linear: mul_var + constant scale + add) -> * c, element for element in the same operation order.
@@ -264,6 +276,7 @@ struct K {
     static void chain_copy_scan(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a, unsigned axes_mask,
                                 unsigned* state, const Mailbox& mb);
     // out[k] = ((0 + A[k]?) +/- B[k]?) like addsub_padded, A / B deferred chains evaluated on the fly
+    static void chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const NestSrc& a, const NestSrc& b, int subtract);
     static void chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& out_shape, const ChainSrc& a,
                              const ChainSrc& b, int subtract);
     // out[k] = ((0 + a[k]?) +/- b[k]?) with a, b leading blocks of out's shape  (mt:873-880, 927-934)

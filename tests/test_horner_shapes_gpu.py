@@ -197,3 +197,116 @@ def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI,
     _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
     if tier == "device" and os.environ.get("GFT_SHALLOW_MAX_TERMS") is None:
         assert genfer_amd.op_stats()["shallow_products"] == before + 2, "the products did not take the shallow kernel"
+
+
+# ---- round 5: recorded operations -------------------------------------------------------------------------------
+def rand(shape, seed, lo=0.0, hi=1.0):
+    from conftest import splitmix64_uniform
+
+    return (lo + (hi - lo) * splitmix64_uniform(seed, int(np.prod(shape)))).reshape(shape)
+
+
+def check(o, g):
+    _check(o, g)
+
+
+def _if_statement(T, g, v, x, cs, m, half, deg_p1):
+    """One arm of `if .. {observe k ~ Poisson(l * X_v)}`: the observation chain on the predecessor g, the scaling substitution
+    X_v -> m * X_v (`subst - constant_term(subst)`: for intervals a loop with a few-ulp constant, for f64 a power table), the
+    branch probability."""
+    obs = g.observe_chain(v, x, cs, deg_p1)
+    sub = T.var_with_degrees_p1(v, x, [deg_p1] * 2) * T.from_scalar(m)
+    sub = sub - T.from_scalar(sub.constant_term())
+    return obs.subst_var(v, sub) * T.from_scalar(half)
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_recorded_chains_epilogues_and_riders_bit_exact(interval, OTP, GTP, OTPI, GTPI, tier):
+    """A ladder of mixture-style `if`s through the handle API: observation chains are RECORDED and launched with the
+    Add of the two arms as their epilogue, a recorded chain on an old predecessor rides along with a later observation launch,
+    and with intervals the Horner loops' linearity scans are answered by the "no exact zero" proof and recorded loops ride on
+    other loops' launches.  Every result must equal the oracle's bit for bit, with each switch on and off, and the counters
+    must show that the fused forms were really taken."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    n = 64  # (4096 coefficients: device tensors under the default dispatch too)
+    base = rand((n, n), 501, 0.05, 1.0)
+    arr = np.stack([base, base * (1 + 1e-15)]) if interval else base
+    sc = (lambda v: (v, v)) if interval else (lambda v: v)
+
+    def run(T, levels=4):
+        g = [T.new(arr, [n, n])]
+        for lvl in range(levels):  # the predecessor of the first arm is one level OLDER than that of the second: old news to the main chain
+            d = n - 3 * (lvl + 1)
+            a1 = _if_statement(T, g[max(0, len(g) - 2)].truncate_to_degree_p1(d + 2), 0, sc(0.9), [sc(0.1), sc(0.05)], sc(0.9048374180359595), sc(0.5), d)
+            a2 = _if_statement(T, g[-1].truncate_to_degree_p1(d + 2), 1, sc(0.8), [sc(0.1), sc(0.05)], sc(0.9048374180359595), sc(0.5), d)
+            g.append(a1 + a2)
+        return g[-1]
+
+    want = run(O)
+    # (tier "host" = the default dispatch, under which the substitutions `m * (x + eps_v) - m * x` stay lazy host handles as in
+    # the interpreter's runs; tier "device" materialises them, which launches the recordings early: same bits, no fusion)
+    try:
+        for opts in ({}, {"lazy_observe": 0}, {"obs_riders": 0}, {"lazy_sum": 0}, {"lazy_horner": 0}, {"horner_riders": 0}, {"nz_proofs": 0},
+                     {"lazy_observe": 0, "lazy_sum": 0, "lazy_horner": 0, "nz_proofs": 0}):
+            for k, v in opts.items():
+                assert L.gft_set_option(k.encode(), float(v)) == 0
+            try:
+                before = genfer_amd.op_stats()
+                got = run(G)
+                check(want, got)
+                after = genfer_amd.op_stats()
+                d = {k: after[k] - before[k] for k in after}
+                if not opts and tier == "host":
+                    if not interval:
+                        assert d["fused_observe_adds"] >= 3, d   # the Adds ran as the observation kernels' epilogues
+                    if interval:
+                        assert d["scans_proven"] >= 4 and d["linear_scans"] == 0, d  # no scan, no round trip
+                if opts.get("lazy_observe") == 0:
+                    assert d["fused_observe_adds"] == 0, d
+            finally:
+                for k in opts:
+                    L.gft_set_option(k.encode(), 1.0)
+    finally:
+        pass
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_recorded_sums_nested_add_bit_exact(interval, OTP, GTP, OTPI, GTPI):
+    """hmm's `if`: both arms end in mul_linear (State ~ Bernoulli(p): c * t + m * shift(t), a two-chain Add) and the merge adds
+    them.  The arms' Adds are RECORDED and the merge evaluates all three in one launch (K<E>::chain_nest); anybody else who
+    reads a recorded sum launches it.  Bit for bit the oracle's result either way."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    shape = (2, 48, 48)  # (4608 coefficients: device tensors under the default dispatch too)
+    a, b = rand(shape, 511, 0.1, 1.0), rand(shape, 512, 0.1, 1.0)
+    mk = (lambda t: np.stack([t, t * (1 + 1e-15)])) if interval else (lambda t: t)
+    sc = (lambda v: (v, v)) if interval else (lambda v: v)
+    deg = [2, 48, 48]
+
+    def run(T):
+        ta, tb = T.new(mk(a), deg), T.new(mk(b), deg)
+        lin1 = T.var_with_degrees_p1(0, sc(0.0), deg) * T.from_scalar(sc(0.2)) + T.from_scalar(sc(0.8))   # 0.8 + 0.2 x_0
+        lin2 = T.var_with_degrees_p1(0, sc(0.0), deg) * T.from_scalar(sc(0.7)) + T.from_scalar(sc(0.3))
+        s1, s2 = ta * lin1, tb * lin2          # mul_linear: recorded two-chain Adds
+        merged = s1 + s2                       # the nested Add
+        again = s1 - tb                        # a second consumer of a recording (plain operand on the right)
+        return merged, again, s2
+
+    want = run(O)
+    try:
+        for lazy in (1.0, 0.0):
+            assert L.gft_set_option(b"lazy_sum", lazy) == 0
+            before = genfer_amd.op_stats()
+            got = run(G)
+            for w, g_ in zip(want, got):
+                check(w, g_)
+            d = genfer_amd.op_stats()
+            if lazy:
+                assert d["nested_adds"] - before["nested_adds"] >= 2, (d, before)
+    finally:
+        L.gft_set_option(b"lazy_sum", 1.0)

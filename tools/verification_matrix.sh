@@ -5,6 +5,17 @@ export HIP_FORCE_DEV_KERNARG=1
 mkdir -p gpurun_out
 OUT=gpurun_out/verification_matrix.txt
 : > $OUT
+# MATRIX=r5 runs the round-5 switches only (plus the baseline), with the e2e snapshot / --bounds goldens added (they are
+# what exercises the recorded observation chains, the riders, the "no exact zero" proofs and the side streams)
+if [ "${MATRIX:-all}" = "r5" ]; then
+  for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_SIDE_STREAMS=4" \
+             "GFT_SIDE_STREAMS=4 GFT_LAZY_OBSERVE=0 GFT_LAZY_HORNER=0" "GFT_RB_PAIRS_CAP_MB=8" "GFT_RB_PAIRS_CAP_MB=8 GFT_RB_PAIRS_LANES=1" "GFT_DIV_RIGHT=1" \
+             "GFT_LAZY_OBSERVE=0 GFT_LAZY_HORNER=0 GFT_NZ_PROOFS=0 GFT_RB_PAIRS_CAP_MB=90000"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x -k "not full_size and not c4_slabs and not whole_tensor" 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res" | tee -a $OUT
+  done
+  exit 0
+fi
 for cfg in "GFT_BASELINE=1" "GFT_DEFER=0" "GFT_ASYNC_LAUNCH=0" "GFT_HORNER_PIPE=0" "GFT_HORNER_LEAN=0" "GFT_DIV_WAVEFRONT=0" "GFT_DWF_DIAG=0" "GFT_DWF_PACK=0" \
            "GFT_CONV_RB_MIN_MACS=0" "GFT_CONV_RB=0" "GFT_TILED_WG_MULT=1" \
            "GFT_SHALLOW_MAX_TERMS=0" "GFT_SHALLOW_MAX_TERMS=64" "GFT_ROWS_WAVEFRONT=0" "GFT_HORNER_AHEAD=0" "GFT_HORNER_HOST_PHASE=0" "GFT_TILED_INPLACE=0" \
