@@ -259,7 +259,9 @@ def test_recorded_chains_epilogues_and_riders_bit_exact(interval, OTP, GTP, OTPI
                 check(want, got)
                 after = genfer_amd.op_stats()
                 d = {k: after[k] - before[k] for k in after}
-                if not opts and tier == "host":
+                switched = any(os.environ.get(k) for k in ("GFT_SIDE_STREAMS", "GFT_LAZY_OBSERVE", "GFT_LAZY_HORNER", "GFT_LAZY_SUM", "GFT_NZ_PROOFS",
+                                                           "GFT_OBS_RIDERS", "GFT_HORNER_RIDERS", "GFT_DEFER", "GFT_FUSE_HORNER", "GFT_HORNER_LOOP_MAX"))
+                if not opts and tier == "host" and not switched:  # (the verification matrix runs this test under every switch: bits only)
                     if not interval:
                         assert d["fused_observe_adds"] >= 3, d   # the Adds ran as the observation kernels' epilogues
                     if interval:
@@ -306,7 +308,7 @@ def test_recorded_sums_nested_add_bit_exact(interval, OTP, GTP, OTPI, GTPI):
             for w, g_ in zip(want, got):
                 check(w, g_)
             d = genfer_amd.op_stats()
-            if lazy:
+            if lazy and not any(os.environ.get(k) for k in ("GFT_SIDE_STREAMS", "GFT_LAZY_SUM", "GFT_DEFER")):
                 assert d["nested_adds"] - before["nested_adds"] >= 2, (d, before)
     finally:
         L.gft_set_option(b"lazy_sum", 1.0)
