@@ -136,7 +136,7 @@ def cpu_baseline_all_cores(shape, x, y, max_threads=64):
     }
 
 
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first
 
 
 def pmc_traffic(world, workload):
@@ -225,7 +225,7 @@ def e2e_seconds(gpu_runs=5, oracle_available=True):
                 best = t["time_infer"] if best is None else min(best, t["time_infer"])
                 if before is not None:  # what one run of the program costs (the same every run)
                     after = genfer_amd.op_stats()
-                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged", "per_output", "side_scopes", "fused_observe_adds"):
+                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged", "per_output", "linear_scans", "fused_observe_adds", "riders", "nested_adds", "scans_proven"):
                         row[k] = after[k] - before[k]
             row[key] = best
             row[key.replace("_s", "_runs")] = runs

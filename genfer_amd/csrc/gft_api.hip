@@ -1998,6 +1998,12 @@ struct Ops {
             size_t terms = 1;
             for (int i = 0; i < a.nd; ++i) terms *= std::min(a.xs[i], a.ys[i]);
             if (terms <= R.shallow_max_terms) {
+                // (one operand a LINE of 16+ coefficients along an outer axis: the tile form, gft_kernels.hip k_conv_line)
+                if (K<E>::conv_line(R.stream, x.p, x.plane, y.p, y.plane, z.p, z.plane, a)) {
+                    R.stats[5]++;
+                    R.stats_shallow[0]++;
+                    return;
+                }
                 ConvEpi e;
                 std::memset(&e, 0, sizeof(e));
                 for (int i = 0; i < a.nd; ++i) e.os[i] = a.zs[i];

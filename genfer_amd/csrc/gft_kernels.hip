@@ -1713,6 +1713,141 @@ bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const d
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Line products (round 5): z = x (*) y where one operand is a LINE — extent 1 on every axis but A, which is not the last
+// axis (three_populations: [100,1,1] x [100,100,100]; mixture: 290 x 290 by [209,1]).  Per output a 1-d sum of up to ~100
+// terms along A: on the one-thread-per-output kernel every term is a global load of the full operand F at stride
+// (product of the later axes) — 192 us for 10^6 outputs.  Here a workgroup owns a tile of TK values of k_A x TC columns
+// (the other axes, flattened: consecutive threads are consecutive along the last axis): it stages the rows of F the tile
+// can see into LDS once (coalesced), then every thread walks its column's TK outputs with F from LDS and the line's
+// coefficient from a uniform load.  The reference's order per output (mt:984-1012 with the line's axis an OUTER axis):
+// acc = acc + (0 + x_j * y_{k-j}) for ascending j of x — ascending line index if the line is x, descending if it is y —
+// separate multiply and add: bit-exact, f64 and interval.
+// ------------------------------------------------------------------------------------------
+struct LineArgs {
+    unsigned zA, fA, LL;      // extents along A: result, full operand, line
+    unsigned Cn;              // product of the extents after A (contiguous run of a column index)
+    unsigned cols;            // columns = (product of the extents before A) * Cn
+    unsigned TC, TK, rows_cap;  // columns and k_A values per workgroup; LDS rows (>= TK + LL - 1)
+    int line_is_x;
+};
+// 256 threads = TC columns x (256 / TC) groups; group g takes the tile's k_A values ka0 + g, ka0 + g + NG, ...  (narrow
+// column tiles keep the LDS tile at <= 32 KB, i.e. >= 16 waves per CU: with one 64-column wave per 64 KB tile the kernel was
+// latency-bound at 2 waves per CU — 170 us for the 100-term case, no better than one thread per output)
+template <class E>
+__global__ void __launch_bounds__(256) k_conv_line(const double* __restrict__ F, size_t fp, const double* __restrict__ L, size_t lp,
+                                                   double* __restrict__ z, size_t zp, LineArgs g) {
+    typedef typename E::V V;
+    extern __shared__ double ln_lds[];  // F tile [plane][row][TC], then the line [plane][LL]
+    const unsigned TC = g.TC, NG = 256u / TC, tid = threadIdx.x;
+    const unsigned col = tid % TC, grp = tid / TC;
+    const unsigned q = blockIdx.x * TC + col;       // this thread's column
+    const unsigned ka0 = blockIdx.y * g.TK;
+    const unsigned ka1 = ka0 + g.TK < g.zA ? ka0 + g.TK : g.zA;
+    // rows of F some output of the tile reads: k_A - j for j < LL, clipped to F
+    const unsigned r0 = ka0 + 1 > g.LL ? ka0 + 1 - g.LL : 0u, r1 = ka1 < g.fA ? ka1 : g.fA;
+    const bool have = q < g.cols;
+    const unsigned b = have ? q / g.Cn : 0u, c = have ? q - b * g.Cn : 0u;
+    const size_t fplane = (size_t)g.rows_cap * TC;
+    double* line = ln_lds + (size_t)E::W * fplane;
+    if (have)
+        for (unsigned r = r0 + grp; r < r1; r += NG) E::st(ln_lds, fplane, (size_t)(r - r0) * TC + col, E::ld(F, fp, ((size_t)b * g.fA + r) * g.Cn + c));
+    for (unsigned i = tid; i < g.LL; i += 256u) E::st(line, g.LL, i, E::ld(L, lp, i));
+    __syncthreads();
+    if (!have) return;
+    for (unsigned ka = ka0 + grp; ka < ka1; ka += NG) {
+        // line indices with a partner in F: ka - jl in [0, fA)
+        const unsigned lo = ka + 1 > g.fA ? ka + 1 - g.fA : 0u, hi = ka + 1 < g.LL ? ka + 1 : g.LL;
+        V acc = E::zero();
+        if (g.line_is_x) {
+            for (unsigned jl = lo; jl < hi; ++jl)
+                acc = E::add(acc, E::add(E::zero(), E::mul(E::ld(line, g.LL, jl), E::ld(ln_lds, fplane, (size_t)(ka - jl - r0) * TC + col))));
+        } else {  // ascending index of x = F: descending line index
+            for (unsigned jl = hi; jl-- > lo;)
+                acc = E::add(acc, E::add(E::zero(), E::mul(E::ld(ln_lds, fplane, (size_t)(ka - jl - r0) * TC + col), E::ld(line, g.LL, jl))));
+        }
+        E::st(z, zp, ((size_t)b * g.zA + ka) * g.Cn + c, acc);
+    }
+}
+template <class E>
+bool K<E>::conv_line(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z, size_t z_plane,
+                     const ConvArgs& a) {
+    static const bool on = [] {
+        const char* e = getenv("GFT_CONV_LINE");  // A/B knob (0 = the one-thread-per-output kernel for these products too)
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (!on || a.nd < 2 || a.nd > MAXD || a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || a.guard || !a.inner_from_zero) return false;
+    if (a.slab_lo != 0 || a.slab_hi != a.zs[0]) return false;
+    // which operand is the line, and along which axis
+    auto line_axis = [&](const unsigned* s) -> int {
+        int ax = -1;
+        for (int i = 0; i < a.nd; ++i)
+            if (s[i] != 1) {
+                if (ax >= 0) return -1;
+                ax = i;
+            }
+        return ax;
+    };
+    const int ax_x = line_axis(a.xs), ax_y = line_axis(a.ys);
+    int A;
+    bool line_is_x;
+    if (ax_x >= 0 && ax_y < 0) {
+        A = ax_x;
+        line_is_x = true;
+    } else if (ax_y >= 0 && ax_x < 0) {
+        A = ax_y;
+        line_is_x = false;
+    } else
+        return false;
+    if (A >= a.nd - 1) return false;  // (a line along the last axis: the reference's inner sum from zero — another order, and strided columns)
+    const unsigned* fs = line_is_x ? a.ys : a.xs;
+    const size_t* fstr = line_is_x ? a.ystr : a.xstr;
+    const unsigned LL = line_is_x ? a.xs[A] : a.ys[A];
+    if (LL < 16) return false;  // (a handful of terms: the stencil kernel)
+    // contiguous operands and result; the full operand spans the result on every other axis
+    size_t zs_ = 1, fs_ = 1;
+    for (int i = a.nd - 1; i >= 0; --i) {
+        if (a.zstr[i] != zs_ || fstr[i] != fs_) return false;
+        if (i != A && fs[i] != a.zs[i]) return false;
+        zs_ *= a.zs[i];
+        fs_ *= fs[i];
+    }
+    if ((line_is_x ? a.xstr[A] : a.ystr[A]) != 1) return false;
+    if (zs_ >= 0x7fffffffull || fs_ >= 0x7fffffffull) return false;
+    LineArgs g;
+    g.zA = a.zs[A];
+    g.fA = fs[A];
+    g.LL = LL;
+    g.Cn = 1;
+    for (int i = A + 1; i < a.nd; ++i) g.Cn *= a.zs[i];
+    g.cols = (unsigned)(zs_ / g.zA);
+    g.line_is_x = line_is_x ? 1 : 0;
+    // the widest column tile whose LDS tile (one k_A per group) stays within 32 KB
+    const size_t budget = (size_t)32 * 1024 - (size_t)LL * 8 * E::W;
+    unsigned TC = 0;
+    for (unsigned tc = 64; tc >= 8; tc /= 2) {
+        const unsigned ng = 256 / tc;
+        if ((size_t)(LL + ng - 1) * tc * 8 * E::W <= budget) {
+            TC = tc;
+            break;
+        }
+    }
+    if (!TC || (size_t)LL * 8 * E::W >= (size_t)16 * 1024) return false;  // (a line too long for the tile)
+    const unsigned NG = 256 / TC, ctiles = (g.cols + TC - 1) / TC;
+    // k_A values per workgroup: multiples of the groups while the tile fits and ~1000 workgroups remain
+    unsigned TK = NG;
+    while ((size_t)(LL + 2 * TK - 1) * TC * 8 * E::W <= budget && (unsigned long long)ctiles * ((g.zA + 2 * TK - 1) / (2 * TK)) >= 1024ull) TK *= 2;
+    g.TC = TC;
+    g.TK = TK;
+    g.rows_cap = TK + LL - 1;
+    const size_t lds = ((size_t)g.rows_cap * TC + LL) * 8 * E::W;
+    const double* F = line_is_x ? y : x;
+    const double* Lp = line_is_x ? x : y;
+    GFT_LAUNCH(k_conv_line<E>, dim3(ctiles, (g.zA + TK - 1) / TK), dim3(256), lds, st, F, line_is_x ? y_plane : x_plane, Lp, line_is_x ? x_plane : y_plane, z,
+               z_plane, g);
+    return true;
+}
+
 template <class E>
 __global__ void __launch_bounds__(256) k_horner_linear(const double* __restrict__ res, size_t rp, const double* __restrict__ a,
                                                        size_t ap, double* __restrict__ out, size_t op, HornerArgs g,

@@ -387,6 +387,11 @@ struct K {
     // loop's witness) fused in: ConvEpi.  false: outside the kernel's domain, nothing launched.
     static bool conv_shallow(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* out,
                              size_t out_plane, const ConvArgs& a, const ConvEpi& e);
+    // a plain product one operand of which is a LINE (extent 1 on every axis but one, which is not the last): a tile of the
+    // other operand in LDS, the line through uniform loads, the reference's order per output (bit-exact).  false: outside
+    // the kernel's domain, nothing launched.
+    static bool conv_line(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z, size_t z_plane,
+                          const ConvArgs& a);
 };
 
 enum SumMode { SUM_SEQ = 0, SUM_UNROLL8 = 1, SUM_WAVE = 2 };

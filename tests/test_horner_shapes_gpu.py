@@ -199,6 +199,29 @@ def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI,
         assert genfer_amd.op_stats()["shallow_products"] == before + 2, "the products did not take the shallow kernel"
 
 
+@pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
+@pytest.mark.parametrize("xs,ys,deg", [((100, 1, 1), (100, 40, 30), [100, 40, 30]),     # three_populations' product, truncated at the operands' length
+                                        ((70, 1), (50, 33), [90, 33]),                   # rank 2, the result shorter than the full product
+                                        ((1, 40, 1), (12, 40, 20), [12, 60, 20]),        # a line along the MIDDLE axis
+                                        ((200, 1), (64, 40), [220, 40]),                 # a long line: 32-column tiles
+                                        ((60, 1, 1), (20, 8, 8), [60, 8, 8]),            # a line longer than the other operand, the result cut at the line's length
+                                        ((17, 1, 1, 1), (5, 3, 4, 6), [21, 3, 4, 6])])  # rank 4, the shortest line the form takes
+def test_line_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI, tier):
+    """A product one operand of which is a line along an outer axis (round 5, k_conv_line: a tile of the other operand in LDS,
+    the reference's order per output): bit-exact against the oracle in both operand orders — the line as x (ascending line
+    index) and as y (descending) — f64 and interval, with signed zeros and a non-finite value in the operands."""
+    rng = np.random.default_rng(5)
+    x, y = rng.random(xs) - 0.3, rng.random(ys) - 0.3
+    x.flat[::7] = 0.0
+    y.flat[::5] = -0.0
+    y[tuple(min(1, n - 1) for n in ys)] = np.inf
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    if interval:
+        x, y = np.stack([x - 1e-3, x + 1e-3]), np.stack([y - 1e-3, y + 1e-3])
+    _check(O.new(x, deg) * O.new(y, deg), G.new(x, deg) * G.new(y, deg))
+    _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
+
+
 # ---- round 5: recorded operations (DESIGN §3.8) -------------------------------------------------------------------------------
 def rand(shape, seed, lo=0.0, hi=1.0):
     from conftest import splitmix64_uniform
