@@ -103,7 +103,17 @@ int gft_set_conv_mode(int mode);
  * negative: the default, 256), "rows_wavefront" (0: rank-2 div / log / exp with rows longer than 64 coefficients row by row
  * instead of the one-launch coefficient-level wavefront), "exp_right" (0: exp's terms in the reference's order everywhere),
  * "recur_tiled_min_macs", "dist_event_slot", and the test knob "debug_fail_next_launch" (1: the next kernel launch requests
- * 1 MB of LDS and fails — on the launch thread; the failure is reported by the next gft_synchronize / value inspection). */
+ * 1 MB of LDS and fails — on the launch thread; the failure is reported by the next gft_synchronize / value inspection).
+ * Round 5: "lazy_observe", "lazy_sum", "lazy_horner" (0: observation chains / the Adds inside mul_linear /
+ * proven linear Horner loops are launched where they are issued instead of being recorded on their result and launched
+ * inside — or alongside — the launch that needs them), "obs_riders", "horner_riders" (0: a recorded chain / loop never shares
+ * another one's launch), "nz_proofs" (0: interval Horner loops always scan their first accumulator for linearity, also where
+ * the coefficient tensor is proven free of exact zeros), "side_streams" (0, the default: one stream; 1..4: operations on old
+ * inputs run on side streams — slower on this part), "side_min_age", "div_right" (1: large f64 div / log as a
+ * blocked right-looking recurrence on the tiled kernel — the tiled product's 1e-10 contract instead of the reference's bits;
+ * off by default), "div_right_block", "div_right_min_macs", "conv_rb_pairs_cap" (bytes of row sums the row-pair form of the
+ * reference-order product may hold at a time, default 2 GiB; 0 restores the default), "conv_rb_pairs", "conv_rb_min_macs",
+ * "pairs_first". */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);

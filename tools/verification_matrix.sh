@@ -8,11 +8,16 @@ OUT=gpurun_out/verification_matrix.txt
 # MATRIX=r5 runs the round-5 switches only (plus the baseline), with the e2e snapshot / --bounds goldens added (they are
 # what exercises the recorded observation chains, the riders, the "no exact zero" proofs and the side streams)
 if [ "${MATRIX:-all}" = "r5" ]; then
-  for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_SIDE_STREAMS=4" \
-             "GFT_SIDE_STREAMS=4 GFT_LAZY_OBSERVE=0 GFT_LAZY_HORNER=0" "GFT_RB_PAIRS_CAP_MB=8" "GFT_RB_PAIRS_CAP_MB=8 GFT_RB_PAIRS_LANES=1" "GFT_DIV_RIGHT=1" \
-             "GFT_LAZY_OBSERVE=0 GFT_LAZY_HORNER=0 GFT_NZ_PROOFS=0 GFT_RB_PAIRS_CAP_MB=90000"; do
-    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x -k "not full_size and not c4_slabs and not whole_tensor" 2>&1 | grep -E "passed|failed" | tail -1)
+  LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
+  for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_SUM=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_CONV_LINE=0" "GFT_SIDE_STREAMS=4" \
+             "GFT_LAZY_OBSERVE=0 GFT_LAZY_SUM=0 GFT_LAZY_HORNER=0 GFT_NZ_PROOFS=0 GFT_CONV_LINE=0"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x -k "$LIGHT" 2>&1 | grep -E "passed|failed" | tail -1)
     echo "$cfg : $res" | tee -a $OUT
+  done
+  # the product / recurrence switches: the tests that exercise them
+  for cfg in "GFT_RB_PAIRS_CAP_MB=8" "GFT_RB_PAIRS_CAP_MB=8 GFT_RB_PAIRS_LANES=1" "GFT_RB_PAIRS_CAP_MB=90000" "GFT_DIV_RIGHT=1"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -q -x -k "register_blocked or row_pair or blocked_right or div_row_wavefront or recurrences_same_bits or fuzz" 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res (product / recurrence tests + fuzz)" | tee -a $OUT
   done
   exit 0
 fi
