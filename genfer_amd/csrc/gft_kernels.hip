@@ -767,10 +767,11 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
 }
 
 // Nested chain add (NestSrc): out = (0 + A) (+|-) B where A / B are chains or recorded two-chain sums.
-template <class E>
-__device__ __forceinline__ bool nest_chain_at(const ChainSrc& c, const unsigned* k, int nd, typename E::V& v) {
-    unsigned off = 0;
-    bool in = true, first = true;
+// Where a leaf is present at output index k, and where its element lies.
+__device__ __forceinline__ bool nest_locate(const ChainSrc& c, const unsigned* k, int nd, unsigned& off, bool& first) {
+    bool in = true;
+    first = true;
+    off = 0;
 #pragma unroll 1
     for (int ax = 0; ax < nd; ++ax) {
         const unsigned ka = k[ax] - (unsigned)c.pad[ax];  // (wraps below the pad: fails the box test)
@@ -778,39 +779,68 @@ __device__ __forceinline__ bool nest_chain_at(const ChainSrc& c, const unsigned*
         if (ka != 0) first = false;
         off += ka * (unsigned)c.stride[ax];
     }
-    if (in) v = chain_eval<E>(c, (size_t)off, k, first);
     return in;
-}
-template <class E>
-__device__ __forceinline__ bool nest_eval(const NestSrc& s, const unsigned* k, int nd, typename E::V& out) {
-    typedef typename E::V V;
-    if (!s.nested) return nest_chain_at<E>(s.a, k, nd, out);
-    bool all0 = true;
-#pragma unroll 1
-    for (int ax = 0; ax < nd; ++ax) {
-        if (k[ax] >= s.box[ax]) return false;
-        if (k[ax]) all0 = false;
-    }
-    V v = E::zero(), t;
-    if (nest_chain_at<E>(s.a, k, nd, t)) v = E::add(v, t);
-    if (nest_chain_at<E>(s.b, k, nd, t)) v = s.sub_inner ? E::sub(v, t) : E::add(v, t);
-    out = chain_apply<E>(s.post, s.npost, nullptr, v, k, all0);
-    return true;
 }
 template <class E>
 __global__ void __launch_bounds__(256) k_chain_nest(double* __restrict__ out, size_t out_plane, Shape sh, NestSrc a, NestSrc b, int subtract, unsigned total) {
     typedef typename E::V V;
     for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < total; lin += gridDim.x * 256u) {
         unsigned k[MAXD], r = lin;
+        bool all0 = true, in_abox = true, in_bbox = true;
 #pragma unroll 1
         for (int ax = sh.nd - 1; ax >= 0; --ax) {
             const unsigned d = sh.d[ax];
             k[ax] = r % d;
             r /= d;
+            if (k[ax]) all0 = false;
+            if (k[ax] >= a.box[ax]) in_abox = false;
+            if (k[ax] >= b.box[ax]) in_bbox = false;
         }
-        V v = E::zero(), t;
-        if (nest_eval<E>(a, k, sh.nd, t)) v = E::add(v, t);
-        if (nest_eval<E>(b, k, sh.nd, t)) v = subtract ? E::sub(v, t) : E::add(v, t);
+        // the (up to) four leaves: located first, then ALL their elements requested before any is used — a launch of this
+        // kind is a few dependent memory latencies long, and four loads one behind the other were most of its 8 us
+        unsigned o0, o1, o2, o3;
+        bool f0, f1, f2, f3;
+        const bool i0 = nest_locate(a.a, k, sh.nd, o0, f0) && (!a.nested || in_abox);
+        const bool i1 = a.nested && in_abox && nest_locate(a.b, k, sh.nd, o1, f1);
+        const bool i2 = nest_locate(b.a, k, sh.nd, o2, f2) && (!b.nested || in_bbox);
+        const bool i3 = b.nested && in_bbox && nest_locate(b.b, k, sh.nd, o3, f3);
+        const V r0 = E::ld(a.a.p, a.a.plane, i0 ? o0 : 0u), r1 = E::ld(a.nested ? a.b.p : a.a.p, a.nested ? a.b.plane : a.a.plane, i1 ? o1 : 0u);
+        const V r2 = E::ld(b.a.p, b.a.plane, i2 ? o2 : 0u), r3 = E::ld(b.nested ? b.b.p : b.a.p, b.nested ? b.b.plane : b.a.plane, i3 ? o3 : 0u);
+        V v = E::zero();
+        {   // operand A
+            V t = E::zero();
+            bool present;
+            if (!a.nested) {
+                present = i0;
+                if (i0) t = chain_apply<E>(a.a.st, a.a.nstages, a.a.pad, r0, k, f0);
+            } else {
+                present = in_abox;
+                if (i0) t = E::add(t, chain_apply<E>(a.a.st, a.a.nstages, a.a.pad, r0, k, f0));
+                if (i1) {
+                    const V w = chain_apply<E>(a.b.st, a.b.nstages, a.b.pad, r1, k, f1);
+                    t = a.sub_inner ? E::sub(t, w) : E::add(t, w);
+                }
+                if (present) t = chain_apply<E>(a.post, a.npost, nullptr, t, k, all0);
+            }
+            if (present) v = E::add(v, t);
+        }
+        {   // operand B
+            V t = E::zero();
+            bool present;
+            if (!b.nested) {
+                present = i2;
+                if (i2) t = chain_apply<E>(b.a.st, b.a.nstages, b.a.pad, r2, k, f2);
+            } else {
+                present = in_bbox;
+                if (i2) t = E::add(t, chain_apply<E>(b.a.st, b.a.nstages, b.a.pad, r2, k, f2));
+                if (i3) {
+                    const V w = chain_apply<E>(b.b.st, b.b.nstages, b.b.pad, r3, k, f3);
+                    t = b.sub_inner ? E::sub(t, w) : E::add(t, w);
+                }
+                if (present) t = chain_apply<E>(b.post, b.npost, nullptr, t, k, all0);
+            }
+            if (present) v = subtract ? E::sub(v, t) : E::add(v, t);
+        }
         E::st(out, out_plane, lin, v);
     }
 }

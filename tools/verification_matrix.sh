@@ -7,6 +7,15 @@ OUT=gpurun_out/verification_matrix.txt
 : > $OUT
 # MATRIX=r5 runs the round-5 switches only (plus the baseline), with the e2e snapshot / --bounds goldens added (they are
 # what exercises the recorded observation chains, the riders, the "no exact zero" proofs and the side streams)
+if [ "${MATRIX:-all}" = "old_light" ]; then  # the earlier rounds' switches on the light test set (what round 5's recorded operations could interact with)
+  LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
+  for cfg in "GFT_DEFER=0" "GFT_ASYNC_LAUNCH=0" "GFT_HORNER_PIPE=0" "GFT_HORNER_LEAN=0" "GFT_FUSE_HORNER=0" "GFT_SHALLOW_MAX_TERMS=0" "GFT_HORNER_AHEAD=0" "GFT_HORNER_HOST_PHASE=0" \
+             "GFT_HORNER_LOOP_MAX=0" "GFT_HOST_MAX_ELEMS=0" "GFT_DEFER=0 GFT_ASYNC_LAUNCH=0 GFT_HORNER_PIPE=0 GFT_SHALLOW_MAX_TERMS=0 GFT_HORNER_AHEAD=0 GFT_HORNER_HOST_PHASE=0"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x -k "$LIGHT" 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res" | tee -a $OUT
+  done
+  exit 0
+fi
 if [ "${MATRIX:-all}" = "r5" ]; then
   LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
   for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_SUM=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_CONV_LINE=0" "GFT_SIDE_STREAMS=4" \
