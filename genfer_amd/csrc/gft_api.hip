@@ -3260,7 +3260,7 @@ struct Ops {
             op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr, b); };
             op->input_birth = birth_of(a.buf.get());
             out.buf->lazy = op;
-            pending_obs().push_back(out.buf);
+            pending_push(pending_obs(), out.buf);
             return out;
         }
         SideScope scope(sid);
@@ -3310,6 +3310,21 @@ struct Ops {
     static std::vector<std::weak_ptr<Buf>>& pending_obs() {
         static std::vector<std::weak_ptr<Buf>> v;
         return v;
+    }
+    // (entries whose buffer has been freed, launched or fused away are dropped where the rider search meets them; a list that
+    // has grown anyway — recordings nobody ever rode with — is swept here, so it stays a few thousand weak pointers at most)
+    static void pending_push(std::vector<std::weak_ptr<Buf>>& v, const std::shared_ptr<Buf>& b) {
+        if (v.size() >= 4096) {
+            size_t k = 0;
+            for (size_t i = 0; i < v.size(); ++i) {
+                std::shared_ptr<Buf> p = v[i].lock();
+                if (!p || !p->lazy) continue;
+                if (p->lazy->obs && static_cast<LazyObs*>(p->lazy->obs.get())->fused) continue;
+                v[k++] = v[i];
+            }
+            v.resize(k);
+        }
+        v.push_back(b);
     }
     // Launches a recorded chain into `outp` (its own buffer `self`, or a consumer's output with the epilogue `epi`).
     static void launch_obs(LazyObs& lo, double* outp, size_t out_numel, const ObsEpi* epi, Buf* self) {
@@ -4101,7 +4116,7 @@ struct Ops {
                 op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr, b); };
                 op->input_birth = std::max(birth_of(res.buf.get()), birth_of(ca.buf.get()));
                 out.buf->lazy = op;
-                pending_horner().push_back(out.buf);
+                pending_push(pending_horner(), out.buf);
                 *result = out;
                 return true;
             }
@@ -4602,6 +4617,10 @@ void gft_shutdown(void) {
     for (int sid = 1; sid <= Runtime::NSIDE; ++sid)
         if (R.ctx[sid].stream) (void)hipStreamSynchronize(R.ctx[sid].stream);
     for (auto& c : g_pow_tabs) c.clear();  // device tables of this context: back into the pool before it is freed
+    Ops<EF64>::pending_obs().clear();      // (weak references to recordings nobody launched)
+    Ops<EIv>::pending_obs().clear();
+    Ops<EF64>::pending_horner().clear();
+    Ops<EIv>::pending_horner().clear();
     dwf_release_orders();
     staged_release_scratch();
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
