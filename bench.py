@@ -335,7 +335,10 @@ def timed_loop_samples(helper, text):
         c = best[1]
         out = {"samples": max(len(c["mhz"]), len(c["w"])), "window_s": rec["seconds"], "source": "amdgpu sysfs (hwmon freq1_input / power1_average), polled by a child forked before GPU initialisation"}
         if c["mhz"]:
-            out["sclk_mhz"] = {"min": float(np.min(c["mhz"])), "median": float(np.median(c["mhz"])), "max": float(np.max(c["mhz"]))}
+            # (the loop starts on a part that was idling: the first samples are the ramp — `steady` is the median of the second
+            # half of the window, what the kernel runs at once the clock has settled)
+            out["sclk_mhz"] = {"min": float(np.min(c["mhz"])), "median": float(np.median(c["mhz"])), "max": float(np.max(c["mhz"])),
+                               "steady": float(np.median(c["mhz"][len(c["mhz"]) // 2:]))}
         if c["w"]:
             out["socket_power_w"] = {"min": float(np.min(c["w"])), "median": float(np.median(c["w"])), "max": float(np.max(c["w"]))}
         return out
@@ -628,7 +631,7 @@ def main():
                 peak_at = FP64_PEAK_TFLOPS * clk["sclk_mhz_under_load"] / 2400.0
                 out["roofline"]["frac_at_observed_clock"] = achieved_tflops / peak_at
         if during and during.get("sclk_mhz"):  # the clock of the timed loop itself, when sysfs gives it
-            out["roofline"]["frac_at_timed_loop_clock"] = achieved_tflops / (FP64_PEAK_TFLOPS * during["sclk_mhz"]["median"] / 2400.0)
+            out["roofline"]["frac_at_timed_loop_clock"] = achieved_tflops / (FP64_PEAK_TFLOPS * during["sclk_mhz"]["steady"] / 2400.0)
     if clock_helper is not None and clock_helper.poll() is None:
         try:
             clock_helper.stdin.close()  # never told to sample: let it go
