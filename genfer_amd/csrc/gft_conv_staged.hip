@@ -1050,7 +1050,7 @@ __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__
     if (n > 0 && c < g.n2) {
         const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)(pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) - g.slot_base) * g.n2 * E::W) + c;
         const size_t pitch = g.n2;  // elements per term
-        constexpr int D = 16;
+        constexpr int D = 32;
         Raw buf[D];
         // (no conditional loads in the steady state: hipcc waits for vmcnt(0) at every basic-block boundary, and a load
         // under `if` is a block of its own — one load in flight instead of D)
