@@ -741,6 +741,9 @@ struct PairArgs {
     // an output slab of the range), a workgroup's x rows share that j0.  band 0: the whole product (klo = 0).
     unsigned band, klo, khi;
     unsigned long long slot_base;
+    // Phase-1 grid: one workgroup per VALID (x rows, y tile) combination, in one dimension (see k_pair_sums): c1tot chunks of
+    // x rows over all tiles of axis 1, s0tot (j0, tile of axis 0) combinations (band 1: j0 from at_lo up, one window each)
+    unsigned c1tot, s0tot, at_lo;
 };
 // terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
 __host__ __device__ inline unsigned pair_lo(unsigned k, unsigned ny) { return k + 1 > ny ? k + 1 - ny : 0u; }
@@ -899,29 +902,53 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned nwaves = blockDim.x >> 6;
     const unsigned T1 = 1u << g.tsh, T0 = 64u >> g.tsh;
-    // the y tile (blockIdx.y) and the chunk of its x rows (blockIdx.x: consecutive workgroups go to consecutive XCDs, so a
-    // tile's chunks spread over all eight — with the tile as the fastest index and 8 tiles along an axis an XCD only ever
-    // saw ONE bt, and a tile's work falls with bt: XCD 0 had 8x the work of XCD 7 at 64^3)
-    unsigned tb = blockIdx.y;
-    const unsigned bt = tb % g.tiles1;
-    tb /= g.tiles1;
-    const unsigned at = tb % g.tiles0, ud = tb / g.tiles0;  // (band 1: `at` is the x rows' j0, tiles0 = x0)
+    // The grid is ONE-dimensional and holds only the valid (x rows, y tile) combinations, every one the same work: workgroup L
+    // is chunk r of the x rows (ju, j0, xch consecutive j1) against tile (ud, at, bt).  (Round 4 launched chunks x tiles and let
+    // the combinations outside the triangle return at once — 44 % of the grid; the dispatcher deals workgroups to the XCDs and
+    // their shader engines by index, so where valid and invalid ones alternate with a short period — the slab ranges: 8 chunks
+    // per tile, the first 8 - bt valid — some engines got only valid ones and the launch waited for them: 1.5x at 64^3,
+    // profiles/r05/interval_pairs_bounded.txt.)
+    const unsigned long long L = blockIdx.x;
+    unsigned r = (unsigned)(L % g.c1tot);
+    const unsigned long long q = L / g.c1tot;
+    unsigned bt = 0, n1 = 0;
+    for (;; ++bt) {  // (uniform; r < c1tot = the sum of the tiles' chunk counts)
+        n1 = g.z1 - T1 * bt < g.x1 ? g.z1 - T1 * bt : g.x1;
+        const unsigned nc = (n1 + g.xch - 1) / g.xch;
+        if (r < nc) break;
+        r -= nc;
+    }
+    unsigned at = 0, ud = 0, j0 = 0, ju = 0;
+    if (g.band == 1) {  // `at` is the x rows' j0
+        at = g.at_lo + (unsigned)q;
+        j0 = at;
+    } else {
+        unsigned q0 = (unsigned)(q % g.s0tot);
+        unsigned long long qu = q / g.s0tot;
+        for (;; ++at) {
+            const unsigned n0 = g.z0 - T0 * at < g.x0 ? g.z0 - T0 * at : g.x0;
+            if (q0 < n0) break;
+            q0 -= n0;
+        }
+        j0 = q0;
+        for (;; ++ud) {  // x terms ju of the leading axis this tile's ud pairs with (band 2: ju + ud in [klo, khi))
+            unsigned nU = g.zU - ud < g.xU ? g.zU - ud : g.xU, ju_lo = 0;
+            if (g.band == 2) {
+                ju_lo = g.klo > ud ? g.klo - ud : 0u;
+                const unsigned hi = g.khi > ud ? (g.khi - ud < nU ? g.khi - ud : nU) : 0u;
+                nU = hi > ju_lo ? hi - ju_lo : 0u;
+            }
+            if (qu < nU) {
+                ju = ju_lo + (unsigned)qu;
+                break;
+            }
+            qu -= nU;
+        }
+    }
     const int d0b = g.band == 1 ? (int)g.klo - (int)at : (int)(T0 * at);
     const unsigned d1b = T1 * bt;
-    // x rows (ju, j0, j1) some lane of the tile pairs with
-    unsigned nU = g.zU - ud < g.xU ? g.zU - ud : g.xU, ju_lo = 0;
-    if (g.band == 2) {  // ju + ud in [klo, khi)
-        ju_lo = g.klo > ud ? g.klo - ud : 0u;
-        const unsigned hi = g.khi > ud ? (g.khi - ud < nU ? g.khi - ud : nU) : 0u;
-        nU = hi > ju_lo ? hi - ju_lo : 0u;
-    }
-    const unsigned n0 = g.band == 1 ? 1u : (g.z0 - (unsigned)d0b < g.x0 ? g.z0 - (unsigned)d0b : g.x0);
-    const unsigned n1 = g.z1 - d1b < g.x1 ? g.z1 - d1b : g.x1;
-    const unsigned long long count = (unsigned long long)nU * n0 * n1;
-    const unsigned long long xi_lo = (unsigned long long)blockIdx.x * g.xch;
-    if (xi_lo >= count) return;
-    if (g.band == 1 && d0b >= (int)g.y0) return;  // (a compact y: the window of this j0 lies above its last row)
-    const unsigned rows_here = (unsigned)(xi_lo + g.xch < count ? g.xch : count - xi_lo);
+    const unsigned j1_lo = r * g.xch;
+    const unsigned rows_here = j1_lo + g.xch < n1 ? g.xch : n1 - j1_lo;
     // ---- stage the tile's 64 y rows, (lo, hi) interleaved, zero beyond the row / for rows outside y
     if (tid == 0) s_tileflag = 0;
     __syncthreads();
@@ -966,10 +993,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         const unsigned row = t / npairs, pr = t - row * npairs;
         if (row != cur_row) {  // (uniform)
             cur_row = row;
-            const unsigned long long xi = xi_lo + row;
-            const unsigned j1 = (unsigned)(xi % n1);
-            const unsigned long long tt = xi / n1;
-            const unsigned j0 = g.band == 1 ? at : (unsigned)(tt % n0), ju = ju_lo + (unsigned)(tt / n0);
+            const unsigned j1 = j1_lo + row;
             const size_t arow = ((size_t)ju * g.x0 + j0) * g.x1 + j1;
             xl = (pair_cptr_t)(x + arow * g.nx2);
             xh = (pair_cptr_t)(x + xp + arow * g.nx2);
@@ -1276,8 +1300,8 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
             }
         }
         const unsigned T1 = 1u << g.tsh, T0 = 64u >> g.tsh;
-        g.tiles0 = (g.y0 + T0 - 1) / T0;
-        g.tiles1 = (g.y1 + T1 - 1) / T1;
+        g.tiles0 = (std::min(g.y0, g.z0) + T0 - 1) / T0;  // (y rows at or beyond z's extent pair with nothing)
+        g.tiles1 = (std::min(g.y1, g.z1) + T1 - 1) / T1;
         g.pitch = E::W * g.n8 + 2;
         // 16 waves per CU (the kernel holds <= 128 VGPRs): two workgroups of 8 where two tiles fit the LDS, else one of 16
         g.NW = (size_t)64 * g.pitch * sizeof(double) * 2 + 1024 <= 160 * 1024 ? 8u : 16u;
@@ -1365,8 +1389,6 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                 wsv[l] = &w;
             }
             // grid limits (per launch)
-            const unsigned long long tiles_full = (unsigned long long)g.yU * g.tiles0 * g.tiles1;
-            if (band == 0 && (tiles_full > 65535ull || (xrows + g.xch - 1) / g.xch > 0x7fffffffull)) ok = false;
             if (ok) {
                 const size_t lds = (size_t)64 * g.pitch * sizeof(double);
                 static bool attr = false;
@@ -1390,25 +1412,45 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                     q.klo = r.lo;
                     q.khi = r.hi;
                     q.slot_base = r.base;
-                    unsigned long long cy = (xrows + q.xch - 1) / q.xch, ty = tiles_full, nrows = zs_ / n2;
-                    if (band == 1) {  // window tiles: T0 = the range's height, one tile row per j0; a workgroup's x rows share j0
+                    unsigned long long nrows = zs_ / n2, combos = 0;  // (x rows sharing (ju, j0)) x (tiles over U and axis 0)
+                    if (band == 1) {  // window tiles: T0 = the range's height, one per j0; a workgroup's x rows share j0
                         const unsigned h = r.hi - r.lo;
                         unsigned tsh = 6;
                         while ((64u >> tsh) < h) --tsh;
                         q.tsh = tsh;
                         const unsigned T1w = 1u << tsh;
-                        q.tiles1 = (q.y1 + T1w - 1) / T1w;
-                        q.tiles0 = std::min(q.x0, r.hi);  // j0 <= k0 < khi
-                        cy = (q.x1 + q.xch - 1) / q.xch;
-                        ty = (unsigned long long)q.tiles0 * q.tiles1;
+                        q.tiles1 = (std::min(q.y1, q.z1) + T1w - 1) / T1w;
+                        q.tiles0 = std::min(q.x0, r.hi);                       // j0 <= k0 < khi
+                        q.at_lo = r.lo + 1 > q.y0 ? r.lo + 1 - q.y0 : 0u;      // (a compact y: the window of a lower j0 lies above y's last row)
+                        combos = q.tiles0 > q.at_lo ? q.tiles0 - q.at_lo : 0u;
                         nrows = (unsigned long long)(r.hi - r.lo) * q.z1;
-                    } else if (band == 2) {
-                        cy = ((unsigned long long)std::min(q.xU, r.hi - r.lo) * q.x0 * q.x1 + q.xch - 1) / q.xch;
-                        nrows = (unsigned long long)(r.hi - r.lo) * q.z0 * q.z1;
+                    } else {
+                        const unsigned T0w = 64u >> q.tsh;
+                        unsigned long long s0 = 0, sU = 0;
+                        for (unsigned at = 0; at < q.tiles0; ++at) s0 += std::min(q.z0 - T0w * at, q.x0);
+                        for (unsigned ud = 0; ud < std::min(q.yU, q.zU); ++ud) {
+                            unsigned nU = std::min(q.zU - ud, q.xU), ju_lo = 0;
+                            if (band == 2) {
+                                ju_lo = r.lo > ud ? r.lo - ud : 0u;
+                                const unsigned hi = r.hi > ud ? std::min(r.hi - ud, nU) : 0u;
+                                nU = hi > ju_lo ? hi - ju_lo : 0u;
+                            }
+                            sU += nU;
+                        }
+                        q.s0tot = (unsigned)s0;
+                        combos = s0 * sU;
+                        if (band == 2) nrows = (unsigned long long)(r.hi - r.lo) * q.z0 * q.z1;
                     }
-                    if (ty > 65535ull || cy > 0x7fffffffull || nrows > 0x7fffffffull || ty == 0 || cy == 0) ok = false;
+                    {
+                        const unsigned T1w = 1u << q.tsh;
+                        unsigned long long c1 = 0;
+                        for (unsigned bt = 0; bt < q.tiles1; ++bt) c1 += (std::min(q.z1 - T1w * bt, q.x1) + q.xch - 1) / q.xch;
+                        q.c1tot = (unsigned)c1;
+                    }
+                    const unsigned long long nwg = combos * q.c1tot;
+                    if (nwg == 0 || nwg > 0x7fffffffull || nrows > 0x7fffffffull) ok = false;
                     gs.push_back(q);
-                    grids.push_back(dim3((unsigned)cy, (unsigned)ty));
+                    grids.push_back(dim3((unsigned)nwg));
                     rows.push_back(nrows);
                 }
                 if (ok) {
