@@ -1173,6 +1173,11 @@ static size_t rb_pairs_cap = [] {
     const char* e = getenv("GFT_RB_PAIRS_CAP_MB");
     return (size_t)(e ? std::max(1, atoi(e)) : 2048) << 20;
 }();
+static int rb_pairs_lanes = [] {
+    const char* e = getenv("GFT_RB_PAIRS_LANES");
+    return e ? atoi(e) : -1;
+}();
+void staged_set_rb_pairs_lanes(double v) { rb_pairs_lanes = v < 0 ? -1 : (v >= 1.0 ? 1 : 0); }  // "conv_rb_pairs_lanes"
 void staged_set_rb_pairs_cap(double bytes) { rb_pairs_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)2048 << 20); }  // "conv_rb_pairs_cap"
 size_t staged_scratch_bytes() {  // what the grow-only workspaces hold right now (gft_pool_stats counts it)
     size_t n = 0;
@@ -1334,32 +1339,43 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         if (plan_ok && need <= rb_pairs_cap) {
             plan.push_back(Range{0, 0, 0, slots});
         } else if (plan_ok && no >= 2) {
-            static const int lanes_on = [] {
-                const char* e = getenv("GFT_RB_PAIRS_LANES");  // A/B knob (0 = every range on the product's own stream)
-                return e ? atoi(e) : 0;  // (measured, profiles/r05/interval_pairs_bounded.txt: 64^3 7.0 -> 6.5 ms, but 88^3 34.9 -> 40.8, 96^3 55.9 -> 61.2:
-            }();                          // half the cap per lane means thinner ranges — narrower window tiles, more launches)
-            use_lanes = lanes_on && pair_lanes().ok;
-            const size_t range_cap = use_lanes ? rb_pairs_cap / 2 : rb_pairs_cap;
+            // Two lanes (see PairLanes) need two workspaces, so each gets half the cap: taken when that does not make the ranges
+            // thinner — then one lane's phase 2 (a few hundred one-wave rows: latency, not bandwidth) runs under the other's phase 1.
+            // MI355X, positive / mixed-sign: 56^3 2.88 / 5.92 -> 2.55 / 5.05 ms, 64^3 5.31 / 11.5 -> 4.92 / 10.2, 72^3 9.40 / 21.0 -> 8.84 / 20.5;
+            // from 80^3 on half the cap halves the window's height and the lanes lose (88^3 29.9 -> 30.4, 96^3 49.8 -> 54.0): off there.
+            const int lanes_on = rb_pairs_lanes;  // 0 never, 1 always, negative: when the ranges stay the same
             band = no == 3 ? 2u : 1u;  // leading axis: U (rank 4) or axis 0 (rank 3: a lane axis — ranges of 1, 2, 4 or 8 slabs, the window's height)
             const unsigned nlead = band == 2 ? g.zU : g.z0, xl = band == 2 ? g.xU : g.x0, yl = band == 2 ? g.yU : g.y0;
             const unsigned long long per = band == 2 ? g.S0 * g.S1 : g.S1;  // slots per term of the leading axis
             auto slots_of = [&](unsigned lo, unsigned hi) { return (pair_pre(hi, xl, yl) - pair_pre(lo, xl, yl)) * per; };
-            for (unsigned lo = 0; lo < nlead && plan_ok;) {
-                unsigned h = 0;
-                if (band == 2) {
-                    while (lo + h < nlead && slots_of(lo, lo + h + 1) * row_bytes <= range_cap) ++h;
-                } else {
-                    for (unsigned c = 8; c >= 1; c /= 2)
-                        if (lo + c <= nlead && slots_of(lo, lo + c) * row_bytes <= range_cap) {
-                            h = c;
-                            break;
-                        }
+            auto make_plan = [&](size_t range_cap, std::vector<Range>& out) {
+                out.clear();
+                for (unsigned lo = 0; lo < nlead;) {
+                    unsigned h = 0;
+                    if (band == 2) {
+                        while (lo + h < nlead && slots_of(lo, lo + h + 1) * row_bytes <= range_cap) ++h;
+                    } else {
+                        for (unsigned c = 8; c >= 1; c /= 2)
+                            if (lo + c <= nlead && slots_of(lo, lo + c) * row_bytes <= range_cap) {
+                                h = c;
+                                break;
+                            }
+                    }
+                    if (h == 0) return false;  // (one slab alone exceeds the cap: not this form's product)
+                    out.push_back(Range{lo, lo + h, pair_pre(lo, xl, yl) * per, slots_of(lo, lo + h)});
+                    lo += h;
                 }
-                if (h == 0) plan_ok = false;  // (one slab alone exceeds the cap: not this form's product)
-                else plan.push_back(Range{lo, lo + h, pair_pre(lo, xl, yl) * per, slots_of(lo, lo + h)});
-                lo += h;
+                return out.size() <= 4096;
+            };
+            plan_ok = make_plan(lanes_on == 1 && pair_lanes().ok ? rb_pairs_cap / 2 : rb_pairs_cap, plan);
+            use_lanes = plan_ok && lanes_on == 1 && pair_lanes().ok;
+            if (plan_ok && lanes_on < 0 && plan.size() >= 2 && pair_lanes().ok) {
+                std::vector<Range> half;
+                if (make_plan(rb_pairs_cap / 2, half) && half.size() == plan.size()) {
+                    plan.swap(half);
+                    use_lanes = true;
+                }
             }
-            if (plan.size() > 4096) plan_ok = false;
         } else
             plan_ok = false;
         if (plan_ok) {
@@ -1368,6 +1384,26 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
             if (plan.size() < 2) use_lanes = false;
             bool ok = true;
             PairWs* wsv[2] = {nullptr, nullptr};
+            {   // the cap bounds what ALL the streams' workspaces hold together: blocks of other streams go when this one's need the room
+                hipStream_t mine[2] = {use_lanes ? pair_lanes().st[0] : st, use_lanes ? pair_lanes().st[1] : st};
+                unsigned long long others = 0, here = 0;
+                for (auto& kv : pair_ws()) {
+                    if (kv.first == mine[0] || kv.first == mine[1]) here += std::max<unsigned long long>(kv.second.bytes, most);
+                    else others += kv.second.bytes;
+                }
+                if (!pair_ws().count(mine[0])) here += most;
+                if (use_lanes && !pair_ws().count(mine[1])) here += most;
+                if (others && others + here > rb_pairs_cap) {
+                    launch_drain();
+                    for (auto& kv : pair_ws())
+                        if (kv.first != mine[0] && kv.first != mine[1] && kv.second.p) {
+                            (void)(hipStreamSynchronize)(kv.first);
+                            (void)(hipFree)(kv.second.p);
+                            kv.second.p = nullptr;
+                            kv.second.bytes = 0;
+                        }
+                }
+            }
             for (int l = 0; l < (use_lanes ? 2 : 1) && ok; ++l) {
                 PairWs& w = pair_ws()[use_lanes ? pair_lanes().st[l] : st];
                 if (w.bytes < most) {

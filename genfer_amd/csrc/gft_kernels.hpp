@@ -413,7 +413,8 @@ template <class E>
 bool conv_pairs(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a, double max_macs);
 void staged_set_rb_min_macs(double v);  // threshold of the register-blocked interval product (negative: never)
 void staged_set_rb_pairs(double v);    // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 by size, 2 always, negative: the default
-void staged_set_rb_pairs_cap(double bytes);  // bytes of row sums it may hold (< 1: the default, 24 GiB)
+void staged_set_rb_pairs_cap(double bytes);  // bytes of row sums it may hold, all streams together (< 1: the default, 2 GiB)
+void staged_set_rb_pairs_lanes(double v);    // slab ranges on two lanes: 0 never, 1 always, negative: when half the cap leaves the ranges as they are
 size_t staged_scratch_bytes();  // bytes the grow-only kernel workspaces of gft_conv_staged.hip hold (gft_pool_stats)
 void staged_release_scratch();  // frees the register-blocked interval product's row-flag scratch (gft_shutdown)
 void dwf_release_orders();  // frees the row wavefront's cached claim-order tables (gft_shutdown)

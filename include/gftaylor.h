@@ -65,7 +65,7 @@ void* gft_get_stream(void);
 int gft_synchronize(void);
 const char* gft_last_error(void);
 /* Device-memory statistics in bytes: {in_use, cached, peak_in_use}.  in_use and peak include the kernels' grow-only
- * workspaces (the row-pair sums of the reference-order product, at most conv_rb_pairs_cap = 2 GiB per stream; the tiled
+ * workspaces (the row-pair sums of the reference-order product, at most conv_rb_pairs_cap = 2 GiB over all streams; the tiled
  * product's plan workspace), which are not pool blocks. */
 void gft_pool_stats(size_t out[3]);
 /* Cumulative operation counters since gft_init: {extract_linear device scans (each a host round trip),
@@ -91,7 +91,7 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
  * to each other and to the CPU algorithm.  Test/bench knob. */
 int gft_set_conv_mode(int mode);
 /* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
- * tiled product), "conv_rb_min_macs" (smallest interval product, in multiply-adds, that takes the register-blocked rows kernel; negative: never), "conv_rb_pairs" (reference-order product, interval and f64, as independent row-pair sums with the ordered additions in a second pass: 0 never, 1 from 3e5 multiply-adds (rank 2: 1e6; rows of 8 .. 128) while the row sums fit "conv_rb_pairs_cap" bytes [default 24 GiB], 2 whenever it applies, negative: the default), "pairs_first" (0: small plain f64 products go to the tiled kernel as before round 4 instead of asking the bit-exact row-pair form first), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
+ * tiled product), "conv_rb_min_macs" (smallest interval product, in multiply-adds, that takes the register-blocked rows kernel; negative: never), "conv_rb_pairs" (reference-order product, interval and f64, as independent row-pair sums with the ordered additions in a second pass: 0 never, 1 from 3e5 multiply-adds (rank 2: 1e6; rows of 8 .. 128) in slab ranges where the row sums exceed "conv_rb_pairs_cap" bytes [default 2 GiB], 2 whenever it applies, negative: the default), "pairs_first" (0: small plain f64 products go to the tiled kernel as before round 4 instead of asking the bit-exact row-pair form first), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
  * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
  * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
  * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div_wavefront" (0: the slab-by-slab blocked division instead of the one-launch row wavefront), "div2d" (0: host-driven division
@@ -112,7 +112,9 @@ int gft_set_conv_mode(int mode);
  * inputs run on side streams — slower on this part), "side_min_age", "div_right" (1: large f64 div / log as a
  * blocked right-looking recurrence on the tiled kernel — the tiled product's 1e-10 contract instead of the reference's bits;
  * off by default), "div_right_block", "div_right_min_macs", "conv_rb_pairs_cap" (bytes of row sums the row-pair form of the
- * reference-order product may hold at a time, default 2 GiB; 0 restores the default), "conv_rb_pairs", "conv_rb_min_macs",
+ * reference-order product may hold at a time, default 2 GiB; 0 restores the default), "conv_rb_pairs_lanes" (the slab ranges of
+ * a product over the cap on two lanes with half the cap each, one lane's additions under the other's row sums: 0 never, 1 always,
+ * negative — the default — when half the cap leaves the ranges as they are), "conv_rb_pairs", "conv_rb_min_macs",
  * "pairs_first". */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */

@@ -1455,16 +1455,21 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
             # <= 128; longer ones fall through to k_conv_staged), and a cap too small for it (back to k_conv_staged)
             # ... and caps that cut it into slab ranges of the leading axis (round 5: the bounded workspace; ranges of 1 - 8
             # slabs for rank 3, of any height for rank 4 — where one slab alone exceeds the cap the product falls back)
-            for thr, pairs, cap in ((0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (-1.0, 2.0, 0.0), (-1.0, 2.0, 4096.0), (-1.0, 2.0, 4.0e6), (-1.0, 2.0, 6.0e5)):
+            # ... the ranges alternating between two lanes (two streams, half the cap each), forced and never
+            for thr, pairs, cap, lanes in ((0.0, 0.0, 0.0, -1.0), (-1.0, 0.0, 0.0, -1.0), (-1.0, 2.0, 0.0, -1.0), (-1.0, 2.0, 4096.0, -1.0),
+                                           (-1.0, 2.0, 4.0e6, -1.0), (-1.0, 2.0, 6.0e5, -1.0), (-1.0, 2.0, 4.0e6, 1.0), (-1.0, 2.0, 1.2e6, 1.0),
+                                           (-1.0, 2.0, 6.0e5, 0.0)):
                 assert L.gft_set_option(b"conv_rb_min_macs", thr) == 0
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
                 assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
+                assert L.gft_set_option(b"conv_rb_pairs_lanes", lanes) == 0
                 try:
                     check(want, GTPI.new(a, deg) * GTPI.new(b, deg))
                 finally:
                     L.gft_set_option(b"conv_rb_min_macs", 1.5e10)
                     L.gft_set_option(b"conv_rb_pairs", -1.0)
                     L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
+                    L.gft_set_option(b"conv_rb_pairs_lanes", -1.0)
     finally:
         L.gft_set_option(b"host_max_elems", -1.0)
 
@@ -1528,14 +1533,17 @@ def test_f64_reference_order_product_as_row_pair_sums_bit_exact(xs, ys, zs, OTP,
     try:
         for a, b in ((x, y), (xz, yz), (xi, yn), (x * 1e-200, y * 1e-200), (x * 1e200, y * 1e160)):
             want = (OTP.new(a, deg) * OTP.new(b, deg)).array()
-            for pairs, cap in ((2.0, 0.0), (0.0, 0.0), (2.0, 2.0e6), (2.0, 3.0e5)):  # (the capped ones: slab ranges of the leading axis)
+            # (the capped ones: slab ranges of the leading axis; lanes 1: the ranges alternate between two streams)
+            for pairs, cap, lanes in ((2.0, 0.0, -1.0), (0.0, 0.0, -1.0), (2.0, 2.0e6, -1.0), (2.0, 3.0e5, 0.0), (2.0, 6.0e5, 1.0)):
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
                 assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
+                assert L.gft_set_option(b"conv_rb_pairs_lanes", lanes) == 0
                 try:
                     got = (GTP.new(a, deg) * GTP.new(b, deg)).array()
                 finally:
                     L.gft_set_option(b"conv_rb_pairs", -1.0)
                     L.gft_set_option(b"conv_rb_pairs_cap", 0.0)
+                    L.gft_set_option(b"conv_rb_pairs_lanes", -1.0)
                 ok = (np.asarray(want).view(np.uint64) == np.asarray(got).view(np.uint64)) | (np.isnan(want) & np.isnan(got))
                 assert np.all(ok), (pairs, cap, np.asarray(want)[~ok][:4], np.asarray(got)[~ok][:4])
     finally:
