@@ -744,6 +744,7 @@ struct PairArgs {
     // Phase-1 grid: one workgroup per VALID (x rows, y tile) combination, in one dimension (see k_pair_sums): c1tot chunks of
     // x rows over all tiles of axis 1, s0tot (j0, tile of axis 0) combinations (band 1: j0 from at_lo up, one window each)
     unsigned c1tot, s0tot, at_lo;
+    unsigned kuf;  // band 1: the slab of U the range lies in (rank 3: 0) — the x rows' ju = kuf - ud for every y slab ud that has one
 };
 // terms of output index k on one axis: j in [max(0, k + 1 - ny), min(k + 1, nx)), and the number of terms of all k' < k
 __host__ __device__ inline unsigned pair_lo(unsigned k, unsigned ny) { return k + 1 > ny ? k + 1 - ny : 0u; }
@@ -768,7 +769,7 @@ __device__ __forceinline__ unsigned long long pair_slot(const PairArgs& g, unsig
 
 // first output row (row-major over (ku, k0, k1)) of a launch's slab range
 __device__ __forceinline__ unsigned long long pair_row_base(const PairArgs& g) {
-    return g.band == 2 ? (unsigned long long)g.klo * g.z0 * g.z1 : (g.band == 1 ? (unsigned long long)g.klo * g.z1 : 0ull);
+    return g.band == 2 ? (unsigned long long)g.klo * g.z0 * g.z1 : (g.band == 1 ? ((unsigned long long)g.kuf * g.z0 + g.klo) * g.z1 : 0ull);
 }
 
 typedef const double __attribute__((address_space(4))) * pair_cptr_t;  // wave-uniform, read-only: scalar loads
@@ -919,9 +920,12 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         r -= nc;
     }
     unsigned at = 0, ud = 0, j0 = 0, ju = 0;
-    if (g.band == 1) {  // `at` is the x rows' j0
-        at = g.at_lo + (unsigned)q;
+    if (g.band == 1) {  // `at` is the x rows' j0; one y slab ud per x slab ju = kuf - ud
+        const unsigned nat = g.tiles0 - g.at_lo;
+        at = g.at_lo + (unsigned)(q % nat);
         j0 = at;
+        ud = (g.kuf + 1 > g.xU ? g.kuf + 1 - g.xU : 0u) + (unsigned)(q / nat);
+        ju = g.kuf - ud;
     } else {
         unsigned q0 = (unsigned)(q % g.s0tot);
         unsigned long long qu = q / g.s0tot;
@@ -1054,52 +1058,102 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     }
 }
 
-// phase 2: the terms of one output row are one contiguous stream in the reference's order; thread = column, sixteen terms in
-// flight (the heaviest row of 64^3 has 4096 terms of 1 KB: its chain of loads is what the launch waits for)
+// phase 2: the terms of one output row are one contiguous stream in the reference's order; thread = column, D terms in
+// flight (the heaviest row of 64^3 has 4096 terms of 1 KB: its chain of loads and dependent additions is what the launch waits for).
+// The ordered sum of the n terms p[0], p[pitch], .. onto acc.  REG 1 (intervals): every term is tested for 0 < lo <= hi and added
+// with the positive regime's integer steps (gft_elem.hpp add_pos: two dependent instructions per bound instead of the general
+// add's nine — the chain, not the bandwidth, bounds a slab range's launch); REG 2: every term is tested for [0,0] (the add's only
+// short-circuit) and added with the finite regime's unguarded outward step (five), whose NaN pattern marks a sum that met an
+// infinity; `bad` says that some term failed its test, the caller redoes the row with the general add (REG 0).
+// (Rows of <= 32 elements with the wave's idle half loading every second term and handing it down through __shfl_down:
+// measured, SLOWER — 32^4 84 -> 95 ms, 32^3 0.147 -> 0.166: the cross-lane reads wait on the same counter as the chain's loads.)
+template <class E, int REG, class Raw>
+__device__ __forceinline__ typename E::V pair_sum_terms(const Raw* __restrict__ p, size_t pitch, unsigned long long n, typename E::V acc, bool& bad) {
+    typedef typename E::V V;
+    if (n == 0) return acc;
+    auto step = [&](V a, const Raw& r) -> V {
+        if constexpr (E::W == 2) {
+            const Iv t = Iv{r.x, r.y};
+            if constexpr (REG == 1) {
+                bad = bad || !(t.lo > 0.0 && t.hi >= t.lo);
+                return E::add_pos(a, t);
+            } else if constexpr (REG == 2) {
+                bad = bad || (t.lo == 0.0 && t.hi == 0.0);
+                return E::widen_fin(a.lo + t.lo, a.hi + t.hi);
+            } else {
+                return E::add(a, t);
+            }
+        } else {
+            return E::add(a, r);
+        }
+    };
+    constexpr int D = 32;
+    Raw buf[D];
+    // (no conditional loads in the steady state: hipcc waits for vmcnt(0) at every basic-block boundary, and a load
+    // under `if` is a block of its own — one load in flight instead of D)
+#pragma unroll
+    for (int u = 0; u < D; ++u) buf[u] = p[(size_t)((unsigned long long)u < n ? u : n - 1) * pitch];
+    unsigned long long i0 = 0;
+    for (; i0 + 2 * D <= n; i0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            acc = step(acc, buf[u]);
+            buf[u] = p[(size_t)(i0 + u + D) * pitch];
+        }
+    }
+    // the last D .. 2 D - 1 terms: D in the buffers, the rest loaded with clamped indices
+    Raw last[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) last[u] = p[(size_t)(i0 + D + u < n ? i0 + D + u : n - 1) * pitch];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (i0 + u < n) acc = step(acc, buf[u]);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (i0 + D + u < n) acc = step(acc, last[u]);
+    return acc;
+}
+
 template <class E>
 __global__ void __launch_bounds__(128) k_pair_collect(const double* __restrict__ ws, double* __restrict__ z, size_t zp, PairArgs g) {
     typedef typename E::V V;
     typedef typename std::conditional<E::W == 2, double2, double>::type Raw;  // a stored element
-    auto val = [](const Raw& r) -> V {
-        if constexpr (E::W == 2) return Iv{r.x, r.y};
-        else return r;
-    };
     const unsigned c = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool act = c < g.n2;
+    const unsigned cc = act ? c : g.n2 - 1;  // (threads beyond the row follow its last column: the wave decides the regime together)
     unsigned long long rr = (unsigned long long)(gridDim.x - 1 - blockIdx.x) + pair_row_base(g);  // heaviest rows first; the launch's slab range
     const unsigned k1 = (unsigned)(rr % g.z1);
     rr /= g.z1;
     const unsigned k0 = (unsigned)(rr % g.z0), ku = (unsigned)(rr / g.z0);
     const unsigned long long n = (unsigned long long)pair_cnt(ku, g.xU, g.yU) * pair_cnt(k0, g.x0, g.y0) * pair_cnt(k1, g.x1, g.y1);
     V acc = E::zero();
-    if (n > 0 && c < g.n2) {
-        const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)(pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) - g.slot_base) * g.n2 * E::W) + c;
+    if (n > 0) {
+        const Raw* p = reinterpret_cast<const Raw*>(ws + (size_t)(pair_slot(g, pair_lo(ku, g.yU), pair_lo(k0, g.y0), pair_lo(k1, g.y1), ku, k0, k1) - g.slot_base) * g.n2 * E::W) + cc;
         const size_t pitch = g.n2;  // elements per term
-        constexpr int D = 32;
-        Raw buf[D];
-        // (no conditional loads in the steady state: hipcc waits for vmcnt(0) at every basic-block boundary, and a load
-        // under `if` is a block of its own — one load in flight instead of D)
-#pragma unroll
-        for (int u = 0; u < D; ++u) buf[u] = p[(size_t)((unsigned long long)u < n ? u : n - 1) * pitch];
-        unsigned long long i0 = 0;
-        for (; i0 + 2 * D <= n; i0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                acc = E::add(acc, val(buf[u]));
-                buf[u] = p[(size_t)(i0 + u + D) * pitch];
+        bool bad = false;
+        if constexpr (E::HAS_POS) {
+            // the reference's sum starts from [0,0], whose add returns the first term itself (interval.rs:126-139); where that term
+            // is positive in every column the row is tried in the positive regime — same operations on the same values while
+            // every term stays 0 < lo <= hi and no bound overflows (inc_pos(inf) is a NaN pattern and stays one), else redone
+            // (a first term that is not [0,0] in any column: the finite regime — the sum is never [0,0] again, widened intervals are not points)
+            const Raw t0 = p[0];
+            const bool pos0 = t0.x > 0.0 && t0.y >= t0.x, nz0 = !(t0.x == 0.0 && t0.y == 0.0);
+            bool done = false;
+            if (!any_lane(!pos0)) {
+                acc = pair_sum_terms<E, 1>(p + pitch, pitch, n - 1, Iv{t0.x, t0.y}, bad);
+                bad = bad || !E::pos_result_ok(acc);
+                done = !any_lane(bad);
+            } else if (!any_lane(!nz0)) {
+                acc = pair_sum_terms<E, 2>(p + pitch, pitch, n - 1, Iv{t0.x, t0.y}, bad);
+                bad = bad || !E::fin_result_ok(acc);
+                done = !any_lane(bad);
             }
+            if (!done) acc = pair_sum_terms<E, 0>(p, pitch, n, E::zero(), bad);
+        } else {
+            acc = pair_sum_terms<E, 0>(p, pitch, n, E::zero(), bad);
         }
-        // the last D .. 2 D - 1 terms: D in the buffers, the rest loaded with clamped indices
-        Raw last[D];
-#pragma unroll
-        for (int u = 0; u < D; ++u) last[u] = p[(size_t)(i0 + D + u < n ? i0 + D + u : n - 1) * pitch];
-#pragma unroll
-        for (int u = 0; u < D; ++u)
-            if (i0 + u < n) acc = E::add(acc, val(buf[u]));
-#pragma unroll
-        for (int u = 0; u < D; ++u)
-            if (i0 + D + u < n) acc = E::add(acc, val(last[u]));
     }
-    if (c < g.n2) E::st(z, zp, (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c, acc);
+    if (act) E::st(z, zp, (((size_t)ku * g.z0 + k0) * g.z1 + k1) * g.n2 + c, acc);
 }
 
 // f64 rows of even length: two columns per thread (16-byte loads, as the interval form has anyway)
@@ -1330,40 +1384,51 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         const unsigned long long need = slots * row_bytes;
         // ---- the plan: one launch pair for the whole product, or slab ranges of the leading outer axis that fit the cap
         struct Range {
-            unsigned lo, hi;
+            unsigned lo, hi, band, ku;  // band 0: the whole product; 2: slabs [lo, hi) of U (rank 4); 1: slabs [lo, hi) of axis 0 inside slab ku of U (rank 3: ku = 0)
             unsigned long long base, slots;
         };
         std::vector<Range> plan;
         bool plan_ok = slots > 0 && zs_ / n2 <= 0x7fffffffull, use_lanes = false;
-        unsigned band = 0;
         if (plan_ok && need <= rb_pairs_cap) {
-            plan.push_back(Range{0, 0, 0, slots});
+            plan.push_back(Range{0, 0, 0, 0, 0, slots});
         } else if (plan_ok && no >= 2) {
             // Two lanes (see PairLanes) need two workspaces, so each gets half the cap: taken when that does not make the ranges
             // thinner — then one lane's phase 2 (a few hundred one-wave rows: latency, not bandwidth) runs under the other's phase 1.
             // MI355X, positive / mixed-sign: 56^3 2.88 / 5.92 -> 2.55 / 5.05 ms, 64^3 5.31 / 11.5 -> 4.92 / 10.2, 72^3 9.40 / 21.0 -> 8.84 / 20.5;
             // from 80^3 on half the cap halves the window's height and the lanes lose (88^3 29.9 -> 30.4, 96^3 49.8 -> 54.0): off there.
             const int lanes_on = rb_pairs_lanes;  // 0 never, 1 always, negative: when the ranges stay the same
-            band = no == 3 ? 2u : 1u;  // leading axis: U (rank 4) or axis 0 (rank 3: a lane axis — ranges of 1, 2, 4 or 8 slabs, the window's height)
-            const unsigned nlead = band == 2 ? g.zU : g.z0, xl = band == 2 ? g.xU : g.x0, yl = band == 2 ? g.yU : g.y0;
-            const unsigned long long per = band == 2 ? g.S0 * g.S1 : g.S1;  // slots per term of the leading axis
-            auto slots_of = [&](unsigned lo, unsigned hi) { return (pair_pre(hi, xl, yl) - pair_pre(lo, xl, yl)) * per; };
+            // rank 3: ranges of 1, 2, 4 or 8 slabs of axis 0 (a lane axis: the range's height is the window's).  Rank 4: ranges of slabs
+            // of U where a slab fits the cap, ranges of axis 0 INSIDE a slab of U where it does not (32^4: the top slab alone is 4.6 GB)
+            auto k0_ranges = [&](unsigned ku, size_t range_cap, std::vector<Range>& out) {
+                const unsigned long long cU = pair_cnt(ku, g.xU, g.yU), ubase = pair_pre(ku, g.xU, g.yU) * g.S0 * g.S1;
+                auto sl = [&](unsigned lo, unsigned hi) { return cU * (pair_pre(hi, g.x0, g.y0) - pair_pre(lo, g.x0, g.y0)) * g.S1; };
+                for (unsigned lo = 0; lo < g.z0;) {
+                    unsigned h = 0;
+                    for (unsigned c = 8; c >= 1; c /= 2)
+                        if (lo + c <= g.z0 && sl(lo, lo + c) * row_bytes <= range_cap) {
+                            h = c;
+                            break;
+                        }
+                    if (h == 0) return false;  // (one slab of axis 0 alone exceeds the cap: not this form's product)
+                    out.push_back(Range{lo, lo + h, 1u, ku, ubase + cU * pair_pre(lo, g.x0, g.y0) * g.S1, sl(lo, lo + h)});
+                    lo += h;
+                }
+                return true;
+            };
             auto make_plan = [&](size_t range_cap, std::vector<Range>& out) {
                 out.clear();
-                for (unsigned lo = 0; lo < nlead;) {
+                if (no == 2) return k0_ranges(0, range_cap, out) && out.size() <= 4096;
+                auto sl = [&](unsigned lo, unsigned hi) { return (pair_pre(hi, g.xU, g.yU) - pair_pre(lo, g.xU, g.yU)) * g.S0 * g.S1; };
+                for (unsigned lo = 0; lo < g.zU;) {
                     unsigned h = 0;
-                    if (band == 2) {
-                        while (lo + h < nlead && slots_of(lo, lo + h + 1) * row_bytes <= range_cap) ++h;
+                    while (lo + h < g.zU && sl(lo, lo + h + 1) * row_bytes <= range_cap) ++h;
+                    if (h) {
+                        out.push_back(Range{lo, lo + h, 2u, 0u, pair_pre(lo, g.xU, g.yU) * g.S0 * g.S1, sl(lo, lo + h)});
+                        lo += h;
                     } else {
-                        for (unsigned c = 8; c >= 1; c /= 2)
-                            if (lo + c <= nlead && slots_of(lo, lo + c) * row_bytes <= range_cap) {
-                                h = c;
-                                break;
-                            }
+                        if (!k0_ranges(lo, range_cap, out)) return false;
+                        lo += 1;
                     }
-                    if (h == 0) return false;  // (one slab alone exceeds the cap: not this form's product)
-                    out.push_back(Range{lo, lo + h, pair_pre(lo, xl, yl) * per, slots_of(lo, lo + h)});
-                    lo += h;
                 }
                 return out.size() <= 4096;
             };
@@ -1444,7 +1509,9 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                 std::vector<unsigned long long> rows;
                 for (const Range& r : plan) {
                     PairArgs q = g;
+                    const unsigned band = r.band;
                     q.band = band;
+                    q.kuf = r.ku;
                     q.klo = r.lo;
                     q.khi = r.hi;
                     q.slot_base = r.base;
@@ -1458,7 +1525,8 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                         q.tiles1 = (std::min(q.y1, q.z1) + T1w - 1) / T1w;
                         q.tiles0 = std::min(q.x0, r.hi);                       // j0 <= k0 < khi
                         q.at_lo = r.lo + 1 > q.y0 ? r.lo + 1 - q.y0 : 0u;      // (a compact y: the window of a lower j0 lies above y's last row)
-                        combos = q.tiles0 > q.at_lo ? q.tiles0 - q.at_lo : 0u;
+                        const unsigned ud_lo = r.ku + 1 > q.xU ? r.ku + 1 - q.xU : 0u, ud_hi = std::min(q.yU - 1, r.ku);  // y slabs ud with an x slab ju = ku - ud
+                        combos = q.tiles0 > q.at_lo && ud_hi >= ud_lo ? (unsigned long long)(q.tiles0 - q.at_lo) * (ud_hi - ud_lo + 1) : 0u;
                         nrows = (unsigned long long)(r.hi - r.lo) * q.z1;
                     } else {
                         const unsigned T0w = 64u >> q.tsh;

@@ -1455,10 +1455,11 @@ def test_interval_rows_register_blocked_bit_exact(xs, ys, zs, OTPI, GTPI):
             # <= 128; longer ones fall through to k_conv_staged), and a cap too small for it (back to k_conv_staged)
             # ... and caps that cut it into slab ranges of the leading axis (round 5: the bounded workspace; ranges of 1 - 8
             # slabs for rank 3, of any height for rank 4 — where one slab alone exceeds the cap the product falls back)
-            # ... the ranges alternating between two lanes (two streams, half the cap each), forced and never
+            # ... the ranges alternating between two lanes (two streams, half the cap each), forced and never; rank 4 under the
+            # smallest caps: ranges of axis 0 inside one slab of the leading axis
             for thr, pairs, cap, lanes in ((0.0, 0.0, 0.0, -1.0), (-1.0, 0.0, 0.0, -1.0), (-1.0, 2.0, 0.0, -1.0), (-1.0, 2.0, 4096.0, -1.0),
                                            (-1.0, 2.0, 4.0e6, -1.0), (-1.0, 2.0, 6.0e5, -1.0), (-1.0, 2.0, 4.0e6, 1.0), (-1.0, 2.0, 1.2e6, 1.0),
-                                           (-1.0, 2.0, 6.0e5, 0.0)):
+                                           (-1.0, 2.0, 6.0e5, 0.0), (-1.0, 2.0, 1.0e5, -1.0), (-1.0, 2.0, 2.0e5, 1.0)):
                 assert L.gft_set_option(b"conv_rb_min_macs", thr) == 0
                 assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
                 assert L.gft_set_option(b"conv_rb_pairs_cap", cap) == 0
