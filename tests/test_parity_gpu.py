@@ -842,6 +842,41 @@ def test_full_size_c5_mixed_sign_interval_product_encloses_f64(GTP, GTPI):
     assert lo[0, 0, 0] <= x[0, 0, 0] * y[0, 0, 0] <= hi[0, 0, 0]
 
 
+@pytest.mark.parametrize("shape", [(72, 72, 72), (88, 88, 88), (20, 20, 20, 24), (32, 32, 32, 32)])
+def test_full_size_interval_row_pair_ranges_equal_the_staged_kernel(GTPI, shape):
+    """The row-pair form under its default 2 GiB workspace at sizes that take every kind of slab range — 72^3 (ranges of 8
+    slabs of axis 0 on two lanes), 88^3 (ranges of 4), 20^3 x 24 (ranges of slabs of the leading axis), 32^4 (ranges of the
+    leading axis below, ranges of axis 0 inside one leading slab above: one such slab alone is 4.6 GB) — against the
+    LDS-staged reference-order kernel (row-pair form off), which the oracle pins at the sizes it finishes: bit for bit,
+    positive data (positive regime in both passes) and mixed-sign data with an exact zero, a one and an infinity in it."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    xp, yp = rand(shape, 301, 0.1, 1.0), rand(shape, 302, 0.1, 1.0)
+    xm, ym = rand(shape, 303, -1.0, 1.0), rand(shape, 304, -1.0, 1.0)
+    xm[(1,) * len(shape)] = 0.0
+    ym[(2,) * len(shape)] = 1.0
+    cases = [(np.stack([xp, xp * (1 + 1e-15)]), np.stack([yp, yp * (1 + 1e-15)])),
+             (np.stack([xm, xm + 1e-15 * np.abs(xm)]), np.stack([ym, ym + 1e-15 * np.abs(ym)]))]
+    cases[1][0][1][(3,) * len(shape)] = np.inf
+    L.gft_set_option(b"host_max_elems", 0.0)
+    try:
+        for a, b in cases:
+            got = {}
+            for pairs in (2.0, 0.0):
+                assert L.gft_set_option(b"conv_rb_pairs", pairs) == 0
+                try:
+                    got[pairs] = np.asarray((GTPI.new(a, list(shape)) * GTPI.new(b, list(shape))).array())
+                finally:
+                    L.gft_set_option(b"conv_rb_pairs", -1.0)
+            u, v = got[2.0].view(np.uint64), got[0.0].view(np.uint64)
+            same = (u == v) | (np.isnan(got[2.0]) & np.isnan(got[0.0]))
+            assert np.all(same), (shape, int((~same).sum()), got[2.0][~same][:4], got[0.0][~same][:4])
+            assert genfer_amd.pool_stats()["in_use"] < (3 << 30)  # (operands, results and a workspace of at most 2 GiB)
+    finally:
+        L.gft_set_option(b"host_max_elems", -1.0)
+
+
 def test_interval_edge_values_bit_exact(OTPI, GTPI):
     """Interval add / sub / mul / div on the edge values of f64 (signed zeros, smallest subnormals, largest finite,
     infinities, NaN, exact 0 / 1 / -1 points): the outward widening (f64.rs:127-171 next_up / next_down) and every
