@@ -4757,6 +4757,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "pairs_first") R.pairs_first = value != 0.0;
     else if (n == "conv_rb_pairs_cap") staged_set_rb_pairs_cap(value);
     else if (n == "conv_rb_pairs_lanes") staged_set_rb_pairs_lanes(value);
+    else if (n == "shallow_pair_min") shallow_set_pair_min(value == -1.0 ? 4096.0 : value);
     else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default

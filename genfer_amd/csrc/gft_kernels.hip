@@ -1708,6 +1708,117 @@ __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__
     }
 }
 
+// smallest result (elements) that takes the pair form of k_conv_shallow; negative: never ("shallow_pair_min", GFT_SHALLOW_PAIR_MIN)
+static double g_shallow_pair_min = [] {
+    const char* en = getenv("GFT_SHALLOW_PAIR_MIN");
+    return en ? atof(en) : 4096.0;
+}();
+void shallow_set_pair_min(double v) { g_shallow_pair_min = v; }
+
+// The same with TWO outputs per thread, neighbours along the last axis, for stencils that are FLAT along it (ys[last] == 1:
+// the binomial-like substitutions, 2 x 2 x 1): both outputs share every outer index, so the loop nest, its bounds and the y
+// coefficients are worked out once for the pair, and the x elements of a term are one 16-byte load (the host checks the
+// parities that make it aligned).  Per output the operations and their order are k_conv_shallow's (mt:984-1012) => same bits.
+template <class E>
+__device__ __forceinline__ void ld_pair(const double* p, size_t plane, size_t i, typename E::V& a, typename E::V& b) {
+    if constexpr (E::W == 2) {
+        const double2 l = *reinterpret_cast<const double2*>(p + i), h = *reinterpret_cast<const double2*>(p + plane + i);
+        a = Iv{l.x, h.x};
+        b = Iv{l.y, h.y};
+    } else {
+        const double2 t = *reinterpret_cast<const double2*>(p + i);
+        a = t.x;
+        b = t.y;
+    }
+}
+template <class E, int AX, int ND, bool INNER0, typename OFF>
+struct ConvLoopPair {
+    __device__ static inline void run(const ConvArgs& a, const unsigned* k, const double* x, size_t xp, const double* y, size_t yp, OFF xoff,
+                                      OFF yoff, typename E::V& acc0, typename E::V& acc1, bool in1) {
+        typedef typename E::V V;
+        const unsigned kk = k[AX];
+        if constexpr (AX == ND - 1) {
+            // flat stencil: the only term of the last axis is j = k (y index 0), if x reaches that far
+            if (kk >= a.xs[AX]) return;
+            const V yv = E::ld(y, yp, yoff);
+            V x0, x1;
+            if (kk + 1 < a.xs[AX]) ld_pair<E>(x, xp, (size_t)(xoff + (OFF)kk), x0, x1);
+            else x0 = x1 = E::ld(x, xp, (size_t)(xoff + (OFF)kk));
+            if (INNER0) {
+                acc0 = E::add(acc0, E::add(E::zero(), E::mul(x0, yv)));
+                if (in1 && kk + 1 < a.xs[AX]) acc1 = E::add(acc1, E::add(E::zero(), E::mul(x1, yv)));
+            } else {
+                acc0 = E::add(acc0, E::mul(x0, yv));
+                if (in1 && kk + 1 < a.xs[AX]) acc1 = E::add(acc1, E::mul(x1, yv));
+            }
+        } else {
+            const unsigned lo = (kk + 1 > a.ys[AX]) ? (kk + 1 - a.ys[AX]) : 0;
+            const unsigned hi = (kk + 1 < a.xs[AX]) ? (kk + 1) : a.xs[AX];
+            for (unsigned j = lo; j < hi; ++j)
+                ConvLoopPair<E, (AX + 1 < ND ? AX + 1 : AX), ND, INNER0, OFF>::run(a, k, x, xp, y, yp, xoff + (OFF)j * (OFF)a.xstr[AX],
+                                                                                  yoff + (OFF)(kk - j) * (OFF)a.ystr[AX], acc0, acc1, in1);
+        }
+    }
+};
+
+template <class E, int ND, bool INNER0, typename OFF>
+__global__ void __launch_bounds__(256) k_conv_shallow_pair(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp,
+                                                           double* __restrict__ out, size_t op, ConvArgs a, ConvEpi e, unsigned pairs) {
+    typedef typename E::V V;
+    int found = 0;
+    for (unsigned pl = blockIdx.x * 256u + threadIdx.x; pl < pairs; pl += gridDim.x * 256u) {
+        const unsigned lin = 2u * pl;  // (os[last] is even: a pair never straddles two rows)
+        unsigned k[ND];
+        unsigned r = lin;
+        bool inz = true, ina = e.mode == 1, big = false;
+        int nz = 0;
+        OFF aoff = 0;
+#pragma unroll
+        for (int ax = ND - 1; ax >= 0; --ax) {
+            const unsigned d = e.os[ax];
+            const unsigned kk = r % d;
+            r /= d;
+            k[ax] = kk;
+            if (ax < ND - 1) {  // (the last axis is tested per output below)
+                if (kk >= a.zs[ax]) inz = false;
+                if (kk >= e.abox[ax]) ina = false;
+                if (kk) nz++;
+                if (kk >= 2) big = true;
+            }
+            aoff += (OFF)kk * (OFF)e.astr[ax];
+        }
+        const unsigned kl = k[ND - 1];
+        const bool inz0 = inz && kl < a.zs[ND - 1], inz1 = inz && kl + 1 < a.zs[ND - 1];
+        V v0 = E::zero(), v1 = E::zero();
+        if (inz0) {
+            V acc0 = E::zero(), acc1 = E::zero();
+            ConvLoopPair<E, 0, ND, INNER0, OFF>::run(a, k, x, xp, y, yp, (OFF)0, (OFF)0, acc0, acc1, inz1);
+            v0 = e.mode == 1 ? E::add(v0, acc0) : acc0;
+            if (inz1) v1 = e.mode == 1 ? E::add(v1, acc1) : acc1;
+        }
+        if (e.mode == 1) {
+            if (ina && kl < e.abox[ND - 1]) v0 = E::add(v0, E::ld(e.ap, e.aplane, (size_t)aoff));
+            if (ina && kl + 1 < e.abox[ND - 1]) v1 = E::add(v1, E::ld(e.ap, e.aplane, (size_t)(aoff + (OFF)e.astr[ND - 1])));
+        } else if (e.mode == 2 && lin == 0) {
+            v0 = E::add(v0, E::ld(e.ap, e.aplane, 0));
+        }
+        if constexpr (E::W == 2) {
+            *reinterpret_cast<double2*>(out + lin) = double2{v0.lo, v1.lo};
+            *reinterpret_cast<double2*>(out + op + lin) = double2{v0.hi, v1.hi};
+        } else {
+            *reinterpret_cast<double2*>(out + lin) = double2{v0, v1};
+        }
+        if (e.wit) {
+            const int nz0 = nz + (kl ? 1 : 0), nz1 = nz + 1;
+            if ((big || kl >= 2 || nz0 >= 2) && !E::is_zero(v0)) found = 1;
+            if ((big || kl + 1 >= 2 || nz1 >= 2) && !E::is_zero(v1)) found = 1;
+        }
+    }
+    if (e.wit) {
+        if (__syncthreads_or(found) && threadIdx.x == 0) wit_raise_once(e.wit);
+    }
+}
+
 template <class E>
 bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* out,
                         size_t out_plane, const ConvArgs& a, const ConvEpi& e) {
@@ -1716,6 +1827,32 @@ bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const d
     unsigned long long total = 1;
     for (int i = 0; i < a.nd; ++i) total *= e.os[i];
     if (total == 0 || total > 0x7fffffffull) return false;
+    {   // the pair form: a stencil flat along the last axis, rows of even length, 16-byte alignment of every pair
+        const int L = a.nd - 1;
+        bool ok = g_shallow_pair_min >= 0.0 && a.nd >= 2 && a.ys[L] == 1 && a.xstr[L] == 1 && e.os[L] % 2 == 0 && (double)total >= g_shallow_pair_min && !((uintptr_t)x & 15) && !((uintptr_t)out & 15) &&
+                  x_plane % 2 == 0 && out_plane % 2 == 0;
+        for (int i = 0; i < L && ok; ++i) ok = a.xstr[i] % 2 == 0;
+        unsigned long long nx = 1, ny = 1, aspan = 1;
+        for (int i = 0; i < a.nd; ++i) {
+            nx *= a.xs[i];
+            ny *= a.ys[i];
+            aspan += (unsigned long long)(e.abox[i] ? e.abox[i] - 1 : 0) * e.astr[i];
+        }
+        if (ok && nx < 0x7fffffffull && ny < 0x7fffffffull && aspan + e.astr[L] < 0x7fffffffull) {
+            const unsigned pairs = (unsigned)(total / 2);
+            dim3 g(grid_for((size_t)pairs)), b(256);
+#define GFT_CASE(N)                                                                                                                                      \
+    case N:                                                                                                                                              \
+        if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow_pair<E, N, true, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, pairs); \
+        else GFT_LAUNCH((k_conv_shallow_pair<E, N, false, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, pairs);                 \
+        return true;
+            switch (a.nd) {
+                GFT_CASE(2) GFT_CASE(3) GFT_CASE(4) GFT_CASE(5) GFT_CASE(6)
+                default: break;
+            }
+#undef GFT_CASE
+        }
+    }
     dim3 g(grid_for((size_t)total)), b(256);
     unsigned long long nx = 1, ny = 1;
     for (int i = 0; i < a.nd; ++i) {

@@ -414,6 +414,7 @@ bool conv_pairs(hipStream_t st, const double* x, size_t xp, const double* y, siz
 void staged_set_rb_min_macs(double v);  // threshold of the register-blocked interval product (negative: never)
 void staged_set_rb_pairs(double v);    // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 by size, 2 always, negative: the default
 void staged_set_rb_pairs_cap(double bytes);  // bytes of row sums it may hold, all streams together (< 1: the default, 2 GiB)
+void shallow_set_pair_min(double v);         // smallest result of k_conv_shallow's two-outputs-per-thread form (negative: never; default 4096)
 void staged_set_rb_pairs_lanes(double v);    // slab ranges on two lanes: 0 never, 1 always, negative: when half the cap leaves the ranges as they are
 size_t staged_scratch_bytes();  // bytes the grow-only kernel workspaces of gft_conv_staged.hip hold (gft_pool_stats)
 void staged_release_scratch();  // frees the register-blocked interval product's row-flag scratch (gft_shutdown)

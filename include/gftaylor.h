@@ -98,6 +98,8 @@ int gft_set_conv_mode(int mode);
  * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "async_launch" (0: kernels are launched by the
  * calling thread instead of the library's launch thread), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
  * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init),
+ * "shallow_pair_min" (smallest result, in elements, for which a stencil that is flat along the last axis computes two
+ * neighbouring outputs per thread with 16-byte accesses; 0: always, -1: the default 4096, below -1: never),
  * "shallow_max_terms" (plain products whose outputs receive at most this many terms each — one operand a stencil of a few
  * coefficients — run on the fused reference-order kernel, general Horner steps res * subst + slab in one launch; 0: never;
  * negative: the default, 256), "rows_wavefront" (0: rank-2 div / log / exp with rows longer than 64 coefficients row by row

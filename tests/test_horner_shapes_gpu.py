@@ -123,6 +123,11 @@ FUSED_CASES = [
     ((4, 3, 3, 4), [6, 5, 5, 6], 0, 3, 0.3),
     ((12, 1, 5), [14, 3, 8], 0, 2, 0.7),       # slabs with a unit axis; the substitution brings axis 2 in
     ((7, 3), [7, 3], 0, 1, 0.5),               # degrees cap the growth at once
+    # stencils FLAT along the last axis with rows of even length: the two-outputs-per-thread form (shallow_pair_min = 0 below)
+    ((6, 5, 4), [9, 9, 4], 0, 1, 0.3),
+    ((5, 6, 3, 8), [7, 8, 3, 8], 1, 0, 0.3),
+    ((8, 9, 10), [10, 11, 12], 0, 1, 0.6),
+    ((6, 7, 2), [8, 8, 2], 1, 0, 0.45),
 ]
 
 
@@ -155,6 +160,15 @@ def test_general_horner_step_fused_bit_exact(case, interval, OTP, GTP, OTPI, GTP
             results[terms] = (after["fused_horner_steps"] - before["fused_horner_steps"], after["launches"] - before["launches"])
         finally:
             L.gft_set_option(b"shallow_max_terms", -1.0)
+    # the fused step's two forms (one / two outputs per thread) on the device tier, whatever the size
+    L.gft_set_option(b"host_max_elems", 0.0)
+    try:
+        for pair_min in (0.0, -2.0):
+            assert L.gft_set_option(b"shallow_pair_min", pair_min) == 0
+            _check(want, G.new(ai, deg).subst_var(v, G.new(si, deg)))
+    finally:
+        L.gft_set_option(b"shallow_pair_min", -1.0)
+        L.gft_set_option(b"host_max_elems", -1.0)
     assert results[0.0][0] == 0
     # on the device tier the loop really took the fused kernel, and with fewer launches
     if results[-1.0][0]:
@@ -181,7 +195,10 @@ def test_general_horner_fused_runs_on_the_device_tier(OTP, GTP):
 @pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
 @pytest.mark.parametrize("xs,ys,deg", [((30, 28, 9), (2, 2, 1), [31, 29, 9]), ((30, 28, 9), (1, 2, 2), [31, 29, 10]),
                                         ((1, 1, 24), (24, 24, 1), [24, 24, 24]), ((24, 1, 1), (24, 24, 24), [24, 24, 24]),
-                                        ((40, 50), (3, 2), [41, 50]), ((5, 4, 3, 20), (2, 1, 2, 3), [6, 4, 4, 20])])
+                                        ((40, 50), (3, 2), [41, 50]), ((5, 4, 3, 20), (2, 1, 2, 3), [6, 4, 4, 20]),
+                                        # flat along the last axis, rows of even length: two outputs per thread (16-byte accesses)
+                                        ((30, 28, 10), (2, 2, 1), [31, 29, 10]), ((90, 50), (3, 1), [92, 50]), ((30, 28, 10), (2, 2, 1), [30, 28, 10]),
+                                        ((12, 11, 6, 8), (2, 1, 2, 1), [13, 11, 7, 8]), ((26, 24, 12), (2, 3, 1), [40, 40, 12])])
 def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI, tier):
     """Products whose outputs receive few terms each (one operand a stencil, or an outer product) run on the reference-
     order kernel: bit-exact against the oracle, both operand orders."""
