@@ -198,7 +198,9 @@ def test_general_horner_fused_runs_on_the_device_tier(OTP, GTP):
                                         ((40, 50), (3, 2), [41, 50]), ((5, 4, 3, 20), (2, 1, 2, 3), [6, 4, 4, 20]),
                                         # flat along the last axis, rows of even length: two outputs per thread (16-byte accesses)
                                         ((30, 28, 10), (2, 2, 1), [31, 29, 10]), ((90, 50), (3, 1), [92, 50]), ((30, 28, 10), (2, 2, 1), [30, 28, 10]),
-                                        ((12, 11, 6, 8), (2, 1, 2, 1), [13, 11, 7, 8]), ((26, 24, 12), (2, 3, 1), [40, 40, 12])])
+                                        ((12, 11, 6, 8), (2, 1, 2, 1), [13, 11, 7, 8]), ((26, 24, 12), (2, 3, 1), [40, 40, 12]),
+                                        # not flat: every x element of the last axis loaded once for the pair
+                                        ((70, 69), (2, 2), [71, 70]), ((30, 28, 9), (1, 2, 2), [31, 29, 10]), ((64, 80), (2, 3), [64, 80]), ((20, 21, 13), (2, 1, 4), [21, 21, 16])])
 def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI, tier):
     """Products whose outputs receive few terms each (one operand a stencil, or an outer product) run on the reference-
     order kernel: bit-exact against the oracle, both operand orders."""
@@ -214,6 +216,15 @@ def test_shallow_products_bit_exact(xs, ys, deg, interval, OTP, GTP, OTPI, GTPI,
     _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
     if tier == "device" and os.environ.get("GFT_SHALLOW_MAX_TERMS") is None:
         assert genfer_amd.op_stats()["shallow_products"] == before + 2, "the products did not take the shallow kernel"
+    # the kernel's two forms — one output per thread, two neighbours along the last axis (rows of even length) — whatever the size
+    L = genfer_amd.lib()
+    try:
+        for pair_min in (0.0, -2.0):
+            assert L.gft_set_option(b"shallow_pair_min", pair_min) == 0
+            _check(O.new(x, deg) * O.new(y, deg), G.new(x, deg) * G.new(y, deg))
+            _check(O.new(y, deg) * O.new(x, deg), G.new(y, deg) * G.new(x, deg))
+    finally:
+        L.gft_set_option(b"shallow_pair_min", -1.0)
 
 
 @pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
