@@ -872,7 +872,8 @@ def test_full_size_interval_row_pair_ranges_equal_the_staged_kernel(GTPI, shape)
             u, v = got[2.0].view(np.uint64), got[0.0].view(np.uint64)
             same = (u == v) | (np.isnan(got[2.0]) & np.isnan(got[0.0]))
             assert np.all(same), (shape, int((~same).sum()), got[2.0][~same][:4], got[0.0][~same][:4])
-            assert genfer_amd.pool_stats()["in_use"] < (3 << 30)  # (operands, results and a workspace of at most 2 GiB)
+            if os.environ.get("GFT_RB_PAIRS_CAP_MB") is None:  # (the verification matrix also runs this with other caps)
+                assert genfer_amd.pool_stats()["in_use"] < (3 << 30)  # (operands, results and a workspace of at most 2 GiB)
     finally:
         L.gft_set_option(b"host_max_elems", -1.0)
 

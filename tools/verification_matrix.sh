@@ -16,6 +16,17 @@ if [ "${MATRIX:-all}" = "old_light" ]; then  # the earlier rounds' switches on t
   done
   exit 0
 fi
+if [ "${MATRIX:-all}" = "r5b" ]; then  # the switches added late in round 5: the row-pair grid / lanes / regime collect, the shallow kernel's pair form
+  for cfg in "GFT_RB_PAIRS_LANES=0" "GFT_RB_PAIRS_LANES=1" "GFT_RB_PAIRS_CAP_MB=8" "GFT_RB_PAIRS_CAP_MB=8 GFT_RB_PAIRS_LANES=1" "GFT_RB_PAIRS_CAP_MB=90000"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -q -x -k "register_blocked or row_pair or reference_order or c5 or fuzz" 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res (interval / reference-order product tests + fuzz)" | tee -a $OUT
+  done
+  for cfg in "GFT_SHALLOW_PAIR_MIN=-2" "GFT_SHALLOW_PAIR_MIN=0"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res (fuzz + Horner shapes + e2e snapshots)" | tee -a $OUT
+  done
+  exit 0
+fi
 if [ "${MATRIX:-all}" = "r5" ]; then
   LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
   for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_SUM=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_CONV_LINE=0" "GFT_SIDE_STREAMS=4" \
