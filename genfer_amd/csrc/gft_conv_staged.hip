@@ -913,10 +913,10 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
     unsigned r = (unsigned)(L % g.c1tot);
     const unsigned long long q = L / g.c1tot;
     unsigned bt = 0, n1 = 0;
-    for (;; ++bt) {  // (uniform; r < c1tot = the sum of the tiles' chunk counts)
+    for (;; ++bt) {  // (uniform; r < c1tot = the sum of the tiles' chunk counts — the loops below end at their last tile whatever the counts say)
         n1 = g.z1 - T1 * bt < g.x1 ? g.z1 - T1 * bt : g.x1;
         const unsigned nc = (n1 + g.xch - 1) / g.xch;
-        if (r < nc) break;
+        if (r < nc || bt + 1 >= g.tiles1) break;
         r -= nc;
     }
     unsigned at = 0, ud = 0, j0 = 0, ju = 0;
@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
         unsigned long long qu = q / g.s0tot;
         for (;; ++at) {
             const unsigned n0 = g.z0 - T0 * at < g.x0 ? g.z0 - T0 * at : g.x0;
-            if (q0 < n0) break;
+            if (q0 < n0 || at + 1 >= g.tiles0) break;
             q0 -= n0;
         }
         j0 = q0;
@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(1024) k_pair_sums(const double* __restrict__ x
                 const unsigned hi = g.khi > ud ? (g.khi - ud < nU ? g.khi - ud : nU) : 0u;
                 nU = hi > ju_lo ? hi - ju_lo : 0u;
             }
-            if (qu < nU) {
+            if (qu < nU || ud + 1 >= g.yU) {
                 ju = ju_lo + (unsigned)qu;
                 break;
             }
