@@ -542,9 +542,22 @@ __device__ __forceinline__ typename E::V chain_apply(const ChainStage* st, int n
 // (always, in practice): 64-bit divisions by a run-time divisor are ~150 instructions each, and on the 10^4-10^5 element
 // tensors of the NeurIPS programs — one element per thread, one wave per SIMD — this kernel's duration IS its instruction
 // count (mixture: 12 000 launches of 5.7 us, hmm: 56 % of the kernel time).
+// A workgroup's copy of the kernel-argument segment in LDS (see k_chain_nest)
+template <class KA>
+__device__ __forceinline__ const KA& kernargs_to_lds(unsigned char* lds) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef const v4u __attribute__((address_space(4))) * seg_t;
+    const seg_t src = (seg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    for (unsigned i = threadIdx.x; i < (sizeof(KA) + 15) / 16; i += blockDim.x) {
+        const v4u t = src[i];
+        reinterpret_cast<v4u*>(lds)[i] = t;
+    }
+    __syncthreads();
+    return *reinterpret_cast<const KA*>(lds);
+}
 template <class E, bool TWO, typename IDX>
-__global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, ChainSrc b,
-                                               int subtract, size_t total) {
+__device__ __forceinline__ void chain_body(double* __restrict__ out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b, int subtract,
+                                           size_t total) {
     typedef typename E::V V;
     for (size_t lin = blockIdx.x * (size_t)blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
         IDX r = (IDX)lin, aoff = 0, boff = 0;
@@ -582,6 +595,48 @@ __global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t 
             }
         }
         E::st(out, out_plane, lin, v);
+    }
+}
+template <class E, bool TWO, typename IDX>
+__global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, ChainSrc b, int subtract, size_t total) {
+    chain_body<E, TWO, IDX>(out, out_plane, sh, a, b, subtract, total);
+}
+// ... with the arguments (two chains: 0.9 KB) copied to LDS first (see k_chain_nest)
+struct ChainKArgs {
+    double* out;
+    size_t out_plane;
+    Shape sh;
+    ChainSrc a, b;
+    int subtract;
+    size_t total;
+};
+template <class E, bool TWO, typename IDX>
+__global__ void __launch_bounds__(256) k_chain_lds(ChainKArgs) {
+    __shared__ __align__(16) unsigned char s_args[(sizeof(ChainKArgs) + 15) / 16 * 16];
+    const ChainKArgs& A = kernargs_to_lds<ChainKArgs>(s_args);
+    chain_body<E, TWO, IDX>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
+}
+static bool args_in_lds() {
+    static const bool on = [] {
+        const char* e = getenv("GFT_ARGS_LDS");  // A/B knob: 0 = arguments read from the kernel-argument segment
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+template <class E, bool TWO, typename IDX>
+static void launch_chain(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b, int subtract, size_t total) {
+    if (args_in_lds()) {
+        ChainKArgs ka;
+        ka.out = out;
+        ka.out_plane = out_plane;
+        ka.sh = sh;
+        ka.a = a;
+        ka.b = b;
+        ka.subtract = subtract;
+        ka.total = total;
+        GFT_LAUNCH((k_chain_lds<E, TWO, IDX>), dim3(grid_for(total)), dim3(256), 0, st, ka);
+    } else {
+        GFT_LAUNCH((k_chain<E, TWO, IDX>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
     }
 }
 // (offsets of lanes outside an operand's box may wrap in 32 bits: they are never dereferenced)
@@ -748,8 +803,8 @@ void K<E>::chain_copy(hipStream_t st, double* out, size_t out_plane, const Shape
         GFT_LAUNCH((k_chain_flat<E, false>), dim3(grid_for((total + 1) / 2)), dim3(256), 0, st, out, out_plane, a, a, 0, total);
         return;
     }
-    if (chain_fits_u32(a, sh, total)) GFT_LAUNCH((k_chain<E, false, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
-    else GFT_LAUNCH((k_chain<E, false, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, a, 0, total);
+    if (chain_fits_u32(a, sh, total)) launch_chain<E, false, unsigned>(st, out, out_plane, sh, a, a, 0, total);
+    else launch_chain<E, false, size_t>(st, out, out_plane, sh, a, a, 0, total);
 }
 template <class E>
 void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b,
@@ -762,8 +817,8 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
         return;
     }
     if (chain_fits_u32(a, sh, total) && chain_fits_u32(b, sh, total))
-        GFT_LAUNCH((k_chain<E, true, unsigned>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
-    else GFT_LAUNCH((k_chain<E, true, size_t>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
+        launch_chain<E, true, unsigned>(st, out, out_plane, sh, a, b, subtract, total);
+    else launch_chain<E, true, size_t>(st, out, out_plane, sh, a, b, subtract, total);
 }
 
 // Nested chain add (NestSrc): out = (0 + A) (+|-) B where A / B are chains or recorded two-chain sums.
@@ -781,8 +836,21 @@ __device__ __forceinline__ bool nest_locate(const ChainSrc& c, const unsigned* k
     }
     return in;
 }
+// The arguments are 2.5 KB.  Read from the kernel-argument segment where they are used they are scalar loads inside
+// run-time loops — one dependent miss of the (cold, per-CU) scalar cache after the other, for the first wave of every
+// workgroup: most of this launch's 8 us.  So the workgroup copies the whole segment to LDS first — one 16-byte vector load
+// per thread, all in flight together — and reads its arguments from there.
+struct NestKArgs {
+    double* out;
+    size_t out_plane;
+    Shape sh;
+    NestSrc a, b;
+    int subtract;
+    unsigned total;
+};
 template <class E>
-__global__ void __launch_bounds__(256) k_chain_nest(double* __restrict__ out, size_t out_plane, Shape sh, NestSrc a, NestSrc b, int subtract, unsigned total) {
+__device__ __forceinline__ void chain_nest_body(double* __restrict__ out, size_t out_plane, const Shape& sh, const NestSrc& a, const NestSrc& b, int subtract,
+                                                unsigned total) {
     typedef typename E::V V;
     for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < total; lin += gridDim.x * 256u) {
         unsigned k[MAXD], r = lin;
@@ -845,11 +913,30 @@ __global__ void __launch_bounds__(256) k_chain_nest(double* __restrict__ out, si
     }
 }
 template <class E>
+__global__ void __launch_bounds__(256) k_chain_nest(NestKArgs) {
+    __shared__ __align__(16) unsigned char s_args[(sizeof(NestKArgs) + 15) / 16 * 16];
+    const NestKArgs& A = kernargs_to_lds<NestKArgs>(s_args);
+    chain_nest_body<E>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
+}
+template <class E>
+__global__ void __launch_bounds__(256) k_chain_nest_args(double* __restrict__ out, size_t out_plane, Shape sh, NestSrc a, NestSrc b, int subtract, unsigned total) {
+    chain_nest_body<E>(out, out_plane, sh, a, b, subtract, total);
+}
+template <class E>
 void K<E>::chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const NestSrc& a, const NestSrc& b, int subtract) {
     size_t total = 1;
     for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
     if (total == 0) return;
-    GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, (unsigned)total);
+    NestKArgs ka;
+    ka.out = out;
+    ka.out_plane = out_plane;
+    ka.sh = sh;
+    ka.a = a;
+    ka.b = b;
+    ka.subtract = subtract;
+    ka.total = (unsigned)total;
+    if (args_in_lds()) GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, ka);
+    else GFT_LAUNCH((k_chain_nest_args<E>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, (unsigned)total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1175,6 +1262,27 @@ __global__ void __launch_bounds__(1024) k_observe_chain2(const double* __restric
     if (blockIdx.x < lines0) observe_chain_line<E, EPI>(a, ap, out, op, g, epi, blockIdx.x, oc_lds);
     else observe_chain_line<E, false>(r.a, r.ap, r.out, r.op, r.g, 0, blockIdx.x - lines0, oc_lds);
 }
+// The same two kernels with their arguments — up to 3.5 KB: the steps' lengths and constants, the epilogue's chain, the rider —
+// copied to LDS by the workgroup first (see k_chain_nest: read in place they are dependent scalar-cache misses, step after step).
+template <bool EPI>
+struct ObsKArgs {
+    const double* a;
+    size_t ap;
+    double* out;
+    size_t op;
+    ObserveChainArgs g;
+    typename std::conditional<EPI, ObsEpi, int>::type epi;
+    unsigned lines0;  // (the two-chain form; the single chain: every workgroup)
+    ObsRider r;
+};
+template <class E, bool EPI, bool TWO>
+__global__ void __launch_bounds__(1024) k_observe_chain_lds(ObsKArgs<EPI>) {
+    extern __shared__ double oc_lds[];
+    __shared__ __align__(16) unsigned char s_args[(sizeof(ObsKArgs<EPI>) + 15) / 16 * 16];
+    const ObsKArgs<EPI>& A = kernargs_to_lds<ObsKArgs<EPI>>(s_args);
+    if (!TWO || blockIdx.x < A.lines0) observe_chain_line<E, EPI>(A.a, A.ap, A.out, A.op, A.g, A.epi, blockIdx.x, oc_lds);
+    else observe_chain_line<E, false>(A.r.a, A.r.ap, A.r.out, A.r.op, A.r.g, 0, blockIdx.x - A.lines0, oc_lds);
+}
 template <class E>
 void K<E>::observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                          const ObserveChainArgs& args, unsigned lines, unsigned longest) {
@@ -1197,17 +1305,35 @@ void K<E>::observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, 
     const unsigned threads = std::min<unsigned>(1024, (lg + 63) / 64 * 64);
     const unsigned pad = two ? std::max(args.lw_pad, rargs->lw_pad) : args.lw_pad;
     const size_t lds = (size_t)2 * E::W * pad * sizeof(double);
+    const bool lds_args = args_in_lds();
+    ObsRider r;
+    std::memset(&r, 0, sizeof r);
+    if (two) {
+        r.a = ra;
+        r.ap = ra_plane;
+        r.out = rout;
+        r.op = rout_plane;
+        r.g = *rargs;
+    }
+    if (lds_args) {
+        if (epi) {
+            ObsKArgs<true> ka;
+            ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = *epi; ka.lines0 = lines; ka.r = r;
+            if (two) GFT_LAUNCH((k_observe_chain_lds<E, true, true>), dim3(lines + rlines), dim3(threads), lds, st, ka);
+            else GFT_LAUNCH((k_observe_chain_lds<E, true, false>), dim3(lines), dim3(threads), lds, st, ka);
+        } else {
+            ObsKArgs<false> ka;
+            ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = 0; ka.lines0 = lines; ka.r = r;
+            if (two) GFT_LAUNCH((k_observe_chain_lds<E, false, true>), dim3(lines + rlines), dim3(threads), lds, st, ka);
+            else GFT_LAUNCH((k_observe_chain_lds<E, false, false>), dim3(lines), dim3(threads), lds, st, ka);
+        }
+        return;
+    }
     if (!two) {
         if (epi) GFT_LAUNCH((k_observe_chain<E, true>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi);
         else GFT_LAUNCH((k_observe_chain<E, false>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0);
         return;
     }
-    ObsRider r;
-    r.a = ra;
-    r.ap = ra_plane;
-    r.out = rout;
-    r.op = rout_plane;
-    r.g = *rargs;
     if (epi) GFT_LAUNCH((k_observe_chain2<E, true>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi, lines, r);
     else GFT_LAUNCH((k_observe_chain2<E, false>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0, lines, r);
 }
@@ -1665,9 +1791,8 @@ __device__ inline void wit_raise_once(unsigned* w) {
 // and, optionally, the speculative Horner loop's witness of non-linearity on the result (k_witness).
 // ------------------------------------------------------------------------------------------
 template <class E, int ND, bool INNER0, typename OFF>
-__global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__ x, size_t xp, const double* __restrict__ y,
-                                                      size_t yp, double* __restrict__ out, size_t op, ConvArgs a, ConvEpi e,
-                                                      unsigned total) {
+__device__ __forceinline__ void conv_shallow_body(const double* __restrict__ x, size_t xp, const double* __restrict__ y, size_t yp, double* __restrict__ out,
+                                                  size_t op, const ConvArgs& a, const ConvEpi& e, unsigned total) {
     typedef typename E::V V;
     int found = 0;
     for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < total; lin += gridDim.x * 256u) {
@@ -1706,6 +1831,30 @@ __global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__
         // (every workgroup of a dense result raises the word: see wit_raise for why that must not be a write-through store)
         if (__syncthreads_or(found) && threadIdx.x == 0) wit_raise_once(e.wit);
     }
+}
+template <class E, int ND, bool INNER0, typename OFF>
+__global__ void __launch_bounds__(256) k_conv_shallow(const double* __restrict__ x, size_t xp, const double* __restrict__ y,
+                                                      size_t yp, double* __restrict__ out, size_t op, ConvArgs a, ConvEpi e,
+                                                      unsigned total) {
+    conv_shallow_body<E, ND, INNER0, OFF>(x, xp, y, yp, out, op, a, e, total);
+}
+// ... with the arguments (shapes, strides, the fused Add's box: 0.8 KB) copied to LDS first (see k_chain_nest)
+struct ShallowKArgs {
+    const double* x;
+    size_t xp;
+    const double* y;
+    size_t yp;
+    double* out;
+    size_t op;
+    ConvArgs a;
+    ConvEpi e;
+    unsigned total;
+};
+template <class E, int ND, bool INNER0, typename OFF>
+__global__ void __launch_bounds__(256) k_conv_shallow_lds(ShallowKArgs) {
+    __shared__ __align__(16) unsigned char s_args[(sizeof(ShallowKArgs) + 15) / 16 * 16];
+    const ShallowKArgs& A = kernargs_to_lds<ShallowKArgs>(s_args);
+    conv_shallow_body<E, ND, INNER0, OFF>(A.x, A.xp, A.y, A.yp, A.out, A.op, A.a, A.e, A.total);
 }
 
 // smallest result (elements) that takes the pair form of k_conv_shallow; negative: never ("shallow_pair_min", GFT_SHALLOW_PAIR_MIN)
@@ -1862,9 +2011,15 @@ bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const d
     unsigned long long aspan = 1;  // largest slab offset + 1
     for (int i = 0; i < a.nd; ++i) aspan += (unsigned long long)(e.abox[i] ? e.abox[i] - 1 : 0) * e.astr[i];
     const bool u32 = nx < 0x7fffffffull && ny < 0x7fffffffull && aspan < 0x7fffffffull;
+    ShallowKArgs ka;
+    ka.x = x; ka.xp = x_plane; ka.y = y; ka.yp = y_plane; ka.out = out; ka.op = out_plane; ka.a = a; ka.e = e; ka.total = (unsigned)total;
+    const bool in_lds = args_in_lds();
 #define GFT_CASE(N)                                                                                                        \
     case N:                                                                                                                \
-        if (u32) {                                                                                                         \
+        if (u32 && in_lds) {                                                                                               \
+            if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow_lds<E, N, true, unsigned>), g, b, 0, st, ka);                \
+            else GFT_LAUNCH((k_conv_shallow_lds<E, N, false, unsigned>), g, b, 0, st, ka);                                 \
+        } else if (u32) {                                                                                                  \
             if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
             else GFT_LAUNCH((k_conv_shallow<E, N, false, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
         } else {                                                                                                           \
