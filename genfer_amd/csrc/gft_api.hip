@@ -4749,6 +4749,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "lazy_sum") R.lazy_sum = value != 0;
     else if (n == "horner_riders") R.horner_riders = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
+    else if (n == "trace_lq_report") lq_report();  // (GFT_TRACE_LQ=1; measurement aid)
     else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default
     else if (n == "debug_fail_next_launch") g_fail_next_launch.store(value != 0 ? 1 : 0);  // test knob (gft_launch.hpp)
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;

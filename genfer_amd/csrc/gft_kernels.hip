@@ -5,6 +5,7 @@
 #include "gft_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -36,14 +37,50 @@ struct LaunchQueue {
     bool enabled = true;
     std::thread::id worker_id;
 
+    // GFT_TRACE_LQ=1: where the two threads' time goes — the worker inside the queued closures (hipLaunchKernel and the
+    // like) vs waiting for the producer, the producer waiting for a free slot / for the worker to catch up (drain); printed
+    // by gft_shutdown / at exit.  Off: one predictable branch per item.
+    bool trace = getenv("GFT_TRACE_LQ") != nullptr;
+    uint64_t tr_items = 0, tr_issue_ns = 0, tr_backlog_sum = 0, tr_empty = 0, tr_max_ns = 0;
+    uint64_t tr_full_ns = 0, tr_full_n = 0, tr_drain_ns = 0, tr_drain_n = 0;
+    std::chrono::steady_clock::time_point tr_first, tr_last;
+    static uint64_t ns_since(std::chrono::steady_clock::time_point t0) {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void report() {
+        if (!trace || !tr_items) return;
+        const double span = std::chrono::duration<double>(tr_last - tr_first).count();
+        fprintf(stderr,
+                "[GFT_TRACE_LQ] worker: %llu items, %.3f ms inside them (mean %.2f us, max %.1f us) over %.3f ms first-to-last; "
+                "found the ring empty %llu times, mean backlog when taking an item %.1f\n"
+                "[GFT_TRACE_LQ] producer: waited %.3f ms for a free slot (%llu times), %.3f ms in %llu drains\n",
+                (unsigned long long)tr_items, tr_issue_ns / 1e6, tr_issue_ns / 1e3 / tr_items, tr_max_ns / 1e3, span * 1e3,
+                (unsigned long long)tr_empty, (double)tr_backlog_sum / tr_items, tr_full_ns / 1e6, (unsigned long long)tr_full_n,
+                tr_drain_ns / 1e6, (unsigned long long)tr_drain_n);
+        tr_items = tr_issue_ns = tr_backlog_sum = tr_empty = tr_max_ns = tr_full_ns = tr_full_n = tr_drain_ns = tr_drain_n = 0;
+    }
+
     void run() {
         if (device >= 0) (void)hipSetDevice(device);
         uint64_t h = head.load(std::memory_order_relaxed);
         unsigned idle = 0;
         for (;;) {
-            if (h != tail.load(std::memory_order_acquire)) {
+            const uint64_t t_now = tail.load(std::memory_order_acquire);
+            if (h != t_now) {
                 LaunchSlot& s = slots[h & (LQ_SLOTS - 1)];
-                s.run(s.payload);
+                if (trace) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (!tr_items) tr_first = t0;
+                    s.run(s.payload);
+                    tr_last = std::chrono::steady_clock::now();
+                    const uint64_t d = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tr_last - t0).count();
+                    tr_issue_ns += d;
+                    if (d > tr_max_ns) tr_max_ns = d;
+                    tr_backlog_sum += t_now - h;
+                    if (idle) tr_empty++;
+                    tr_items++;
+                } else
+                    s.run(s.payload);
                 head.store(++h, std::memory_order_release);
                 idle = 0;
                 continue;
@@ -79,9 +116,19 @@ struct LaunchQueue {
     void drain() {
         if (!worker.joinable() || std::this_thread::get_id() == worker_id) return;
         const uint64_t t = tail.load(std::memory_order_relaxed);
+        if (trace && head.load(std::memory_order_acquire) < t) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (head.load(std::memory_order_acquire) < t) __builtin_ia32_pause();
+            tr_drain_ns += ns_since(t0);
+            tr_drain_n++;
+            return;
+        }
         while (head.load(std::memory_order_acquire) < t) __builtin_ia32_pause();
     }
-    ~LaunchQueue() { shutdown(); }
+    ~LaunchQueue() {
+        shutdown();
+        report();
+    }
 };
 LaunchQueue g_lq;
 }  // namespace
@@ -136,7 +183,12 @@ void lq_configure(int device, bool enabled) {
 }
 void lq_shutdown() {
     g_lq.shutdown();
+    g_lq.report();
     g_lq_err_set.store(false);  // a failure nobody asked about dies with the runtime
+}
+void lq_report() {
+    g_lq.drain();
+    g_lq.report();
 }
 void launch_drain_nothrow() { g_lq.drain(); }
 void launch_drain() {
@@ -146,6 +198,12 @@ void launch_drain() {
 LaunchSlot* lq_begin() {
     if (!g_lq.worker.joinable()) g_lq.start();
     const uint64_t t = g_lq.tail.load(std::memory_order_relaxed);
+    if (g_lq.trace && t - g_lq.head.load(std::memory_order_acquire) >= LQ_SLOTS) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (t - g_lq.head.load(std::memory_order_acquire) >= LQ_SLOTS) __builtin_ia32_pause();
+        g_lq.tr_full_ns += LaunchQueue::ns_since(t0);
+        g_lq.tr_full_n++;
+    }
     while (t - g_lq.head.load(std::memory_order_acquire) >= LQ_SLOTS) __builtin_ia32_pause();  // ring full: the worker is behind
     return &g_lq.slots[t & (LQ_SLOTS - 1)];
 }

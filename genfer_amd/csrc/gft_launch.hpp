@@ -44,6 +44,7 @@ bool lq_enabled();
 int lq_debug();  // GFT_ASYNC_DEBUG bits: 1 = wait for the worker after every queued item, 2 = non-launch tasks run on the calling thread
 void lq_configure(int device, bool enabled);  // gft_init / options
 void lq_shutdown();                           // drains and stops the worker
+void lq_report();                             // GFT_TRACE_LQ=1: prints the two threads' time split since the last report (stderr)
 LaunchSlot* lq_begin();                       // next free slot (waits while the ring is full; starts the worker on first use)
 void lq_commit();                             // publishes the slot written since lq_begin
 void launch_drain();                          // returns when the worker has issued everything queued before this call;
