@@ -29,6 +29,7 @@
 
 #include "../../include/gftaylor.h"
 #include "gft_kernels.hpp"
+#include "gft_small_alloc.hpp"
 #include "gft_host.hpp"
 #include "gft_fmt.hpp"
 
@@ -434,7 +435,7 @@ static unsigned long long birth_of(const Buf* b) { return b->lazy ? b->lazy->inp
 // (+ 8 doubles of slack: the tiled product reads operands in place and its pipelined x loads request one 64-byte chunk
 // beyond the last one they use — gft_conv_tiled.hip, ConvArgs::operands_slack)
 static std::shared_ptr<Buf> alloc_doubles(size_t n) {
-    auto b = std::make_shared<Buf>();
+    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
     b->home = b->prod = (unsigned char)R.cur;
     b->birth = main_ops_now();
@@ -442,7 +443,7 @@ static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     return b;
 }
 static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
-    auto b = std::make_shared<Buf>();
+    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->host = true;
     b->p = (double*)host_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
     return b;
@@ -677,6 +678,9 @@ std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<Tab
 // polynomial handle
 // ------------------------------------------------------------------------------------------
 struct gft_poly {
+    // handles come from the small-block lists (gft_small_alloc.hpp): 10^5-10^6 of them per program
+    static void* operator new(size_t n) { return gft_small::get(n); }
+    static void operator delete(void* p, size_t n) noexcept { gft_small::put(p, n); }
     int width = 1;              // 1: F64, 2: Interval (lo plane, hi plane)
     Dims shape;                 // stored (compact) coefficient shape
     Dims deg;                   // degrees_p1
@@ -1106,7 +1110,7 @@ struct Ops {
         r.c0_known = src.c0_known;
         r.c0[0] = src.c0[0];
         r.c0[1] = src.c0[1];
-        r.pend = std::make_shared<Pend>();
+        r.pend = std::allocate_shared<Pend>(gft_small::Alloc<Pend>());
         if (src.pend) {
             r.pend->base_shape = src.pend->base_shape;
             r.pend->base_numel = src.pend->base_numel;
@@ -1694,12 +1698,12 @@ struct Ops {
                     // launch (fuse_lazy_sums); anybody else launches it through use_buf().  Other two-chain Adds are launched
                     // where they stand: their consumers are observation chains, and a later launch is only less overlap
                     // (mixture f64 0.129 -> 0.145 s with every Add recorded)
-                    auto ls = std::make_shared<LazySum>();
+                    auto ls = std::allocate_shared<LazySum>(gft_small::Alloc<LazySum>());
                     ls->a = self;
                     ls->b = other;
                     ls->subtract = subtract;
                     ls->shape = shape;
-                    auto op = std::make_shared<LazyOp>();
+                    auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
                     op->sum = ls;
                     op->run = [ls](Buf* b) { launch_sum(*ls, b->p); };
                     unsigned long long ib = 0;
@@ -3246,7 +3250,7 @@ struct Ops {
         if (sid == 0 && R.lazy_observe && R.cur == 0 && !R.nside && a.buf && !a.buf->host) {
             P out = make(S, G);
             out.buf->nz = out_nz;
-            auto lo = std::make_shared<LazyObs>();
+            auto lo = std::allocate_shared<LazyObs>(gft_small::Alloc<LazyObs>());
             lo->a = a;
             lo->tab = tab;
             lo->g = g;
@@ -3255,7 +3259,7 @@ struct Ops {
             lo->S = S;
             lo->okeep = okeep;
             lo->out_numel = out.numel;
-            auto op = std::make_shared<LazyOp>();
+            auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
             op->obs = lo;
             op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr, b); };
             op->input_birth = birth_of(a.buf.get());
@@ -4105,13 +4109,13 @@ struct Ops {
             if (K<E>::horner_can_ride(g)) {
                 if (!rview) (void)dp<E>(res);  // (in memory already if a scan read it; a chain is settled here, once)
                 if (!ca.buf->lazy) (void)dp<E>(ca);  // (a recorded observation stays recorded: it rides first, then this loop)
-                auto lh = std::make_shared<LazyHorner>();
+                auto lh = std::allocate_shared<LazyHorner>(gft_small::Alloc<LazyHorner>());
                 lh->res = res;
                 lh->ca = ca;
                 lh->g = g;
                 lh->lines = lines;
                 lh->fn = fn;
-                auto op = std::make_shared<LazyOp>();
+                auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
                 op->horner = lh;
                 op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr, b); };
                 op->input_birth = std::max(birth_of(res.buf.get()), birth_of(ca.buf.get()));

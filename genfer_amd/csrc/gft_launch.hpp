@@ -90,16 +90,44 @@ inline void enqueue_task(F&& f) {
     enqueue(std::forward<F>(f));
 }
 
-template <class... KArgs, class... Args>
-inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
-    ++g_launches;
-    std::tuple<typename std::decay<KArgs>::type...> t(std::forward<Args>(args)...);
-    if (g_fail_next_launch.load(std::memory_order_relaxed) && g_fail_next_launch.exchange(0)) lds = (size_t)1 << 20;
-    enqueue([kernel, grid, block, lds, st, t]() mutable {
-        std::apply([&](auto&... a) { hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, a...); }, t);
+// One queued kernel launch.  The argument tuple is built ONCE, in the ring slot (the fused observation / nested-Add launches
+// carry 2.5-3.5 KB of arguments: built on the stack, captured and moved into the slot they were copied three times, and the
+// calling thread is what the launch-bound programs wait for — profiles/r05/host_profile.txt).
+template <class... KArgs>
+struct LaunchFn {
+    void (*kernel)(KArgs...);
+    dim3 grid, block;
+    unsigned lds;
+    hipStream_t st;
+    std::tuple<typename std::decay<KArgs>::type...> t;
+    template <class... Args>
+    LaunchFn(void (*k)(KArgs...), dim3 g, dim3 b, unsigned l, hipStream_t s, Args&&... args)
+        : kernel(k), grid(g), block(b), lds(l), st(s), t(std::forward<Args>(args)...) {}
+    void operator()() {
+        std::apply([&](auto&... a) { hipLaunchKernelGGL(kernel, grid, block, lds, st, a...); }, t);
         const hipError_t e = hipGetLastError();  // this thread's state: the launch just made
         if (e != hipSuccess) lq_note(e, reinterpret_cast<const void*>(kernel), nullptr);
-    });
+    }
+};
+template <class... KArgs, class... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+    typedef LaunchFn<KArgs...> Fn;
+    ++g_launches;
+    if (g_fail_next_launch.load(std::memory_order_relaxed) && g_fail_next_launch.exchange(0)) lds = (size_t)1 << 20;
+    if (!lq_enabled() || sizeof(Fn) > LQ_SLOT_BYTES) {  // (the arguments are evaluated by now: nothing below launches)
+        enqueue(Fn(kernel, grid, block, (unsigned)lds, st, std::forward<Args>(args)...));
+        return;
+    }
+    ++g_stream_ops;
+    LaunchSlot* s = lq_begin();
+    new (s->payload) Fn(kernel, grid, block, (unsigned)lds, st, std::forward<Args>(args)...);
+    s->run = [](void* p) {
+        Fn* fn = static_cast<Fn*>(p);
+        (*fn)();
+        fn->~Fn();
+    };
+    lq_commit();
+    if (lq_debug() & 1) launch_drain();
 }
 
 }  // namespace gft

@@ -5,6 +5,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include "../gft_small_alloc.hpp"
+
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -67,7 +69,16 @@ struct Api {
     void* (*remove_last_variable)(const void*);
     void* (*extend_to_dim)(const void*, size_t, size_t);
 
+    // One table per (library, prefix) for the life of the process: value wrappers keep a plain pointer to theirs (Poly::H).
     static std::shared_ptr<Api> load(const std::string& path, const std::string& prefix) {
+        static std::map<std::pair<std::string, std::string>, std::shared_ptr<Api>> loaded;
+        auto it = loaded.find({path, prefix});
+        if (it != loaded.end()) return it->second;
+        auto a = load_new(path, prefix);
+        loaded[{path, prefix}] = a;
+        return a;
+    }
+    static std::shared_ptr<Api> load_new(const std::string& path, const std::string& prefix) {
         auto a = std::make_shared<Api>();
         a->lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (!a->lib) throw std::runtime_error(std::string("cannot load backend library: ") + dlerror());
@@ -114,8 +125,11 @@ inline SizeTrace& size_trace() { static SizeTrace t; return t; }
 // The value type: shared immutable handle (clone = refcount, like the ABI's O(1) clone).
 template <class T>
 class Poly {
+    // (the wrapper keeps a plain pointer to its backend's table — tables live as long as the process, Api::load —, so a handle
+    // that outlives a re-bind still frees itself through the library that made it, and 10^6 wrappers per program do not each
+    // count a reference on the one table)
     struct H {
-        std::shared_ptr<Api> api;
+        const Api* api = nullptr;
         void* h = nullptr;
         H() {}
         H(const H&) = delete;
@@ -128,8 +142,8 @@ class Poly {
         auto& a = api_slot();
         if (!h) throw std::runtime_error(std::string("TaylorPoly backend error: ") + a->last_error());
         Poly r;
-        r.p_ = std::make_shared<H>();
-        r.p_->api = a;
+        r.p_ = std::allocate_shared<H>(gft_small::Alloc<H>());  // small-block lists: ../gft_small_alloc.hpp
+        r.p_->api = a.get();
         r.p_->h = h;
         return r;
     }
@@ -213,10 +227,11 @@ class Poly {
         c.store(cb);
         return wrap(api().observe_step(h(), v, xb, cb, d));
     }
-    Poly observe_chain(size_t v, const T& x, const std::vector<T>& cs, size_t d) const {
+    template <class Vec>
+    Poly observe_chain(size_t v, const T& x, const Vec& cs, size_t d) const {
         double xb[2];
         x.store(xb);
-        std::vector<double> cb(cs.size() * T::WIDTH + 2);
+        std::vector<double, gft_small::Alloc<double>> cb(cs.size() * T::WIDTH + 2);
         for (size_t i = 0; i < cs.size(); ++i) cs[i].store(cb.data() + i * T::WIDTH);
         return traced("observe_chain", nel(*this), wrap(api().observe_chain(h(), v, xb, cb.data(), cs.size(), d)));
     }

@@ -36,7 +36,7 @@ struct GenFun {
     };
     std::shared_ptr<const Node> p;
 
-    static GenFun mk(Node n) { GenFun g; g.p = std::make_shared<const Node>(std::move(n)); return g; }
+    static GenFun mk(Node n) { GenFun g; g.p = std::allocate_shared<const Node>(gft_small::Alloc<Node>(), std::move(n)); return g; }  // (eval builds nodes too: gf.rs:684-706)
     static GenFun var(size_t v) { Node n; n.kind = Var; n.var = v; return mk(std::move(n)); }
     static GenFun constant(const T& x) { Node n; n.kind = Const; n.c = x; return mk(std::move(n)); }
     static GenFun zero() { return constant(T::zero()); }
@@ -235,15 +235,17 @@ struct GenFun {
     // ---- eval (gf.rs:180-222, 548-765) ------------------------------------------------------------------
     // `gf` keeps the node alive so its address cannot be recycled for another node while it is a cache key
     // (the reference stores `gf: self.clone()` for the same reason, gf.rs:212-219)
-    struct EvalResult { GenFun gf; std::vector<T> inputs; size_t degree_p1; TP output; };
-    typedef std::unordered_map<const Node*, EvalResult> EvalCache;
+    // (the evaluator copies its input points at every Subst node and into every cache entry: small vectors from the small-block lists)
+    typedef std::vector<T, gft_small::Alloc<T>> Inputs;
+    struct EvalResult { GenFun gf; Inputs inputs; size_t degree_p1; TP output; };
+    typedef std::unordered_map<const Node*, EvalResult, std::hash<const Node*>, std::equal_to<const Node*>, gft_small::Alloc<std::pair<const Node* const, EvalResult>>> EvalCache;
 
     TP eval(const std::vector<T>& inputs, size_t degree_p1) const {
         EvalCache cache;
         cache.reserve(1u << 18);
-        return eval_with(inputs, degree_p1, cache);
+        return eval_with(Inputs(inputs.begin(), inputs.end()), degree_p1, cache);
     }
-    TP eval_with(const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) const {
+    TP eval_with(const Inputs& inputs, size_t degree_p1, EvalCache& cache) const {
         const bool shared = p.use_count() > 1;
         if (shared) {
             auto it = cache.find(p.get());
@@ -253,7 +255,7 @@ struct GenFun {
         if (shared) cache[p.get()] = EvalResult{*this, inputs, degree_p1, result};
         return result;
     }
-    TP eval_node(const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) const {
+    TP eval_node(const Inputs& inputs, size_t degree_p1, EvalCache& cache) const {
         const Node& x = *p;
         switch (x.kind) {
             case Var: return TP::var(x.var, inputs.at(x.var), degree_p1);
@@ -277,7 +279,7 @@ struct GenFun {
                     size_t v = 0;
                     const GenFun* inner = nullptr;
                     if (step_of(x, &v, &inner)) {
-                        std::vector<T> cs{x.b.p->c};  // outermost first
+                        Inputs cs{x.b.p->c};  // outermost first
                         size_t v2 = 0;
                         const GenFun* in2 = nullptr;
                         while (step_of(*inner->p, &v2, &in2) && v2 == v) {
@@ -334,7 +336,7 @@ struct GenFun {
                 return (numerator / xx).truncate_to_degree_p1(degree_p1);
             }
             case Subst: {
-                std::vector<T> new_inputs = inputs;
+                Inputs new_inputs = inputs;
                 TP subst = x.b.eval_with(inputs, degree_p1, cache);
                 T c = subst.constant_term();
                 subst = subst - TP::from(c);
@@ -353,7 +355,7 @@ struct GenFun {
             }
             case Derivative: return x.a.eval_with(inputs, degree_p1 + x.order, cache).derivative_truncated(x.var, x.order, degree_p1);  // = .derivative(v, n).truncate_to_degree_p1(d), one call
             case TaylorPolynomial: {
-                std::vector<T> ni = inputs;
+                Inputs ni = inputs;
                 ni.at(x.var) = T::zero();
                 size_t max_order = 0;
                 for (size_t o : x.orders) max_order = std::max(max_order, o);
@@ -420,7 +422,7 @@ struct GenFun {
         return false;
     }
 
-    static TP eval_taylor_coeff_at_zero(const GenFun& g, size_t v, size_t order, const std::vector<T>& inputs, size_t degree_p1, EvalCache& cache) {
+    static TP eval_taylor_coeff_at_zero(const GenFun& g, size_t v, size_t order, const Inputs& inputs, size_t degree_p1, EvalCache& cache) {
         size_t pv;
         T lambda;
         GenFun inner;
@@ -453,7 +455,7 @@ struct GenFun {
                 lahs_cur = next;
             }
             TP sum = TP::zero_with(Dims(inputs.size(), degree_p1));
-            std::vector<T> ni = inputs;
+            Inputs ni = inputs;
             ni.at(pv) = pr * inputs[pv];
             TP inner_result = inner.eval_with(ni, degree_p1 + order, cache);
             TP p_pow = TP::one();
@@ -467,7 +469,7 @@ struct GenFun {
             }
             return sum.truncate_to_degree_p1(degree_p1);
         }
-        std::vector<T> ni = inputs;
+        Inputs ni = inputs;
         TP result;
         if (v == ni.size()) {
             ni.push_back(T::zero());
