@@ -10,14 +10,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
-maps, samples = [], []
+maps, samples, stacks = [], [], []
 for line in open(path):
     if line.startswith("M "):
         p = line[2:].split()
         lo, hi = (int(x, 16) for x in p[0].split("-"))
         maps.append((lo, hi, int(p[2], 16), p[5] if len(p) > 5 else "[anon]", p[1]))
     elif line.startswith("S "):
-        samples.append(int(line[2:], 16))
+        fr = [int(x, 16) for x in line[2:].split()]
+        samples.append(fr[0])
+        stacks.append(fr)
 base = {}
 for lo, hi, off, name, perm in maps:
     if off == 0 and name not in base:
@@ -57,21 +59,28 @@ def symtab(name):
     return symtabs[name]
 
 
-by_obj, by_fn = collections.Counter(), collections.Counter()
-for pc in samples:
+def resolve(pc):
     i = bisect.bisect_right(starts, pc) - 1
     if i < 0 or pc >= exec_maps[i][1]:
-        by_obj["?"] += 1
-        by_fn[("?", "?")] += 1
-        continue
+        return "?", "?"
     lo, hi, off, name, _ = exec_maps[i]
     vaddr = pc - base.get(name, lo - off)
     addrs, names = symtab(name)
     j = bisect.bisect_right(addrs, vaddr) - 1
-    fn = names[j] if j >= 0 else "?"
-    short = os.path.basename(name)
+    return os.path.basename(name), (names[j] if j >= 0 else "?")[:150]
+
+
+by_obj, by_fn, by_caller = collections.Counter(), collections.Counter(), collections.Counter()
+for fr in stacks:
+    short, fn = resolve(fr[0])
     by_obj[short] += 1
-    by_fn[(short, fn[:150])] += 1
+    by_fn[(short, fn)] += 1
+    if len(fr) > 1 and short.startswith("libc.so"):  # SAMPLE_STACKS=1: who called into libc
+        for pc in fr[1:]:
+            o, f = resolve(pc - 1)
+            if not o.startswith("libc.so") and not o.startswith("libstdc++"):
+                by_caller[(fn[:28], o, f[:110])] += 1
+                break
 n = len(samples)
 print(f"{n} samples")
 for k, v in by_obj.most_common():
@@ -79,3 +88,7 @@ for k, v in by_obj.most_common():
 print()
 for (o, f), v in by_fn.most_common(top):
     print(f"  {100.0 * v / n:5.1f} %  {o:18s} {f}")
+if by_caller:
+    print("\nlibc samples by their first caller outside libc / libstdc++:")
+    for (fn, o, f), v in by_caller.most_common(top):
+        print(f"  {100.0 * v / n:5.1f} %  {fn:28s} <- {o:16s} {f}")
