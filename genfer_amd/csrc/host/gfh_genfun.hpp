@@ -37,21 +37,33 @@ struct GenFun {
     std::shared_ptr<const Node> p;
 
     static GenFun mk(Node n) { GenFun g; g.p = std::allocate_shared<const Node>(gft_small::Alloc<Node>(), std::move(n)); return g; }  // (eval builds nodes too: gf.rs:684-706)
-    static GenFun var(size_t v) { Node n; n.kind = Var; n.var = v; return mk(std::move(n)); }
+    // the node kinds eval itself builds by the thousand (observation chains): filled in where they live, no Node moved twice
+    static GenFun mk_in_place(Kind k, const GenFun* a, const GenFun* b, size_t var_, size_t order_) {
+        auto sp = std::allocate_shared<Node>(gft_small::Alloc<Node>());
+        sp->kind = k;
+        if (a) sp->a = *a;
+        if (b) sp->b = *b;
+        sp->var = var_;
+        sp->order = order_;
+        GenFun g;
+        g.p = std::move(sp);
+        return g;
+    }
+    static GenFun var(size_t v) { return mk_in_place(Var, nullptr, nullptr, v, 0); }
     static GenFun constant(const T& x) { Node n; n.kind = Const; n.c = x; return mk(std::move(n)); }
     static GenFun zero() { return constant(T::zero()); }
     static GenFun one() { return constant(T::one()); }
     static GenFun from_u32(uint32_t u) { return constant(T::from_u32(u)); }
     static GenFun from_ratio(const PosRatio& r) { return constant(T::from_ratio(r.numer, r.denom)); }
     static GenFun polynomial(std::vector<T> coeffs, Dims shape) { Node n; n.kind = Polynomial; n.coeffs = std::move(coeffs); n.shape = std::move(shape); return mk(std::move(n)); }
-    static GenFun un(Kind k, const GenFun& a) { Node n; n.kind = k; n.a = a; return mk(std::move(n)); }
-    static GenFun bin(Kind k, const GenFun& a, const GenFun& b) { Node n; n.kind = k; n.a = a; n.b = b; return mk(std::move(n)); }
+    static GenFun un(Kind k, const GenFun& a) { return mk_in_place(k, &a, nullptr, 0, 0); }
+    static GenFun bin(Kind k, const GenFun& a, const GenFun& b) { return mk_in_place(k, &a, &b, 0, 0); }
     GenFun exp() const { return un(Exp, *this); }
     GenFun log() const { return un(Log, *this); }
     GenFun pow(uint32_t e) const { Node n; n.kind = Pow; n.a = *this; n.n = e; return mk(std::move(n)); }
     GenFun max(const GenFun& g) const { return bin(Max, *this, g); }
     static GenFun uniform_mgf(const GenFun& g) { return un(UniformMgf, g); }
-    GenFun derive(size_t v, size_t order) const { Node n; n.kind = Derivative; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
+    GenFun derive(size_t v, size_t order) const { return mk_in_place(Derivative, this, nullptr, v, order); }
     GenFun taylor_polynomial_at_zero(size_t v, Dims orders) const { Node n; n.kind = TaylorPolynomial; n.a = *this; n.var = v; n.orders = std::move(orders); return mk(std::move(n)); }
     GenFun taylor_coeff_at_zero(size_t v, size_t order) const { Node n; n.kind = TaylorCoeffAtZero; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
     GenFun taylor_coeff(size_t v, size_t order) const { Node n; n.kind = TaylorCoeff; n.a = *this; n.var = v; n.order = order; return mk(std::move(n)); }
@@ -243,6 +255,10 @@ struct GenFun {
     TP eval(const std::vector<T>& inputs, size_t degree_p1) const {
         EvalCache cache;
         cache.reserve(1u << 18);
+        struct ChainScope {  // the chains live as long as this evaluation
+            ChainScope() { chain_table().clear(); }
+            ~ChainScope() { chain_table().clear(); }
+        } chains;
         return eval_with(Inputs(inputs.begin(), inputs.end()), degree_p1, cache);
     }
     TP eval_with(const Inputs& inputs, size_t degree_p1, EvalCache& cache) const {
@@ -422,23 +438,60 @@ struct GenFun {
         return false;
     }
 
+    // The observation chains of the two Poisson recognisers (gf.rs:684-706) depend on (g, v, order) only, and a program
+    // evaluates the same observe statement at thousands of input points: the 3 * order + 4 nodes are built once per
+    // top-level eval() and kept here.  While a chain is being evaluated it is TAKEN OUT of the table, so its nodes have
+    // exactly the reference counts the freshly built chain has in the reference — eval_with's "shared" test, hence the
+    // result cache and the sequence of TaylorPoly operations, are unchanged.
+    struct ChainKey {
+        const Node* n;
+        size_t v, order;
+        bool operator==(const ChainKey& o) const { return n == o.n && v == o.v && order == o.order; }
+    };
+    struct ChainKeyHash {
+        size_t operator()(const ChainKey& k) const { return std::hash<const Node*>()(k.n) ^ (k.v * 0x9e3779b97f4a7c15ull) ^ (k.order * 0xc2b2ae3d27d4eb4full); }
+    };
+    struct ChainVal { GenFun g, gf; };  // g keeps the key's node alive (its address cannot be recycled while it is a key)
+    typedef std::unordered_map<ChainKey, ChainVal, ChainKeyHash> ChainTable;
+    static ChainTable& chain_table() {
+        static thread_local ChainTable t;
+        return t;
+    }
+    static TP eval_chain(const GenFun& g, size_t v, size_t order, GenFun gf, const Inputs& inputs, size_t degree_p1, EvalCache& cache) {
+        TP r = gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+        ChainTable& tab = chain_table();
+        if (tab.size() >= 8192) tab.clear();
+        tab[ChainKey{g.p.get(), v, order}] = ChainVal{g, std::move(gf)};
+        return r;
+    }
+
     static TP eval_taylor_coeff_at_zero(const GenFun& g, size_t v, size_t order, const Inputs& inputs, size_t degree_p1, EvalCache& cache) {
+        {
+            ChainTable& tab = chain_table();
+            auto it = tab.find(ChainKey{g.p.get(), v, order});
+            if (it != tab.end()) {
+                GenFun gf = std::move(it->second.gf);
+                tab.erase(it);
+                return eval_chain(g, v, order, std::move(gf), inputs, degree_p1, cache);
+            }
+        }
         size_t pv;
         T lambda;
         GenFun inner;
+        // (the chain is handed over as its only owner: in the reference the local `replacement` is a second owner of that one
+        // node while the chain is evaluated, which makes eval cache its value under a key nobody asks for again — a chain that
+        // is kept must not have such an entry, or later evaluations would find it and skip operations the reference performs)
         if (recognize_discrete_poisson(g, v, pv, lambda, inner)) {
             GenFun gf = inner;
             for (size_t k = 1; k <= order; ++k) gf = gf.derive(pv, 1) * var(pv) * constant(lambda / T::from_u32((uint32_t)k));
-            GenFun replacement = constant((-lambda).exp()) * var(pv);
-            gf = gf.substitute_var(pv, replacement);
-            return gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+            gf = gf.substitute_var(pv, constant((-lambda).exp()) * var(pv));
+            return eval_chain(g, v, order, std::move(gf), inputs, degree_p1, cache);
         }
         if (recognize_continuous_poisson(g, v, pv, lambda, inner)) {
             GenFun gf = inner;
             for (size_t k = 1; k <= order; ++k) gf = gf.derive(pv, 1) * constant(lambda / T::from_u32((uint32_t)k));
-            GenFun replacement = var(pv) - constant(lambda);
-            gf = gf.substitute_var(pv, replacement);
-            return gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+            gf = gf.substitute_var(pv, var(pv) - constant(lambda));
+            return eval_chain(g, v, order, std::move(gf), inputs, degree_p1, cache);
         }
         T pr;
         if (recognize_negative_binomial(g, v, pv, pr, inner)) {

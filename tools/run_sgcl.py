@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import genfer_amd  # noqa: E402
 
+if os.environ.get("GENFER_HOST_LIB"):  # A/B of interpreter builds: another libgfhost
+    genfer_amd.HOST_LIB_PATH = os.path.abspath(os.environ["GENFER_HOST_LIB"])
 path = sys.argv[1]
 flags = sys.argv[2] if len(sys.argv) > 2 else ""
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 3
