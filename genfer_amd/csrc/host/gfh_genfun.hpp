@@ -194,8 +194,9 @@ struct GenFun {
     // ---- simplify (gf.rs:152-158, 474-545) ----------------------------------------------------------
     typedef Poly<T> TP;
     struct MaybeTP { bool some = false; TP v; };
+    typedef std::unordered_map<const Node*, MaybeTP, std::hash<const Node*>, std::equal_to<const Node*>, gft_small::Alloc<std::pair<const Node* const, MaybeTP>>> SimplifyCache;
     GenFun simplify() const {
-        std::unordered_map<const Node*, MaybeTP> cache;
+        SimplifyCache cache;
         cache.reserve(1u << 18);  // (switchpoint: 2e5 nodes — growing the table by rehashing was a tenth of its run time)
         MaybeTP r = simplify_with(cache);
         if (!r.some) return *this;
@@ -203,14 +204,14 @@ struct GenFun {
         std::vector<T> data = r.v.to_vector(&shape);
         return polynomial(std::move(data), shape);
     }
-    MaybeTP simplify_with(std::unordered_map<const Node*, MaybeTP>& cache) const {
+    MaybeTP simplify_with(SimplifyCache& cache) const {
         auto it = cache.find(p.get());
         if (it != cache.end()) return it->second;
         MaybeTP r = simplify_node(cache);
         cache[p.get()] = r;
         return r;
     }
-    MaybeTP simplify_node(std::unordered_map<const Node*, MaybeTP>& cache) const {
+    MaybeTP simplify_node(SimplifyCache& cache) const {
         const Node& x = *p;
         auto some = [](TP v) { MaybeTP m; m.some = true; m.v = v; return m; };
         MaybeTP none;
