@@ -460,14 +460,22 @@ struct GenFun {
     }
     static TP eval_chain(const GenFun& g, size_t v, size_t order, GenFun gf, const Inputs& inputs, size_t degree_p1, EvalCache& cache) {
         TP r = gf.eval_with(inputs, degree_p1, cache).truncate_to_degree_p1(degree_p1);
+        if (!chain_table_on()) return r;
         ChainTable& tab = chain_table();
         if (tab.size() >= 8192) tab.clear();
         tab[ChainKey{g.p.get(), v, order}] = ChainVal{g, std::move(gf)};
         return r;
     }
 
+    static bool chain_table_on() {  // GFH_CHAIN_TABLE=0: every evaluation rebuilds its chain, as the reference does (A/B, tests)
+        static const bool on = [] {
+            const char* e = getenv("GFH_CHAIN_TABLE");
+            return !e || e[0] != '0';
+        }();
+        return on;
+    }
     static TP eval_taylor_coeff_at_zero(const GenFun& g, size_t v, size_t order, const Inputs& inputs, size_t degree_p1, EvalCache& cache) {
-        {
+        if (chain_table_on()) {
             ChainTable& tab = chain_table();
             auto it = tab.find(ChainKey{g.p.get(), v, order});
             if (it != tab.end()) {
