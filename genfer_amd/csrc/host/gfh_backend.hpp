@@ -71,7 +71,8 @@ struct Api {
 
     // One table per (library, prefix) for the life of the process: value wrappers keep a plain pointer to theirs (Poly::H).
     static std::shared_ptr<Api> load(const std::string& path, const std::string& prefix) {
-        static std::map<std::pair<std::string, std::string>, std::shared_ptr<Api>> loaded;
+        // (never destroyed: a wrapper dropped during static destruction still finds its table)
+        static auto& loaded = *new std::map<std::pair<std::string, std::string>, std::shared_ptr<Api>>;
         auto it = loaded.find({path, prefix});
         if (it != loaded.end()) return it->second;
         auto a = load_new(path, prefix);
