@@ -453,7 +453,7 @@ struct GenFun {
         size_t operator()(const ChainKey& k) const { return std::hash<const Node*>()(k.n) ^ (k.v * 0x9e3779b97f4a7c15ull) ^ (k.order * 0xc2b2ae3d27d4eb4full); }
     };
     struct ChainVal { GenFun g, gf; };  // g keeps the key's node alive (its address cannot be recycled while it is a key)
-    typedef std::unordered_map<ChainKey, ChainVal, ChainKeyHash> ChainTable;
+    typedef std::unordered_map<ChainKey, ChainVal, ChainKeyHash, std::equal_to<ChainKey>, gft_small::Alloc<std::pair<const ChainKey, ChainVal>>> ChainTable;
     static ChainTable& chain_table() {
         static thread_local ChainTable t;
         return t;
@@ -478,9 +478,9 @@ struct GenFun {
         if (chain_table_on()) {
             ChainTable& tab = chain_table();
             auto it = tab.find(ChainKey{g.p.get(), v, order});
-            if (it != tab.end()) {
+            if (it != tab.end() && it->second.gf.p) {  // (the entry stays, emptied, while its chain is out)
                 GenFun gf = std::move(it->second.gf);
-                tab.erase(it);
+                it->second.gf.p = nullptr;
                 return eval_chain(g, v, order, std::move(gf), inputs, degree_p1, cache);
             }
         }
