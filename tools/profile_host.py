@@ -17,7 +17,11 @@ runs = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 backend = sys.argv[4] if len(sys.argv) > 4 else "gpu"
 f = [p for p in sorted(glob.glob(os.path.join(ROOT, "tests/golden/sgcl/**/*.sgcl"), recursive=True)) if only in p][0]
 src = open(f).read()
-S = ctypes.CDLL(os.path.join(ROOT, "tools", "sampler", "libsampler.so"))
+SO = os.path.join(ROOT, "tools", "sampler", "libsampler.so")
+if not os.path.exists(SO):  # (built here, before anything initialises the GPU)
+    import subprocess
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", SO, os.path.join(ROOT, "tools", "sampler", "sampler.c"), "-lrt"])
+S = ctypes.CDLL(SO)
 S.sampler_start.argtypes, S.sampler_stop.argtypes, S.sampler_stop.restype = [ctypes.c_int, ctypes.c_size_t], [ctypes.c_char_p], ctypes.c_long
 bounds = "--bounds" in flags
 if backend == "gpu":
