@@ -27,6 +27,14 @@ if [ "${MATRIX:-all}" = "r5b" ]; then  # the switches added late in round 5: the
   done
   exit 0
 fi
+if [ "${MATRIX:-all}" = "r5c" ]; then  # the host-runtime switches of late round 5: arguments through LDS, small-block lists, the interpreter's kept chains
+  LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
+  for cfg in "GFT_ARGS_LDS=0" "GFT_SMALL_ALLOC=0" "GFH_CHAIN_TABLE=0" "GFT_ARGS_LDS=0 GFT_SMALL_ALLOC=0 GFH_CHAIN_TABLE=0"; do
+    res=$(env $cfg timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_horner_shapes_gpu.py tests/test_e2e_snapshots.py -m gpu -q -x -k "$LIGHT" 2>&1 | grep -E "passed|failed" | tail -1)
+    echo "$cfg : $res" | tee -a $OUT
+  done
+  exit 0
+fi
 if [ "${MATRIX:-all}" = "r5" ]; then
   LIGHT="not full_size and not c4_slabs and not whole_tensor and not register_blocked and not row_pair and not blocked_right and not div_row_wavefront and not recurrences_same_bits"
   for cfg in "GFT_BASELINE=1" "GFT_LAZY_OBSERVE=0" "GFT_OBS_RIDERS=0" "GFT_LAZY_SUM=0" "GFT_LAZY_HORNER=0" "GFT_HORNER_RIDERS=0" "GFT_NZ_PROOFS=0" "GFT_CONV_LINE=0" "GFT_SIDE_STREAMS=4" \
