@@ -252,7 +252,7 @@ def e2e_seconds(gpu_runs=5, oracle_available=True):
 
 
 _CLOCK_HELPER = r"""
-import glob, json, select, shutil, subprocess, sys, time
+import glob, json, os, select, shutil, subprocess, sys, time
 # Two services for a parent that must not fork after it has initialised the GPU:
 #   "start" ... "stop": poll the amdgpu sysfs nodes (shader clock, socket power) every ~10 ms while the parent's TIMED
 #                       loop runs -> one JSON line of samples per card (no exec, no GPU access: plain file reads);
@@ -285,11 +285,26 @@ def read_dpm(path):
     return None
 exe = shutil.which("rocm-smi")
 cs = cards()
+# (commands are read UNBUFFERED from fd 0: select() below looks at the descriptor, and a "stop" that arrived in the same
+# pipe read as "start" would otherwise sit in Python's buffer where select() never sees it)
+pending = b""
+def next_cmd(timeout=None):
+    global pending
+    while b"\n" not in pending:
+        if timeout is not None:
+            r, _, _ = select.select([0], [], [], timeout)
+            if not r:
+                return None
+        chunk = os.read(0, 4096)
+        if not chunk:
+            return ""
+        pending += chunk
+    line, _, pending = pending.partition(b"\n")
+    return line.decode().strip() or " "
 while True:
-    line = sys.stdin.readline()
-    if not line:
+    cmd = next_cmd()
+    if cmd == "":
         break
-    cmd = line.strip()
     if cmd == "start":
         samples = [{"mhz": [], "w": []} for _ in cs]
         t0 = time.time()
@@ -300,9 +315,7 @@ while True:
                 uw = read_num(c["power"]) if c["power"] else None
                 if mhz is not None: s["mhz"].append(mhz)
                 if uw is not None: s["w"].append(uw / 1e6)
-            r, _, _ = select.select([sys.stdin], [], [], 0.01)
-            if r:
-                sys.stdin.readline()
+            if next_cmd(0.01) is not None:
                 break
             if time.time() - t0 > 120:
                 break

@@ -116,61 +116,13 @@ thread_local std::string g_err;
             throw Error(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #call);           \
     } while (0)
 
-// ---- side streams (round 5) ----------------------------------------------------------------------------------------
-// A Genfer program is tens of thousands of dependent 5-50 us launches on ONE stream, but its dataflow is wider than that:
-// the first arm of an `if` reads a MEMOISED predecessor (generating_function.rs:186-222, 557-566) that was computed a whole
-// subtree ago, so its observation chain / Horner loop depends on nothing the main stream still has to do.  Such work runs
-// in a SIDE SCOPE: every launch of the operation goes to one of NSIDE side streams, and the buffers carry what orders
-// them against the other streams:
-//   * a scope starts with "side waits for everything issued on main so far" (one event; skipped when main has issued
-//     nothing since this side stream's last scope) — so a side operation may read any main-stream buffer;
-//   * a scope ends with an event on the side stream that every buffer written inside it keeps (`Buf::ready`); the first
-//     access from another stream (dp() / chain_src() / peek: `use_buf`) makes THAT stream wait for it, once;
-//   * each stream has its own pool, mailbox, scan state and witness words (`StreamCtx`, swapped into the Runtime's
-//     fields while the stream is current, so no kernel-issuing code knows about streams); a block returns to its home
-//     pool at once unless another stream has work on it in flight — then it waits in that pool's `limbo` behind events
-//     recorded on those streams and is taken out when they have completed (polled, never waited for).
-// Which operations take a side scope, and when: Ops::pick_stream.  "side_streams" / GFT_SIDE_STREAMS = 0 (the default): one
-// stream.  Side streams and RECORDED operations (Buf::lazy) are alternatives: with side streams on nothing is recorded.
-struct EvHolder;
-struct Buf;
-struct LimboBlock {
-    void* p;
-    size_t cls;
-    std::vector<std::shared_ptr<EvHolder>> after;
-};
-struct StreamCtx {
-    hipStream_t stream = nullptr;
-    std::map<size_t, std::vector<void*>> free_blocks;
-    std::deque<LimboBlock> limbo;
-    unsigned* d_flag = nullptr;
-    double* d_scratch = nullptr;
-    unsigned* d_wit = nullptr;
-    double* h_pinned = nullptr;
-    double* h_mail = nullptr;
-    double* d_mail = nullptr;
-    unsigned long long mail_seq = 0;
-    hipEvent_t ev_entry = nullptr;          // "main has got this far" for this side stream's scopes
-    unsigned long long entry_ops = ~0ull;   // main-stream operation count at the last such record
-};
-
 struct Runtime {
     bool ready = false;
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    static constexpr int NSIDE = 4;
-    int cur = 0;                   // stream context the Runtime's per-stream fields belong to right now (0: main)
-    int nside = 0;                 // side streams in use ("side_streams" / GFT_SIDE_STREAMS, at most NSIDE; 0 — the default, see below — everything on the main stream)
-    StreamCtx ctx[1 + NSIDE];      // the per-stream fields of the streams that are NOT current (ctx[cur] is stale)
-    unsigned next_side = 0;
-    unsigned long long side_ops = 0;        // stream operations issued inside side scopes (g_stream_ops - side_ops: main's)
-    unsigned long long scope_ops0 = 0;      // g_stream_ops when the open scope began
-    unsigned long long side_min_age = 2;    // main-stream operations since an input was produced for it to count as "old"
-    unsigned side_dirty = 0;                // side streams with work since the last gft_synchronize (bits)
-    std::vector<std::weak_ptr<Buf>> scope_bufs;  // device buffers written inside the open side scope
-    std::vector<hipEvent_t> ev_free;        // recycled events (disable-timing)
-    size_t stats_side[4] = {0, 0, 0, 0};    // {side scopes, cross-stream waits, observation chains that rode along with another launch, lazy observations fused}
+    unsigned long long side_min_age = 2;    // stream operations since an input was produced for it to count as "old" (recorded Horner loops)
+    size_t stats_side[4] = {0, 0, 0, 0};    // {-, -, recordings that rode along with another launch of their kind, lazy observations fused}
     bool obs_riders = true;                 // "obs_riders" / GFT_OBS_RIDERS: recorded chains ride along with other observation launches
     size_t stats_nz = 0;                    // linearity scans answered by a "no exact zero" proof
     size_t stats_sum = 0;                   // Adds that evaluated a recorded Add of two chains in their own launch (K<E>::chain_nest)
@@ -190,7 +142,7 @@ struct Runtime {
     // copy of this library is ordered on the one stream.
     std::map<size_t, std::vector<void*>> free_blocks;  // size class -> free device blocks (vectors: no node churn)
     size_t in_use = 0, cached = 0, peak = 0;
-    size_t ws_peak = 0;          // largest total of the kernels' grow-only workspaces seen by gft_pool_stats
+    size_t peak_total = 0;       // largest (pool blocks in use + the kernels' grow-only workspaces) seen at an allocation or by gft_pool_stats
     unsigned* d_flag = nullptr;  // small device scratch for predicates / counters
     double* d_scratch = nullptr; // small device scratch for packed read-backs
     unsigned* d_wit = nullptr;   // sticky non-linearity witnesses of a speculative Horner loop (Ops::WIT_SLOTS words)
@@ -264,112 +216,44 @@ static size_t size_class(size_t bytes) {
 
 static void release_kernel_scratch() { staged_release_scratch(); }  // (the device is idle when this is called)
 
-struct EvHolder {
-    hipEvent_t ev = nullptr;
-    // set by the launch thread once the record has really been issued: hipEventQuery of an event whose record is still in
-    // the launch queue would say "complete"
-    std::shared_ptr<std::atomic<int>> issued = std::make_shared<std::atomic<int>>(0);
-    ~EvHolder() {
-        if (ev) R.ev_free.push_back(ev);  // (holders die on the API thread: handles, limbo entries)
-    }
-};
-static inline hipStream_t stream_of(int sid) { return sid == R.cur ? R.stream : R.ctx[sid].stream; }
-static inline std::map<size_t, std::vector<void*>>& blocks_of(int sid) { return sid == R.cur ? R.free_blocks : R.ctx[sid].free_blocks; }
-static inline unsigned long long main_ops_now() { return gft::g_stream_ops - R.side_ops - (R.cur ? gft::g_stream_ops - R.scope_ops0 : 0); }
-// an event on stream `sid` behind everything issued to it so far (queued like a launch: program order)
-static std::shared_ptr<EvHolder> record_event(int sid) {
-    auto h = std::make_shared<EvHolder>();
-    if (!R.ev_free.empty()) {
-        h->ev = R.ev_free.back();
-        R.ev_free.pop_back();
-    } else {
-        launch_drain();
-        HIP_OK(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
-    }
-    hipEvent_t ev = h->ev;
-    hipStream_t st = stream_of(sid);
-    std::shared_ptr<std::atomic<int>> flag = h->issued;
-    enqueue_task([ev, st, flag] {
-        lq_note((hipEventRecord)(ev, st), nullptr, "hipEventRecord (stream hand-over)");
-        flag->store(1, std::memory_order_release);
-    });
-    return h;
-}
-static bool event_done(const EvHolder& h) {
-    return h.issued->load(std::memory_order_acquire) && (hipEventQuery)(h.ev) == hipSuccess;
-}
-static bool limbo_done(const LimboBlock& l) {
-    for (const auto& e : l.after)
-        if (!event_done(*e)) return false;
-    return true;
-}
+static inline unsigned long long main_ops_now() { return gft::g_stream_ops; }
 
 static void* pool_alloc(size_t bytes, size_t* cls_out) {
     size_t cls = size_class(bytes);
     *cls_out = cls;
     std::vector<void*>& fl = R.free_blocks[cls];
     void* p = nullptr;
-    std::deque<LimboBlock>& limbo = R.ctx[R.cur].limbo;
-    // blocks whose last foreign reader has finished come home (a few per allocation: the queue stays short)
-    for (int k = 0; k < 4 && !limbo.empty() && limbo_done(limbo.front()); ++k) {
-        R.free_blocks[limbo.front().cls].push_back(limbo.front().p);
-        limbo.pop_front();
-    }
     if (!fl.empty()) {
         p = fl.back();
         fl.pop_back();
         R.cached -= cls;
-    } else {
-        size_t looked = 0;
-        for (auto it = limbo.begin(); it != limbo.end() && looked < 32; ++it, ++looked)
-            if (it->cls == cls && limbo_done(*it)) {
-                p = it->p;
-                limbo.erase(it);
-                R.cached -= cls;
-                break;
-            }
     }
     if (!p) {
         hipError_t e = hipMalloc(&p, cls);
-        if (e != hipSuccess) {  // release every cache (all streams idle first: limbo blocks are then free too) and retry once
+        if (e != hipSuccess) {  // release every cache (the stream idle first) and retry once
             launch_drain();
             (void)(hipDeviceSynchronize)();
-            for (int sid = 0; sid <= Runtime::NSIDE; ++sid) {
-                for (auto& kv : blocks_of(sid))
-                    for (void* q : kv.second) (void)hipFree(q);
-                blocks_of(sid).clear();
-                for (auto& l : R.ctx[sid].limbo) (void)hipFree(l.p);
-                R.ctx[sid].limbo.clear();
-            }
+            for (auto& kv : R.free_blocks)
+                for (void* q : kv.second) (void)hipFree(q);
+            R.free_blocks.clear();
             R.cached = 0;
             release_kernel_scratch();  // the row-pair workspace and the register-blocked kernel's scratch (gft_conv_staged.hip)
             HIP_OK(hipMalloc(&p, cls));
         }
     }
     R.in_use += cls;
-    R.peak = std::max(R.peak, R.in_use);
+    if (R.in_use > R.peak) {  // (a new pool high: what do the workspaces hold at this moment?)
+        R.peak = R.in_use;
+        R.peak_total = std::max(R.peak_total, R.in_use + staged_scratch_bytes() + R.conv_ws_bytes);
+    }
     return p;
 }
 
-// `touched`: bits of the streams OTHER than `home` that have issued work on the block.  Nobody else: the block is
-// reusable at once by its home stream (stream order).  Otherwise it waits in limbo behind an event on each of them.
-static void pool_free(void* p, size_t cls, int home = 0, unsigned touched = 0) {
+// Everything is ordered on one stream: a freed block is reusable at once.
+static void pool_free(void* p, size_t cls) {
     R.in_use -= cls;
     R.cached += cls;
-    touched &= ~(1u << home);
-    if (!touched) {
-        blocks_of(home)[cls].push_back(p);
-        return;
-    }
-    LimboBlock l{p, cls, {}};
-    try {
-        for (int sid = 0; sid <= Runtime::NSIDE; ++sid)
-            if (touched & (1u << sid)) l.after.push_back(record_event(sid));
-    } catch (...) {  // (a destructor must not throw: without the events the block is simply never reused)
-        R.cached -= cls;
-        return;
-    }
-    R.ctx[home].limbo.push_back(std::move(l));
+    R.free_blocks[cls].push_back(p);
 }
 
 static void* host_alloc(size_t bytes, size_t* cls_out) {
@@ -393,16 +277,15 @@ struct Buf : std::enable_shared_from_this<Buf> {
     size_t cls = 0;
     bool borrowed = false;
     bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
-    // streams (see StreamCtx): the pool the block returns to, the stream that wrote the contents, the event recorded behind
-    // that write (side-stream producers only), who has waited for it, and which streams besides `home` have work on the block
-    unsigned char home = 0, prod = 0, seen = 0, touched = 0;
-    std::shared_ptr<EvHolder> ready;
-    unsigned long long birth = 0;   // main-stream operations issued when the buffer was created (Ops::pick_stream)
+    unsigned long long birth = 0;   // stream operations issued when the buffer was created (see birth_of)
     // the contents have not been launched yet (a recorded observation chain): use_buf() launches, or the consumer fuses
     std::shared_ptr<LazyOp> lazy;
     // interval tensors: 2 = PROVEN to hold no coefficient that is exactly [0,0] (Ops::nz_of), 1 = holds one / descends from a
     // tensor that does (nobody asks again), 0 = unknown
     unsigned char nz = 0;
+    // force_buf() is launching the producer of this buffer right now: its values are being WRITTEN by the launch under
+    // construction, so nothing that reads it may ride in that same launch (launch_obs / launch_horner rider searches)
+    bool writing = false;
     std::shared_ptr<Buf> dev;
     // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
     // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
@@ -417,7 +300,7 @@ struct Buf : std::enable_shared_from_this<Buf> {
     ~Buf() {
         if (!p || borrowed) return;
         if (host) host_free(p, cls);
-        else if (R.ready) pool_free(p, cls, home, touched);
+        else if (R.ready) pool_free(p, cls);
     }
 };
 // What a lazy buffer needs to become real: `run(b)` launches the producer into b->p on the current stream; `fuse` (optional)
@@ -437,9 +320,7 @@ static unsigned long long birth_of(const Buf* b) { return b->lazy ? b->lazy->inp
 static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
-    b->home = b->prod = (unsigned char)R.cur;
     b->birth = main_ops_now();
-    if (R.cur) R.scope_bufs.push_back(b);
     return b;
 }
 static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
@@ -450,121 +331,27 @@ static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
 }
 static std::shared_ptr<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
 
-// ---- stream contexts -------------------------------------------------------------------------------------------------------
-static void ctx_swap(StreamCtx& c) {  // the Runtime's per-stream fields <-> a saved context
-    std::swap(c.stream, R.stream);
-    c.free_blocks.swap(R.free_blocks);
-    std::swap(c.d_flag, R.d_flag);
-    std::swap(c.d_scratch, R.d_scratch);
-    std::swap(c.d_wit, R.d_wit);
-    std::swap(c.h_pinned, R.h_pinned);
-    std::swap(c.h_mail, R.h_mail);
-    std::swap(c.d_mail, R.d_mail);
-    std::swap(c.mail_seq, R.mail_seq);
-}
-static void switch_ctx(int to) {
-    if (to == R.cur) return;
-    ctx_swap(R.ctx[R.cur]);  // park the current fields
-    ctx_swap(R.ctx[to]);     // bring in the target's
-    R.cur = to;
-}
-static void stream_wait(const EvHolder& h) {  // the CURRENT stream waits for the event
-    hipEvent_t ev = h.ev;
-    hipStream_t st = R.stream;
-    enqueue_task([ev, st] { lq_note((hipStreamWaitEvent)(st, ev, 0), nullptr, "hipStreamWaitEvent (stream hand-over)"); });
-    R.stats_side[1]++;
-}
 static void force_buf(Buf* b);
-// Every access to a device buffer's contents on behalf of work about to be issued on the current stream.
+// Every access to a device buffer's contents on behalf of work about to be issued on the stream.
 static inline void use_buf(Buf* b) {
-    if (b->host) return;
-    if (b->lazy) force_buf(b);
-    const unsigned bit = 1u << R.cur;
-    if (b->prod != R.cur && b->ready && !(b->seen & bit)) {
-        stream_wait(*b->ready);
-        b->seen |= (unsigned char)bit;
-    }
-    if (b->home != R.cur) b->touched |= (unsigned char)bit;
-}
-// Side scope: the launches between enter and leave go to side stream `sid` (see StreamCtx).
-static void side_enter(int sid) {
-    if (R.cur != 0) throw Error("internal: nested side scope");
-    StreamCtx& c = R.ctx[sid];
-    const unsigned long long mo = main_ops_now();
-    if (c.entry_ops != mo) {  // main has issued something since this stream last synchronised with it
-        hipEvent_t ev = c.ev_entry;
-        hipStream_t ms = R.stream, ss = c.stream;
-        enqueue_task([ev, ms, ss] {
-            lq_note((hipEventRecord)(ev, ms), nullptr, "hipEventRecord (main stream, side scope)");
-            lq_note((hipStreamWaitEvent)(ss, ev, 0), nullptr, "hipStreamWaitEvent (side scope)");
-        });
-        c.entry_ops = main_ops_now();  // (the task itself counted as a main-stream operation)
-    }
-    switch_ctx(sid);
-    R.scope_bufs.clear();
-    R.scope_ops0 = gft::g_stream_ops;
-    R.stats_side[0]++;
-}
-// Ends the scope; the buffers written inside it keep the event that marks their completion.  `join`: the main stream waits
-// for it at once (an operation that found out in mid-flight that it needs main-stream state: ensure_main).
-static void side_leave(bool join) {
-    if (R.cur == 0) return;
-    const int sid = R.cur;
-    std::shared_ptr<EvHolder> ev;
-    if (gft::g_stream_ops != R.scope_ops0) {
-        ev = record_event(sid);
-        for (auto& w : R.scope_bufs)
-            if (auto b = w.lock()) {
-                b->ready = ev;
-                b->seen = (unsigned char)(1u << sid);
-            }
-        R.side_dirty |= 1u << sid;
-    }
-    R.scope_bufs.clear();
-    R.side_ops += gft::g_stream_ops - R.scope_ops0;
-    switch_ctx(0);
-    if (join && ev) {
-        stream_wait(*ev);
-        // (every buffer of the scope is now ordered before main's next operation; they find out one by one in use_buf)
-    }
-}
-struct SideScope {
-    bool on = false;
-    explicit SideScope(int sid) {
-        if (sid > 0 && R.cur == 0) {
-            side_enter(sid);
-            on = true;
-        }
-    }
-    ~SideScope() {
-        if (on && R.cur != 0) {
-            try {
-                side_leave(std::uncaught_exceptions() > 0);
-            } catch (...) {
-                switch_ctx(0);
-            }
-        }
-    }
-};
-// Operations that own main-stream state (the product workspace, the recurrences' side stream) call this first.
-static inline void ensure_main() {
-    if (R.cur != 0) side_leave(true);
+    if (!b->host && b->lazy) force_buf(b);
 }
 static void force_buf(Buf* b) {
     std::shared_ptr<LazyOp> op = b->lazy;
+    const unsigned long long birth0 = b->birth;
     b->lazy = nullptr;  // (first: run() reaches dp() of OTHER buffers only)
-    b->prod = (unsigned char)R.cur;
+    b->writing = true;  // (... and a recording that READS this buffer must not ride in the launch that writes it)
     b->birth = op->input_birth;  // (its inputs' age, not the launch's: what reads it may still be "old news" to the main chain)
-    if (R.cur != 0) R.scope_bufs.push_back(b->shared_from_this());  // written inside the open side scope: gets its event
-    op->run(b);
+    try {
+        op->run(b);
+    } catch (...) {  // nothing was launched into b->p (pool exhaustion, a refused launch): the buffer is still a recording
+        b->lazy = op;
+        b->birth = birth0;
+        b->writing = false;
+        throw;
+    }
+    b->writing = false;
 }
-static void sync_all_streams() {
-    HIP_OK(hipStreamSynchronize(R.stream));
-    for (int sid = 1; sid <= Runtime::NSIDE; ++sid)
-        if ((R.side_dirty >> sid) & 1u) HIP_OK(hipStreamSynchronize(stream_of(sid)));
-    R.side_dirty = 0;
-}
-
 static void require_ready() {
     if (!R.ready) {
         if (gft_init(-1) != 0) throw Error("gftaylor: no usable HIP device (" + g_err + "); there is no CPU fallback");
@@ -1508,7 +1295,7 @@ struct Ops {
     // sum(s) and this one, element for element the operations of the separate launches (K<E>::chain_nest).  false = not this
     // case (nothing launched).
     static bool fuse_lazy_sums(const P& self, const P& other, bool subtract, const Dims& shape, const Dims& rd, P* result) {
-        if (!R.lazy_sum || R.cur != 0) return false;
+        if (!R.lazy_sum) return false;
         auto sum_of = [&](const P& p) -> LazySum* {
             if (!p.buf || p.buf->host || !p.buf->lazy || !p.buf->lazy->sum) return nullptr;
             LazySum* ls = static_cast<LazySum*>(p.buf->lazy->sum.get());
@@ -1692,7 +1479,7 @@ struct Ops {
                 P out = make(shape, rd);
                 out.buf->nz = sum_nz(self, other, shape);
                 const bool shifted = (self.pend && self.pend->padded) || (other.pend && other.pend->padded);
-                if (R.lazy_sum && R.cur == 0 && !R.nside && prod(shape) >= 64 && shifted) {
+                if (R.lazy_sum && prod(shape) >= 64 && shifted) {
                     // The Add inside mul_linear (c * t + m * shift(t): one operand carries a front pad) is RECORDED, not launched:
                     // if an Add consumes it (the merge of an `if` whose arms both end in `State ~ Bernoulli(p)`), both run as one
                     // launch (fuse_lazy_sums); anybody else launches it through use_buf().  Other two-chain Adds are launched
@@ -1947,7 +1734,6 @@ struct Ops {
     // recurrence step (axis 0 is always an "outer" axis, see gft_kernels.hip).
     static void conv(const HV& x, const HV& y, const HV& z, size_t slab_lo, size_t slab_hi, bool accumulate,
                      bool slab_mode, int j0_min, int j0_excl, int j0_desc) {
-        ensure_main();  // the product workspace, plan arena and non-finite epoch are the main stream's
         Dims keep = collapse_mask({&z.shape}, slab_mode);
         Dims xs = pick(x.shape, keep), ys = pick(y.shape, keep), zs = pick(z.shape, keep);
         if (zs.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
@@ -3168,7 +2954,7 @@ struct Ops {
         if (n == 0) return a;
         // (a single step takes the chain kernel too when chains are recorded: as the epilogue-carrying launch of the Add that
         // follows, or as a rider, it costs no launch of its own — k_observe_step is the one-launch form)
-        if ((n == 1 && !(R.lazy_observe && R.cur == 0 && !R.nside)) || tier_host(a.numel, a) || n > 4096) return stepwise();
+        if ((n == 1 && !R.lazy_observe) || tier_host(a.numel, a) || n > 4096) return stepwise();
         if (n > (size_t)OC_MAX) {  // long chains: OC_MAX steps per launch
             P r = a;
             for (size_t i = 0; i < n; i += OC_MAX) {
@@ -3233,9 +3019,7 @@ struct Ops {
         g.tab_plane = a.shape[v] - 1;
         g.lw_pad = (longest + 8) / 8 * 8;
         const unsigned lines = (unsigned)(prod(S) / S[v]);
-        // Where and when (round 5).  An input that is old news to the main stream — the memoised predecessor the first arm of
-        // an `if` reads — starts a chain of its own on a side stream (pick_stream): launched now, beside whatever the main
-        // stream is doing.  Otherwise the chain is RECORDED, not launched: what usually follows is a scaling or two (deferred
+        // Where and when (round 5).  The chain is RECORDED, not launched: what usually follows is a scaling or two (deferred
         // stages) and the Add of the two arms, and then the observation kernel runs with that Add as its epilogue (addsub ->
         // fuse_lazy_observe) — one launch instead of two on the critical path of every `if`.  Anything else that wants the
         // values launches the plain kernel through use_buf().
@@ -3246,8 +3030,7 @@ struct Ops {
         // (a recorded SUM as the input is launched now: only an Add could have launched it for free, and a chain whose input is
         // not in memory can neither ride along with another launch nor let the Horner loop behind it do so)
         if (a.buf && !a.buf->host && a.buf->lazy && a.buf->lazy->sum) use_buf(a.buf.get());
-        const int sid = pick_stream(a);
-        if (sid == 0 && R.lazy_observe && R.cur == 0 && !R.nside && a.buf && !a.buf->host) {
+        if (R.lazy_observe && a.buf && !a.buf->host) {
             P out = make(S, G);
             out.buf->nz = out_nz;
             auto lo = std::allocate_shared<LazyObs>(gft_small::Alloc<LazyObs>());
@@ -3267,7 +3050,6 @@ struct Ops {
             pending_push(pending_obs(), out.buf);
             return out;
         }
-        SideScope scope(sid);
         P out = make(S, G);
         out.buf->nz = out_nz;
         K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, lines, longest);
@@ -3352,6 +3134,9 @@ struct Ops {
                 if (b.get() == self || c == &lo) continue;
                 const Buf* ib = c->a.buf.get();
                 if (!ib || ib->host || ib->lazy || c->a.pend) continue;  // its input is not in device memory (yet)
+                // ... or is what THIS launch (or a force_buf() further up the stack) is about to write: a rider reads its
+                // input while the carrier's workgroups of the same grid are still producing it
+                if (ib->writing || ib->p == outp) continue;
                 ride = b;
                 rop = b->lazy;
                 ro = c;
@@ -3362,36 +3147,26 @@ struct Ops {
             K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, nullptr, 0, nullptr, 0, nullptr, 0, 0);
             return;
         }
-        const double* rap = dp<E>(ro->a);  // (in memory: no launch; another stream's event if need be)
+        const double* rap = dp<E>(ro->a);  // (in memory: no launch)
+        const unsigned long long rbirth = ride->birth;
         ride->lazy = nullptr;
-        ride->prod = (unsigned char)R.cur;
         ride->birth = rop->input_birth;
-        if (R.cur != 0) R.scope_bufs.push_back(ride);
-        K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, rap, ro->a.numel, ride->p,
-                                  ro->out_numel, &ro->g, ro->lines, ro->longest);
-        R.stats_side[2]++;
-    }
-    // Which stream an operation whose (large) input is `in` is issued to — 0: main.  (i) The input was written on a side
-    // stream and the main stream has not caught up with it yet: stay on that stream (a chain of operations on one arm of an
-    // `if` needs no event at all).  (ii) The input is OLD — at least side_min_age operations have been issued on the main
-    // stream since it was produced, i.e. the main stream has other things to do: the operation starts a chain on the next
-    // side stream.  (iii) Otherwise it is probably the next link of the main stream's own chain: main.
-    static int pick_stream(const P& in, size_t min_numel = 1024) {
-        if (!R.nside || R.cur != 0) return 0;
-        Buf* b = in.buf.get();
-        if (!b || b->host || b->borrowed || b->lazy || in.numel < min_numel) return 0;
-        if (b->prod != 0 && b->ready && !(b->seen & 1u)) return b->prod <= R.nside ? b->prod : 0;
-        if (main_ops_now() - birth_of(b) >= R.side_min_age) {
-            R.next_side = R.next_side % (unsigned)R.nside + 1;
-            return (int)R.next_side;
+        try {
+            K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, rap, ro->a.numel, ride->p,
+                                      ro->out_numel, &ro->g, ro->lines, ro->longest);
+        } catch (...) {  // nothing was launched: the rider is still a recording
+            ride->lazy = rop;
+            ride->birth = rbirth;
+            pending_push(pend, ride);
+            throw;
         }
-        return 0;
+        R.stats_side[2]++;
     }
     // addsub(self, other) where one operand is a chain on top of a recorded observation whose result is the whole output:
     // the observation kernel runs with the other operand's chain and the Add as its epilogue (ObsEpi).  false = not this
     // case (nothing launched).
     static bool fuse_lazy_observe(const P& self, const P& other, bool subtract, const Dims& shape, const Dims& rd, P* result) {
-        if (!R.lazy_observe || R.cur != 0) return false;
+        if (!R.lazy_observe) return false;
         auto lazy_of = [&](const P& p) -> LazyObs* {
             if (!p.buf || p.buf->host || !p.buf->lazy || !p.buf->lazy->obs) return nullptr;
             LazyObs* lo = static_cast<LazyObs*>(p.buf->lazy->obs.get());
@@ -3522,7 +3297,7 @@ struct Ops {
         if (v >= a.shape.size()) return a;
         // (before anything below launches a recorded input) is the operand old news to the main chain?  Then its Horner loop,
         // if it comes to one, is recorded and rides along with a later loop's launch (horner_linear_rest, LazyHorner)
-        const bool old_input = R.lazy_horner && R.cur == 0 && !R.nside && a.buf && !a.buf->host && !a.buf->borrowed &&
+        const bool old_input = R.lazy_horner && a.buf && !a.buf->host && !a.buf->borrowed &&
                                main_ops_now() - birth_of(a.buf.get()) >= R.side_min_age;
         Dims deg = min_degrees(a, subst);
         if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
@@ -3600,10 +3375,6 @@ struct Ops {
         P ca = with_meta_unchecked(a, cshape);
         // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
         const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2;
-        // A Horner loop with a linear substitution (the `--bounds` form of a scaling: subst - constant_term(subst) is a few
-        // ulps around zero) is tens of microseconds of one wave per line — and in the first arm of an `if` it reads a memoised
-        // predecessor: it runs beside the main stream (pick_stream; scans, mailbox and witness words are the side stream's own)
-        SideScope scope(lin_known && (subst.numel <= 2 || on_host(subst)) ? pick_stream(ca) : 0);
         P res;
         if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res, old_input)) return res;
         return horner_exact(ca, v, subst, deg);
@@ -3994,6 +3765,7 @@ struct Ops {
         HornerRider riders[2];
         std::shared_ptr<Buf> rbuf[2];
         std::shared_ptr<LazyOp> rop[2];
+        unsigned long long rbirth[2] = {0, 0};
         int nr = 0;
         auto& pend = pending_horner();
         if (R.horner_riders && !pend.empty() && K<E>::horner_can_carry(g))
@@ -4005,7 +3777,8 @@ struct Ops {
                 }
                 if (b.get() == self) continue;
                 LazyHorner* h = static_cast<LazyHorner*>(b->lazy->horner.get());
-                auto in_memory = [](const P& p) { return p.buf && !p.buf->lazy && !p.pend; };
+                // (in memory, and not what this launch — or a force_buf() further up the stack — is about to write)
+                auto in_memory = [outp](const P& p) { return p.buf && !p.buf->lazy && !p.pend && !p.buf->writing && p.buf->p != outp; };
                 const bool hview = res_is_view(h->res, h->ca);
                 if (!(hview || in_memory(h->res)) || !in_memory(h->ca) || !K<E>::horner_can_ride(h->g)) continue;
                 rbuf[nr] = b;
@@ -4019,15 +3792,24 @@ struct Ops {
                 r.plane = h->fn;
                 r.g = h->g;
                 r.lines = h->lines;
+                rbirth[nr] = b->birth;
                 b->lazy = nullptr;
-                b->prod = (unsigned char)R.cur;
                 b->birth = rop[nr]->input_birth;
-                if (R.cur != 0) R.scope_bufs.push_back(b);
                 pend.erase(pend.begin() + (long)k);
                 ++nr;
                 R.stats_side[2]++;
             }
-        K<E>::horner_linear_loop(R.stream, rp, rplane, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
+        try {
+            K<E>::horner_linear_loop(R.stream, rp, rplane, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
+        } catch (...) {  // nothing was launched: the riders are still recordings
+            for (int r = 0; r < nr; ++r) {
+                rbuf[r]->lazy = rop[r];
+                rbuf[r]->birth = rbirth[r];
+                pending_push(pend, rbuf[r]);
+                R.stats_side[2]--;
+            }
+            throw;
+        }
     }
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
                                    const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr, bool defer = false) {
@@ -4484,7 +4266,6 @@ static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
     } catch (const std::exception& e) {
         g_err = e.what();
         g_scan_mail_open = 0;
-        if (R.cur != 0) switch_ctx(0);
         return nullptr;
     }
 }
@@ -4498,7 +4279,6 @@ static int guard_int(F&& f, const char* fn = __builtin_FUNCTION()) {
     } catch (const std::exception& e) {
         g_err = e.what();
         g_scan_mail_open = 0;
-        if (R.cur != 0) switch_ctx(0);
         return -1;
     }
 }
@@ -4546,29 +4326,6 @@ int gft_init(int device) {
         std::memset(R.h_mail, 0, 4096);
         HIP_OK(hipHostGetDevicePointer((void**)&R.d_mail, R.h_mail, 0));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
-        // side streams: each with the per-stream scratch the main stream has (scan state, witness words, mailbox, staging)
-        for (int sid = 1; sid <= Runtime::NSIDE; ++sid) {
-            StreamCtx& c = R.ctx[sid];
-            HIP_OK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-            HIP_OK(hipEventCreateWithFlags(&c.ev_entry, hipEventDisableTiming));
-            HIP_OK(hipMalloc((void**)&c.d_flag, 1024 + 128 * 64));
-            HIP_OK(hipMemset(c.d_flag, 0, 1024 + 128 * 64));
-            unsigned init[64] = {0};
-            init[8] = 0xffffffffu;
-            HIP_OK(hipMemcpy(c.d_flag, init, sizeof(init), hipMemcpyHostToDevice));
-            HIP_OK(hipMalloc((void**)&c.d_scratch, 256));
-            HIP_OK(hipMalloc((void**)&c.d_wit, sizeof(unsigned) * 8192));
-            HIP_OK(hipHostMalloc((void**)&c.h_pinned, 4096, hipHostMallocDefault));
-            HIP_OK(hipHostMalloc((void**)&c.h_mail, 4096, hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(c.h_mail, 0, 4096);
-            HIP_OK(hipHostGetDevicePointer((void**)&c.d_mail, c.h_mail, 0));
-            c.mail_seq = 0;
-            c.entry_ops = ~0ull;
-        }
-        R.cur = 0;
-        R.side_ops = 0;
-        R.side_dirty = 0;
-        if (const char* ss = getenv("GFT_SIDE_STREAMS")) R.nside = std::max(0, std::min(Runtime::NSIDE, atoi(ss)));
         if (const char* sa = getenv("GFT_SIDE_MIN_AGE")) R.side_min_age = (unsigned long long)std::max(0, atoi(sa));
         if (const char* lo = getenv("GFT_LAZY_OBSERVE")) R.lazy_observe = atoi(lo) != 0;
         if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
@@ -4615,11 +4372,8 @@ int gft_init(int device) {
 void gft_shutdown(void) {
     if (!R.ready) return;
     lq_shutdown();
-    if (R.cur != 0) switch_ctx(0);
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
-    for (int sid = 1; sid <= Runtime::NSIDE; ++sid)
-        if (R.ctx[sid].stream) (void)hipStreamSynchronize(R.ctx[sid].stream);
     for (auto& c : g_pow_tabs) c.clear();  // device tables of this context: back into the pool before it is freed
     Ops<EF64>::pending_obs().clear();      // (weak references to recordings nobody launched)
     Ops<EIv>::pending_obs().clear();
@@ -4634,27 +4388,6 @@ void gft_shutdown(void) {
     for (auto& kv : R.free_blocks)
         for (void* q : kv.second) (void)hipFree(q);
     R.free_blocks.clear();
-    for (auto& l : R.ctx[0].limbo) (void)hipFree(l.p);
-    R.ctx[0].limbo.clear();
-    for (int sid = 1; sid <= Runtime::NSIDE; ++sid) {
-        StreamCtx& c = R.ctx[sid];
-        for (auto& kv : c.free_blocks)
-            for (void* q : kv.second) (void)hipFree(q);
-        c.free_blocks.clear();
-        for (auto& l : c.limbo) (void)hipFree(l.p);
-        c.limbo.clear();
-        if (c.d_flag) (void)hipFree(c.d_flag);
-        if (c.d_scratch) (void)hipFree(c.d_scratch);
-        if (c.d_wit) (void)hipFree(c.d_wit);
-        if (c.h_pinned) (void)hipHostFree(c.h_pinned);
-        if (c.h_mail) (void)hipHostFree(c.h_mail);
-        if (c.ev_entry) (void)hipEventDestroy(c.ev_entry);
-        if (c.stream) (void)hipStreamDestroy(c.stream);
-        c = StreamCtx();
-    }
-    R.scope_bufs.clear();
-    for (hipEvent_t ev : R.ev_free) (void)hipEventDestroy(ev);
-    R.ev_free.clear();
     R.cached = 0;
     if (R.conv_ws) (void)hipFree(R.conv_ws);
     R.conv_ws = nullptr;
@@ -4678,16 +4411,15 @@ void gft_shutdown(void) {
 
 int gft_set_stream(void* s) {
     return guard_int([&] {
-        sync_all_streams();
+        HIP_OK(hipStreamSynchronize(R.stream));
         R.stream = s ? (hipStream_t)s : R.own_stream;
-        for (int sid = 1; sid <= Runtime::NSIDE; ++sid) R.ctx[sid].entry_ops = ~0ull;  // (a new main stream: nothing is ordered against it yet)
         return 0;
     });
 }
 void* gft_get_stream(void) { return (void*)R.stream; }
 int gft_synchronize(void) {
     return guard_int([&] {
-        sync_all_streams();  // the main stream and every side stream that has had work since the last call
+        HIP_OK(hipStreamSynchronize(R.stream));
         return 0;
     });
 }
@@ -4708,8 +4440,8 @@ void gft_pool_stats(size_t out[3]) {
     const size_t ws = staged_scratch_bytes() + R.conv_ws_bytes;
     out[0] = R.in_use + ws;
     out[1] = R.cached;
-    out[2] = std::max(R.peak, R.in_use) + std::max(R.ws_peak, ws);
-    R.ws_peak = std::max(R.ws_peak, ws);
+    R.peak_total = std::max(R.peak_total, R.in_use + ws);  // (sampled at every new pool high and here: a simultaneous figure)
+    out[2] = R.peak_total;
 }
 int gft_event_record(int slot) {
     return guard_int([&] {
@@ -4744,7 +4476,6 @@ int gft_set_option(const char* name, double value) {
     else if (n == "div_right_min_macs") R.div_right_min_macs = value < 0 ? 1.0e9 : value;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
-    else if (n == "side_streams") R.nside = value < 0 ? 0 : std::min<int>(Runtime::NSIDE, (int)value);  // < 0: default (off)
     else if (n == "side_min_age") R.side_min_age = value < 0 ? 2 : (unsigned long long)value;
     else if (n == "lazy_observe") R.lazy_observe = value != 0;
     else if (n == "obs_riders") R.obs_riders = value != 0;
@@ -5228,7 +4959,7 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] { return Ops<E>::derivative_truncated(*a, v, n, d); });                              \
     }                                                                                                         \
     gft_poly* PFX##observe_step(const gft_poly* a, size_t v, const double* x, const double* c, size_t d) {    \
-        return guard([&] { return (R.lazy_observe && !R.nside) ? Ops<E>::observe_chain(*a, v, x, c, 1, d) : Ops<E>::observe_step(*a, v, x, c, d); }); \
+        return guard([&] { return R.lazy_observe ? Ops<E>::observe_chain(*a, v, x, c, 1, d) : Ops<E>::observe_step(*a, v, x, c, d); }); \
     }                                                                                                         \
     gft_poly* PFX##observe_chain(const gft_poly* a, size_t v, const double* x, const double* cs, size_t n, size_t d) { \
         return guard([&] { return Ops<E>::observe_chain(*a, v, x, cs, n, d); });                              \

@@ -22,12 +22,18 @@ constexpr size_t MAX_BYTES = 512;           // larger requests: operator new / d
 constexpr size_t LIST_BYTES = 8u << 20;     // per size class and thread
 constexpr size_t NCLASS = MAX_BYTES / 16;
 
+// The thread is ending (or the process is, for the main thread): straight to operator new / delete.  A trivially
+// destructible thread_local of its own — later thread_local / static destructors that release handles read it after
+// `Lists` has been destroyed, which reading a member of the destroyed object would not allow.
+inline bool& dead() {
+    static thread_local bool d = false;
+    return d;
+}
 struct Lists {
     void* head[NCLASS + 1] = {};
     unsigned count[NCLASS + 1] = {};
-    bool dead = false;  // the thread is ending (or the process is, for the main thread): straight to operator new / delete
     ~Lists() {
-        dead = true;
+        dead() = true;
         for (size_t c = 0; c <= NCLASS; ++c) {
             while (void* p = head[c]) {
                 head[c] = *static_cast<void**>(p);
@@ -52,6 +58,7 @@ inline void* get(size_t bytes) {
     if (bytes == 0) bytes = 1;
     if (bytes > MAX_BYTES) return ::operator new(bytes);
     const size_t c = (bytes + 15) >> 4;
+    if (dead()) return ::operator new(c << 4);
     Lists& L = lists();
     if (void* p = L.head[c]) {
         L.head[c] = *static_cast<void**>(p);
@@ -68,8 +75,12 @@ inline void put(void* p, size_t bytes) noexcept {
         return;
     }
     const size_t c = (bytes + 15) >> 4;
+    if (dead() || !enabled()) {
+        ::operator delete(p);
+        return;
+    }
     Lists& L = lists();
-    if (L.dead || !enabled() || (size_t)L.count[c] * (c << 4) >= LIST_BYTES) {
+    if ((size_t)L.count[c] * (c << 4) >= LIST_BYTES) {
         ::operator delete(p);
         return;
     }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <cstddef>
 #include <cstdint>
 #include <algorithm>
@@ -73,6 +74,8 @@ struct Api {
     static std::shared_ptr<Api> load(const std::string& path, const std::string& prefix) {
         // (never destroyed: a wrapper dropped during static destruction still finds its table)
         static auto& loaded = *new std::map<std::pair<std::string, std::string>, std::shared_ptr<Api>>;
+        static auto& mu = *new std::mutex;  // (two host threads may run programs side by side: bench.py's replicas do not, callers may)
+        std::lock_guard<std::mutex> lock(mu);
         auto it = loaded.find({path, prefix});
         if (it != loaded.end()) return it->second;
         auto a = load_new(path, prefix);

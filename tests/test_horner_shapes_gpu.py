@@ -363,3 +363,50 @@ def test_recorded_sums_nested_add_bit_exact(interval, OTP, GTP, OTPI, GTPI):
                 assert d["nested_adds"] - before["nested_adds"] >= 2, (d, before)
     finally:
         L.gft_set_option(b"lazy_sum", 1.0)
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_dependent_recordings_do_not_ride_with_their_producer(interval, OTP, GTP, OTPI, GTPI, tier):
+    """A recording whose INPUT is another recording (B = observe(A), r2 = subst_var(r1)) must not ride in the launch that is
+    still writing that input: the rider's workgroups share the carrier's grid, nothing orders them after its stores (round-5
+    advisor finding; `Buf::writing`).  Reading the producer first, then the dependent, must give the oracle's bits — with
+    riders on and off."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    n = 64
+    base = rand((n, n), 521, 0.05, 1.0)
+    arr = np.stack([base, base * (1 + 1e-15)]) if interval else base
+    sc = (lambda v: (v, v)) if interval else (lambda v: v)
+
+    def run(T):
+        out = []
+        g = T.new(arr, [n, n])
+        a = g.observe_chain(0, sc(0.9), [sc(0.1), sc(0.05)], n - 4)      # recorded
+        b = a.observe_chain(1, sc(0.8), [sc(0.2), sc(0.07)], n - 8)      # recorded on a recording
+        c = b.observe_chain(0, sc(0.7), [sc(0.3)], n - 10)               # ... and one more level
+        out += [a.array().copy(), b.array().copy(), c.array().copy()]    # producer first, then the dependents
+        # nested linear Horner loops on an operand that is old news to the main chain (recorded when proven: intervals)
+        p = T.new(arr, [n, n])
+        for _ in range(3):
+            _ = (g + g).constant_term()                                  # unrelated stream operations: p ages
+        lin = T.var_with_degrees_p1(0, sc(0.25), [n, n]) * T.from_scalar(sc(0.5))
+        r1 = p.subst_var(0, lin)
+        r2 = r1.subst_var(0, lin)
+        r3 = r2.subst_var(1, T.var_with_degrees_p1(1, sc(0.125), [n, n]) * T.from_scalar(sc(0.75)))
+        out += [r1.array().copy(), r2.array().copy(), r3.array().copy()]
+        return out
+
+    want = run(O)
+    try:
+        for opts in ({}, {"obs_riders": 0, "horner_riders": 0}):
+            for k, v in opts.items():
+                assert L.gft_set_option(k.encode(), float(v)) == 0
+            got = run(G)
+            for i, (w, g_) in enumerate(zip(want, got)):
+                assert w.shape == g_.shape, (i, w.shape, g_.shape)
+                assert np.array_equal(w, g_), (opts, i, float(np.max(np.abs(w - g_))))
+    finally:
+        for k in ("obs_riders", "horner_riders"):
+            L.gft_set_option(k.encode(), 1.0)
