@@ -157,7 +157,8 @@ def run_sgcl(source: str, flags: str = ""):
 OP_STATS = ("linear_scans", "scalar_readbacks", "coefficient_readbacks", "tiled", "staged", "per_output", "host_tier_ops",
             "host_to_device_mirrors")
 OP_STATS_EX = ("launches", "deferred_ops", "chains_materialised", "chain_addsub_launches", "launches_in_place", "shallow_products",
-               "fused_horner_steps", "side_scopes", "cross_stream_waits", "riders", "fused_observe_adds", "scans_proven", "nested_adds")
+               "fused_horner_steps", "unused_7", "unused_8", "riders", "fused_observe_adds", "scans_proven", "nested_adds",
+               "graph_executions", "graph_recordings", "batch_launches", "batch_items", "graph_us")
 
 
 def pool_stats() -> dict:
@@ -171,9 +172,9 @@ def pool_stats() -> dict:
 def op_stats() -> dict:
     """Cumulative counters of the library since gft_init (gft_op_stats + gft_op_stats_ex) by name."""
     L = lib()
-    a, b = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 16)()
+    a, b = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 32)()
     L.gft_op_stats(a)
-    n = min(L.gft_op_stats_ex(b, 16), 16)
+    n = min(L.gft_op_stats_ex(b, 32), 32)
     out = dict(zip(OP_STATS, (int(v) for v in a)))
     out.update(dict(zip(OP_STATS_EX, (int(v) for v in b[:n]))))
     return out

@@ -130,6 +130,7 @@ struct Runtime {
     bool nz_proofs = true;                  // "nz_proofs" / GFT_NZ_PROOFS: interval tensors proven free of exact zeros skip the Horner loops' linearity scans
     bool lazy_horner = true;                // "lazy_horner" / GFT_LAZY_HORNER: proven Horner loops on old operands are recorded (Ops::horner_linear_rest)
     bool horner_riders = true;              // "horner_riders" / GFT_HORNER_RIDERS: ... and ride along with other loops' launches
+    bool batch_dag = true;                  // "batch_dag" / GFT_BATCH: recordings form a launch graph issued level by level as batches (gft_batch.hpp)
     bool lazy_observe = true;               // "lazy_observe" / GFT_LAZY_OBSERVE: observation chains are recorded, not launched (Ops::observe_chain)
     // Side stream of the blocked recurrences (div / log): the bulk of a right-looking update runs here while the main
     // stream already divides the next slab.  Joined before the recurrence returns, so the pool's "one stream" rule holds
@@ -286,6 +287,10 @@ struct Buf : std::enable_shared_from_this<Buf> {
     // force_buf() is launching the producer of this buffer right now: its values are being WRITTEN by the launch under
     // construction, so nothing that reads it may ride in that same launch (launch_obs / launch_horner rider searches)
     bool writing = false;
+    // a recording's buffer gets its pool block when it is launched (ensure_alloc): `want` doubles; p == nullptr until then
+    size_t want = 0;
+    unsigned dag_mark = 0;       // run_dag: visited in this execution
+    int dag_level = 0;           // ... and its level (longest path from tensors in memory)
     std::shared_ptr<Buf> dev;
     // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
     // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
@@ -305,8 +310,10 @@ struct Buf : std::enable_shared_from_this<Buf> {
 };
 // What a lazy buffer needs to become real: `run(b)` launches the producer into b->p on the current stream; `fuse` (optional)
 // launches it with a consumer's Add folded into its epilogue, writing somewhere else (Ops::observe_chain).
+struct DagRec;
 struct LazyOp {
     std::function<void(Buf*)> run;
+    std::shared_ptr<DagRec> rec;   // (round 6) the recording as a node of the deferred launch graph (gft_batch.hpp); null: launched by run() only
     std::shared_ptr<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
     std::shared_ptr<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
     std::shared_ptr<void> sum;     // Ops<E>::LazySum: a recorded Add / Sub of two chains (an Add that consumes it launches both: K<E>::chain_nest)
@@ -323,6 +330,17 @@ static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     b->birth = main_ops_now();
     return b;
 }
+// a recording's result: no memory yet (ensure_alloc, when the recording is launched)
+static std::shared_ptr<Buf> alloc_recorded(size_t n) {
+    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
+    b->want = std::max<size_t>(n, 1);
+    b->birth = main_ops_now();
+    return b;
+}
+static void ensure_alloc(Buf* b) {
+    if (b->p || b->host) return;
+    b->p = (double*)pool_alloc((std::max<size_t>(b->want, 1) + 8) * sizeof(double), &b->cls);
+}
 static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
     auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->host = true;
@@ -332,12 +350,19 @@ static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
 static std::shared_ptr<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
 
 static void force_buf(Buf* b);
+static void ensure_alloc(Buf* b);
+#include "gft_batch.hpp"
 // Every access to a device buffer's contents on behalf of work about to be issued on the stream.
 static inline void use_buf(Buf* b) {
     if (!b->host && b->lazy) force_buf(b);
 }
 static void force_buf(Buf* b) {
     std::shared_ptr<LazyOp> op = b->lazy;
+    if (op->rec && R.batch_dag) {  // a node of the deferred launch graph: everything it depends on, level by level
+        run_dag(b);
+        return;
+    }
+    ensure_alloc(b);
     const unsigned long long birth0 = b->birth;
     b->lazy = nullptr;  // (first: run() reaches dp() of OTHER buffers only)
     b->writing = true;  // (... and a recording that READS this buffer must not ride in the launch that writes it)
@@ -505,15 +530,18 @@ static bool same_dims_mod_trailing_ones(const Dims& a, const Dims& b) {
     return true;
 }
 // The chain of `p` (or the plain tensor, as a chain without stages) as a kernel operand over the output axes `keep`.
+// (`touch` = false: geometry only — nothing is launched, c.p stays null: what a recording may look at before its inputs exist)
 template <class E>
-static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
+static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep, bool touch = true) {
     gft::ChainSrc c;
     std::memset(&c, 0, sizeof(c));
     const Dims& bs = p.pend ? p.pend->base_shape : p.shape;
     Dims st(bs.size(), 1);
     for (size_t i = bs.size(); i-- > 1;) st[i - 1] = st[i] * bs[i];
-    use_buf(p.buf.get());
-    c.p = p.buf->p + (p.pend ? p.pend->base_off : 0);
+    if (touch) {
+        use_buf(p.buf.get());
+        c.p = p.buf->p + (p.pend ? p.pend->base_off : 0);
+    }
     c.plane = p.pend ? p.pend->base_numel : p.numel;
     for (size_t j = 0; j < keep.size(); ++j) {
         const size_t ax = keep[j];
@@ -541,7 +569,7 @@ static gft::ChainSrc chain_src(const gft_poly& p, const Dims& keep) {
                         found = true;
                     }
                 if (!found) throw Error("internal: table axis of a deferred chain was collapsed");
-                use_buf(g.tab->dev.get());
+                if (touch) use_buf(g.tab->dev.get());
                 o.tab = g.tab->dev->p;
                 o.tab_plane = g.tab->len;
             }
@@ -816,6 +844,17 @@ struct Ops {
         r.deg = deg;
         r.numel = prod(shape);
         r.buf = alloc_tier(host, r.numel * W);
+        return r;
+    }
+    // the result of a RECORDED operation: shape, degrees and every host-visible fact now, memory when it is launched
+    static P make_recorded(const Dims& shape, const Dims& deg) {
+        check_invariants(shape, deg);
+        P r;
+        r.width = W;
+        r.shape = shape;
+        r.deg = deg;
+        r.numel = prod(shape);
+        r.buf = alloc_recorded(r.numel * W);
         return r;
     }
     static P with_meta(const P& src, const Dims& shape, const Dims& deg) {  // metadata-only reshape
@@ -1344,6 +1383,33 @@ struct Ops {
         if (keep.size() > (size_t)MAXD || prod(shape) >= 0x7fffffffull) return false;
         // hold the recordings: bringing a leaf into memory may launch other recordings, never these (they are not in any rider list)
         std::shared_ptr<LazyOp> keep_a = la ? self.buf->lazy : nullptr, keep_b = lb ? other.buf->lazy : nullptr;
+        if (R.batch_dag) {  // a node of the launch graph (the leaves' geometry is known now, their memory when the level is issued)
+            auto fits_meta = [&](const P& p) {
+                const ChainSrc c = chain_src<E>(p, keep, false);
+                unsigned long long span = 1;
+                for (size_t j = 0; j < keep.size(); ++j) span += (unsigned long long)(c.box[j] ? c.box[j] - 1 : 0) * c.stride[j];
+                return span < 0x7fffffffull;
+            };
+            auto all_fit = [&](const P& p, LazySum* l) { return l ? (fits_meta(l->a) && fits_meta(l->b)) : fits_meta(p); };
+            if (!all_fit(self, la) || !all_fit(other, lb)) return false;
+            auto rec = std::allocate_shared<NestRec>(gft_small::Alloc<NestRec>());
+            rec->self = self;
+            rec->other = other;
+            rec->keep_a = keep_a;
+            rec->keep_b = keep_b;
+            rec->shape = shape;
+            rec->keep = keep;
+            rec->subtract = subtract;
+            P out = make_recorded(shape, rd);
+            out.buf->nz = sum_nz(self, other, shape);
+            unsigned long long ib = 0;
+            std::vector<Buf*> ds;
+            rec->deps(ds);
+            for (Buf* d : ds) ib = std::max(ib, birth_of(d));
+            out.buf->lazy = op_of(rec, ib);
+            *result = out;
+            return true;
+        }
         auto leaf = [&](const P& p) {
             if (!p.pend) (void)dp<E>(p);
             return chain_src_dev(p, keep);
@@ -1476,10 +1542,11 @@ struct Ops {
                 P fused;
                 if (fuse_lazy_observe(self, other, subtract, shape, rd, &fused)) return fused;
                 if (fuse_lazy_sums(self, other, subtract, shape, rd, &fused)) return fused;
-                P out = make(shape, rd);
-                out.buf->nz = sum_nz(self, other, shape);
                 const bool shifted = (self.pend && self.pend->padded) || (other.pend && other.pend->padded);
-                if (R.lazy_sum && prod(shape) >= 64 && shifted) {
+                const bool record = R.lazy_sum && ((prod(shape) >= 64 && shifted) || (R.batch_dag && prod(shape) >= 4));
+                P out = record ? make_recorded(shape, rd) : make(shape, rd);
+                out.buf->nz = sum_nz(self, other, shape);
+                if (record) {
                     // The Add inside mul_linear (c * t + m * shift(t): one operand carries a front pad) is RECORDED, not launched:
                     // if an Add consumes it (the merge of an `if` whose arms both end in `State ~ Bernoulli(p)`), both run as one
                     // launch (fuse_lazy_sums); anybody else launches it through use_buf().  Other two-chain Adds are launched
@@ -1493,6 +1560,9 @@ struct Ops {
                     auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
                     op->sum = ls;
                     op->run = [ls](Buf* b) { launch_sum(*ls, b->p); };
+                    auto rec = std::allocate_shared<SumRec>(gft_small::Alloc<SumRec>());
+                    rec->ls = ls;
+                    op->rec = rec;
                     unsigned long long ib = 0;
                     if (self.buf && !self.buf->host) ib = std::max(ib, birth_of(self.buf.get()));
                     if (other.buf && !other.buf->host) ib = std::max(ib, birth_of(other.buf.get()));
@@ -3029,9 +3099,10 @@ struct Ops {
         const unsigned char out_nz = (unsigned char)(in_nz == 2 ? (val_is_zero(x) ? 0 : 2) : in_nz);
         // (a recorded SUM as the input is launched now: only an Add could have launched it for free, and a chain whose input is
         // not in memory can neither ride along with another launch nor let the Horner loop behind it do so)
-        if (a.buf && !a.buf->host && a.buf->lazy && a.buf->lazy->sum) use_buf(a.buf.get());
+        // (in the launch graph the sum is simply this chain's predecessor)
+        if (!R.batch_dag && a.buf && !a.buf->host && a.buf->lazy && a.buf->lazy->sum) use_buf(a.buf.get());
         if (R.lazy_observe && a.buf && !a.buf->host) {
-            P out = make(S, G);
+            P out = make_recorded(S, G);
             out.buf->nz = out_nz;
             auto lo = std::allocate_shared<LazyObs>(gft_small::Alloc<LazyObs>());
             lo->a = a;
@@ -3046,8 +3117,11 @@ struct Ops {
             op->obs = lo;
             op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr, b); };
             op->input_birth = birth_of(a.buf.get());
+            auto rec = std::allocate_shared<ObsRec>(gft_small::Alloc<ObsRec>());
+            rec->lo = lo;
+            op->rec = rec;
             out.buf->lazy = op;
-            pending_push(pending_obs(), out.buf);
+            if (!R.batch_dag) pending_push(pending_obs(), out.buf);  // (riders are what a level of the launch graph generalises)
             return out;
         }
         P out = make(S, G);
@@ -3148,6 +3222,7 @@ struct Ops {
             return;
         }
         const double* rap = dp<E>(ro->a);  // (in memory: no launch)
+        ensure_alloc(ride.get());
         const unsigned long long rbirth = ride->birth;
         ride->lazy = nullptr;
         ride->birth = rop->input_birth;
@@ -3217,6 +3292,20 @@ struct Ops {
                     e.post[i].tab_plane = s.tab->len;
                 }
             }
+        }
+        if (R.batch_dag) {  // a node of the launch graph: the chain with this Add as its epilogue, issued with its level
+            auto rec = std::allocate_shared<ObsAddRec>(gft_small::Alloc<ObsAddRec>());
+            rec->xop = X.buf->lazy;
+            rec->lo = lo;
+            rec->e = e;
+            rec->Y = Y;
+            P out = make_recorded(shape, rd);
+            out.buf->nz = sum_nz(self, other, shape);
+            rec->out_numel = out.numel;
+            lo->fused = true;
+            out.buf->lazy = op_of(rec, birth_of_inputs({&lo->a, &Y}));
+            *result = out;
+            return true;
         }
         // From here on the recording is spoken for: bringing Y into memory may launch OTHER recorded chains (Y's own base, with
         // a rider) and must not pick this one as its rider — its LazyOp would be released under our feet.
@@ -3504,7 +3593,7 @@ struct Ops {
                             if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
                             // a proven loop on an operand the main chain has long passed: RECORDED (its launch needs no guard —
                             // nobody looks at the handle before the verdict below is in — and is dropped if the verdict is "linear")
-                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16, proven && old_input);
+                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16, proven && (old_input || R.batch_dag));
                         }
                         // ... or the single fused step where the whole-loop launch does not apply: the last step (nothing is
                         // speculated about its result), or any step of a proven loop (no witness to raise)
@@ -3576,7 +3665,7 @@ struct Ops {
             bool witnessed = false;
             if (lin_known && res.shape.size() == deg.size()) {
                 // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
-                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots, nullptr, proven && old_input)) {
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots, nullptr, proven && (old_input || R.batch_dag))) {
                     if (!proven) slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
                     break;
                 }
@@ -3788,6 +3877,7 @@ struct Ops {
                 r.res0 = hview ? r.a + h->res.pend->base_off : dp<E>(h->res);
                 r.rp0 = hview ? h->res.pend->base_numel : h->res.numel;
                 r.ap = h->ca.numel;
+                ensure_alloc(b.get());
                 r.out = b->p;
                 r.plane = h->fn;
                 r.g = h->g;
@@ -3828,7 +3918,7 @@ struct Ops {
         if (fn > R.horner_loop_max || fs[w] > K<E>::HORNER_LINE_MAX || fn / fs[w] > 0x7fffffffu) return false;
         Dims keep = collapse_mask({&fs}, false);
         if (keep.size() > (size_t)MAXD) return false;
-        P out = make(fs, deg);
+        P out = make_recorded(fs, deg);  // (memory when the loop is launched: here below, or with its level of the launch graph)
         HornerLoopArgs g;
         std::memset(&g, 0, sizeof(g));
         g.nd = (int)keep.size();
@@ -3889,8 +3979,10 @@ struct Ops {
         if (defer && !wit && !(hdiag & 64) && res.buf && ca.buf) {
             g.guard = nullptr;
             if (K<E>::horner_can_ride(g)) {
-                if (!rview) (void)dp<E>(res);  // (in memory already if a scan read it; a chain is settled here, once)
-                if (!ca.buf->lazy) (void)dp<E>(ca);  // (a recorded observation stays recorded: it rides first, then this loop)
+                if (!R.batch_dag) {  // (the launch graph brings its inputs into memory when the loop's level is issued)
+                    if (!rview) (void)dp<E>(res);  // (in memory already if a scan read it; a chain is settled here, once)
+                    if (!ca.buf->lazy) (void)dp<E>(ca);  // (a recorded observation stays recorded: it rides first, then this loop)
+                }
                 auto lh = std::allocate_shared<LazyHorner>(gft_small::Alloc<LazyHorner>());
                 lh->res = res;
                 lh->ca = ca;
@@ -3901,13 +3993,17 @@ struct Ops {
                 op->horner = lh;
                 op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr, b); };
                 op->input_birth = std::max(birth_of(res.buf.get()), birth_of(ca.buf.get()));
+                auto rec = std::allocate_shared<HornerRec>(gft_small::Alloc<HornerRec>());
+                rec->lh = lh;
+                op->rec = rec;
                 out.buf->lazy = op;
-                pending_push(pending_horner(), out.buf);
+                if (!R.batch_dag) pending_push(pending_horner(), out.buf);
                 *result = out;
                 return true;
             }
             g.guard = guard;
         }
+        ensure_alloc(out.buf.get());
         launch_horner(res, ca, dp<E>(out), fn, g, lines, wit, out.buf.get());
         *result = out;
         return true;
@@ -4185,6 +4281,8 @@ struct Ops {
         return out;
     }
 
+#include "gft_api_dag.inc"
+
     static bool equal(const P& a, const P& b) {
         if (a.deg != b.deg || a.shape != b.shape) return false;
         if (on_host(a) && on_host(b)) return HK<E>::count_neq(hp<E>(a), a.numel, hp<E>(b), b.numel, a.numel) == 0;
@@ -4328,6 +4426,7 @@ int gft_init(int device) {
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
         if (const char* sa = getenv("GFT_SIDE_MIN_AGE")) R.side_min_age = (unsigned long long)std::max(0, atoi(sa));
         if (const char* lo = getenv("GFT_LAZY_OBSERVE")) R.lazy_observe = atoi(lo) != 0;
+        if (const char* bd = getenv("GFT_BATCH")) R.batch_dag = atoi(bd) != 0;
         if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
         if (const char* lh = getenv("GFT_LAZY_HORNER")) R.lazy_horner = atoi(lh) != 0;
         if (const char* np = getenv("GFT_NZ_PROOFS")) R.nz_proofs = atoi(np) != 0;
@@ -4381,6 +4480,7 @@ void gft_shutdown(void) {
     Ops<EIv>::pending_horner().clear();
     dwf_release_orders();
     staged_release_scratch();
+    g_arena.release();
     (void)gft_dist_shutdown();  // the communicator refers to this device and its streams
     for (auto& kv : R.host_blocks)
         for (void* q : kv.second) std::free(q);
@@ -4429,10 +4529,11 @@ void gft_op_stats(size_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = R.stats[i];
 }
 size_t gft_op_stats_ex(size_t* out, size_t cap) {
-    const size_t v[13] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
-                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3], R.stats_nz, R.stats_sum};
-    for (size_t i = 0; i < 13 && i < cap; ++i) out[i] = v[i];
-    return 13;
+    const size_t v[18] = {(size_t)gft::g_launches, R.stats_ex[0], R.stats_ex[1], R.stats_ex[2], (size_t)gft::g_launches_in_place,
+                          R.stats_shallow[0], R.stats_shallow[1], R.stats_side[0], R.stats_side[1], R.stats_side[2], R.stats_side[3], R.stats_nz, R.stats_sum,
+                          g_dag_stats[0], g_dag_stats[1], g_dag_stats[2], g_dag_stats[3], g_dag_stats[4]};
+    for (size_t i = 0; i < 18 && i < cap; ++i) out[i] = v[i];
+    return 18;
 }
 void gft_pool_stats(size_t out[3]) {
     // (the grow-only kernel workspaces — row-pair sums, row flags, the tiled product's — are not pool blocks: counted here so that
@@ -4478,6 +4579,7 @@ int gft_set_option(const char* name, double value) {
     else if (n == "defer") R.defer = value != 0;
     else if (n == "side_min_age") R.side_min_age = value < 0 ? 2 : (unsigned long long)value;
     else if (n == "lazy_observe") R.lazy_observe = value != 0;
+    else if (n == "batch_dag") R.batch_dag = value != 0;
     else if (n == "obs_riders") R.obs_riders = value != 0;
     else if (n == "lazy_horner") R.lazy_horner = value != 0;
     else if (n == "nz_proofs") R.nz_proofs = value != 0;

@@ -613,6 +613,19 @@ __device__ __forceinline__ const KA& kernargs_to_lds(unsigned char* lds) {
     __syncthreads();
     return *reinterpret_cast<const KA*>(lds);
 }
+// A workgroup's copy of ITS item of a batch (gft_kernels.hpp ObsItem): blockIdx.y = item
+template <class IT>
+__device__ __forceinline__ const IT& item_to_lds(const IT* __restrict__ items, unsigned char* lds) {
+    static_assert(sizeof(IT) % 16 == 0, "batch items are copied in 16-byte pieces");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u* src = reinterpret_cast<const v4u*>(items + blockIdx.y);
+    for (unsigned i = threadIdx.x; i < sizeof(IT) / 16; i += blockDim.x) {
+        const v4u t = src[i];
+        reinterpret_cast<v4u*>(lds)[i] = t;
+    }
+    __syncthreads();
+    return *reinterpret_cast<const IT*>(lds);
+}
 template <class E, bool TWO, typename IDX>
 __device__ __forceinline__ void chain_body(double* __restrict__ out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b, int subtract,
                                            size_t total) {
@@ -708,7 +721,7 @@ static bool chain_fits_u32(const ChainSrc& c, const Shape& sh, size_t total) {
 // element index IS the offset — no per-element odometer (64-bit divisions per axis: the general kernel reached 33 % of the
 // HBM roof at 384^3, tools/bench_streaming.py), two elements per thread and iteration in flight.
 template <class E, bool TWO>
-__global__ void __launch_bounds__(256) k_chain_flat(double* __restrict__ out, size_t out_plane, ChainSrc a, ChainSrc b, int subtract, size_t total) {
+__device__ __forceinline__ void chain_flat_body(double* __restrict__ out, size_t out_plane, const ChainSrc& a, const ChainSrc& b, int subtract, size_t total) {
     typedef typename E::V V;
     const unsigned k0[MAXD] = {0};
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -734,6 +747,10 @@ __global__ void __launch_bounds__(256) k_chain_flat(double* __restrict__ out, si
         E::st(out, out_plane, lin, v0);
         if (two) E::st(out, out_plane, lin2, v1);
     }
+}
+template <class E, bool TWO>
+__global__ void __launch_bounds__(256) k_chain_flat(double* __restrict__ out, size_t out_plane, ChainSrc a, ChainSrc b, int subtract, size_t total) {
+    chain_flat_body<E, TWO>(out, out_plane, a, b, subtract, total);
 }
 // the operand is its whole base tensor, laid out like the output, and none of its stages looks at coordinates beyond "element 0"
 static bool chain_is_flat(const ChainSrc& c, const Shape& sh) {
@@ -879,6 +896,43 @@ void K<E>::chain_addsub(hipStream_t st, double* out, size_t out_plane, const Sha
     else launch_chain<E, true, size_t>(st, out, out_plane, sh, a, b, subtract, total);
 }
 
+// ---- batches of chain launches (gft_kernels.hpp ChainItem): variant = 4 * two + {0: flat, 1: 32-bit odometer, 2: 64-bit} ----
+template <class E, bool TWO, int MODE>
+__global__ void __launch_bounds__(256) k_chain_batch(const ChainItem* __restrict__ items) {
+    __shared__ __align__(16) unsigned char s_args[sizeof(ChainItem)];
+    const ChainItem& A = item_to_lds<ChainItem>(items, s_args);
+    if (MODE == 0) chain_flat_body<E, TWO>(A.out, A.out_plane, A.a, A.b, A.subtract, A.total);
+    else if (MODE == 1) chain_body<E, TWO, unsigned>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
+    else chain_body<E, TWO, size_t>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
+}
+template <class E>
+typename K<E>::Geometry K<E>::chain_geometry(const ChainItem& it) {
+    Geometry g;
+    const bool two = it.two != 0;
+    int mode;
+    if (it.total >= 4096 && chain_is_flat(it.a, it.sh) && (!two || chain_is_flat(it.b, it.sh))) mode = 0;
+    else if (chain_fits_u32(it.a, it.sh, it.total) && (!two || chain_fits_u32(it.b, it.sh, it.total))) mode = 1;
+    else mode = 2;
+    g.variant = (two ? 4 : 0) + mode;
+    g.gx = grid_for(mode == 0 ? (it.total + 1) / 2 : it.total);
+    g.threads = 256;
+    g.lds = 0;
+    g.ok = it.total != 0;
+    return g;
+}
+template <class E>
+void K<E>::chain_batch(hipStream_t st, const ChainItem* items, unsigned n, const Geometry& g) {
+    const dim3 grid(g.gx, n), block(256);
+    switch (g.variant) {
+        case 0: GFT_LAUNCH((k_chain_batch<E, false, 0>), grid, block, 0, st, items); break;
+        case 1: GFT_LAUNCH((k_chain_batch<E, false, 1>), grid, block, 0, st, items); break;
+        case 2: GFT_LAUNCH((k_chain_batch<E, false, 2>), grid, block, 0, st, items); break;
+        case 4: GFT_LAUNCH((k_chain_batch<E, true, 0>), grid, block, 0, st, items); break;
+        case 5: GFT_LAUNCH((k_chain_batch<E, true, 1>), grid, block, 0, st, items); break;
+        default: GFT_LAUNCH((k_chain_batch<E, true, 2>), grid, block, 0, st, items); break;
+    }
+}
+
 // Nested chain add (NestSrc): out = (0 + A) (+|-) B where A / B are chains or recorded two-chain sums.
 // Where a leaf is present at output index k, and where its element lies.
 __device__ __forceinline__ bool nest_locate(const ChainSrc& c, const unsigned* k, int nd, unsigned& off, bool& first) {
@@ -995,6 +1049,24 @@ void K<E>::chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape
     ka.total = (unsigned)total;
     if (args_in_lds()) GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, ka);
     else GFT_LAUNCH((k_chain_nest_args<E>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, (unsigned)total);
+}
+template <class E>
+__global__ void __launch_bounds__(256) k_chain_nest_batch(const NestItem* __restrict__ items) {
+    __shared__ __align__(16) unsigned char s_args[sizeof(NestItem)];
+    const NestItem& A = item_to_lds<NestItem>(items, s_args);
+    chain_nest_body<E>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
+}
+template <class E>
+typename K<E>::Geometry K<E>::chain_nest_geometry(const NestItem& it) {
+    Geometry g;
+    g.gx = grid_for(it.total);
+    g.threads = 256;
+    g.ok = it.total != 0;
+    return g;
+}
+template <class E>
+void K<E>::chain_nest_batch(hipStream_t st, const NestItem* items, unsigned n, const Geometry& g) {
+    GFT_LAUNCH((k_chain_nest_batch<E>), dim3(g.gx, n), dim3(256), 0, st, items);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1394,6 +1466,31 @@ void K<E>::observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, 
     }
     if (epi) GFT_LAUNCH((k_observe_chain2<E, true>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi, lines, r);
     else GFT_LAUNCH((k_observe_chain2<E, false>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0, lines, r);
+}
+
+template <class E, bool EPI>
+__global__ void __launch_bounds__(1024) k_observe_chain_batch(const ObsItem* __restrict__ items) {
+    extern __shared__ double oc_lds[];
+    __shared__ __align__(16) unsigned char s_args[sizeof(ObsItem)];
+    const ObsItem& A = item_to_lds<ObsItem>(items, s_args);
+    if (blockIdx.x >= A.lines) return;
+    if constexpr (EPI) observe_chain_line<E, true>(A.a, A.ap, A.out, A.op, A.g, A.epi, blockIdx.x, oc_lds);
+    else observe_chain_line<E, false>(A.a, A.ap, A.out, A.op, A.g, 0, blockIdx.x, oc_lds);
+}
+template <class E>
+typename K<E>::Geometry K<E>::observe_chain_geometry(const ObsItem& it) {
+    Geometry g;
+    g.gx = it.lines;
+    g.threads = std::min<unsigned>(1024, (it.longest + 63) / 64 * 64);
+    g.lds = (size_t)2 * E::W * it.g.lw_pad * sizeof(double);
+    g.variant = it.epi.mode != 0 ? 1 : 0;
+    g.ok = it.lines != 0 && it.g.nsteps != 0;
+    return g;
+}
+template <class E>
+void K<E>::observe_chain_batch(hipStream_t st, const ObsItem* items, unsigned n, const Geometry& g) {
+    if (g.variant) GFT_LAUNCH((k_observe_chain_batch<E, true>), dim3(g.gx, n), dim3(g.threads), g.lds, st, items);
+    else GFT_LAUNCH((k_observe_chain_batch<E, false>), dim3(g.gx, n), dim3(g.threads), g.lds, st, items);
 }
 
 template <class E>
@@ -3055,6 +3152,28 @@ bool K<E>::horner_can_carry(const HornerLoopArgs& args) {
 template <class E>
 bool K<E>::horner_can_ride(const HornerLoopArgs& args) {
     return args.nsteps != 0 && horner_pipe_point_lds<E>(args) != 0 && args.guard == nullptr;
+}
+// a batch of whole loops on the POINT pipeline (each item = what a rider is)
+template <class E>
+__global__ void __launch_bounds__(1024) k_horner_pipe_point_batch(const HornerRider* __restrict__ items) {
+    extern __shared__ double hp_lds[];
+    __shared__ __align__(16) unsigned char s_args[sizeof(HornerRider)];
+    const HornerRider& A = item_to_lds<HornerRider>(items, s_args);
+    if (blockIdx.x >= A.lines) return;
+    horner_pipe_point_line<E>(A.res0, A.rp0, A.a, A.ap, A.out, A.plane, A.g, nullptr, blockIdx.x, (A.g.fs[A.g.w] + 63u) >> 6, hp_lds);
+}
+template <class E>
+typename K<E>::Geometry K<E>::horner_geometry(const HornerRider& it) {
+    Geometry g;
+    g.ok = it.lines != 0 && horner_can_ride(it.g);
+    g.gx = it.lines;
+    g.threads = (it.g.fs[it.g.w] + 63) / 64 * 64;
+    g.lds = horner_pipe_point_lds<E>(it.g);
+    return g;
+}
+template <class E>
+void K<E>::horner_batch(hipStream_t st, const HornerRider* items, unsigned n, const Geometry& g) {
+    GFT_LAUNCH((k_horner_pipe_point_batch<E>), dim3(g.gx, n), dim3(g.threads), g.lds, st, items);
 }
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,

@@ -202,7 +202,7 @@ struct HornerLoopArgs {
 };
 
 // A whole linear Horner loop that shares another loop's launch (K<E>::horner_linear_loop's riders).
-struct HornerRider {
+struct alignas(16) HornerRider {
     const double* res0;
     size_t rp0;
     const double* a;
@@ -212,6 +212,41 @@ struct HornerRider {
     HornerLoopArgs g;
     unsigned lines;
 };
+
+// ---- batched launches (round 6) ------------------------------------------------------------------------------------------
+// A Genfer program evaluates the same statement at many input points that do not depend on each other (the d + 1 points of
+// depth d of the memoised recursion, generating_function.rs:186-222): the host records such operations and issues all the
+// independent ones of one kind as ONE launch (gft_api.hip, "deferred launch graph").  A batch is an array of ITEMS in device
+// memory — each the argument block the unbatched kernel takes — and a two-dimensional grid: blockIdx.y = item, blockIdx.x =
+// what blockIdx.x is in the unbatched launch.  A workgroup copies its item to LDS first (as the unbatched kernels copy their
+// kernel-argument segment) and then runs the unbatched kernel's body on it: the same instructions on the same data, so the
+// same bits as one launch per item.
+struct alignas(16) ObsItem {               // one observation chain (K<E>::observe_chain_multi without a rider); epi.mode == 0: plain store
+    const double* a;
+    size_t ap;
+    double* out;
+    size_t op;
+    ObserveChainArgs g;
+    ObsEpi epi;
+    unsigned lines, longest;
+};
+struct alignas(16) ChainItem {             // out = chain(a) (two == 0) or (0 + a) (+|-) b (K<E>::chain_copy / chain_addsub)
+    double* out;
+    size_t out_plane;
+    Shape sh;
+    ChainSrc a, b;
+    int subtract, two;
+    size_t total;
+};
+struct alignas(16) NestItem {              // K<E>::chain_nest
+    double* out;
+    size_t out_plane;
+    Shape sh;
+    NestSrc a, b;
+    int subtract;
+    unsigned total;
+};
+// (a whole linear Horner loop on the POINT pipeline: HornerRider is the item)
 
 // Host mailbox in mapped, coherent pinned memory: a kernel writes up to 7 doubles of payload and then the
 // sequence number (system-scope release); the host polls the sequence word instead of paying a D2H copy launch
@@ -321,6 +356,23 @@ struct K {
                                   const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi& epi);
     static void observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                               const ObserveChainArgs& args, unsigned lines, unsigned longest);
+    // ---- batches (see ObsItem): `items` is DEVICE memory holding n items that share the launch geometry the *_geometry
+    // functions report (the host groups by it); n >= 1
+    struct Geometry {
+        unsigned gx = 0, threads = 0;   // grid.x, workgroup size
+        size_t lds = 0;                 // dynamic LDS bytes
+        int variant = 0;                // which instantiation (kernel-specific)
+        bool ok = true;                 // false: this item cannot run in a batch (launch it on its own)
+        bool operator==(const Geometry& o) const { return gx == o.gx && threads == o.threads && lds == o.lds && variant == o.variant; }
+    };
+    static Geometry observe_chain_geometry(const ObsItem& it);
+    static void observe_chain_batch(hipStream_t st, const ObsItem* items, unsigned n, const Geometry& g);
+    static Geometry chain_geometry(const ChainItem& it);
+    static void chain_batch(hipStream_t st, const ChainItem* items, unsigned n, const Geometry& g);
+    static Geometry chain_nest_geometry(const NestItem& it);
+    static void chain_nest_batch(hipStream_t st, const NestItem* items, unsigned n, const Geometry& g);
+    static Geometry horner_geometry(const HornerRider& it);
+    static void horner_batch(hipStream_t st, const HornerRider* items, unsigned n, const Geometry& g);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);
     // like map_inplace with MAP_*_S but the scalar is read from device memory (s_ptr[0], s_ptr[s_plane])

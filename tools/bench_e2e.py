@@ -60,5 +60,5 @@ for f in files:
                 row["gpu_op_stats_per_run"] = {k: after[k] - before[k] for k in after}
         row[name + "_s"] = best
     rows.append(row)
-    print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}  launches {row.get('gpu_op_stats_per_run', {}).get('launches')}", flush=True)
+    print(f"{row['program']:55s} gpu {row['gpu_s']!s:>10}  cpu {row.get('cpu_oracle_s')!s:>10}  launches {row.get('gpu_op_stats_per_run', {}).get('launches')}  graph {({k: row.get('gpu_op_stats_per_run', {}).get(k) for k in ('graph_executions', 'graph_recordings', 'batch_launches', 'batch_items', 'graph_us', 'linear_scans', 'scalar_readbacks', 'chains_materialised')})}", flush=True)
 print(json.dumps({"limit": limit, "runs": runs, "host_cores": os.cpu_count(), "rows": rows}))
