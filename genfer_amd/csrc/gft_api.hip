@@ -41,44 +41,102 @@ static const size_t UMAX = SIZE_MAX;
 // the reference's programs have <= 8 variables, the ABI admits 32.
 template <class T>
 struct SmallVecT {
-    static constexpr size_t CAP = 32;
+    // (round 6: 8 entries inline, up to 32 on the heap.  With 32 inline a gft_poly was 616 bytes and every recording, handle
+    // copy and argument of the host logic moved two of them: memcpy was 13 % of mixture's calling thread.)
+    static constexpr size_t INL = 8, CAP = 32;
     size_t n = 0;
-    T v[CAP];
+    T inl[INL];
+    T* heap = nullptr;  // CAP entries once n has exceeded INL
+    T* data() { return heap ? heap : inl; }
+    const T* data() const { return heap ? heap : inl; }
     SmallVecT() {}
     SmallVecT(size_t count, T val) {
-        grow(count);
+        reserve(count);
+        T* v = data();
         for (size_t i = 0; i < count; ++i) v[i] = val;
         n = count;
     }
     SmallVecT(std::initializer_list<T> l) {
-        grow(l.size());
+        reserve(l.size());
+        T* v = data();
         for (T x : l) v[n++] = x;
     }
     template <class It>
     SmallVecT(It a, It b) {
         for (; a != b; ++a) push_back((T)*a);
     }
-    static void grow(size_t want) {
+    SmallVecT(const SmallVecT& o) {
+        if (__builtin_expect(o.heap == nullptr, 1)) {  // (the common case is a fixed-size copy: no loop, no branch on n)
+            n = o.n;
+            std::memcpy(inl, o.inl, sizeof(inl));
+        } else
+            assign(o);
+    }
+    SmallVecT(SmallVecT&& o) noexcept {
+        n = o.n;
+        if (__builtin_expect(o.heap != nullptr, 0)) {
+            heap = o.heap;
+            o.heap = nullptr;
+            o.n = 0;
+        } else
+            std::memcpy(inl, o.inl, sizeof(inl));
+    }
+    SmallVecT& operator=(const SmallVecT& o) {
+        if (__builtin_expect(o.heap == nullptr && heap == nullptr, 1)) {
+            n = o.n;
+            std::memcpy(inl, o.inl, sizeof(inl));
+        } else if (this != &o)
+            assign(o);
+        return *this;
+    }
+    SmallVecT& operator=(SmallVecT&& o) noexcept {
+        if (this == &o) return *this;
+        if (o.heap) {
+            delete[] heap;
+            heap = o.heap;
+            o.heap = nullptr;
+            n = o.n;
+            o.n = 0;
+        } else
+            assign(o);
+        return *this;
+    }
+    ~SmallVecT() {
+        if (__builtin_expect(heap != nullptr, 0)) delete[] heap;
+    }
+    void assign(const SmallVecT& o) {
+        reserve(o.n);
+        T* v = data();
+        const T* w = o.data();
+        for (size_t i = 0; i < o.n; ++i) v[i] = w[i];
+        n = o.n;
+    }
+    void reserve(size_t want) {
         if (want > CAP) throw std::runtime_error("more than 32 variables are not supported");
+        if (want > INL && !heap) {
+            heap = new T[CAP];
+            for (size_t i = 0; i < n; ++i) heap[i] = inl[i];
+        }
     }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
-    T& operator[](size_t i) { return v[i]; }
-    const T& operator[](size_t i) const { return v[i]; }
-    T* begin() { return v; }
-    T* end() { return v + n; }
-    const T* begin() const { return v; }
-    const T* end() const { return v + n; }
-    T& back() { return v[n - 1]; }
-    const T& back() const { return v[n - 1]; }
+    T& operator[](size_t i) { return data()[i]; }
+    const T& operator[](size_t i) const { return data()[i]; }
+    T* begin() { return data(); }
+    T* end() { return data() + n; }
+    const T* begin() const { return data(); }
+    const T* end() const { return data() + n; }
+    T& back() { return data()[n - 1]; }
+    const T& back() const { return data()[n - 1]; }
     void push_back(T x) {
-        grow(n + 1);
-        v[n++] = x;
+        reserve(n + 1);
+        data()[n++] = x;
     }
     void pop_back() { --n; }
     void clear() { n = 0; }
     void resize(size_t m, T val = 0) {
-        grow(m);
+        reserve(m);
+        T* v = data();
         for (size_t i = n; i < m; ++i) v[i] = val;
         n = m;
     }
@@ -89,8 +147,10 @@ struct SmallVecT {
     }
     bool operator==(const SmallVecT& o) const {
         if (n != o.n) return false;
+        const T* v = data();
+        const T* w = o.data();
         for (size_t i = 0; i < n; ++i)
-            if (v[i] != o.v[i]) return false;
+            if (v[i] != w[i]) return false;
         return true;
     }
     bool operator!=(const SmallVecT& o) const { return !(*this == o); }
@@ -1284,6 +1344,22 @@ struct Ops {
         return r;
     }
 
+    // the two-element tensor c = [e0, e1] (planes 2 doubles apart) along axis v as a lazy handle (gft_from_host)
+    static P affine_like(size_t v, const double* c, const Dims& shape, const Dims& deg) {
+        check_invariants(shape, deg);
+        P r;
+        r.width = W;
+        r.shape = shape;
+        r.deg = deg;
+        r.numel = 2;
+        r.lazy_lin = true;
+        r.lazy_var = v;
+        r.cv[0] = c[0];
+        r.cv1[0] = c[1];
+        r.cv[1] = W == 2 ? c[2] : 0.0;
+        r.cv1[1] = W == 2 ? c[3] : 0.0;
+        return r;
+    }
     // lazy (0 + m*eps_v) (+|-) cached scalar d -> lazy (d or -d) + m*eps_v; false if the constant is not an exact zero
     static bool lazy_zero_plus(const P& lazy, const P& scalar, bool subtract, P* out) {
         const double d0 = scalar.cv[0], d1 = scalar.cv[1];
@@ -1403,7 +1479,7 @@ struct Ops {
             P out = make_recorded(shape, rd);
             out.buf->nz = sum_nz(self, other, shape);
             unsigned long long ib = 0;
-            std::vector<Buf*> ds;
+            DagRec::Deps ds;
             rec->deps(ds);
             for (Buf* d : ds) ib = std::max(ib, birth_of(d));
             out.buf->lazy = op_of(rec, ib);
@@ -4935,6 +5011,12 @@ int gft_plan_slabs(size_t n0, int world, int rank, size_t out[4]) {
         return guard([&] {                                                                                    \
             Dims shape = dims(sh, nd);                                                                        \
             const size_t n = prod(shape);                                                                     \
+            if (n == 2 && nd >= 1) { /* [e0, e1] along one axis: a host value like var()'s (no buffer until a kernel reads it) */ \
+                size_t ax = 0;                                                                                \
+                for (size_t i = 0; i < nd; ++i)                                                               \
+                    if (shape[i] == 2) ax = i;                                                                \
+                return Ops<E>::affine_like(ax, c, shape, dims(dg, nd));                                       \
+            }                                                                                                 \
             const bool host = R.host_max_elems && n <= R.host_max_elems;  /* small: stays host-resident */    \
             gft_poly r = Ops<E>::make(shape, dims(dg, nd), host);                                             \
             if (host) {                                                                                       \

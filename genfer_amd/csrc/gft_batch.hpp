@@ -19,8 +19,18 @@
 
 struct DagRec {  // what the scheduler needs from a recording (implemented per kind in Ops<E>)
     virtual ~DagRec() {}
-    // device buffers the launch reads; recordings among them are predecessors in the graph
-    virtual void deps(std::vector<Buf*>& out) = 0;
+    // device buffers the launch reads (at most MAX_DEPS); recordings among them are predecessors in the graph
+    static constexpr int MAX_DEPS = 4;
+    struct Deps {
+        Buf* b[MAX_DEPS];
+        int n = 0;
+        void push_back(Buf* x) {
+            if (n < MAX_DEPS) b[n++] = x;
+        }
+        Buf** begin() { return b; }
+        Buf** end() { return b + n; }
+    };
+    virtual void deps(Deps& out) = 0;
     // brings the inputs into memory (they are: their levels have been issued), allocates the output, appends the launch to
     // the current level's groups.  false: not a batch item after all — the caller launches it with LazyOp::run
     virtual bool emit(Buf* self) = 0;
@@ -104,8 +114,9 @@ struct DagLevelCtx {
 static DagLevelCtx* g_level = nullptr;  // innermost level under construction (nullptr: nothing is being scheduled)
 static size_t g_dag_stats[5] = {0, 0, 0, 0, 0};  // {graph executions, recordings issued through them, batch launches, items in them, microseconds of the calling thread inside run_dag}
 
+// room for one more item of the group (launch, geometry): the caller fills it in place (zeroed)
 template <class IT>
-static void batch_append(void (*launch)(const BatchGroup&, const void*, const void*), unsigned gx, unsigned threads, size_t lds, int variant, const IT& item) {
+static IT* batch_alloc(void (*launch)(const BatchGroup&, const void*, const void*), unsigned gx, unsigned threads, size_t lds, int variant) {
     static_assert(sizeof(IT) % 16 == 0, "batch items are copied in 16-byte pieces");
     if (!g_level) throw Error("internal: batch item outside a graph execution");
     BatchGroup* g = nullptr;
@@ -124,11 +135,12 @@ static void batch_append(void (*launch)(const BatchGroup&, const void*, const vo
         g->threads = threads;
         g->lds = lds;
         g->variant = variant;
+        g->bytes.reserve(sizeof(IT) * 16);
     }
     const size_t at = g->bytes.size();
-    g->bytes.resize(at + sizeof(IT));
-    std::memcpy(g->bytes.data() + at, &item, sizeof(IT));
+    g->bytes.resize(at + sizeof(IT));  // (value-initialised: zero)
     g->n++;
+    return reinterpret_cast<IT*>(g->bytes.data() + at);
 }
 // issues the groups: one upload for all of them, one launch each
 static void batch_flush(DagLevelCtx& L) {
@@ -185,8 +197,8 @@ static void run_dag(Buf* root) {
     // 1. closure in post-order (iterative: the graph of a program is thousands of levels deep)
     struct Frame {
         Buf* b;
-        std::vector<Buf*> deps;
-        size_t next = 0;
+        DagRec::Deps deps;
+        int next = 0;
     };
     std::vector<Buf*> order;
     std::vector<Frame> stack;
@@ -200,8 +212,8 @@ static void run_dag(Buf* root) {
     open(root);
     while (!stack.empty()) {
         Frame& f = stack.back();
-        if (f.next < f.deps.size()) {
-            Buf* d = f.deps[f.next++];
+        if (f.next < f.deps.n) {
+            Buf* d = f.deps.b[f.next++];
             if (!d || d->host || !d->lazy) continue;         // in memory
             if (!d->lazy->rec) {                              // a recording of the old kind: launched where it stands
                 force_buf(d);

@@ -1057,11 +1057,11 @@ __global__ void __launch_bounds__(256) k_chain_nest_batch(const NestItem* __rest
     chain_nest_body<E>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
 }
 template <class E>
-typename K<E>::Geometry K<E>::chain_nest_geometry(const NestItem& it) {
+typename K<E>::Geometry K<E>::chain_nest_geometry(size_t total) {
     Geometry g;
-    g.gx = grid_for(it.total);
+    g.gx = grid_for(total);
     g.threads = 256;
-    g.ok = it.total != 0;
+    g.ok = total != 0;
     return g;
 }
 template <class E>
@@ -1478,13 +1478,13 @@ __global__ void __launch_bounds__(1024) k_observe_chain_batch(const ObsItem* __r
     else observe_chain_line<E, false>(A.a, A.ap, A.out, A.op, A.g, 0, blockIdx.x, oc_lds);
 }
 template <class E>
-typename K<E>::Geometry K<E>::observe_chain_geometry(const ObsItem& it) {
+typename K<E>::Geometry K<E>::observe_chain_geometry(unsigned lines, unsigned longest, unsigned lw_pad, unsigned nsteps, bool epi) {
     Geometry g;
-    g.gx = it.lines;
-    g.threads = std::min<unsigned>(1024, (it.longest + 63) / 64 * 64);
-    g.lds = (size_t)2 * E::W * it.g.lw_pad * sizeof(double);
-    g.variant = it.epi.mode != 0 ? 1 : 0;
-    g.ok = it.lines != 0 && it.g.nsteps != 0;
+    g.gx = lines;
+    g.threads = std::min<unsigned>(1024, (longest + 63) / 64 * 64);
+    g.lds = (size_t)2 * E::W * lw_pad * sizeof(double);
+    g.variant = epi ? 1 : 0;
+    g.ok = lines != 0 && nsteps != 0;
     return g;
 }
 template <class E>
@@ -3163,12 +3163,12 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point_batch(const HornerRi
     horner_pipe_point_line<E>(A.res0, A.rp0, A.a, A.ap, A.out, A.plane, A.g, nullptr, blockIdx.x, (A.g.fs[A.g.w] + 63u) >> 6, hp_lds);
 }
 template <class E>
-typename K<E>::Geometry K<E>::horner_geometry(const HornerRider& it) {
+typename K<E>::Geometry K<E>::horner_geometry(const HornerLoopArgs& a, unsigned lines) {
     Geometry g;
-    g.ok = it.lines != 0 && horner_can_ride(it.g);
-    g.gx = it.lines;
-    g.threads = (it.g.fs[it.g.w] + 63) / 64 * 64;
-    g.lds = horner_pipe_point_lds<E>(it.g);
+    g.ok = lines != 0 && horner_can_ride(a);
+    g.gx = lines;
+    g.threads = (a.fs[a.w] + 63) / 64 * 64;
+    g.lds = horner_pipe_point_lds<E>(a);
     return g;
 }
 template <class E>

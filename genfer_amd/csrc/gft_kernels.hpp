@@ -122,7 +122,8 @@ struct ObserveArgs {
 // * (x + eps_v) -> * c_k) in ONE launch: the steps couple positions along v only, so every line along v runs all of them
 // on its own (one workgroup per line, intermediates in LDS), and only the lines inside the FINAL truncated box are
 // computed at all.  Per step and element exactly ObserveArgs' operations.
-constexpr int OC_MAX = 48;  // steps per launch (longer chains are cut by the host)
+constexpr int OC_MAX = 16;  // steps per launch (longer chains are cut by the host; round 6: 48 -> 16 — the argument block of a chain is copied
+                            // four times on its way into a batch, and programs observe counts of 0 .. 12)
 struct ObserveChainArgs {
     int nd;                    // collapsed rank of the final shape
     unsigned fs[MAXD];         // final shape
@@ -365,13 +366,13 @@ struct K {
         bool ok = true;                 // false: this item cannot run in a batch (launch it on its own)
         bool operator==(const Geometry& o) const { return gx == o.gx && threads == o.threads && lds == o.lds && variant == o.variant; }
     };
-    static Geometry observe_chain_geometry(const ObsItem& it);
+    static Geometry observe_chain_geometry(unsigned lines, unsigned longest, unsigned lw_pad, unsigned nsteps, bool epi);
     static void observe_chain_batch(hipStream_t st, const ObsItem* items, unsigned n, const Geometry& g);
     static Geometry chain_geometry(const ChainItem& it);
     static void chain_batch(hipStream_t st, const ChainItem* items, unsigned n, const Geometry& g);
-    static Geometry chain_nest_geometry(const NestItem& it);
+    static Geometry chain_nest_geometry(size_t total);
     static void chain_nest_batch(hipStream_t st, const NestItem* items, unsigned n, const Geometry& g);
-    static Geometry horner_geometry(const HornerRider& it);
+    static Geometry horner_geometry(const HornerLoopArgs& g, unsigned lines);
     static void horner_batch(hipStream_t st, const HornerRider* items, unsigned n, const Geometry& g);
     // in-place elementwise map over n contiguous elements
     static void map_inplace(hipStream_t st, double* p, size_t plane, size_t n, int op, unsigned u, Scalar2 s);

@@ -18,8 +18,8 @@
 
 namespace gft_small {
 
-constexpr size_t MAX_BYTES = 512;           // larger requests: operator new / delete
-constexpr size_t LIST_BYTES = 8u << 20;     // per size class and thread
+constexpr size_t MAX_BYTES = 4096;          // larger requests: operator new / delete (round 6: the launch graph's recordings are 1-3 KB)
+constexpr size_t LIST_BYTES = 64u << 20;    // per size class and thread (a program's pending recordings: tens of thousands of 1-3 KB blocks)
 constexpr size_t NCLASS = MAX_BYTES / 16;
 
 // The thread is ending (or the process is, for the main thread): straight to operator new / delete.  A trivially

@@ -172,6 +172,20 @@ class Poly {
         return wrap(api().from_host(planes.data(), shape.data(), degs.data(), shape.size()));
     }
     static Poly from(const T& x) { double b[2]; x.store(b); return wrap(api().scalar(b)); }          // mt:626-630
+    // the two-element tensor [e0, e1] along axis v with degrees_p1 = [d] * (v + 1): what `var(v, x, d)` (mt:239-248, d >= 2)
+    // becomes under elementwise operations (GenFun::subst_shortcut)
+    static Poly affine(size_t v, const T& e0, const T& e1, size_t d) {
+        double planes[2 * T::WIDTH];
+        e0.store_plane(planes, 2, 0);
+        e1.store_plane(planes, 2, 1);
+        size_t shape[33], degs[33];
+        if (v >= 32) throw std::runtime_error("more than 32 variables are not supported");
+        for (size_t i = 0; i <= v; ++i) {
+            shape[i] = i == v ? 2 : 1;
+            degs[i] = d;
+        }
+        return wrap(api().from_host(planes, shape, degs, v + 1));
+    }
     static Poly zero() { return from(T::zero()); }
     static Poly one() { return from(T::one()); }
     static Poly zero_with(const Dims& d) { return wrap(api().zero_with(d.data(), d.size())); }        // mt:208-216

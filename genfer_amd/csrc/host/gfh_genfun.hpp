@@ -33,6 +33,10 @@ struct GenFun {
         // DAG at every statement (semantics/gf.rs), which the reference answers with a fresh traversal each time
         mutable bool uv_known = false;
         mutable VarRange uv;
+        // Const nodes: the backend handle of `c` (handles are immutable values), and the backend table it belongs to
+        mutable Poly<T> const_tp;
+        mutable const Api* const_api = nullptr;
+        mutable bool const_tp_set = false;
     };
     std::shared_ptr<const Node> p;
 
@@ -276,7 +280,14 @@ struct GenFun {
         const Node& x = *p;
         switch (x.kind) {
             case Var: return TP::var(x.var, inputs.at(x.var), degree_p1);
-            case Const: return TP::from(x.c);
+            case Const: {  // (the handle of a constant is formed once per node and backend: programs evaluate their Const nodes 10^5 times)
+                if (!x.const_tp_set || x.const_api != &TP::api()) {
+                    x.const_tp = TP::from(x.c);
+                    x.const_api = &TP::api();
+                    x.const_tp_set = true;
+                }
+                return x.const_tp;
+            }
             case Add: { TP g = x.a.eval_with(inputs, degree_p1, cache); TP h = x.b.eval_with(inputs, degree_p1, cache); return g + h; }
             case Neg: return -x.a.eval_with(inputs, degree_p1, cache);
             case Mul: {
@@ -354,9 +365,13 @@ struct GenFun {
             }
             case Subst: {
                 Inputs new_inputs = inputs;
-                TP subst = x.b.eval_with(inputs, degree_p1, cache);
-                T c = subst.constant_term();
-                subst = subst - TP::from(c);
+                TP subst;
+                T c;
+                if (!subst_shortcut(*x.b.p, inputs, degree_p1, subst, c)) {
+                    subst = x.b.eval_with(inputs, degree_p1, cache);
+                    c = subst.constant_term();
+                    subst = subst - TP::from(c);
+                }
                 if (x.var < inputs.size()) new_inputs[x.var] = c;
                 else {
                     if (x.var != inputs.size()) throw std::runtime_error("assertion failed: v.id() == inputs.len()");
@@ -395,6 +410,38 @@ struct GenFun {
             }
         }
         throw std::runtime_error("unreachable");
+    }
+
+    // The substitution of a Subst node is almost always a constant (marginalisation, `[t -> 1]`) or `k * var` (the scalings of
+    // the observe statements, gf.rs:496): six TaylorPoly operations on one- and two-element tensors per node and input point
+    // (from, var, mul, constant_term, from, sub) — 60 % of the 566 000 backend calls of a mixture run, all on the calling
+    // thread.  Their values follow from the reference's own definitions on such tensors: `from(k) * var(v, x, d)` takes Mul's
+    // constant path, k * e for both elements (mt:1041-1047; k * 1 included, k = 1 returns the operand, which k * e reproduces
+    // bit for bit), `p - from(c)` touches element 0 only (mt:919-926).  So `subst - constant_term(subst)` is formed here with
+    // the evaluator's own number type and handed to the backend as ONE tensor.  Anything else — k = 0 (Mul's zero shortcut
+    // changes the shape), a degree below 2, other node kinds — takes the general path.  GFH_SUBST_SHORTCUT=0: always (A/B, tests).
+    static bool subst_shortcut_on() {
+        static const bool on = [] {
+            const char* e = getenv("GFH_SUBST_SHORTCUT");
+            return !e || e[0] != '0';
+        }();
+        return on;
+    }
+    static bool subst_shortcut(const Node& b, const Inputs& inputs, size_t degree_p1, TP& subst, T& c) {
+        if (!subst_shortcut_on()) return false;
+        if (b.kind == Const) {  // from(c) - from(c): two 0-dimensional tensors, element 0 (mt:919-926)
+            c = b.c;
+            subst = TP::from(c - c);
+            return true;
+        }
+        if (b.kind != Mul || degree_p1 < 2) return false;
+        const Node *kn = b.a.p.get(), *vn = b.b.p.get();
+        if (kn->kind == Var && vn->kind == Const) std::swap(kn, vn);
+        if (kn->kind != Const || vn->kind != Var || kn->c.is_zero() || vn->var >= inputs.size()) return false;
+        const T e0 = kn->c * inputs[vn->var], e1 = kn->c * T::one();
+        c = e0;
+        subst = TP::affine(vn->var, e0 - c, e1, degree_p1);
+        return true;
     }
 
     // recognisers (gf.rs:840-914)

@@ -1008,7 +1008,7 @@ def test_derive_scale_fused_equals_reference_sequence(interval, OTP, GTP, OTPI, 
 def test_observe_chain_fused_equals_stepwise_reference(interval, OTP, GTP, OTPI, GTPI):
     """gft_observe_chain = n observation steps (derivative -> truncate -> * (x + eps_v) -> * c_k, generating_function.rs:
     684-689), each one degree lower than the one inside it, in ONE launch: bit-identical to the oracle's unfused loop —
-    ordinary chains, chains longer than one launch takes (48 steps), x = 0 / 1, constants 0 / 1 / non-finite, 1-element
+    ordinary chains, chains longer than one launch takes (16 steps), x = 0 / 1, constants 0 / 1 / non-finite, 1-element
     intermediates (all of which make the library fall back to single steps)."""
     O, G = (OTPI, GTPI) if interval else (OTP, GTP)
     mk = (lambda a: np.stack([a, a + np.abs(a) * 1e-12])) if interval else (lambda a: a)
