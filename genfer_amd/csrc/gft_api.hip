@@ -344,6 +344,10 @@ struct Buf : std::enable_shared_from_this<Buf> {
     // interval tensors: 2 = PROVEN to hold no coefficient that is exactly [0,0] (Ops::nz_of), 1 = holds one / descends from a
     // tensor that does (nobody asks again), 0 = unknown
     unsigned char nz = 0;
+    // (round 6) 3 = the exact zeros are PROVEN to be exactly the leading slabs: coefficient k is [0,0] iff k_u < zpre[u] for some
+    // axis u < ZAX (what `observe k ~ Poisson(l * X)` leaves behind when X is evaluated at 0: slab 0 along X) — see Support
+    static constexpr int ZAX = 8;
+    unsigned short zpre[ZAX] = {0, 0, 0, 0, 0, 0, 0, 0};
     // force_buf() is launching the producer of this buffer right now: its values are being WRITTEN by the launch under
     // construction, so nothing that reads it may ride in that same launch (launch_obs / launch_horner rider searches)
     bool writing = false;
@@ -660,20 +664,78 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
 // non-zero c and m, sums of equal shape — and such a tensor with >= 3 coefficients is never of the form c + m*x_v: the
 // per-subst_var linearity scan of the accumulator (a launch and a host round trip, 18 000 per mixture --bounds run) has a
 // known answer.  2 = proven, 1 = holds a zero (or descends from such a tensor: nobody asks again), 0 = unknown.
+// (round 6) ... and where the zeros ARE is inherited just as well when they form whole leading slabs.  hmm's tensors have them:
+// an observation `observe k ~ Poisson(l * X)` evaluated at X = 0 (the variable whose probabilities are asked for) multiplies by
+// eps_X alone, so slab 0 along X is exactly zero and everything else is not — "holds a zero", hence no proof, hence 4 464
+// linearity scans with a host round trip each in hmm --bounds.  A Support says which coefficients of a tensor are exactly [0,0]:
+//   kind 2: none;   kind 3: exactly those with k_u < z[u] for some axis u (z != 0);   kind 4: AT LEAST those (a front-padded
+//   view: its data may end before the handle's box does);   kind 1: some, pattern unknown;   kind 0: unknown.
+struct Support {
+    int kind = 0;
+    unsigned z[Buf::ZAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool exact() const { return kind == 2 || kind == 3; }
+    void normalise() {
+        if (kind != 3) return;
+        bool any = false;
+        for (unsigned v : z) any = any || v != 0;
+        if (!any) kind = 2;
+    }
+    // the leading slabs as the buffer stores them (anything beyond 65535 slabs, or an axis beyond ZAX: not representable)
+    void store(Buf* b) const {
+        b->nz = (unsigned char)(kind == 4 ? 1 : kind);
+        for (int u = 0; u < Buf::ZAX; ++u) b->zpre[u] = (unsigned short)(kind == 3 ? std::min<unsigned>(z[u], 0xffffu) : 0);
+        if (kind == 3)
+            for (unsigned v : z)
+                if (v > 0xffffu) b->nz = 1;
+    }
+};
 template <class E>
-static int nz_of_poly(const gft_poly& p) {
-    if (E::W != 2 || !p.buf || p.buf->host) return 0;
-    const int base = p.buf->nz;
-    if (base != 2 || !p.pend) return base;
+static Support support_of_poly(const gft_poly& p) {
+    Support s;
+    if (E::W != 2 || !p.buf || p.buf->host) return s;
+    s.kind = p.buf->nz;
+    if (s.kind == 3) {
+        if (p.shape.size() > (size_t)Buf::ZAX && !p.pend) {  // (axes the buffer's record does not cover: unit ones are fine)
+            for (size_t u = Buf::ZAX; u < p.shape.size(); ++u)
+                if (p.shape[u] != 1) return Support{1};
+        }
+        for (int u = 0; u < Buf::ZAX; ++u) s.z[u] = p.buf->zpre[u];
+    }
+    if (!s.exact()) return s;
+    auto clip = [&](const Dims& shape) {  // a leading box keeps the pattern; a slab pattern that swallows the box is "all zero"
+        for (size_t u = 0; u < (size_t)Buf::ZAX; ++u) {
+            const size_t ext = u < shape.size() ? shape[u] : 1;
+            if (s.z[u] >= ext && s.z[u] > 0) {
+                s.kind = 1;
+                return;
+            }
+        }
+    };
+    if (!p.pend) {
+        clip(p.shape);
+        s.normalise();
+        return s;
+    }
     const Pend& q = *p.pend;
-    if (q.padded) return 1;  // zeros in front
+    if (q.base_shape.size() > (size_t)Buf::ZAX) {
+        for (size_t u = Buf::ZAX; u < q.base_shape.size(); ++u)
+            if (q.base_shape[u] != 1 && s.kind == 3) return Support{1};
+    }
+    if (q.base_off != 0 && s.kind == 3) {  // a sub-box that does not start at the origin: the pattern seen from its own origin
+        size_t off = q.base_off;
+        for (size_t u = q.base_shape.size(); u-- > 0;) {
+            const size_t o = off % q.base_shape[u];
+            off /= q.base_shape[u];
+            if (u < (size_t)Buf::ZAX) s.z[u] = s.z[u] > o ? (unsigned)(s.z[u] - o) : 0u;
+        }
+    }
     for (int i = 0; i < q.n; ++i) {
         const PendStage& g = q.st[i];
         switch (g.kind) {
             case gft::CH_LMUL_S:
             case gft::CH_MUL_S:
             case gft::CH_DIV_S:
-                if (g.s[0] == 0.0 && g.s[1] == 0.0) return 1;  // x * [0,0]
+                if (g.s[0] == 0.0 && g.s[1] == 0.0) return Support{1};  // x * [0,0]
                 break;
             case gft::CH_MUL_TAB: {
                 TabEntry& t = *g.tab;
@@ -682,13 +744,46 @@ static int nz_of_poly(const gft_poly& p) {
                     for (size_t k = 0; k < t.len; ++k)
                         if (t.host[k] == 0.0 && t.host[t.len + k] == 0.0) t.nz = 0;
                 }
-                if (!t.nz) return 0;
+                if (!t.nz) return Support{0};
                 break;
             }
-            default: break;  // neg, element 0 +/- s: a sum is [0,0] only if both terms are
+            case gft::CH_FIRST_ADD:
+            case gft::CH_FIRST_SUB:
+            case gft::CH_FIRST_SUB_NEG_ALL:
+                // element 0 (+|-) s: a sum is [0,0] only if both terms are — an element 0 that lies in a zero slab becomes s
+                if (s.kind == 3 && !(g.s[0] == 0.0 && g.s[1] == 0.0)) return Support{0};
+                break;
+            default: break;  // neg
         }
     }
-    return 2;
+    if (q.padded) {  // zeros in front (mul_var): the data, shifted — and possibly zeros behind it
+        for (size_t u = 0; u < q.pad.size() && u < (size_t)Buf::ZAX; ++u) s.z[u] += (unsigned)q.pad[u];
+        for (size_t u = Buf::ZAX; u < q.pad.size(); ++u)
+            if (q.pad[u] != 0) return Support{1};
+        s.kind = 4;
+        return s;
+    }
+    clip(p.shape);
+    s.normalise();
+    return s;
+}
+// what the rounds-5 callers ask: 2 = no exact zero anywhere, 1 = holds one, 0 = unknown
+template <class E>
+static int nz_of_poly(const gft_poly& p) {
+    const int k = support_of_poly<E>(p).kind;
+    return k == 2 ? 2 : ((k == 1 || k == 3 || k == 4) ? 1 : 0);
+}
+// A tensor with this support is PROVEN not to be of the form c + m * x_v (mt:275-294) iff a non-zero coefficient sits at an
+// index with two non-zero coordinates or a coordinate >= 2 — the largest index of the box is such a one whenever any exists
+// (the support {k >= z} contains it unless the pattern swallows the box, which clip() has excluded).
+static bool support_proves_nonlinear(const Support& s, const Dims& shape) {
+    if (!s.exact()) return false;
+    int nonunit = 0;
+    for (size_t u = 0; u < shape.size(); ++u) {
+        if (shape[u] >= 3) return true;
+        if (shape[u] == 2) ++nonunit;
+    }
+    return nonunit >= 2;
 }
 static void trace_settle();  // GFT_TRACE_API: which entry point materialised a chain (below)
 static void trace_mirror(size_t numel);  // ... and which one mirrored a host-tier tensor to the device
@@ -706,7 +801,7 @@ static void settle(const gft_poly& p) {
         for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)p.shape[keep[j]];
         K<E>::chain_copy(R.stream, out->p, p.numel, sh, chain_src<E>(p, keep));
         trace_settle();
-        out->nz = (unsigned char)nz_of_poly<E>(p);
+        support_of_poly<E>(p).store(out.get());
         q.mat = out;
         q.mat_shape = p.shape;
         R.stats_ex[1]++;
@@ -1477,7 +1572,7 @@ struct Ops {
             rec->keep = keep;
             rec->subtract = subtract;
             P out = make_recorded(shape, rd);
-            out.buf->nz = sum_nz(self, other, shape);
+            sum_nz_store(self, other, shape, out.buf.get());
             unsigned long long ib = 0;
             DagRec::Deps ds;
             rec->deps(ds);
@@ -1521,7 +1616,7 @@ struct Ops {
         // (a leaf's dp() may have launched one of the recordings after all — as a leaf of itself it cannot, but be safe)
         if ((la && !self.buf->lazy) || (lb && !other.buf->lazy)) return false;
         P out = make(shape, rd);
-        out.buf->nz = sum_nz(self, other, shape);
+        sum_nz_store(self, other, shape, out.buf.get());
         Shape sh;
         sh.nd = (int)keep.size();
         for (size_t j = 0; j < keep.size(); ++j) sh.d[j] = (unsigned)shape[keep[j]];
@@ -1532,14 +1627,29 @@ struct Ops {
         return true;
     }
     // (intervals) a sum of two tensors of the result's own shape: [0,0] only where both are
-    static unsigned char sum_nz(const P& a, const P& b, const Dims& shape) {
-        if (W != 2) return 0;
-        const int x = nz_of(a), y = nz_of(b);
+    // (round 6: with Supports — the union of two "leading zero slabs" patterns over the whole box is the smaller of the two when
+    // one contains the other; a front-padded operand (kind 4: zero AT LEAST there) can only be the contained one)
+    static Support sum_support(const P& a, const P& b, const Dims& shape) {
+        Support r;
+        if (W != 2) return r;
+        const Support x = support_of_poly<E>(a), y = support_of_poly<E>(b);
         const bool whole = same_dims_mod_trailing_ones(a.shape, shape) && same_dims_mod_trailing_ones(b.shape, shape);
-        if (whole && (x == 2 || y == 2)) return 2;
-        if (x == 2 && y == 2) return 0;  // (an L-shaped union of two boxes has a corner neither covers)
-        return (unsigned char)((x == 1 || y == 1) ? 1 : 0);
+        auto le = [](const Support& p, const Support& q) {  // p's zero slabs are a subset of q's: p.z <= q.z on every axis
+            for (int u = 0; u < Buf::ZAX; ++u)
+                if (p.z[u] > q.z[u]) return false;
+            return true;
+        };
+        if (whole) {
+            if (x.kind == 2 || y.kind == 2) return Support{2};
+            if (x.kind == 3 && (y.kind == 3 || y.kind == 4) && le(x, y)) return x;
+            if (y.kind == 3 && (x.kind == 3 || x.kind == 4) && le(y, x)) return y;
+            if (x.kind == 3 && y.kind == 3) return Support{1};  // (an L-shaped zero set: zeros, pattern not of this family)
+        } else if (x.kind == 2 && y.kind == 2)
+            return Support{0};  // (an L-shaped union of two boxes has a corner neither covers)
+        r.kind = (x.kind == 1 || y.kind == 1 || x.kind == 3 || y.kind == 3 || x.kind == 4 || y.kind == 4) ? 1 : 0;
+        return r;
     }
+    static void sum_nz_store(const P& a, const P& b, const Dims& shape, Buf* out) { sum_support(a, b, shape).store(out); }
     // ---- Add / Sub / Neg (mt:854-937) -----------------------------------------------------------------
     static P addsub(P self, P other, bool subtract) {
         Dims rd = min_degrees(self, other);
@@ -1621,7 +1731,7 @@ struct Ops {
                 const bool shifted = (self.pend && self.pend->padded) || (other.pend && other.pend->padded);
                 const bool record = R.lazy_sum && ((prod(shape) >= 64 && shifted) || (R.batch_dag && prod(shape) >= 4));
                 P out = record ? make_recorded(shape, rd) : make(shape, rd);
-                out.buf->nz = sum_nz(self, other, shape);
+                sum_nz_store(self, other, shape, out.buf.get());
                 if (record) {
                     // The Add inside mul_linear (c * t + m * shift(t): one operand carries a front pad) is RECORDED, not launched:
                     // if an Add consumes it (the merge of an `if` whose arms both end in `State ~ Bernoulli(p)`), both run as one
@@ -3171,15 +3281,30 @@ struct Ops {
         // values launches the plain kernel through use_buf().
         // (intervals) no exact zero in, none out: every position of every step receives a term src * factor (* x), the
         // derivative factors j + 1 and the constants c are non-zero (checked above), x is not [0,0]
-        const int in_nz = nz_of(a);
-        const unsigned char out_nz = (unsigned char)(in_nz == 2 ? (val_is_zero(x) ? 0 : 2) : in_nz);
+        // (round 6) ... and at x = [0,0] a step is D * eps_v alone: slab 0 along v is exactly zero and nothing else is (Support).
+        // Per step the derivative moves the leading zero slabs of axis v down by one, (x + eps_v) * D keeps them where x is not
+        // zero (out[k] = D[k-1] + x * D[k]: non-zero iff one of the two is) and moves them up by one where it is.
+        Support out_sup = support_of_poly<E>(a);
+        if (out_sup.exact()) {
+            if (v < (size_t)Buf::ZAX) {
+                out_sup.kind = 3;
+                for (size_t i = 0; i < n; ++i) {
+                    const unsigned zd = out_sup.z[v] > 0 ? out_sup.z[v] - 1 : 0;
+                    out_sup.z[v] = val_is_zero(x) ? zd + 1 : zd;
+                }
+                for (size_t u = 0; u < (size_t)Buf::ZAX; ++u)
+                    if (out_sup.z[u] > 0 && out_sup.z[u] >= (u < S.size() ? S[u] : 1)) out_sup.kind = 1;  // (nothing but zeros)
+                out_sup.normalise();
+            } else
+                out_sup.kind = val_is_zero(x) ? 0 : out_sup.kind;
+        }
         // (a recorded SUM as the input is launched now: only an Add could have launched it for free, and a chain whose input is
         // not in memory can neither ride along with another launch nor let the Horner loop behind it do so)
         // (in the launch graph the sum is simply this chain's predecessor)
         if (!R.batch_dag && a.buf && !a.buf->host && a.buf->lazy && a.buf->lazy->sum) use_buf(a.buf.get());
         if (R.lazy_observe && a.buf && !a.buf->host) {
             P out = make_recorded(S, G);
-            out.buf->nz = out_nz;
+            out_sup.store(out.buf.get());
             auto lo = std::allocate_shared<LazyObs>(gft_small::Alloc<LazyObs>());
             lo->a = a;
             lo->tab = tab;
@@ -3201,7 +3326,7 @@ struct Ops {
             return out;
         }
         P out = make(S, G);
-        out.buf->nz = out_nz;
+        out_sup.store(out.buf.get());
         K<E>::observe_chain(R.stream, dp<E>(a), a.numel, dp<E>(out), out.numel, g, lines, longest);
         return out;
     }
@@ -3217,11 +3342,46 @@ struct Ops {
             --skip;
             return 0;
         }
-        Mailbox mb = next_mail();
-        K<E>::any_zero(R.stream, dp<E>(p), p.numel, p.numel, R.d_flag + 24, mb);
+        // (round 6) where the zeros are, if there are any: whole slabs 0 of some axes are a pattern the proofs can carry (Support)
+        Dims keep = collapse_mask({&p.shape}, false);
+        bool axes_ok = keep.size() <= 6 && p.numel < 0xffffffffull;
+        for (size_t ax : keep) axes_ok = axes_ok && ax < (size_t)Buf::ZAX;
         double has = 1.0;
-        wait_mail(mb, &has, 1);
-        R.stats[1]++;
+        if (axes_ok) {
+            Shape sh = to_shape(pick(p.shape, keep));
+            Mailbox mb = next_mail();
+            K<E>::zero_pattern(R.stream, dp<E>(p), p.numel, sh, p.numel, R.d_flag + 32, mb);
+            double cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+            wait_mail(mb, cnt, 7);
+            R.stats[1]++;
+            has = cnt[0];
+            if (has != 0.0) {
+                Support sp;
+                sp.kind = 3;
+                double outside = 1.0;  // coefficients in none of the all-zero slabs 0
+                for (size_t j = 0; j < keep.size(); ++j) {
+                    const double ext = (double)p.shape[keep[j]], slab = (double)p.numel / ext;
+                    if (cnt[1 + j] == slab && ext >= 2) {
+                        sp.z[keep[j]] = 1;
+                        outside *= ext - 1.0;
+                    } else
+                        outside *= ext;
+                }
+                if ((double)p.numel - outside == cnt[0]) {  // every zero lies in one of those slabs, and they hold nothing else
+                    sp.normalise();
+                    if (sp.kind == 3) {
+                        sp.store(p.buf.get());
+                        backoff = 0;
+                        return p.buf->nz;
+                    }
+                }
+            }
+        } else {
+            Mailbox mb = next_mail();
+            K<E>::any_zero(R.stream, dp<E>(p), p.numel, p.numel, R.d_flag + 24, mb);
+            wait_mail(mb, &has, 1);
+            R.stats[1]++;
+        }
         p.buf->nz = has != 0.0 ? 1 : 2;
         if (has != 0.0) {
             backoff = backoff ? std::min(backoff * 2, 4096u) : 32;
@@ -3376,7 +3536,7 @@ struct Ops {
             rec->e = e;
             rec->Y = Y;
             P out = make_recorded(shape, rd);
-            out.buf->nz = sum_nz(self, other, shape);
+            sum_nz_store(self, other, shape, out.buf.get());
             rec->out_numel = out.numel;
             lo->fused = true;
             out.buf->lazy = op_of(rec, birth_of_inputs({&lo->a, &Y}));
@@ -3390,7 +3550,7 @@ struct Ops {
         if (!Y.pend) (void)dp<E>(Y);  // a lazy handle / host-tier tensor gets its device buffer
         e.y = chain_src_dev(Y, lo->okeep);
         P out = make(shape, rd);
-        out.buf->nz = sum_nz(self, other, shape);
+        sum_nz_store(self, other, shape, out.buf.get());
         launch_obs(*lo, dp<E>(out), out.numel, &e, X.buf.get());
         R.stats_side[3]++;
         R.stats_ex[2]++;
@@ -3632,7 +3792,8 @@ struct Ops {
                 // at least 3 coefficients — cannot be linear (nz_of_poly): no scan, no round trip; the verdict is memoised as
                 // if the scan had delivered it
                 if (!res_nonlinear_seen && W == 2 && proven && R.nz_proofs && res.numel >= 3 && res.buf &&
-                    (nz_of(res) == 2 || (res.buf.get() == ca.buf.get() && nz_of(ca) == 0 && nz_query(ca) == 2 && nz_of(res) == 2))) {
+                    (nz_of(res) == 2 || (res.buf.get() == ca.buf.get() && nz_of(ca) == 0 && nz_query(ca) == 2 && nz_of(res) == 2) ||
+                     support_proves_nonlinear(support_of_poly<E>(res), res.shape))) {
                     // (the loop reads the slab in place where it is a pure view — res_is_view —, from memory otherwise: dp() in
                     // launch_horner materialises it then)
                     if (!res.pend && res.buf && !res.buf->host && !res.buf->lin_state) res.buf->lin_state = 1;
@@ -4048,8 +4209,16 @@ struct Ops {
         // (intervals, c and m not [0,0]) no exact zero among the coefficients, none in the result: position (o, k_w) of the final
         // box receives coeff_i[o, k'] * C(i,j) c^(i-j) m^j for every k' + j = k_w — at least one such term exists, none cancels
         if (W == 2) {
-            const int cn = nz_of(ca);
-            out.buf->nz = (unsigned char)((cn == 2 && !val_is_zero(c) && !val_is_zero(m)) ? 2 : (cn == 1 ? 1 : 0));
+            // (round 6, Support) leading zero slabs on the other axes stay where they are; along the substituted axis every
+            // position receives a term from the top coefficient slab
+            Support sp = support_of_poly<E>(ca);
+            if (sp.exact() && !val_is_zero(c) && !val_is_zero(m)) {
+                if (v < (size_t)Buf::ZAX) sp.z[v] = 0;
+                sp.kind = 3;
+                sp.normalise();
+            } else
+                sp.kind = (sp.kind == 1 || sp.kind == 3 || sp.kind == 4) ? 1 : 0;
+            sp.store(out.buf.get());
         }
         const unsigned lines = (unsigned)(fn / fs[w]);
         if (defer && !wit && !(hdiag & 64) && res.buf && ca.buf) {

@@ -1809,6 +1809,44 @@ __global__ void __launch_bounds__(256) k_any_zero(const double* __restrict__ p, 
     mb.payload[0] = v ? 1.0 : 0.0;
     mailbox_publish(mb);
 }
+// The same question with the answer "WHERE": payload[0] = number of coefficients that are exactly zero, payload[1 + u] = how
+// many of them lie in slab 0 of (collapsed) axis u < 6 — enough for the host to recognise "the zeros are exactly the slabs 0
+// of some axes" (gft_api.hip Support: what an observation at X = 0 leaves behind).  state[0 .. 6] count, state[7] arrivals;
+// the last block publishes and leaves all eight words zero.
+template <class E>
+__global__ void __launch_bounds__(256) k_zero_pattern(const double* __restrict__ p, size_t plane, Shape sh, unsigned n, unsigned* state, Mailbox mb) {
+    __shared__ unsigned s_cnt[7];
+    if (threadIdx.x < 7) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned mine[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!E::is_zero(E::ld(p, plane, i))) continue;
+        mine[0]++;
+        unsigned r = i;
+        for (int ax = sh.nd - 1; ax >= 0; --ax) {
+            const unsigned d = sh.d[ax];
+            if (r % d == 0 && ax < 6) mine[1 + ax]++;
+            r /= d;
+        }
+    }
+    for (int k = 0; k < 7; ++k)
+        if (mine[k]) atomicAdd(&s_cnt[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x < 7 && s_cnt[threadIdx.x]) atomicAdd(&state[threadIdx.x], s_cnt[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (atomicAdd(&state[7], 1u) != gridDim.x - 1) return;
+    __threadfence();
+    for (int k = 0; k < 7; ++k) mb.payload[k] = (double)atomicExch(&state[k], 0u);
+    atomicExch(&state[7], 0u);
+    mailbox_publish(mb);
+}
+template <class E>
+void K<E>::zero_pattern(hipStream_t st, const double* p, size_t plane, const Shape& sh, size_t n, unsigned* state, const Mailbox& mb) {
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 64));
+    GFT_LAUNCH(k_zero_pattern<E>, dim3(blocks), dim3(256), 0, st, p, plane, sh, (unsigned)n, state, mb);
+}
 template <class E>
 void K<E>::any_zero(hipStream_t st, const double* p, size_t plane, size_t n, unsigned* state, const Mailbox& mb) {
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 64));

@@ -431,6 +431,8 @@ struct K {
     // *count += number of positions where a != b  (n contiguous elements)
     static void div_by_index(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t nslabs, size_t slab, unsigned first);
     static void any_zero(hipStream_t st, const double* p, size_t plane, size_t n, unsigned* state, const Mailbox& mb);
+    // payload[0] = exact zeros among the n < 2^32 coefficients, payload[1 + u] = those in slab 0 of axis u < 6 of `sh`; state: 8 zeroed words
+    static void zero_pattern(hipStream_t st, const double* p, size_t plane, const Shape& sh, size_t n, unsigned* state, const Mailbox& mb);
     static void count_neq(hipStream_t st, const double* a, size_t a_plane, const double* b, size_t b_plane,
                           size_t n, unsigned* count);
     // reference-order truncated N-d Cauchy product, one thread per output element (mt:984-1012)

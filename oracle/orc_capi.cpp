@@ -53,6 +53,28 @@ static P<S>* from_host(const double* data, const size_t* shape, const size_t* de
     return new P<S>(std::move(a), vec(degs, ndim));
 }
 
+// ORC_TRACE_SUBST=1 (diagnostics for the build's own design work, never on in tests): the zero pattern of the operand of every
+// subst_var — how many coefficients are exactly zero, and how many non-zero ones each of the top slabs along v holds
+template <class S>
+static void trace_subst(const P<S>& a, size_t v, const P<S>& s) {
+    static const bool on = getenv("ORC_TRACE_SUBST") != nullptr;
+    if (!on || v >= a.coeffs.shape.size() || a.coeffs.len() < 8) return;
+    const auto& sh = a.coeffs.shape;
+    usize inner = 1;
+    for (usize i = v + 1; i < sh.size(); ++i) inner *= sh[i];
+    std::vector<usize> per(sh[v], 0);
+    usize zeros = 0;
+    for (usize lin = 0; lin < a.coeffs.len(); ++lin) {
+        if (a.coeffs.data[lin].is_zero()) zeros++;
+        else per[(lin / inner) % sh[v]]++;
+    }
+    std::string shs, tops;
+    for (usize x : sh) shs += std::to_string(x) + "x";
+    for (usize k = sh[v]; k-- > 0 && tops.size() < 60;) tops += std::to_string(per[k]) + " ";
+    fprintf(stderr, "[orc subst] a %s v=%zu zeros=%zu/%zu top-slab nonzeros: %s| subst len %zu\n", shs.c_str(), v, zeros, a.coeffs.len(), tops.c_str(),
+            s.coeffs.len());
+}
+
 // Display / Debug of a TaylorPoly (mt:632-636, 694-730).  Floats: shortest decimal that round-trips (searched with
 // printf precision 1..17 — independent of the product's std::to_chars route), laid out like ryu's format64 (f64:41-45).
 static std::string fmt_num(double x) {
@@ -283,6 +305,7 @@ static std::string format_poly(const P<S>& p, bool debug) {
                                         P<S>::from_scalar(Tr<S>::load(c)))))                                  \
     }                                                                                                      \
     void* PFX##subst_var(const void* a, size_t v, const void* s) {                                         \
+        trace_subst(*(const P<S>*)a, v, *(const P<S>*)s);                                                  \
         ORC_TRY((void*)new P<S>(((const P<S>*)a)->subst_var(v, *(const P<S>*)s)))                          \
     }                                                                                                      \
     void* PFX##coefficients_of_term(const void* a, size_t v, size_t o) {                                   \
@@ -393,6 +416,39 @@ int orc_mul_rows(const double* xs, const size_t* xshape, const double* ys, const
                 View<F64> z = slab.index0(k1);
                 usize lo1 = sat_sub(k1 + 1, yj.len_of(0)), hi1 = std::min(k1 + 1, xj.len_of(0));
                 for (usize j1 = lo1; j1 < hi1; ++j1) mul_rec<F64>(xj.index0(j1), yj.index0(k1 - j1), z);
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// The same row cut for Interval<F64> tensors (BASELINE configs[4] at its headline size: the tests spread the leading slabs
+// {0, 63, 127} of the 128^3 interval product over the host's threads).  Layout: ARRAY OF INTERVALS — element i is
+// {lo, hi} at doubles 2 i, 2 i + 1 (the oracle's own Arr<Interval>; the planes of the handle API would have to be
+// re-packed by every one of the concurrent calls) — for operands and result alike.
+int orci_mul_rows(const double* xs, const size_t* xshape, const double* ys, const size_t* yshape, double* res,
+                  const size_t* rshape, size_t ndim, size_t k0, size_t k1_lo, size_t k1_hi) {
+    static_assert(sizeof(Interval) == 2 * sizeof(double), "Interval is {lo, hi}");
+    try {
+        if (ndim < 3) panic("orci_mul_rows: rank >= 3 required");
+        usize nonunit = 0;
+        for (usize a = 1; a < ndim; ++a) nonunit += rshape[a] != 1;
+        if (nonunit < 2) panic("orci_mul_rows: the slab would take the 1-d shortcut");
+        View<const Interval> xv{reinterpret_cast<const Interval*>(xs), vec(xshape, ndim), c_strides(vec(xshape, ndim))};
+        View<const Interval> yv{reinterpret_cast<const Interval*>(ys), vec(yshape, ndim), c_strides(vec(yshape, ndim))};
+        View<Interval> rv{reinterpret_cast<Interval*>(res), vec(rshape, ndim), c_strides(vec(rshape, ndim))};
+        if (k0 >= rshape[0]) return 0;
+        View<Interval> slab = rv.index0(k0);
+        usize lo0 = sat_sub(k0 + 1, yv.len_of(0)), hi0 = std::min(k0 + 1, xv.len_of(0));
+        for (usize j0 = lo0; j0 < hi0; ++j0) {
+            View<const Interval> xj = xv.index0(j0), yj = yv.index0(k0 - j0);
+            for (usize k1 = k1_lo; k1 < k1_hi && k1 < rshape[1]; ++k1) {
+                View<Interval> z = slab.index0(k1);
+                usize lo1 = sat_sub(k1 + 1, yj.len_of(0)), hi1 = std::min(k1 + 1, xj.len_of(0));
+                for (usize j1 = lo1; j1 < hi1; ++j1) mul_rec<Interval>(xj.index0(j1), yj.index0(k1 - j1), z);
             }
         }
         return 0;
