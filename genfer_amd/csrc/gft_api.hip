@@ -353,6 +353,7 @@ struct Buf : std::enable_shared_from_this<Buf> {
     bool writing = false;
     // a recording's buffer gets its pool block when it is launched (ensure_alloc): `want` doubles; p == nullptr until then
     size_t want = 0;
+    const char* origin = nullptr;  // the entry point whose result first owned this buffer (diagnostics: GFT_TRACE_SCANS)
     unsigned dag_mark = 0;       // run_dag: visited in this execution
     int dag_level = 0;           // ... and its level (longest path from tensors in memory)
     std::shared_ptr<Buf> dev;
@@ -668,11 +669,15 @@ static Dims chain_keep(const Dims& shape, std::initializer_list<const gft_poly*>
 // an observation `observe k ~ Poisson(l * X)` evaluated at X = 0 (the variable whose probabilities are asked for) multiplies by
 // eps_X alone, so slab 0 along X is exactly zero and everything else is not — "holds a zero", hence no proof, hence 4 464
 // linearity scans with a host round trip each in hmm --bounds.  A Support says which coefficients of a tensor are exactly [0,0]:
-//   kind 2: none;   kind 3: exactly those with k_u < z[u] for some axis u (z != 0);   kind 4: AT LEAST those (a front-padded
-//   view: its data may end before the handle's box does);   kind 1: some, pattern unknown;   kind 0: unknown.
+//   kind 2: none;   kind 3: exactly those with k_u < z[u] for some axis u (z != 0);   kind 4: exactly those outside the box
+//   z[u] <= k_u < h[u] (a front-padded view: zeros in front, and its data may end before the handle's box does — the
+//   operands of mul_linear's Add, c * t and m * shift(t), each cover what the other leaves);   kind 5: all of them;   kind 1: some, in no such pattern — MEASURED
+//   on this very buffer (nz_query);   kind 0: unknown (a descendant of a kind-1 tensor is unknown, not 1: hmm's first statements
+//   have irregular zeros — `State := 1` —, the steady state has slabs, and nz_query asks again after its back-off).
 struct Support {
     int kind = 0;
     unsigned z[Buf::ZAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned h[Buf::ZAX] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};  // kind 4 only
     bool exact() const { return kind == 2 || kind == 3; }
     void normalise() {
         if (kind != 3) return;
@@ -682,11 +687,11 @@ struct Support {
     }
     // the leading slabs as the buffer stores them (anything beyond 65535 slabs, or an axis beyond ZAX: not representable)
     void store(Buf* b) const {
-        b->nz = (unsigned char)(kind == 4 ? 1 : kind);
+        b->nz = (unsigned char)(kind == 4 ? 0 : kind);
         for (int u = 0; u < Buf::ZAX; ++u) b->zpre[u] = (unsigned short)(kind == 3 ? std::min<unsigned>(z[u], 0xffffu) : 0);
         if (kind == 3)
             for (unsigned v : z)
-                if (v > 0xffffu) b->nz = 1;
+                if (v > 0xffffu) b->nz = 0;
     }
 };
 template <class E>
@@ -697,16 +702,27 @@ static Support support_of_poly(const gft_poly& p) {
     if (s.kind == 3) {
         if (p.shape.size() > (size_t)Buf::ZAX && !p.pend) {  // (axes the buffer's record does not cover: unit ones are fine)
             for (size_t u = Buf::ZAX; u < p.shape.size(); ++u)
-                if (p.shape[u] != 1) return Support{1};
+                if (p.shape[u] != 1) return Support{0};
         }
         for (int u = 0; u < Buf::ZAX; ++u) s.z[u] = p.buf->zpre[u];
     }
+    if (s.kind == 5) {  // all zero: so is every view of it under stages that keep zeros zero
+        if (p.pend)
+            for (int i = 0; i < p.pend->n; ++i) {
+                const int k = p.pend->st[i].kind;
+                const double* sv = p.pend->st[i].s;
+                if ((k == gft::CH_FIRST_ADD || k == gft::CH_FIRST_SUB || k == gft::CH_FIRST_SUB_NEG_ALL) && !(sv[0] == 0.0 && sv[1] == 0.0)) return Support{0};
+                if (k == gft::CH_DIV_S) return Support{0};  // (0 / 0)
+            }
+        return s;
+    }
+    if (s.kind == 1) return Support{0};  // (what was measured on the BUFFER says nothing usable about a view of it; nz_of_poly maps it)
     if (!s.exact()) return s;
     auto clip = [&](const Dims& shape) {  // a leading box keeps the pattern; a slab pattern that swallows the box is "all zero"
         for (size_t u = 0; u < (size_t)Buf::ZAX; ++u) {
             const size_t ext = u < shape.size() ? shape[u] : 1;
             if (s.z[u] >= ext && s.z[u] > 0) {
-                s.kind = 1;
+                s.kind = 5;
                 return;
             }
         }
@@ -719,7 +735,7 @@ static Support support_of_poly(const gft_poly& p) {
     const Pend& q = *p.pend;
     if (q.base_shape.size() > (size_t)Buf::ZAX) {
         for (size_t u = Buf::ZAX; u < q.base_shape.size(); ++u)
-            if (q.base_shape[u] != 1 && s.kind == 3) return Support{1};
+            if (q.base_shape[u] != 1 && s.kind == 3) return Support{0};
     }
     if (q.base_off != 0 && s.kind == 3) {  // a sub-box that does not start at the origin: the pattern seen from its own origin
         size_t off = q.base_off;
@@ -735,7 +751,7 @@ static Support support_of_poly(const gft_poly& p) {
             case gft::CH_LMUL_S:
             case gft::CH_MUL_S:
             case gft::CH_DIV_S:
-                if (g.s[0] == 0.0 && g.s[1] == 0.0) return Support{1};  // x * [0,0]
+                if (g.s[0] == 0.0 && g.s[1] == 0.0) return Support{0};  // x * [0,0]
                 break;
             case gft::CH_MUL_TAB: {
                 TabEntry& t = *g.tab;
@@ -757,9 +773,13 @@ static Support support_of_poly(const gft_poly& p) {
         }
     }
     if (q.padded) {  // zeros in front (mul_var): the data, shifted — and possibly zeros behind it
-        for (size_t u = 0; u < q.pad.size() && u < (size_t)Buf::ZAX; ++u) s.z[u] += (unsigned)q.pad[u];
+        for (size_t u = 0; u < q.pad.size() && u < (size_t)Buf::ZAX; ++u) {
+            s.z[u] += (unsigned)q.pad[u];
+            s.h[u] = (unsigned)std::min<size_t>(q.pad[u] + q.src_box[u], u < p.shape.size() ? p.shape[u] : 1);
+            if (s.z[u] >= s.h[u]) return Support{5};
+        }
         for (size_t u = Buf::ZAX; u < q.pad.size(); ++u)
-            if (q.pad[u] != 0) return Support{1};
+            if (q.pad[u] != 0) return Support{0};
         s.kind = 4;
         return s;
     }
@@ -771,13 +791,14 @@ static Support support_of_poly(const gft_poly& p) {
 template <class E>
 static int nz_of_poly(const gft_poly& p) {
     const int k = support_of_poly<E>(p).kind;
-    return k == 2 ? 2 : ((k == 1 || k == 3 || k == 4) ? 1 : 0);
+    if (k == 0 && p.buf && !p.buf->host && p.buf->nz == 1) return 1;
+    return k == 2 ? 2 : ((k == 3 || k == 4 || k == 5) ? 1 : 0);
 }
 // A tensor with this support is PROVEN not to be of the form c + m * x_v (mt:275-294) iff a non-zero coefficient sits at an
 // index with two non-zero coordinates or a coordinate >= 2 — the largest index of the box is such a one whenever any exists
 // (the support {k >= z} contains it unless the pattern swallows the box, which clip() has excluded).
 static bool support_proves_nonlinear(const Support& s, const Dims& shape) {
-    if (!s.exact()) return false;
+    if (!s.exact()) return false;  // (kind 5, all zero, is the constant 0: linear)
     int nonunit = 0;
     for (size_t u = 0; u < shape.size(); ++u) {
         if (shape[u] >= 3) return true;
@@ -1633,20 +1654,84 @@ struct Ops {
         Support r;
         if (W != 2) return r;
         const Support x = support_of_poly<E>(a), y = support_of_poly<E>(b);
-        const bool whole = same_dims_mod_trailing_ones(a.shape, shape) && same_dims_mod_trailing_ones(b.shape, shape);
-        auto le = [](const Support& p, const Support& q) {  // p's zero slabs are a subset of q's: p.z <= q.z on every axis
-            for (int u = 0; u < Buf::ZAX; ++u)
-                if (p.z[u] > q.z[u]) return false;
+        // each operand's non-zero coefficients as a box lo <= k < hi of the sum's index space (interval sums do not cancel: the
+        // sum is zero exactly where both operands are); the union of two boxes is a box when they agree on all axes but one and
+        // touch or overlap on that one, or when one contains the other
+        struct Box {
+            bool known = false, empty = false;
+            unsigned lo[Buf::ZAX], hi[Buf::ZAX];
+        };
+        auto box_of = [&](const Support& sp, const P& p) {
+            Box bx;
+            if (sp.kind == 5) {
+                bx.known = bx.empty = true;
+                return bx;
+            }
+            if (!(sp.kind == 2 || sp.kind == 3 || sp.kind == 4)) return bx;
+            for (size_t u = Buf::ZAX; u < p.shape.size(); ++u)
+                if (p.shape[u] != 1) return bx;
+            bx.known = true;
+            for (int u = 0; u < Buf::ZAX; ++u) {
+                const unsigned ext = (size_t)u < p.shape.size() ? (unsigned)std::min<size_t>(p.shape[u], 0xfffffffeu) : 1u;
+                bx.lo[u] = sp.z[u];
+                bx.hi[u] = sp.kind == 4 ? std::min(sp.h[u], ext) : ext;
+                if (bx.lo[u] >= bx.hi[u]) bx.empty = true;
+            }
+            return bx;
+        };
+        const Box A = box_of(x, a), B = box_of(y, b);
+        auto full = [&](const Box& bx) {  // no coefficient of the sum's box is zero in this operand: none is in the sum
+            if (!bx.known || bx.empty) return false;
+            for (int u = 0; u < Buf::ZAX; ++u) {
+                const unsigned ext = (size_t)u < shape.size() ? (unsigned)std::min<size_t>(shape[u], 0xfffffffeu) : 1u;
+                if (bx.lo[u] != 0 || bx.hi[u] != ext) return false;
+            }
+            for (size_t u = Buf::ZAX; u < shape.size(); ++u)
+                if (shape[u] != 1) return false;
             return true;
         };
-        if (whole) {
-            if (x.kind == 2 || y.kind == 2) return Support{2};
-            if (x.kind == 3 && (y.kind == 3 || y.kind == 4) && le(x, y)) return x;
-            if (y.kind == 3 && (x.kind == 3 || x.kind == 4) && le(y, x)) return y;
-            if (x.kind == 3 && y.kind == 3) return Support{1};  // (an L-shaped zero set: zeros, pattern not of this family)
-        } else if (x.kind == 2 && y.kind == 2)
-            return Support{0};  // (an L-shaped union of two boxes has a corner neither covers)
-        r.kind = (x.kind == 1 || y.kind == 1 || x.kind == 3 || y.kind == 3 || x.kind == 4 || y.kind == 4) ? 1 : 0;
+        if (full(A) || full(B)) return Support{2};
+        if (!A.known || !B.known) {
+            if (g_scan_trace.on) {
+                char key[160];
+                snprintf(key, sizeof key, "sum_support -> unknown: x.kind=%d (nz %d pend %d) y.kind=%d (nz %d pend %d)", x.kind, a.buf ? (int)a.buf->nz : -1, (int)(a.pend != nullptr), y.kind,
+                         b.buf ? (int)b.buf->nz : -1, (int)(b.pend != nullptr));
+                g_scan_trace.counts[key]++;
+            }
+            return r;
+        }
+        Box U;
+        U.known = true;
+        auto contains = [](const Box& p, const Box& q) {
+            for (int u = 0; u < Buf::ZAX; ++u)
+                if (q.lo[u] < p.lo[u] || q.hi[u] > p.hi[u]) return false;
+            return true;
+        };
+        if (A.empty && B.empty) return Support{5};
+        if (A.empty || (!B.empty && contains(B, A))) U = B;
+        else if (B.empty || contains(A, B)) U = A;
+        else {
+            int diff = -1;
+            for (int u = 0; u < Buf::ZAX; ++u)
+                if (A.lo[u] != B.lo[u] || A.hi[u] != B.hi[u]) {
+                    if (diff >= 0) return r;  // (they differ on two axes: an L-shaped union)
+                    diff = u;
+                }
+            if (std::max(A.lo[diff], B.lo[diff]) > std::min(A.hi[diff], B.hi[diff])) return r;  // (a gap between them)
+            U = A;
+            U.lo[diff] = std::min(A.lo[diff], B.lo[diff]);
+            U.hi[diff] = std::max(A.hi[diff], B.hi[diff]);
+        }
+        // storable when the box reaches the end of the sum's own box on every axis: "leading zero slabs"
+        for (int u = 0; u < Buf::ZAX; ++u) {
+            const unsigned ext = (size_t)u < shape.size() ? (unsigned)std::min<size_t>(shape[u], 0xfffffffeu) : 1u;
+            if (U.hi[u] != ext) return r;
+            r.z[u] = U.lo[u];
+        }
+        for (size_t u = Buf::ZAX; u < shape.size(); ++u)
+            if (shape[u] != 1) return Support{0};
+        r.kind = 3;
+        r.normalise();
         return r;
     }
     static void sum_nz_store(const P& a, const P& b, const Dims& shape, Buf* out) { sum_support(a, b, shape).store(out); }
@@ -3285,6 +3370,12 @@ struct Ops {
         // Per step the derivative moves the leading zero slabs of axis v down by one, (x + eps_v) * D keeps them where x is not
         // zero (out[k] = D[k-1] + x * D[k]: non-zero iff one of the two is) and moves them up by one where it is.
         Support out_sup = support_of_poly<E>(a);
+        if (g_scan_trace.on && W == 2) {
+            char key[160];
+            snprintf(key, sizeof key, "observe_chain input: kind=%d (buf nz %d, pend %d, from %s)", out_sup.kind, a.buf ? (int)a.buf->nz : -1, (int)(a.pend != nullptr),
+                     a.buf && a.buf->origin ? a.buf->origin : "?");
+            g_scan_trace.counts[key]++;
+        }
         if (out_sup.exact()) {
             if (v < (size_t)Buf::ZAX) {
                 out_sup.kind = 3;
@@ -3293,7 +3384,7 @@ struct Ops {
                     out_sup.z[v] = val_is_zero(x) ? zd + 1 : zd;
                 }
                 for (size_t u = 0; u < (size_t)Buf::ZAX; ++u)
-                    if (out_sup.z[u] > 0 && out_sup.z[u] >= (u < S.size() ? S[u] : 1)) out_sup.kind = 1;  // (nothing but zeros)
+                    if (out_sup.z[u] > 0 && out_sup.z[u] >= (u < S.size() ? S[u] : 1)) out_sup.kind = 5;  // (nothing but zeros)
                 out_sup.normalise();
             } else
                 out_sup.kind = val_is_zero(x) ? 0 : out_sup.kind;
@@ -3337,7 +3428,7 @@ struct Ops {
     static int nz_query(const P& p) {
         static unsigned skip = 0, backoff = 0;
         if (W != 2 || !R.nz_proofs || !p.buf || p.buf->host || p.pend || p.numel < 64) return nz_of(p);
-        if (p.buf->nz) return p.buf->nz;
+        if (p.buf->nz) return p.buf->nz;  // (answered — 1: measured on this buffer, no slab pattern)
         if (skip) {
             --skip;
             return 0;
@@ -3355,6 +3446,13 @@ struct Ops {
             wait_mail(mb, cnt, 7);
             R.stats[1]++;
             has = cnt[0];
+            if (g_scan_trace.on) {
+                char key[200];
+                std::string shs;
+                for (size_t q = 0; q < p.shape.size(); ++q) shs += std::to_string(p.shape[q]) + "x";
+                snprintf(key, sizeof key, "zero pattern query: %s zeros=%g per-axis slab0 zeros: %g %g %g (backoff %u)", shs.c_str(), cnt[0], cnt[1], cnt[2], cnt[3], backoff);
+                g_scan_trace.counts[key]++;
+            }
             if (has != 0.0) {
                 Support sp;
                 sp.kind = 3;
@@ -3804,7 +3902,26 @@ struct Ops {
                     double c_[2], m_[2];
                     size_t u_;
                     ScanCtx sc_res("subst_var.accumulator");
+                    const Support sr_pre = g_scan_trace.on ? support_of_poly<E>(res) : Support();
+                    const int res_nz_pre = res.buf ? (int)res.buf->nz : -1, res_pend_pre = res.pend ? res.pend->n + 100 * (res.pend->base_off != 0) : -1;
+                    const bool res_same_pre = res.buf.get() == ca.buf.get();
+                    const bool res_lazy_pre = res.buf && res.buf->lazy != nullptr;
                     ScanToken tok = extract_linear_begin(res);
+                    if (g_scan_trace.on && W == 2) {  // why no proof: what is known about the operand's and the accumulator's zeros
+                        char key[200];
+                        const Support sc = support_of_poly<E>(ca), sr = support_of_poly<E>(res);
+                        std::string st;
+                        if (ca.pend) {
+                            st = ca.pend->padded ? "pad " : "";
+                            for (int q = 0; q < ca.pend->n; ++q) st += std::to_string(ca.pend->st[q].kind) + ",";
+                            if (ca.pend->base_off) st += "off";
+                        }
+                        (void)sr;
+                        snprintf(key, sizeof key, "no proof: ca buf.nz=%d kind=%d pend=[%s] from %s | res BEFORE the scan: kind=%d buf.nz=%d pend=%d same_buf=%d lazy=%d numel=%s res_seen=%d",
+                                 ca.buf ? (int)ca.buf->nz : -1, sc.kind, st.c_str(), ca.buf && ca.buf->origin ? ca.buf->origin : "?", sr_pre.kind, res_nz_pre, res_pend_pre, (int)res_same_pre,
+                                 (int)res_lazy_pre, res.numel < 64 ? "<64" : ">=64", (int)res_nonlinear_seen);
+                        g_scan_trace.counts[key]++;
+                    }
                     if (g_scan_trace.on) {
                         char key[160];
                         snprintf(key, sizeof key, "horner scan: done=%d lin_known=%d rank_ok=%d i=%s proven=%d len_v=%s", (int)tok.done, (int)lin_known,
@@ -3939,6 +4056,12 @@ struct Ops {
             double missing = 0.0;
             wait_mail(mb, &missing, 1);
             if (missing != 0.0) return false;
+        }
+        if (g_scan_trace.on && W == 2 && res.buf && !res.buf->host) {
+            char key[160];
+            const Support sr = support_of_poly<E>(res), sc = support_of_poly<E>(ca);
+            snprintf(key, sizeof key, "subst_var (speculative) result: kind=%d from ca kind=%d lin_known=%d proven=%d", sr.kind, sc.kind, (int)lin_known, (int)proven);
+            g_scan_trace.counts[key]++;
         }
         *result = res;
         return true;
@@ -4217,7 +4340,7 @@ struct Ops {
                 sp.kind = 3;
                 sp.normalise();
             } else
-                sp.kind = (sp.kind == 1 || sp.kind == 3 || sp.kind == 4) ? 1 : 0;
+                sp.kind = 0;
             sp.store(out.buf.get());
         }
         const unsigned lines = (unsigned)(fn / fs[w]);
@@ -4604,6 +4727,7 @@ static gft_poly* guard(F&& f, const char* fn = __builtin_FUNCTION()) {
         g_api_trace.hit(fn);
         ApiTrace::Timer timer(g_api_trace, fn);
         gft_poly* r = new gft_poly(f());
+        if (r->buf && !r->buf->origin) r->buf->origin = fn;
         g_api_trace.result(fn, *r);
         return r;
     } catch (const std::exception& e) {
