@@ -1333,6 +1333,28 @@ struct Ops {
         }
         P out = make(out_shape, out_deg, host);
         if (out.numel == 0) return out;
+        if (W == 2 && !host && !tab && !keep && (op == OP_COPY || op == OP_MUL_S || op == OP_DIV_S || op == OP_NEG || op == OP_LMUL_S) &&
+            !((op == OP_MUL_S || op == OP_LMUL_S) && s && val_is_zero(s))) {
+            // (round 6, Support) a box of the source that lies inside it keeps the source's zero pattern, seen from its own origin
+            Support sp = support_of_poly<E>(src);
+            bool inside = sp.exact() && out_shape.size() <= src.shape.size() && out_shape.size() <= (size_t)Buf::ZAX;
+            for (size_t ax = 0; ax < out_shape.size() && inside; ++ax) {
+                if (shift[ax] < 0 || (size_t)shift[ax] + out_shape[ax] > std::min(src_len[ax], src.shape[ax])) inside = false;
+                else {
+                    sp.z[ax] = sp.z[ax] > (size_t)shift[ax] ? (unsigned)(sp.z[ax] - (size_t)shift[ax]) : 0u;
+                    if (sp.z[ax] > 0 && sp.z[ax] >= out_shape[ax]) sp.kind = 5;
+                }
+            }
+            for (size_t ax = out_shape.size(); ax < src.shape.size() && inside; ++ax)
+                if (src.shape[ax] != 1) inside = false;
+            if (inside) {
+                if (sp.kind != 5) {
+                    sp.kind = 3;
+                    sp.normalise();
+                }
+                sp.store(out.buf.get());
+            }
+        }
         Dims sst = c_strides(src.shape);
         // collapse axes that are trivial in the output and read index 0 (+shift) of the source
         GatherArgs a;
@@ -3482,7 +3504,7 @@ struct Ops {
         }
         p.buf->nz = has != 0.0 ? 1 : 2;
         if (has != 0.0) {
-            backoff = backoff ? std::min(backoff * 2, 4096u) : 32;
+            backoff = backoff ? std::min(backoff * 2, 256u) : 16;  // (round 6: 4096 -> 256 — a program whose first statements have irregular zeros settles into slabs later)
             skip = backoff;
         } else
             backoff = 0;
@@ -3883,6 +3905,20 @@ struct Ops {
             ca_h_lo = lo;
             ca_h_hi = i_top + 1;
         };
+        // (round 6) a proven loop on a tensor nothing is known about: ask once where its zeros are (nz_query: one launch and round
+        // trip, what a single linearity scan costs — and the answer is inherited by everything computed from the tensor)
+        if (W == 2 && proven && R.nz_proofs && !on_host(ca) && ca.numel >= 64 && ca.buf->nz == 0) {
+            if (!ca.pend) (void)nz_query(ca);
+            else if (!ca.pend->mat) {  // a chain: the question goes to its base tensor, the chain's stages carry the answer over
+                P base;
+                base.width = W;
+                base.shape = ca.pend->base_shape;
+                base.deg = ca.pend->base_shape;
+                base.numel = ca.pend->base_numel;
+                base.buf = ca.buf;
+                if (base.numel >= 64 && prod(base.shape) == base.numel) (void)nz_query(base);
+            }
+        }
         for (size_t i = ca.shape[v]; i-- > 0;) {
             bool speculate = false;
             if (!on_host(res) && res.numel > 1) {
@@ -4011,6 +4047,18 @@ struct Ops {
                         res = horner_linear_step(res, ca, v, i, c, m, w, deg);
                         continue;
                     }
+                }
+                if (g_scan_trace.on && W == 2 && !on_host(ca)) {
+                    P hc = horner_coeff(ca, v, i, deg);
+                    P pr = mul(res, subst);
+                    P nx = addsub(pr, hc, false);
+                    char key[200];
+                    snprintf(key, sizeof key, "reference step: coeff pend=%d off=%d same=%d | prod numel=%zu cached=%d host=%d | next pend=%d same=%d host=%d numel=%s", hc.pend ? hc.pend->n : -1,
+                             hc.pend ? (int)(hc.pend->base_off != 0) : -1, (int)(hc.buf.get() == ca.buf.get()), pr.numel, (int)pr.cached, (int)on_host(pr), nx.pend ? nx.pend->n : -1,
+                             (int)(nx.buf.get() == ca.buf.get()), (int)on_host(nx), nx.numel < 64 ? "<64" : ">=64");
+                    g_scan_trace.counts[key]++;
+                    res = nx;
+                    continue;
                 }
                 res = addsub(mul(res, subst), horner_coeff(ca, v, i, deg), false);
                 continue;
