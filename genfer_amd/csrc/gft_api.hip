@@ -181,15 +181,12 @@ struct Runtime {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    unsigned long long side_min_age = 2;    // stream operations since an input was produced for it to count as "old" (recorded Horner loops)
     size_t stats_side[4] = {0, 0, 0, 0};    // {-, -, recordings that rode along with another launch of their kind, lazy observations fused}
-    bool obs_riders = true;                 // "obs_riders" / GFT_OBS_RIDERS: recorded chains ride along with other observation launches
     size_t stats_nz = 0;                    // linearity scans answered by a "no exact zero" proof
     size_t stats_sum = 0;                   // Adds that evaluated a recorded Add of two chains in their own launch (K<E>::chain_nest)
     bool lazy_sum = true;                   // "lazy_sum" / GFT_LAZY_SUM: Adds of two chains are recorded, not launched (Ops::fuse_lazy_sums)
     bool nz_proofs = true;                  // "nz_proofs" / GFT_NZ_PROOFS: interval tensors proven free of exact zeros skip the Horner loops' linearity scans
     bool lazy_horner = true;                // "lazy_horner" / GFT_LAZY_HORNER: proven Horner loops on old operands are recorded (Ops::horner_linear_rest)
-    bool horner_riders = true;              // "horner_riders" / GFT_HORNER_RIDERS: ... and ride along with other loops' launches
     bool batch_dag = true;                  // "batch_dag" / GFT_BATCH: recordings form a launch graph issued level by level as batches (gft_batch.hpp)
     bool lazy_observe = true;               // "lazy_observe" / GFT_LAZY_OBSERVE: observation chains are recorded, not launched (Ops::observe_chain)
     // Side stream of the blocked recurrences (div / log): the bulk of a right-looking update runs here while the main
@@ -213,7 +210,7 @@ struct Runtime {
     unsigned long long mail_seq = 0;
     hipEvent_t events[64] = {};
     int conv_mode = 0;
-    int pairs_first = 1;                 // small plain f64 products ask the row-pair form before the tiled kernel ("pairs_first", GFT_PAIRS_FIRST)
+    static constexpr int pairs_first = 1;  // small plain f64 products ask the row-pair form before the tiled kernel ("pairs_first", GFT_PAIRS_FIRST)
     double pairs_first_max = 1.0e7, pairs_first_max_rank2 = 2.0e8;  // ... up to this many multiply-adds (rank >= 3 / rank 2)
     double tiled_min_macs = 2.0e5;  // auto mode: products below this stay on the reference-order kernels
     double tiled_min_override = -1;  // >= 0 while a div / log recurrence issues its accumulation products (recur_tiled_min_macs)
@@ -221,25 +218,16 @@ struct Runtime {
     // quotient of a division cancels, and the tiled kernel's summation order showed up as 4e-10 relative on single
     // coefficients of a 64^3 quotient (profiles/r02/recurrences.txt) — inside the normwise bound of SURVEY 8d, outside
     // the 1e-10-per-coefficient contract.  gft_set_option("recur_tiled_min_macs", 5e7) trades that for ~20 % at 64^3.
-    double recur_tiled_min_macs = 1.0e300;
+    static constexpr double recur_tiled_min_macs = 1.0e300;  // (round 6: no longer an option — the recurrences keep the reference's order)
     size_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see gft_op_stats
     size_t stats_ex[4] = {0, 0, 0, 0};  // {operations deferred into a chain, chains materialised, fused chain add/sub launches, -}
     bool defer = true;             // GFT_DEFER=0 / "defer": one launch per elementwise operation (A/B, bisecting)
     size_t horner_loop_max = (size_t)1 << 40;  // elements of the final tensor up to which the whole Horner loop is one launch
-    bool fuse_horner = true;       // GFT_FUSE_HORNER=0: generic Horner loop (A/B and bisecting)
-    bool div2d = true;             // GFT_DIV2D=0: host-driven division recursion down to 1-d rows (A/B and bisecting)
+    static constexpr bool fuse_horner = true;  // (the fused / speculative Horner loop; the generic loop is horner_exact)
+    static constexpr bool div2d = true;  // (the last two axes of the division recurrence in one launch; the host-driven recursion is the fallback for shapes outside the kernels' domains)
     bool div_wavefront = true;     // GFT_DIV_WAVEFRONT=0 / "div_wavefront": the blocked recurrence instead of the one-launch row wavefront
-    bool rows_wavefront = true;    // GFT_ROWS_WAVEFRONT=0 / "rows_wavefront": rank-2 recurrences with rows > 64 row by row (A/B, bisecting)
+    static constexpr bool rows_wavefront = true;  // (rank-2 recurrences with rows > 64 as a coefficient-level wavefront)
     bool exp_right = true;         // GFT_EXP_RIGHT=0 / "exp_right": left-looking exp steps everywhere (A/B and bisecting)
-    // "div_right" / GFT_DIV_RIGHT=1: large f64 div / log as a blocked right-looking recurrence on the tiled kernel (Ops::div_right_blocked).
-    // OFF by default: measured (profiles/r05/recurrences_div_right.txt) the diagonal blocks are bound by their dependency DEPTH
-    // (B + n1 row steps of ~11 us each), not by their work, so four blocks of a 64^3 quotient cost what the whole wavefront
-    // costs (4.5 vs 4.0 ms; 3.6 ms with two blocks of 32; 24^4 with blocks of 8: 6.2 -> 3.6 ms) — and the form gives up the
-    // reference's bits for the tiled kernel's 1e-10 contract.
-    bool div_right = false;
-    double div_right_min_macs = 1.0e9;  // "div_right_min_macs": ... from this many multiply-adds
-    size_t div_right_block = 16;   // "div_right_block": leading slabs per diagonal block
-    size_t stats_right[2] = {0, 0};  // {blocked divisions, blocked logarithms}
     // Shallow products (round 4): a plain product whose outputs receive at most this many terms each (prod_i min(xs_i, ys_i):
     // one operand is a stencil — the substitutions of `+~ Binomial(other, p)` statements are 3-6 coefficients) runs on the
     // reference-order one-thread-per-output kernel with the Horner step's Add fused in (K<E>::conv_shallow) instead of the
@@ -277,7 +265,6 @@ static size_t size_class(size_t bytes) {
 
 static void release_kernel_scratch() { staged_release_scratch(); }  // (the device is idle when this is called)
 
-static inline unsigned long long main_ops_now() { return gft::g_stream_ops; }
 
 static void* pool_alloc(size_t bytes, size_t* cls_out) {
     size_t cls = size_class(bytes);
@@ -338,7 +325,6 @@ struct Buf : std::enable_shared_from_this<Buf> {
     size_t cls = 0;
     bool borrowed = false;
     bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
-    unsigned long long birth = 0;   // stream operations issued when the buffer was created (see birth_of)
     // the contents have not been launched yet (a recorded observation chain): use_buf() launches, or the consumer fuses
     std::shared_ptr<LazyOp> lazy;
     // interval tensors: 2 = PROVEN to hold no coefficient that is exactly [0,0] (Ops::nz_of), 1 = holds one / descends from a
@@ -348,9 +334,6 @@ struct Buf : std::enable_shared_from_this<Buf> {
     // axis u < ZAX (what `observe k ~ Poisson(l * X)` leaves behind when X is evaluated at 0: slab 0 along X) — see Support
     static constexpr int ZAX = 8;
     unsigned short zpre[ZAX] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // force_buf() is launching the producer of this buffer right now: its values are being WRITTEN by the launch under
-    // construction, so nothing that reads it may ride in that same launch (launch_obs / launch_horner rider searches)
-    bool writing = false;
     // a recording's buffer gets its pool block when it is launched (ensure_alloc): `want` doubles; p == nullptr until then
     size_t want = 0;
     const char* origin = nullptr;  // the entry point whose result first owned this buffer (diagnostics: GFT_TRACE_SCANS)
@@ -382,24 +365,19 @@ struct LazyOp {
     std::shared_ptr<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
     std::shared_ptr<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
     std::shared_ptr<void> sum;     // Ops<E>::LazySum: a recorded Add / Sub of two chains (an Add that consumes it launches both: K<E>::chain_nest)
-    unsigned long long input_birth = 0;  // when the recording's inputs were there (main-stream operation count): the buffer's age once launched
 };
-// When the values of a buffer were (or, for a recording, could have been) there, in main-stream operations.
-static unsigned long long birth_of(const Buf* b) { return b->lazy ? b->lazy->input_birth : b->birth; }
 
 // (+ 8 doubles of slack: the tiled product reads operands in place and its pipelined x loads request one 64-byte chunk
 // beyond the last one they use — gft_conv_tiled.hip, ConvArgs::operands_slack)
 static std::shared_ptr<Buf> alloc_doubles(size_t n) {
     auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
-    b->birth = main_ops_now();
     return b;
 }
 // a recording's result: no memory yet (ensure_alloc, when the recording is launched)
 static std::shared_ptr<Buf> alloc_recorded(size_t n) {
     auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
     b->want = std::max<size_t>(n, 1);
-    b->birth = main_ops_now();
     return b;
 }
 static void ensure_alloc(Buf* b) {
@@ -428,19 +406,13 @@ static void force_buf(Buf* b) {
         return;
     }
     ensure_alloc(b);
-    const unsigned long long birth0 = b->birth;
     b->lazy = nullptr;  // (first: run() reaches dp() of OTHER buffers only)
-    b->writing = true;  // (... and a recording that READS this buffer must not ride in the launch that writes it)
-    b->birth = op->input_birth;  // (its inputs' age, not the launch's: what reads it may still be "old news" to the main chain)
     try {
         op->run(b);
     } catch (...) {  // nothing was launched into b->p (pool exhaustion, a refused launch): the buffer is still a recording
         b->lazy = op;
-        b->birth = birth0;
-        b->writing = false;
         throw;
     }
-    b->writing = false;
 }
 static void require_ready() {
     if (!R.ready) {
@@ -1616,11 +1588,7 @@ struct Ops {
             rec->subtract = subtract;
             P out = make_recorded(shape, rd);
             sum_nz_store(self, other, shape, out.buf.get());
-            unsigned long long ib = 0;
-            DagRec::Deps ds;
-            rec->deps(ds);
-            for (Buf* d : ds) ib = std::max(ib, birth_of(d));
-            out.buf->lazy = op_of(rec, ib);
+            out.buf->lazy = op_of(rec);
             *result = out;
             return true;
         }
@@ -1856,10 +1824,6 @@ struct Ops {
                     auto rec = std::allocate_shared<SumRec>(gft_small::Alloc<SumRec>());
                     rec->ls = ls;
                     op->rec = rec;
-                    unsigned long long ib = 0;
-                    if (self.buf && !self.buf->host) ib = std::max(ib, birth_of(self.buf.get()));
-                    if (other.buf && !other.buf->host) ib = std::max(ib, birth_of(other.buf.get()));
-                    op->input_birth = ib;
                     out.buf->lazy = op;
                     return out;
                 }
@@ -2700,7 +2664,6 @@ struct Ops {
             if (rs[i] == UMAX) throw Error("div: untruncated result shape (degrees_p1 == usize::MAX)");
         const bool host = tier_host(prod(rs), self, other) && est_macs(rs, other.shape, rs) <= R.host_max_macs;
         P out = make(rs, deg, host);
-        if (!host && div_right_blocked(self, other, out)) return out;
         if (!host && div_wavefront(self, other, out)) return out;
         div_rec(view(self, host), view(other, host), view(out, host));
         return seal(out);
@@ -2742,114 +2705,6 @@ struct Ops {
         zero_elems(false, fl->p, (rows + 1 + 1) / 2 + 1);
         return K<E>::div_wavefront(R.stream, x.p, x.plane, xs, y.p, y.plane, ys, z.p, z.plane, zs, (int)nd, reinterpret_cast<unsigned*>(fl->p));
     }
-    // Large f64 quotients: the recurrence BLOCKED over the leading axis, right-looking (round 5).  The wavefronts keep the
-    // reference's order and pay for it with two 8-byte LDS reads per multiply-add on one workgroup per CU: 2-6 % of the FP64
-    // roof at every size, 8-10x the time of the product of the same multiply-adds.  But only the terms INSIDE a block of B
-    // leading slabs depend on each other slab by slab:
-    //   res[b0..b1) = (xs[b0..b1) - sum_{j < b0} res[j] (*) ys[k - j]) / ys[0..B)        -- a division of B slabs: the wavefront
-    //   acc[k] += sum_{j in block} res[j] (*) ys[k - j]   for k >= b1                       -- ONE slab-range product, accumulating:
-    // the tiled FMA kernel (gft_conv_raw's own accumulate mode).  The quotient's memory holds the running sums, as in div_rec.
-    // Contract: the tiled kernel's (explicit FMA, its own summation order) — 1e-10 against the oracle, normwise on data whose
-    // quotient cancels; non-finite operands reach the guarded reference-order product, so the non-finite pattern is the
-    // reference's.  "div_right" = 0 (GFT_DIV_RIGHT) keeps the reference order everywhere; below div_right_min_macs it is kept
-    // anyway (the wavefront alone is faster there).
-    static bool div_right_blocked(const P& self, const P& other, const P& out) {
-        if (W != 1 || !R.div_right) return false;
-        Dims keep = collapse_mask({&out.shape}, false);
-        if (keep.size() < 2 || keep.size() > 4) return false;
-        Dims xsh = pick(self.shape, keep), ysh = pick(other.shape, keep), zsh = pick(out.shape, keep);
-        if (!div_right_applies(xsh, ysh, zsh)) return false;  // (before dp(): nothing is launched for a product this form declines)
-        HV x{dp<E>(self), self.numel, xsh, false}, y{dp<E>(other), other.numel, ysh, false}, z{dp<E>(out), out.numel, zsh, false};
-        div_right_hv(x, y, z);
-        R.stats_right[0]++;
-        return true;
-    }
-    static size_t div_right_block_of(const Dims& zsh) {
-        const size_t nd = zsh.size(), n0 = zsh[0], last = zsh[nd - 1], rows_per_slab = prod(zsh) / n0 / last;
-        size_t B = std::max<size_t>(R.div_right_block, 1);
-        if (last <= 64) B = std::max(B, (64 + rows_per_slab - 1) / rows_per_slab);  // the block's row wavefront wants >= 64 rows
-        else B = std::max<size_t>(B, 8);                                               // ... the long-row one >= 8
-        return B;
-    }
-    static bool div_right_applies(const Dims& xsh, const Dims& ysh, const Dims& zsh) {
-        if (W != 1 || !R.div_right || !R.div_wavefront || !R.div2d || R.conv_mode == 1 || R.conv_mode == 3) return false;
-        const size_t nd = zsh.size();
-        if (nd < 2 || nd > 4 || xsh.size() != nd || ysh.size() != nd) return false;
-        const size_t last = zsh[nd - 1];
-        if (last < 2 || !(last <= 64 || (nd == 2 && last <= 4096 && R.rows_wavefront))) return false;
-        for (size_t i = 0; i < nd; ++i)
-            if (xsh[i] > zsh[i] || ysh[i] > zsh[i] || ysh[i] == 0 || zsh[i] < 2) return false;
-        if (est_macs(zsh, ysh, zsh) < R.div_right_min_macs) return false;
-        return zsh[0] >= 2 * div_right_block_of(zsh);
-    }
-    // z = x / y on contiguous views without unit axes (div_right_applies holds).  x may be shorter than z on any axis.
-    static void div_right_hv(const HV& x, const HV& y, const HV& z) {
-        const Dims &xsh = x.shape, &ysh = y.shape, &zsh = z.shape;
-        const size_t n0 = zsh[0], B = div_right_block_of(zsh);
-        const size_t slab = z.numel() / n0, xslab = xsh[0] ? x.numel() / xsh[0] : 0;
-        Dims rest(zsh.begin() + 1, zsh.end()), yrest(ysh.begin() + 1, ysh.end()), xrest(xsh.begin() + 1, xsh.end());
-        const bool x_full = xrest == rest;
-        zero_elems(false, z.p, z.numel());
-        for (size_t b0 = 0; b0 < n0;) {
-            const size_t b1 = n0 - (b0 + B) < B ? n0 : b0 + B, nb = b1 - b0;  // (a short remainder joins the last block)
-            // the block's dividend: xs[b0..b1) - (what the earlier blocks have accumulated into res[b0..b1))
-            std::shared_ptr<Buf> tmp = alloc_doubles(nb * slab);
-            Dims bsh{nb};
-            bsh.insert(bsh.end(), rest.begin(), rest.end());
-            HV tv{tmp->p, nb * slab, bsh, false}, zb{z.p + b0 * slab, z.plane, bsh, false};
-            if (b0 == 0) zero_elems(false, tmp->p, nb * slab);
-            else {
-                copy_elems(false, tmp->p, zb.p, nb * slab);
-                x_map_inplace(tv, MAP_NEG, 0);
-            }
-            if (b0 < xsh[0]) {
-                const size_t nx = std::min(b1, xsh[0]) - b0;
-                if (x_full) {
-                    Dims s{nx};
-                    s.insert(s.end(), rest.begin(), rest.end());
-                    x_block_op(HV{tmp->p, nb * slab, s, false}, HV{x.p + b0 * xslab, x.plane, s, false}, BLK_ADD, 0);
-                } else {
-                    for (size_t k = 0; k < nx; ++k) x_block_op(tv.index0(k), HV{x.p + (b0 + k) * xslab, x.plane, xrest, false}, BLK_ADD, 0);
-                }
-            }
-            Dims ybsh{std::min(nb, ysh[0])};
-            ybsh.insert(ybsh.end(), yrest.begin(), yrest.end());
-            if (!div_wavefront_hv(tv, HV{y.p, y.plane, ybsh, false}, zb)) throw Error("internal: blocked division: the block's wavefront declined");
-            if (b1 < n0 && ysh[0] >= 2) {  // trailing update: res[b0 + k'] += sum_{j' < nb} res[b0 + j'] (*) ys[k' - j'] for k' in [nb, ..)
-                const size_t hi = std::min(n0 - b0, nb + ysh[0] - 1);
-                Dims zt{n0 - b0};
-                zt.insert(zt.end(), rest.begin(), rest.end());
-                conv(zb, y, HV{z.p + b0 * slab, z.plane, zt, false}, nb, hi, true, false, 0, 0, 0);
-            }
-            b0 = b1;
-        }
-    }
-    // The slabs k0 >= 1 of log(xs) the same way (slab 0 — a logarithm one dimension down — is there already): with
-    // q_k = k * res[k] the recurrence mt:1362-1384 reads q_k = (k xs[k] - sum_{1 <= j < k} xs[k-j] (*) q_j) / xs[0], which is the
-    // division (k xs[k])_{k >= 1} / xs, and res[k] = q_k / k.  Same contract as div_right_blocked.
-    static bool log_right(const HV& xs, const HV& res) {
-        if (W != 1 || res.host || xs.host) return false;
-        const size_t nd = res.shape.size();
-        if (nd < 2 || nd > 4 || xs.shape.size() != nd || xs.shape[0] < 2) return false;
-        for (size_t i = 0; i < nd; ++i)
-            if (res.shape[i] < 2 || xs.shape[i] > res.shape[i]) return false;
-        Dims qsh = res.shape, xq = xs.shape;
-        qsh[0] -= 1;
-        xq[0] -= 1;
-        Dims yq = xs.shape;  // the divisor: the slabs of xs the quotient's q0 slabs can see
-        yq[0] = std::min(yq[0], qsh[0]);
-        if (qsh[0] < 2 || !div_right_applies(xq, yq, qsh)) return false;
-        HV scaled;
-        std::shared_ptr<Buf> sb = scaled_by_index(xs, &scaled);  // xs[j] * j
-        const size_t xslab = xs.numel() / xs.shape[0], slab = res.numel() / res.shape[0];
-        std::shared_ptr<Buf> qb = alloc_doubles(qsh[0] * slab);
-        HV q{qb->p, qsh[0] * slab, qsh, false};
-        div_right_hv(HV{scaled.p + xslab, scaled.plane, xq, false}, HV{xs.p, xs.plane, yq, false}, q);
-        K<E>::div_by_index(R.stream, q.p, q.plane, res.p + slab, res.plane, qsh[0], slab, 1u);
-        R.stats_right[1]++;
-        return true;
-    }
-
     // ---- exp / log (mt:406-430, 1270-1386) ---------------------------------------------------------------------
     // xs scaled slab-wise by T::from(j) along axis 0 (mt:1308-1310): xs[j] * j
     static std::shared_ptr<Buf> scaled_by_index(const HV& xs, HV* out) {
@@ -3028,7 +2883,6 @@ struct Ops {
         log_rec(xs.index0(0), res.index0(0), seed);
         size_t n0 = res.shape[0];
         if (n0 <= 1) return;
-        if (!host && log_right(xs, res)) return;  // (large f64 logarithms: blocked right-looking, the tiled product's contract)
         if (!host && log_wavefront(xs, res)) return;
         // rs[j] = res[j] * j, filled slab by slab as res becomes known (mt:1362-1365)
         std::shared_ptr<Buf> rsbuf = alloc_tier(host, res.numel() * W);
@@ -3167,10 +3021,7 @@ struct Ops {
         std::shared_ptr<Buf> tab = alloc_tier(host, len * W);
         if (host) HK<E>::factor_table(table_op, (unsigned)n, (unsigned)len, nullptr, 0, tab->p, len);
         else if (len * W <= 1920 && [] {
-                     static const bool on = [] {
-                         const char* e = getenv("GFT_HOST_TABLES");  // A/B knob
-                         return e ? atoi(e) != 0 : true;
-                     }();
+                     static const bool on = true;
                      return on;
                  }()) {
             // a data-independent table is a serial chain (a running product): one GPU lane takes 8 us for 200 f64 factors
@@ -3429,13 +3280,11 @@ struct Ops {
             lo->out_numel = out.numel;
             auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
             op->obs = lo;
-            op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr, b); };
-            op->input_birth = birth_of(a.buf.get());
+            op->run = [lo](Buf* b) { launch_obs(*lo, b->p, lo->out_numel, nullptr); };
             auto rec = std::allocate_shared<ObsRec>(gft_small::Alloc<ObsRec>());
             rec->lo = lo;
             op->rec = rec;
             out.buf->lazy = op;
-            if (!R.batch_dag) pending_push(pending_obs(), out.buf);  // (riders are what a level of the launch graph generalises)
             return out;
         }
         P out = make(S, G);
@@ -3520,78 +3369,11 @@ struct Ops {
         size_t out_numel = 0;
         bool fused = false;         // a consumer has launched it with its Add folded in: the plain values are (so far) nobody's business
     };
-    // Recorded chains that nobody has needed yet, most recent last.  The next observation launch of this element type takes
-    // the most recent one whose input is in memory along as its second chain (K<E>::observe_chain_multi): on the way back up
-    // a chain of `if`s every launch of the critical path carries the independent arm of a statement further up.
-    static std::vector<std::weak_ptr<Buf>>& pending_obs() {
-        static std::vector<std::weak_ptr<Buf>> v;
-        return v;
-    }
-    // (entries whose buffer has been freed, launched or fused away are dropped where the rider search meets them; a list that
-    // has grown anyway — recordings nobody ever rode with — is swept here, so it stays a few thousand weak pointers at most)
-    static void pending_push(std::vector<std::weak_ptr<Buf>>& v, const std::shared_ptr<Buf>& b) {
-        if (v.size() >= 4096) {
-            size_t k = 0;
-            for (size_t i = 0; i < v.size(); ++i) {
-                std::shared_ptr<Buf> p = v[i].lock();
-                if (!p || !p->lazy) continue;
-                if (p->lazy->obs && static_cast<LazyObs*>(p->lazy->obs.get())->fused) continue;
-                v[k++] = v[i];
-            }
-            v.resize(k);
-        }
-        v.push_back(b);
-    }
-    // Launches a recorded chain into `outp` (its own buffer `self`, or a consumer's output with the epilogue `epi`).
-    static void launch_obs(LazyObs& lo, double* outp, size_t out_numel, const ObsEpi* epi, Buf* self) {
+    // Launches a recorded chain into `outp` (its own buffer, or a consumer's output with the epilogue `epi`) — the unbatched
+    // form ("batch_dag" off; with it on a recording is issued with its level of the launch graph, gft_api_dag.inc).
+    static void launch_obs(LazyObs& lo, double* outp, size_t out_numel, const ObsEpi* epi) {
         const double* ap = dp<E>(lo.a);  // (a recorded input is launched first, on its own)
-        std::shared_ptr<Buf> ride;
-        std::shared_ptr<LazyOp> rop;
-        LazyObs* ro = nullptr;
-        auto& pend = pending_obs();
-        if (R.obs_riders)
-            for (size_t i = pend.size(); i-- > 0;) {
-                std::shared_ptr<Buf> b = pend[i].lock();
-                if (!b || !b->lazy || !b->lazy->obs) {
-                    pend.erase(pend.begin() + (long)i);
-                    continue;
-                }
-                LazyObs* c = static_cast<LazyObs*>(b->lazy->obs.get());
-                if (c->fused) {
-                    pend.erase(pend.begin() + (long)i);
-                    continue;
-                }
-                if (b.get() == self || c == &lo) continue;
-                const Buf* ib = c->a.buf.get();
-                if (!ib || ib->host || ib->lazy || c->a.pend) continue;  // its input is not in device memory (yet)
-                // ... or is what THIS launch (or a force_buf() further up the stack) is about to write: a rider reads its
-                // input while the carrier's workgroups of the same grid are still producing it
-                if (ib->writing || ib->p == outp) continue;
-                ride = b;
-                rop = b->lazy;
-                ro = c;
-                pend.erase(pend.begin() + (long)i);
-                break;
-            }
-        if (!ro) {
-            K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, nullptr, 0, nullptr, 0, nullptr, 0, 0);
-            return;
-        }
-        const double* rap = dp<E>(ro->a);  // (in memory: no launch)
-        ensure_alloc(ride.get());
-        const unsigned long long rbirth = ride->birth;
-        ride->lazy = nullptr;
-        ride->birth = rop->input_birth;
-        try {
-            K<E>::observe_chain_multi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi, rap, ro->a.numel, ride->p,
-                                      ro->out_numel, &ro->g, ro->lines, ro->longest);
-        } catch (...) {  // nothing was launched: the rider is still a recording
-            ride->lazy = rop;
-            ride->birth = rbirth;
-            pending_push(pend, ride);
-            throw;
-        }
-        R.stats_side[2]++;
+        K<E>::observe_chain_epi(R.stream, ap, lo.a.numel, outp, out_numel, lo.g, lo.lines, lo.longest, epi);
     }
     // addsub(self, other) where one operand is a chain on top of a recorded observation whose result is the whole output:
     // the observation kernel runs with the other operand's chain and the Add as its epilogue (ObsEpi).  false = not this
@@ -3659,7 +3441,7 @@ struct Ops {
             sum_nz_store(self, other, shape, out.buf.get());
             rec->out_numel = out.numel;
             lo->fused = true;
-            out.buf->lazy = op_of(rec, birth_of_inputs({&lo->a, &Y}));
+            out.buf->lazy = op_of(rec);
             *result = out;
             return true;
         }
@@ -3671,7 +3453,7 @@ struct Ops {
         e.y = chain_src_dev(Y, lo->okeep);
         P out = make(shape, rd);
         sum_nz_store(self, other, shape, out.buf.get());
-        launch_obs(*lo, dp<E>(out), out.numel, &e, X.buf.get());
+        launch_obs(*lo, dp<E>(out), out.numel, &e);
         R.stats_side[3]++;
         R.stats_ex[2]++;
         *result = out;
@@ -3740,10 +3522,6 @@ struct Ops {
     // ---- subst_var (mt:540-580) -----------------------------------------------------------------------------------------
     static P subst_var(const P& a, size_t v, const P& subst) {
         if (v >= a.shape.size()) return a;
-        // (before anything below launches a recorded input) is the operand old news to the main chain?  Then its Horner loop,
-        // if it comes to one, is recorded and rides along with a later loop's launch (horner_linear_rest, LazyHorner)
-        const bool old_input = R.lazy_horner && a.buf && !a.buf->host && !a.buf->borrowed &&
-                               main_ops_now() - birth_of(a.buf.get()) >= R.side_min_age;
         Dims deg = min_degrees(a, subst);
         if (is_zero(subst)) return slab_range(a, v, 0, 1, deg);
         double c[2], m[2];
@@ -3785,10 +3563,7 @@ struct Ops {
                     // same functor on the host, so the same bits — are formed here.  Up to HTAB_CAP of them travel BY VALUE
                     // with the gather (no table launch, no per-thread running product, no device mirror of a host-resident
                     // subst); longer tables are uploaded.
-                    static const bool htab_on = [] {
-                        const char* e = getenv("GFT_POW_HTAB");  // A/B knob
-                        return e ? atoi(e) != 0 : true;
-                    }();
+                    static const bool htab_on = true;
                     if (htab_on) {
                         std::vector<double> pw(lens[v] * W);
                         typename E::V f = E::one();
@@ -3821,7 +3596,7 @@ struct Ops {
         // linear substitution known from the scan above (memoised on subst's buffer): fused Horner steps
         const bool lin_known = extract_linear(subst, c, m, &w) && w < deg.size() && deg[w] >= 2;
         P res;
-        if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res, old_input)) return res;
+        if (R.fuse_horner && cshape[v] <= WIT_SLOTS && horner_speculative(ca, v, subst, deg, lin_known, c, m, w, &res)) return res;
         return horner_exact(ca, v, subst, deg);
     }
     // One Horner coefficient: a[.., i, ..] clipped to deg (mt:571-576)
@@ -3861,7 +3636,7 @@ struct Ops {
     }
     static constexpr size_t WIT_SLOTS = 8192;
     static bool horner_speculative(const P& ca, size_t v, const P& subst, const Dims& deg, bool lin_known, const double c[2],
-                                   const double m[2], size_t w, P* result, bool old_input = false) {
+                                   const double m[2], size_t w, P* result) {
         ScanCtx sc_hs("subst_var.horner_speculative");
         P res = zero_with(deg);
         bool res_nonlinear_seen = false;
@@ -3895,10 +3670,7 @@ struct Ops {
         constexpr size_t HBLK = 8;
         P ca_h;                       // host-tier copy of the slabs [ca_h_lo, ca_h_hi) of ca along v
         size_t ca_h_lo = 0, ca_h_hi = 0;
-        static const bool host_phase_on = [] {
-            const char* e = getenv("GFT_HORNER_HOST_PHASE");  // A/B knob
-            return e ? atoi(e) != 0 : true;
-        }();
+        static const bool host_phase_on = true;
         auto fetch_block = [&](size_t i_top) {
             const size_t lo = i_top + 1 > HBLK ? i_top + 1 - HBLK : 0;
             ca_h = to_host_tier(slab_range(ca, v, lo, i_top + 1, ca.deg, OP_COPY, -1, nullptr, 0, 0));
@@ -3973,17 +3745,14 @@ struct Ops {
                     P ahead;
                     bool queued = false;
                     unsigned* ahead_wit = (proven || slots + (unsigned)i > WIT_SLOTS) ? nullptr : R.d_wit + slots;
-                    static const bool ahead_on = [] {
-                        const char* e = getenv("GFT_HORNER_AHEAD");  // A/B knob: 0 = wait for the verdict, then launch
-                        return e ? atoi(e) != 0 : true;
-                    }();
+                    static const bool ahead_on = true;
                     bool queued_step = false;
                     if (ahead_on && !tok.done && R.fuse_horner && lin_known && res.shape.size() == deg.size()) {
                         if (i >= 1 && (proven || ahead_wit)) {
                             if (slots == 0 && !proven) HIP_OK(hipMemsetAsync(R.d_wit, 0, sizeof(unsigned) * WIT_SLOTS, R.stream));
                             // a proven loop on an operand the main chain has long passed: RECORDED (its launch needs no guard —
                             // nobody looks at the handle before the verdict below is in — and is dropped if the verdict is "linear")
-                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16, proven && (old_input || R.batch_dag));
+                            queued = horner_linear_rest(res, ca, v, i, c, m, w, deg, &ahead, ahead_wit, R.d_flag + 16, proven && R.lazy_horner && R.batch_dag);
                         }
                         // ... or the single fused step where the whole-loop launch does not apply: the last step (nothing is
                         // speculated about its result), or any step of a proven loop (no witness to raise)
@@ -4067,17 +3836,14 @@ struct Ops {
             bool witnessed = false;
             if (lin_known && res.shape.size() == deg.size()) {
                 // every remaining step in one launch (one workgroup per line along w); witnesses are raised in the kernel
-                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots, nullptr, proven && (old_input || R.batch_dag))) {
+                if (i >= 1 && horner_linear_rest(res, ca, v, i, c, m, w, deg, &res, proven ? nullptr : R.d_wit + slots, nullptr, proven && R.lazy_horner && R.batch_dag)) {
                     if (!proven) slots += (unsigned)i;  // the accumulators after the in-kernel steps 0 .. i-1 (the last one is the result)
                     break;
                 }
                 res = horner_linear_step(res, ca, v, i, c, m, w, deg);
             } else {
                 P nxt;
-                static const int shallow_diag = [] {
-                    const char* e = getenv("GFT_SHALLOW_DIAG");  // 1: witness in its own launch (A/B)
-                    return e ? atoi(e) : 0;
-                }();
+                static const int shallow_diag = 0;
                 const bool fuse_wit = !(shallow_diag & 1);
                 if (horner_general_step_fused(res, subst, ca, v, i, deg, (fuse_wit && i > 0 && !proven) ? R.d_wit + slots : nullptr, &nxt)) {
                     res = nxt;
@@ -4248,66 +4014,14 @@ struct Ops {
         unsigned lines = 0;
         size_t fn = 0;
     };
-    static std::vector<std::weak_ptr<Buf>>& pending_horner() {  // recorded loops nobody has needed yet, most recent last
-        static std::vector<std::weak_ptr<Buf>> v;
-        return v;
-    }
-    // Launches a loop — a recorded one into its own buffer `self`, or a fresh one — and takes up to two recorded loops along
-    // (K<E>::horner_linear_loop's riders) where the kernel the launch resolves to can carry them.
-    static void launch_horner(const P& res, const P& ca, double* outp, size_t fn, const HornerLoopArgs& g, unsigned lines, unsigned* wit, Buf* self) {
+    // Launches a loop — a recorded one into its own buffer, or a fresh one (the unbatched form; a recording with "batch_dag" on is
+    // issued with its level of the launch graph, gft_api_dag.inc HornerRec).
+    static void launch_horner(const P& res, const P& ca, double* outp, size_t fn, const HornerLoopArgs& g, unsigned lines, unsigned* wit) {
         const double* cp = dp<E>(ca);
         const bool rview = res_is_view(res, ca);  // (as when the arguments were built: the handle keeps its own chain)
         const double* rp = rview ? cp + res.pend->base_off : dp<E>(res);
         const size_t rplane = rview ? res.pend->base_numel : res.numel;
-        HornerRider riders[2];
-        std::shared_ptr<Buf> rbuf[2];
-        std::shared_ptr<LazyOp> rop[2];
-        unsigned long long rbirth[2] = {0, 0};
-        int nr = 0;
-        auto& pend = pending_horner();
-        if (R.horner_riders && !pend.empty() && K<E>::horner_can_carry(g))
-            for (size_t k = pend.size(); k-- > 0 && nr < 2;) {
-                std::shared_ptr<Buf> b = pend[k].lock();
-                if (!b || !b->lazy || !b->lazy->horner) {
-                    pend.erase(pend.begin() + (long)k);
-                    continue;
-                }
-                if (b.get() == self) continue;
-                LazyHorner* h = static_cast<LazyHorner*>(b->lazy->horner.get());
-                // (in memory, and not what this launch — or a force_buf() further up the stack — is about to write)
-                auto in_memory = [outp](const P& p) { return p.buf && !p.buf->lazy && !p.pend && !p.buf->writing && p.buf->p != outp; };
-                const bool hview = res_is_view(h->res, h->ca);
-                if (!(hview || in_memory(h->res)) || !in_memory(h->ca) || !K<E>::horner_can_ride(h->g)) continue;
-                rbuf[nr] = b;
-                rop[nr] = b->lazy;
-                HornerRider& r = riders[nr];
-                r.a = dp<E>(h->ca);  // (in memory: no launch)
-                r.res0 = hview ? r.a + h->res.pend->base_off : dp<E>(h->res);
-                r.rp0 = hview ? h->res.pend->base_numel : h->res.numel;
-                r.ap = h->ca.numel;
-                ensure_alloc(b.get());
-                r.out = b->p;
-                r.plane = h->fn;
-                r.g = h->g;
-                r.lines = h->lines;
-                rbirth[nr] = b->birth;
-                b->lazy = nullptr;
-                b->birth = rop[nr]->input_birth;
-                pend.erase(pend.begin() + (long)k);
-                ++nr;
-                R.stats_side[2]++;
-            }
-        try {
-            K<E>::horner_linear_loop(R.stream, rp, rplane, cp, ca.numel, outp, fn, g, lines, wit, riders, nr);
-        } catch (...) {  // nothing was launched: the riders are still recordings
-            for (int r = 0; r < nr; ++r) {
-                rbuf[r]->lazy = rop[r];
-                rbuf[r]->birth = rbirth[r];
-                pending_push(pend, rbuf[r]);
-                R.stats_side[2]--;
-            }
-            throw;
-        }
+        K<E>::horner_linear_loop(R.stream, rp, rplane, cp, ca.numel, outp, fn, g, lines, wit);
     }
     static bool horner_linear_rest(const P& res, const P& ca, size_t v, size_t i, const double c[2], const double m[2], size_t w,
                                    const Dims& deg, P* result, unsigned* wit, const unsigned* guard = nullptr, bool defer = false) {
@@ -4354,28 +4068,8 @@ struct Ops {
         g.c_one = val_is_one(c) ? 1 : 0;
         g.coeff_scalar = coeff_scalar ? 1 : 0;
         g.lw_pad = (unsigned)((fs[w] + 7) / 8 * 8);
-        static const int hdiag = [] {
-            const char* e = getenv("GFT_HORNER_DIAG");
-            return e ? atoi(e) : 0;
-        }();
-        g.diag = hdiag;
+        g.diag = 0;
         g.stat = nullptr;
-        if (hdiag & 64) {
-            static unsigned long long* d_stat = nullptr;
-            if (!d_stat) {
-                HIP_OK(hipMalloc((void**)&d_stat, 16));
-                HIP_OK(hipMemsetAsync(d_stat, 0, 16, R.stream));
-                static struct Printer {
-                    unsigned long long** p;
-                    ~Printer() {
-                        unsigned long long h[2] = {0, 0};
-                        if (*p && hipMemcpy(h, *p, 16, hipMemcpyDeviceToHost) == hipSuccess)
-                            fprintf(stderr, "[gft horner] lean wave-steps %llu of %llu\n", h[0], h[1]);
-                    }
-                } printer{&d_stat};
-            }
-            g.stat = d_stat;
-        }
         g.guard = guard;
         // (intervals, c and m not [0,0]) no exact zero among the coefficients, none in the result: position (o, k_w) of the final
         // box receives coeff_i[o, k'] * C(i,j) c^(i-j) m^j for every k' + j = k_w — at least one such term exists, none cancels
@@ -4392,13 +4086,9 @@ struct Ops {
             sp.store(out.buf.get());
         }
         const unsigned lines = (unsigned)(fn / fs[w]);
-        if (defer && !wit && !(hdiag & 64) && res.buf && ca.buf) {
+        if (defer && !wit && res.buf && ca.buf) {
             g.guard = nullptr;
             if (K<E>::horner_can_ride(g)) {
-                if (!R.batch_dag) {  // (the launch graph brings its inputs into memory when the loop's level is issued)
-                    if (!rview) (void)dp<E>(res);  // (in memory already if a scan read it; a chain is settled here, once)
-                    if (!ca.buf->lazy) (void)dp<E>(ca);  // (a recorded observation stays recorded: it rides first, then this loop)
-                }
                 auto lh = std::allocate_shared<LazyHorner>(gft_small::Alloc<LazyHorner>());
                 lh->res = res;
                 lh->ca = ca;
@@ -4407,20 +4097,18 @@ struct Ops {
                 lh->fn = fn;
                 auto op = std::allocate_shared<LazyOp>(gft_small::Alloc<LazyOp>());
                 op->horner = lh;
-                op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr, b); };
-                op->input_birth = std::max(birth_of(res.buf.get()), birth_of(ca.buf.get()));
+                op->run = [lh](Buf* b) { launch_horner(lh->res, lh->ca, b->p, lh->fn, lh->g, lh->lines, nullptr); };
                 auto rec = std::allocate_shared<HornerRec>(gft_small::Alloc<HornerRec>());
                 rec->lh = lh;
                 op->rec = rec;
                 out.buf->lazy = op;
-                if (!R.batch_dag) pending_push(pending_horner(), out.buf);
                 *result = out;
                 return true;
             }
             g.guard = guard;
         }
         ensure_alloc(out.buf.get());
-        launch_horner(res, ca, dp<E>(out), fn, g, lines, wit, out.buf.get());
+        launch_horner(res, ca, dp<E>(out), fn, g, lines, wit);
         *result = out;
         return true;
     }
@@ -4841,28 +4529,18 @@ int gft_init(int device) {
         std::memset(R.h_mail, 0, 4096);
         HIP_OK(hipHostGetDevicePointer((void**)&R.d_mail, R.h_mail, 0));
         for (auto& ev : R.events) HIP_OK(hipEventCreate(&ev));
-        if (const char* sa = getenv("GFT_SIDE_MIN_AGE")) R.side_min_age = (unsigned long long)std::max(0, atoi(sa));
         if (const char* lo = getenv("GFT_LAZY_OBSERVE")) R.lazy_observe = atoi(lo) != 0;
         if (const char* bd = getenv("GFT_BATCH")) R.batch_dag = atoi(bd) != 0;
-        if (const char* ri = getenv("GFT_OBS_RIDERS")) R.obs_riders = atoi(ri) != 0;
         if (const char* lh = getenv("GFT_LAZY_HORNER")) R.lazy_horner = atoi(lh) != 0;
         if (const char* np = getenv("GFT_NZ_PROOFS")) R.nz_proofs = atoi(np) != 0;
         if (const char* lsum = getenv("GFT_LAZY_SUM")) R.lazy_sum = atoi(lsum) != 0;
-        if (const char* hr = getenv("GFT_HORNER_RIDERS")) R.horner_riders = atoi(hr) != 0;
         R.device = device;
         if (const char* tm = getenv("GFT_TILED_MIN_MACS")) {  // tuning knob for the auto-mode crossover
             double v = atof(tm);
             if (v >= 0) R.tiled_min_macs = v;
         }
-        if (const char* fh = getenv("GFT_FUSE_HORNER")) R.fuse_horner = atoi(fh) != 0;
-        if (const char* dv = getenv("GFT_DIV2D")) R.div2d = atoi(dv) != 0;
         if (const char* dw = getenv("GFT_DIV_WAVEFRONT")) R.div_wavefront = atoi(dw) != 0;
-        if (const char* rw = getenv("GFT_ROWS_WAVEFRONT")) R.rows_wavefront = atoi(rw) != 0;
         if (const char* er = getenv("GFT_EXP_RIGHT")) R.exp_right = atoi(er) != 0;
-        if (const char* dr = getenv("GFT_DIV_RIGHT")) R.div_right = atoi(dr) != 0;
-        if (const char* db = getenv("GFT_DIV_RIGHT_BLOCK")) R.div_right_block = (size_t)std::max(1, atoi(db));
-        if (const char* dm = getenv("GFT_DIV_RIGHT_MIN_MACS")) R.div_right_min_macs = atof(dm);
-        if (const char* ro = getenv("GFT_RECUR_OVERLAP")) R.recur_overlap = atoi(ro) != 0;
         if (const char* df = getenv("GFT_DEFER")) R.defer = atoi(df) != 0;
         {
             const char* al = getenv("GFT_ASYNC_LAUNCH");
@@ -4872,7 +4550,6 @@ int gft_init(int device) {
         if (const char* hm = getenv("GFT_HOST_MAX_MACS")) R.host_max_macs = atof(hm);
         if (const char* hl = getenv("GFT_HORNER_LOOP_MAX")) R.horner_loop_max = (size_t)atoll(hl);
         if (const char* sm = getenv("GFT_SHALLOW_MAX_TERMS")) R.shallow_max_terms = (size_t)atoll(sm);
-        if (const char* pf = getenv("GFT_PAIRS_FIRST")) R.pairs_first = atoi(pf) != 0;  // A/B: 0 = small f64 products on the tiled kernel as before
         if (const char* cm = getenv("GFT_CONV_MODE")) {  // test knob, same meaning as gft_set_conv_mode
             int m = atoi(cm);
             if (m >= 0 && m <= 3) R.conv_mode = m;
@@ -4891,10 +4568,6 @@ void gft_shutdown(void) {
     (void)hipStreamSynchronize(R.stream);
     if (R.side) (void)hipStreamSynchronize(R.side);
     for (auto& c : g_pow_tabs) c.clear();  // device tables of this context: back into the pool before it is freed
-    Ops<EF64>::pending_obs().clear();      // (weak references to recordings nobody launched)
-    Ops<EIv>::pending_obs().clear();
-    Ops<EF64>::pending_horner().clear();
-    Ops<EIv>::pending_horner().clear();
     dwf_release_orders();
     staged_release_scratch();
     g_arena.release();
@@ -4984,24 +4657,15 @@ float gft_event_elapsed_ms(int a, int b) {
 int gft_set_option(const char* name, double value) {
     std::string n = name ? name : "";
     if (n == "horner_loop_max") R.horner_loop_max = value < 0 ? 0 : (size_t)value;
-    else if (n == "fuse_horner") R.fuse_horner = value != 0;
-    else if (n == "div2d") R.div2d = value != 0;
     else if (n == "div_wavefront") R.div_wavefront = value != 0;
-    else if (n == "rows_wavefront") R.rows_wavefront = value != 0;
     else if (n == "exp_right") R.exp_right = value != 0;
-    else if (n == "div_right") R.div_right = value != 0;
-    else if (n == "div_right_block") R.div_right_block = value < 1 ? 16 : (size_t)value;
-    else if (n == "div_right_min_macs") R.div_right_min_macs = value < 0 ? 1.0e9 : value;
     else if (n == "recur_overlap") R.recur_overlap = value != 0;
     else if (n == "defer") R.defer = value != 0;
-    else if (n == "side_min_age") R.side_min_age = value < 0 ? 2 : (unsigned long long)value;
     else if (n == "lazy_observe") R.lazy_observe = value != 0;
     else if (n == "batch_dag") R.batch_dag = value != 0;
-    else if (n == "obs_riders") R.obs_riders = value != 0;
     else if (n == "lazy_horner") R.lazy_horner = value != 0;
     else if (n == "nz_proofs") R.nz_proofs = value != 0;
     else if (n == "lazy_sum") R.lazy_sum = value != 0;
-    else if (n == "horner_riders") R.horner_riders = value != 0;
     else if (n == "async_launch") lq_configure(R.device, value != 0);
     else if (n == "trace_lq_report") lq_report();  // (GFT_TRACE_LQ=1; measurement aid)
     else if (n == "shallow_max_terms") R.shallow_max_terms = value < 0 ? 256 : (size_t)value;  // < 0: default
@@ -5009,11 +4673,9 @@ int gft_set_option(const char* name, double value) {
     else if (n == "tiled_min_macs") R.tiled_min_macs = value;
     else if (n == "conv_rb_min_macs") staged_set_rb_min_macs(value);
     else if (n == "conv_rb_pairs") staged_set_rb_pairs(value);
-    else if (n == "pairs_first") R.pairs_first = value != 0.0;
     else if (n == "conv_rb_pairs_cap") staged_set_rb_pairs_cap(value);
     else if (n == "conv_rb_pairs_lanes") staged_set_rb_pairs_lanes(value);
     else if (n == "shallow_pair_min") shallow_set_pair_min(value == -1.0 ? 4096.0 : value);
-    else if (n == "recur_tiled_min_macs") R.recur_tiled_min_macs = value;
     else if (n == "tiled_tile") tiled_set_lane_tile((int)value);
     else if (n == "host_max_elems") R.host_max_elems = value < 0 ? Runtime::HOST_MAX_ELEMS_DEFAULT : (size_t)value;  // < 0: default
     else if (n == "host_max_macs") R.host_max_macs = value < 0 ? Runtime::HOST_MAX_MACS_DEFAULT : value;

@@ -250,7 +250,6 @@ static void run_dag(Buf* root) {
                 if (!b->lazy) continue;  // (launched by a nested execution)
                 std::shared_ptr<LazyOp> op = b->lazy;
                 keep.push_back(op);
-                b->writing = true;
                 if (!op->rec->emit(b)) {
                     ensure_alloc(b);
                     op->run(b);
@@ -260,16 +259,12 @@ static void run_dag(Buf* root) {
         } catch (...) {
             g_level = ctx.prev;
             ctx.groups.clear();
-            for (Buf* b : nodes) b->writing = false;  // (what was not launched is still a recording)
+            // (what was not launched is still a recording)
             throw;
         }
         g_level = ctx.prev;
         for (Buf* b : nodes) {
-            if (b->lazy) {
-                b->birth = b->lazy->input_birth;
-                b->lazy = nullptr;
-            }
-            b->writing = false;
+            b->lazy = nullptr;
         }
     }
 }

@@ -34,10 +34,7 @@ namespace gft {
 namespace {
 
 constexpr int MAXO = MAXD - 1;  // max number of outer axes
-static const size_t R_BATCH_MAX = [] {
-    const char* e = getenv("GFT_STAGED_BATCH");  // tuning knob: rows per batch in row mode
-    return (size_t)(e ? std::max(1, atoi(e)) : 8);
-}();
+static const size_t R_BATCH_MAX = (size_t)(8);
 
 struct StagedArgs {
     int S;                   // staged axes (1 or 2)
@@ -1223,15 +1220,9 @@ static std::map<hipStream_t, PairWs>& pair_ws() {
 // bytes of row sums the row-pair form may hold AT A TIME (2 GiB; round 4 held a whole product's: up to 24 GiB).  A product whose
 // row sums exceed it runs in slab ranges of its leading outer axis (PairArgs::band), each range through both phases from the
 // same workspace; per output the terms still arrive in the reference's order, so the bits do not depend on the cut.
-static size_t rb_pairs_cap = [] {
-    const char* e = getenv("GFT_RB_PAIRS_CAP_MB");
-    return (size_t)(e ? std::max(1, atoi(e)) : 2048) << 20;
-}();
-static int rb_pairs_lanes = [] {
-    const char* e = getenv("GFT_RB_PAIRS_LANES");
-    return e ? atoi(e) : -1;
-}();
-void staged_set_rb_pairs_lanes(double v) { rb_pairs_lanes = v < 0 ? -1 : (v >= 1.0 ? 1 : 0); }  // "conv_rb_pairs_lanes"
+static size_t rb_pairs_cap = (size_t)2048 << 20;
+static int rb_pairs_lanes = -1;  // slab ranges on two lanes when half the cap leaves the ranges as they are (56^3 .. 72^3)
+void staged_set_rb_pairs_lanes(double v) { rb_pairs_lanes = v < 0 ? -1 : (v >= 1.0 ? 1 : 0); }  // "conv_rb_pairs_lanes" (tests: both forms bit for bit)
 void staged_set_rb_pairs_cap(double bytes) { rb_pairs_cap = bytes >= 1.0 ? (size_t)bytes : ((size_t)2048 << 20); }  // "conv_rb_pairs_cap"
 size_t staged_scratch_bytes() {  // what the grow-only workspaces hold right now (gft_pool_stats counts it)
     size_t n = 0;
@@ -1241,25 +1232,12 @@ size_t staged_scratch_bytes() {  // what the grow-only workspaces hold right now
 }
 // row-pair form (k_pair_sums + k_pair_collect): 0 never, 1 products of [rb_pairs_min, ..) multiply-adds whose row sums fit the
 // workspace cap, 2 whenever it applies (tests)
-static int rb_pairs_default() {
-    const char* e = getenv("GFT_RB_PAIRS");
-    return e ? atoi(e) : 1;
-}
-static int rb_pairs_mode = rb_pairs_default();
-static double rb_pairs_min = [] {  // rank >= 3 (profiles/r04/interval_shapes.txt: 12^3 = 5e5 multiply-adds 0.098 -> 0.036 ms, 16^3 0.20 -> 0.05)
-    const char* e = getenv("GFT_RB_PAIRS_MIN_MACS");
-    return e ? atof(e) : 3.0e5;
-}();
-static double rb_pairs_min_rank2 = [] {  // (64^2 = 4e6 multiply-adds 0.064 -> 0.033 ms, 128^2 0.31 -> 0.07)
-    const char* e = getenv("GFT_RB_PAIRS_MIN_MACS_RANK2");
-    return e ? atof(e) : 1.0e6;
-}();
-void staged_set_rb_pairs(double v) { rb_pairs_mode = v < 0.0 ? rb_pairs_default() : (int)v; }  // "conv_rb_pairs" (negative: back to the default)
+static int rb_pairs_mode = 1;
+static const double rb_pairs_min = 3.0e5;  // rank >= 3 (profiles/r04/interval_shapes.txt: 12^3 = 5e5 multiply-adds 0.098 -> 0.036 ms, 16^3 0.20 -> 0.05)
+static const double rb_pairs_min_rank2 = 1.0e6;  // (64^2 = 4e6 multiply-adds 0.064 -> 0.033 ms, 128^2 0.31 -> 0.07)
+void staged_set_rb_pairs(double v) { rb_pairs_mode = v < 0.0 ? 1 : (int)v; }  // "conv_rb_pairs" (negative: back to the default)
 // measured crossover against k_conv_staged between 64^3 and 80^3 (profiles/r03/interval_product.txt)
-static double rb_min_macs = [] {
-    const char* e = getenv("GFT_CONV_RB_MIN_MACS");
-    return e ? atof(e) : 1.5e10;  // (72^3 = 1.8e10: 29.4 -> 24.5 ms on this kernel; 64^3 = 9e9 stays on k_conv_staged: 10.6 vs 14.1 ms — profiles/r04/interval_rb_crossover.txt)
-}();
+static double rb_min_macs = 1.5e10;  // (72^3 = 1.8e10: 29.4 -> 24.5 ms on this kernel; 64^3 = 9e9 stays on k_conv_staged: 10.6 vs 14.1 ms — profiles/r04/interval_rb_crossover.txt)
 void staged_set_rb_min_macs(double v) { rb_min_macs = v; }  // "conv_rb_min_macs" (tests; negative = never)
 void staged_release_scratch() {
     for (auto& kv : rb_scratch())
@@ -1297,10 +1275,7 @@ static PairLanes& pair_lanes() {
 template <class E>
 static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const double* y, size_t yp, double* z, size_t zp, const ConvArgs& a,
                          bool pairs_only = false, double pairs_max_macs = 1e300) {
-    static const int on = [] {
-        const char* e = getenv("GFT_CONV_RB");  // A/B knob (0 = k_conv_staged for these products too)
-        return e ? atoi(e) : 1;
-    }();
+    static const int on = 1;
     const int nd = a.nd;
     if (nd < 2 || nd > 4) return false;
     if (a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || !a.inner_from_zero || a.guard) return false;
@@ -1364,15 +1339,9 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
         g.pitch = E::W * g.n8 + 2;
         // 16 waves per CU (the kernel holds <= 128 VGPRs): two workgroups of 8 where two tiles fit the LDS, else one of 16
         g.NW = (size_t)64 * g.pitch * sizeof(double) * 2 + 1024 <= 160 * 1024 ? 8u : 16u;
-        static const unsigned nw_env = [] {
-            const char* e = getenv("GFT_RB_PAIRS_WAVES");  // tuning knob: waves of a phase-1 workgroup
-            return (unsigned)(e ? std::max(0, std::min(16, atoi(e))) : 0);
-        }();
+        static const unsigned nw_env = (unsigned)(0);
         if (nw_env) g.NW = nw_env;
-        static const unsigned xch_env = [] {
-            const char* e = getenv("GFT_RB_PAIRS_XCH");  // tuning knob: x rows per phase-1 workgroup
-            return (unsigned)(e ? std::max(1, atoi(e)) : 8);  // (sweep in profiles/r04/interval_pairs_sweep.txt: 4 .. 12 equal, 32 loses 10 % to the last round of workgroups)
-        }();
+        static const unsigned xch_env = 8;  // x rows per phase-1 workgroup (sweep in profiles/r04/interval_pairs_sweep.txt: 4 .. 12 equal, 32 loses 10 % to the last round of workgroups)
         g.xch = xch_env;
         // (small products: fewer x rows per workgroup until there are ~1000 workgroups — half of the (tile, chunk) grid is
         // outside the triangle)
@@ -1499,10 +1468,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
                     if (hipFuncSetAttribute((const void*)k_pair_sums<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) (void)hipGetLastError();
                     attr = true;
                 }
-                static const unsigned cw_env = [] {
-                    const char* e = getenv("GFT_RB_PAIRS_COLS");  // tuning knob: columns per phase-2 workgroup
-                    return (unsigned)(e ? std::max(1, std::min(128, atoi(e))) : 64);
-                }();
+                static const unsigned cw_env = (unsigned)(64);
                 // (checked for every range BEFORE the first launch: a false return promises that nothing was launched)
                 std::vector<PairArgs> gs;
                 std::vector<dim3> grids;
@@ -1608,10 +1574,7 @@ static bool conv_rows_rb(hipStream_t st, const double* x, size_t xp, const doubl
     g.ntiles = (n2 + 15) / 16;
     g.n2 = n2;
     g.nx2 = nx2;
-    static const unsigned rg_env = [] {
-        const char* e = getenv("GFT_RB_GROUPS");  // tuning knob: wave groups (= y rows per batch) of a workgroup
-        return (unsigned)(e ? std::max(1, atoi(e)) : 0);
-    }();
+    static const unsigned rg_env = (unsigned)(0);
     g.ntw = (g.ntiles + 1) / 2;
     // groups cut the longest chain of a workgroup (what bounds mid sizes) but leave one workgroup per CU with nothing to
     // overlap its staging with; two groups once the workgroups outnumber the CUs ~6 times (128^3: 257 ms with 2, 299 with 4;
@@ -1691,10 +1654,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     // S = 2 (planes of the last two axes) while the planes are small enough for >= 4 workgroups per CU;
     // larger planes would leave one fat workgroup per CU with a triangular load => rows (S = 1) instead,
     // unless the rows are too short to fill a wave.
-    static const int force_s = [] {
-        const char* e = getenv("GFT_STAGED_S");  // experiment knob
-        return e ? atoi(e) : 0;
-    }();
+    static const int force_s = 0;
     auto fits = [&](int s, size_t budget) {
         unsigned sxa = s == 2 ? a.xs[nd - 2] : 1, sya = s == 2 ? a.ys[nd - 2] : 1;
         size_t xcap = (size_t)sxa * a.xs[nd - 1], ycap = (size_t)sya * (s == 2 ? a.zs[nd - 1] : a.ys[nd - 1]);
@@ -1752,10 +1712,7 @@ bool conv_staged(hipStream_t st, const double* x, size_t xp, const double* y, si
     chunks = (span + threads - 1) / threads;
     g.chunks = (unsigned)chunks;
     // row groups (see the kernel): as many as the batch has rows and the block has room for
-    static const unsigned rw_cap = [] {
-        const char* e = getenv("GFT_STAGED_RW");  // experiment knob: cap on the row groups of a block
-        return (unsigned)(e ? std::max(1, atoi(e)) : 1024);
-    }();
+    static const unsigned rw_cap = (unsigned)(1024);
     if (S == 1 && a.inner_from_zero && g.batch > 1) {
         unsigned rw = std::min<unsigned>(std::min<unsigned>(g.batch, 1024u / threads), rw_cap);
         // Row groups shorten the serial chain of ONE block (a recurrence step has a handful of blocks and nothing else to

@@ -689,10 +689,7 @@ int num_cus() {
 static void assign_blocks(TiledArgs& T, unsigned NW);
 
 int& tiled_force_tsh() {  // A/B and test knob (GFT_TILED_TSH / "tiled_tile"): 3..6 forces the lane tile 8x8 .. 1x64
-    static int v = [] {
-        const char* e = getenv("GFT_TILED_TSH");
-        return e ? atoi(e) : 0;
-    }();
+    static int v = 0;
     return v;
 }
 
@@ -804,25 +801,17 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
     // the dispatcher even that out — as many (2, 4, 8) as leave a range >= ~190 steps (128^3: 2312 steps per slot, eight ranges, 27.0 -> 28.7
     // TMAC/s in three alternating runs on one box; 96^3 and 100^3 four, +3 %; 64^3, 81 steps per slot, stays at one: two
     // are neutral, four lose 4 % to the extra partial slabs).
-    static const int wg_mult_env = [] {
-        const char* e = getenv("GFT_TILED_WG_MULT");  // tuning knob (0 = the rule above)
-        return e ? std::max(0, atoi(e)) : 0;
-    }();
+    static const int wg_mult_env = 0;
     unsigned long long n_wg = (unsigned long long)num_cus() * wg_per_cu;
     const unsigned long long per_slot = S / n_wg;  // steps (one lane tile x one (ju, j0, j1)) per resident slot
     const unsigned long long fit = per_slot / 190;  // ranges of >= ~190 steps
     n_wg *= wg_mult_env ? (unsigned)wg_mult_env : (fit >= 8 ? 8u : (fit >= 4 ? 4u : (fit >= 2 ? 2u : 1u)));
-    static const bool plan_debug = getenv("GFT_TILED_PLAN_DEBUG") != nullptr;
-    if (plan_debug) fprintf(stderr, "[gft tiled plan] zU=%u z0=%u z1=%u zI=%u steps=%llu slots=%llu steps/slot=%llu ranges=%llu\n", T.zU, T.z0, T.z1, T.zI, S, n_wg / (n_wg / ((unsigned long long)num_cus() * wg_per_cu) ? n_wg / ((unsigned long long)num_cus() * wg_per_cu) : 1), per_slot, n_wg);
     // Every range pays a window fill and, if it splits a tile, a 4 KB-per-block partial slab plus its share of the
     // reduction, so small products must not be cut into confetti.  A step costs ~ (chunk pairs + 3) units
     // (pairs = nb(nb+1)/2 8x8x8 chunk products per lane tile, 3 ~ barriers + refill) and the fixed part grows
     // with the row length; ranges get >= ~(64 + 20 nb) units (sweep on MI355X: 24^3 171 -> 50 us,
     // 30^3 91 -> 71 us, 10x10x100 154 -> 92 us per product).
-    static const unsigned long long MIN_UNITS = [] {
-        const char* e = getenv("GFT_TILED_MIN_UNITS");  // tuning knob (base of the model)
-        return (unsigned long long)(e ? std::max(1, atoi(e)) : 64);
-    }();
+    static const unsigned long long MIN_UNITS = 64;
     const unsigned long long step_units = (unsigned long long)T.nb * (T.nb + 1) / 2 + 3;
     const unsigned long long min_steps =
         std::max<unsigned long long>(1, (MIN_UNITS + 20ull * T.nb + step_units / 2) / step_units);
@@ -936,10 +925,7 @@ bool build_plan(const ConvArgs& a, Plan& P, hipStream_t st) {
 // SIMD 0 and one on the others, and the whole CU waits for SIMD 0 — measured 62% of the nb = 16 rate.
 // Longest-processing-time assignment over SIMDs instead, then over the waves of the SIMD.
 static void assign_blocks(TiledArgs& T, unsigned NW) {
-    static const int mode = [] {
-        const char* e = getenv("GFT_TILED_BLOCK_MAP");  // 0 = classic pairs, 1 = LPT with SIMD = w % 4, 2 = SIMD = w / 2
-        return e ? atoi(e) : 1;
-    }();
+    static const int mode = 1;
     for (int w = 0; w < 8; ++w) T.blk1[w] = T.blk2[w] = 0xff;
     // (classic pairs are only balanced when every block c costs c + 1: compact operands — the piece-split products'
     // untruncated inner axis costs min(c + 1, nxc, nyc, nb - c) — always take the LPT assignment)
@@ -1020,10 +1006,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     if (a.nd >= 2 && a.nd <= 4) {  // the pipelined fast path (bits 1|2) needs x and y to span every chunk of z's inner axis
         unsigned nb = (a.zs[a.nd - 1] + 7) / 8;
         if ((a.xs[a.nd - 1] + 7) / 8 < nb || (a.ys[a.nd - 1] + 7) / 8 < nb) {
-            static const bool compact_fast = [] {
-                const char* e = getenv("GFT_TILED_COMPACT_FAST");  // A/B knob: 0 = unpipelined general path
-                return e ? atoi(e) != 0 : true;
-            }();
+            static const bool compact_fast = true;
             if (compact_fast && (a.variant & 3) == 3) a.variant = (a.variant & ~0xff) | (a.variant & 7) | 8;  // pipelined path for compact operands
             else a.variant &= ~3;
         }
@@ -1067,10 +1050,7 @@ bool conv_tiled_f64(hipStream_t st, const double* x, const double* y, double* z,
     // every chunk of the result's rows.  There is then no zero padding anywhere, so inf / NaN operands cannot create NaNs the reference does not produce: no verdict,
     // no guarded fallback launch — ONE launch per product.  Everything else is packed by k_prep_operands (rows padded to
     // whole chunks plus one chunk of slack after the last row), which also takes the non-finite verdict.
-    static const bool inplace_env = [] {
-        const char* e = getenv("GFT_TILED_INPLACE");  // A/B knob: 0 = always pack
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool inplace_env = true;
     // (full inner extents only: the compact-operand path multiplies a zero window where a block reaches beyond y's last chunk —
     // artificial zeros again, which need the verdict)
     const bool inplace = inplace_env && a.operands_slack && B.nx8 == B.xI && B.ny8 == B.yI && B.nxc >= B.nb && B.nyc >= B.nb &&

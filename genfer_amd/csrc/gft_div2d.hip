@@ -648,10 +648,7 @@ bool K<E>::div_1d(hipStream_t st, const double* xs, size_t x_plane, unsigned nx,
         GFT_LAUNCH(k_div_1d_serial<E>, dim3(1), dim3(64), 0, st, xs, x_plane, nx, ys, y_plane, ny, res, r_plane, n);
         return true;
     }
-    static const bool wave_on = [] {
-        const char* e = getenv("GFT_DIV1D_WAVE");  // A/B knob
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool wave_on = true;
     if (wave_on && n <= 1024) {
 #define GFT_D1W(SEG)                                                                                                        \
     GFT_LAUNCH((k_div_1d_wave<E, SEG>), dim3(1), dim3(64), (size_t)E::W * 64 * (SEG + 1) * sizeof(double), st, xs, x_plane, \
@@ -769,10 +766,7 @@ struct DwfCfg {
 // coefficient is an 8-byte store); the per-row flags (release / acquire) remain the authority when a row keeps looking
 // unwritten, so a genuine coefficient of that pattern only costs time.
 constexpr unsigned long long DWF_EMPTY = 0x7ff8dead0badf00dull;
-static const int dwf_pack = [] {
-    const char* e = getenv("GFT_DWF_PACK");
-    return e ? atoi(e) : 1;
-}();
+static const int dwf_pack = 1;
 __global__ void __launch_bounds__(256) k_fill_bits(double* p, size_t n, unsigned long long bits) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         reinterpret_cast<unsigned long long*>(p)[i] = bits;
@@ -1367,10 +1361,7 @@ __global__ void __launch_bounds__(64 * QNW) k_div_wavefront_q(const double* __re
 template <class E>
 static void launch_dwf(hipStream_t st, unsigned blocks, const double* xs, size_t xp, const double* ys, size_t yp, double* res, size_t rp, const DivWfArgs& g) {
     // f64 rows of 33 .. 64 coefficients: four source rows per wave, four coefficients per lane (k_div_wavefront_q)
-    static const int quad_on = [] {
-        const char* e = getenv("GFT_DWF_QUAD");  // A/B knob: 0 = never, 2 = whenever the rows allow (tests)
-        return e ? atoi(e) : 1;
-    }();
+    static const int quad_on = 1;
     // (where a row has thousands of source rows — 64^3 div 4.8 -> 4.0 ms, 24^4 7.7 -> 6.2; thin or small quotients, whose time is the
     // chain of rows, lose to its larger batches: 1000 x 32 6.2 -> 8.0 ms, 32^3 0.53 -> 0.62 — they keep one or two rows per wave)
     size_t max_sources = 1;
@@ -1424,10 +1415,7 @@ static std::map<DwfOrderKey, unsigned*>& dwf_orders() {
     static std::map<DwfOrderKey, unsigned*> m;
     return m;
 }
-static const int dwf_diag = [] {
-    const char* e = getenv("GFT_DWF_DIAG");
-    return e ? atoi(e) : 1;
-}();
+static const int dwf_diag = 1;
 // rows (k0 >= first, k1, ..) of an n[0] x .. x n[L-1] grid, task-relative index (row index - first * rows per slab)
 static const unsigned* dwf_order(int L, const unsigned* n, unsigned first) {
     if (!dwf_diag || L < 2) return nullptr;
@@ -1627,11 +1615,7 @@ bool K<E>::div_2d(hipStream_t st, const double* x, size_t x_plane, unsigned nx1,
     g.res2 = res2;
     g.r2p = r2_plane;
     if (fused == 2 && (!res2 || log_k == 0)) return false;
-    static const int diag = [] {
-        const char* e = getenv("GFT_DIV2D_DIAG");
-        return e ? atoi(e) : 0;
-    }();
-    g.diag = diag;
+    g.diag = 0;
     g.n2p = n2 | 1;   // odd pitches: rows of one column do not share a bank
     g.ny2p = ny2 | 1;
     if (n2 <= 64) {

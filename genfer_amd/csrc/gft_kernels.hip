@@ -170,10 +170,7 @@ static void lq_raise() {
 
 bool lq_enabled() { return g_lq.enabled; }
 int lq_debug() {
-    static const int d = [] {
-        const char* e = getenv("GFT_ASYNC_DEBUG");
-        return e ? atoi(e) : 0;
-    }();
+    static const int d = 0;
     return d;
 }
 void lq_configure(int device, bool enabled) {
@@ -451,10 +448,7 @@ void K<E>::gather(hipStream_t st, const double* src, size_t src_plane, double* o
         return;
     }
     // rows of at least a wave's width that missed the 16-byte path: one wave per row (no per-element index arithmetic)
-    static const bool rows_on = [] {
-        const char* e = getenv("GFT_GATHER_ROWS");  // A/B knob
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool rows_on = true;
     // (only where bandwidth is the issue: on a 180 x 180 tensor one wave per row is 180 waves walking their rows serially
     // where the per-element kernel has 32 000 threads in flight — mixture --bounds 3.0 -> 3.7 s when it was unconditional)
     // (and only with rows enough to fill the chip: four_populations gathers 1e6 elements in a few dozen rows of tens of
@@ -668,11 +662,7 @@ __device__ __forceinline__ void chain_body(double* __restrict__ out, size_t out_
         E::st(out, out_plane, lin, v);
     }
 }
-template <class E, bool TWO, typename IDX>
-__global__ void __launch_bounds__(256) k_chain(double* __restrict__ out, size_t out_plane, Shape sh, ChainSrc a, ChainSrc b, int subtract, size_t total) {
-    chain_body<E, TWO, IDX>(out, out_plane, sh, a, b, subtract, total);
-}
-// ... with the arguments (two chains: 0.9 KB) copied to LDS first (see k_chain_nest)
+// the arguments (two chains: 0.9 KB) are copied to LDS first (see k_chain_nest)
 struct ChainKArgs {
     double* out;
     size_t out_plane;
@@ -687,28 +677,17 @@ __global__ void __launch_bounds__(256) k_chain_lds(ChainKArgs) {
     const ChainKArgs& A = kernargs_to_lds<ChainKArgs>(s_args);
     chain_body<E, TWO, IDX>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
 }
-static bool args_in_lds() {
-    static const bool on = [] {
-        const char* e = getenv("GFT_ARGS_LDS");  // A/B knob: 0 = arguments read from the kernel-argument segment
-        return !e || atoi(e) != 0;
-    }();
-    return on;
-}
 template <class E, bool TWO, typename IDX>
 static void launch_chain(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const ChainSrc& a, const ChainSrc& b, int subtract, size_t total) {
-    if (args_in_lds()) {
-        ChainKArgs ka;
-        ka.out = out;
-        ka.out_plane = out_plane;
-        ka.sh = sh;
-        ka.a = a;
-        ka.b = b;
-        ka.subtract = subtract;
-        ka.total = total;
-        GFT_LAUNCH((k_chain_lds<E, TWO, IDX>), dim3(grid_for(total)), dim3(256), 0, st, ka);
-    } else {
-        GFT_LAUNCH((k_chain<E, TWO, IDX>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, total);
-    }
+    ChainKArgs ka;
+    ka.out = out;
+    ka.out_plane = out_plane;
+    ka.sh = sh;
+    ka.a = a;
+    ka.b = b;
+    ka.subtract = subtract;
+    ka.total = total;
+    GFT_LAUNCH((k_chain_lds<E, TWO, IDX>), dim3(grid_for(total)), dim3(256), 0, st, ka);
 }
 // (offsets of lanes outside an operand's box may wrap in 32 bits: they are never dereferenced)
 static bool chain_fits_u32(const ChainSrc& c, const Shape& sh, size_t total) {
@@ -1031,10 +1010,6 @@ __global__ void __launch_bounds__(256) k_chain_nest(NestKArgs) {
     chain_nest_body<E>(A.out, A.out_plane, A.sh, A.a, A.b, A.subtract, A.total);
 }
 template <class E>
-__global__ void __launch_bounds__(256) k_chain_nest_args(double* __restrict__ out, size_t out_plane, Shape sh, NestSrc a, NestSrc b, int subtract, unsigned total) {
-    chain_nest_body<E>(out, out_plane, sh, a, b, subtract, total);
-}
-template <class E>
 void K<E>::chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape& sh, const NestSrc& a, const NestSrc& b, int subtract) {
     size_t total = 1;
     for (int i = 0; i < sh.nd; ++i) total *= sh.d[i];
@@ -1047,8 +1022,7 @@ void K<E>::chain_nest(hipStream_t st, double* out, size_t out_plane, const Shape
     ka.b = b;
     ka.subtract = subtract;
     ka.total = (unsigned)total;
-    if (args_in_lds()) GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, ka);
-    else GFT_LAUNCH((k_chain_nest_args<E>), dim3(grid_for(total)), dim3(256), 0, st, out, out_plane, sh, a, b, subtract, (unsigned)total);
+    GFT_LAUNCH((k_chain_nest<E>), dim3(grid_for(total)), dim3(256), 0, st, ka);
 }
 template <class E>
 __global__ void __launch_bounds__(256) k_chain_nest_batch(const NestItem* __restrict__ items) {
@@ -1367,33 +1341,8 @@ __device__ __forceinline__ void observe_chain_line(const double* __restrict__ a,
         lds_barrier();  // the line passes through LDS only
     }
 }
-template <class E, bool EPI>
-__global__ void __launch_bounds__(1024) k_observe_chain(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
-                                                        ObserveChainArgs g, typename std::conditional<EPI, ObsEpi, int>::type epi) {
-    extern __shared__ double oc_lds[];  // [buffer][plane][lw_pad]
-    observe_chain_line<E, EPI>(a, ap, out, op, g, epi, blockIdx.x, oc_lds);
-}
-// Two independent observation chains in ONE launch (round 5: horizontal fusion).  A recorded chain whose input has been
-// there for a while — the first arm of an `if` reads a memoised predecessor — rides along with the next observation launch
-// of the main chain instead of costing a launch (and its ~5 us of dependent latencies) of its own: workgroups
-// [0, lines0) run the first chain (with its epilogue, if any), the rest the second.
-struct ObsRider {
-    const double* a;
-    size_t ap;
-    double* out;
-    size_t op;
-    ObserveChainArgs g;
-};
-template <class E, bool EPI>
-__global__ void __launch_bounds__(1024) k_observe_chain2(const double* __restrict__ a, size_t ap, double* __restrict__ out, size_t op,
-                                                         ObserveChainArgs g, typename std::conditional<EPI, ObsEpi, int>::type epi,
-                                                         unsigned lines0, ObsRider r) {
-    extern __shared__ double oc_lds[];
-    if (blockIdx.x < lines0) observe_chain_line<E, EPI>(a, ap, out, op, g, epi, blockIdx.x, oc_lds);
-    else observe_chain_line<E, false>(r.a, r.ap, r.out, r.op, r.g, 0, blockIdx.x - lines0, oc_lds);
-}
-// The same two kernels with their arguments — up to 3.5 KB: the steps' lengths and constants, the epilogue's chain, the rider —
-// copied to LDS by the workgroup first (see k_chain_nest: read in place they are dependent scalar-cache misses, step after step).
+// The kernel with its arguments — up to 1.9 KB: the steps' lengths and constants, the epilogue's chain — copied to LDS by the
+// workgroup first (see k_chain_nest: read in place they are dependent scalar-cache misses, step after step).
 template <bool EPI>
 struct ObsKArgs {
     const double* a;
@@ -1402,70 +1351,35 @@ struct ObsKArgs {
     size_t op;
     ObserveChainArgs g;
     typename std::conditional<EPI, ObsEpi, int>::type epi;
-    unsigned lines0;  // (the two-chain form; the single chain: every workgroup)
-    ObsRider r;
 };
-template <class E, bool EPI, bool TWO>
+template <class E, bool EPI>
 __global__ void __launch_bounds__(1024) k_observe_chain_lds(ObsKArgs<EPI>) {
     extern __shared__ double oc_lds[];
     __shared__ __align__(16) unsigned char s_args[(sizeof(ObsKArgs<EPI>) + 15) / 16 * 16];
     const ObsKArgs<EPI>& A = kernargs_to_lds<ObsKArgs<EPI>>(s_args);
-    if (!TWO || blockIdx.x < A.lines0) observe_chain_line<E, EPI>(A.a, A.ap, A.out, A.op, A.g, A.epi, blockIdx.x, oc_lds);
-    else observe_chain_line<E, false>(A.r.a, A.r.ap, A.r.out, A.r.op, A.r.g, 0, blockIdx.x - A.lines0, oc_lds);
+    observe_chain_line<E, EPI>(A.a, A.ap, A.out, A.op, A.g, A.epi, blockIdx.x, oc_lds);
 }
 template <class E>
 void K<E>::observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                          const ObserveChainArgs& args, unsigned lines, unsigned longest) {
-    observe_chain_multi(st, a, a_plane, out, out_plane, args, lines, longest, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0);
+    observe_chain_epi(st, a, a_plane, out, out_plane, args, lines, longest, nullptr);
 }
+// optional epilogue (the consumer's Add: ObsEpi)
 template <class E>
 void K<E>::observe_chain_epi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
-                             const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi& epi) {
-    observe_chain_multi(st, a, a_plane, out, out_plane, args, lines, longest, &epi, nullptr, 0, nullptr, 0, nullptr, 0, 0);
-}
-// the general form: optional epilogue on the first chain, optional second chain (rider)
-template <class E>
-void K<E>::observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
-                               const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi,
-                               const double* ra, size_t ra_plane, double* rout, size_t rout_plane, const ObserveChainArgs* rargs,
-                               unsigned rlines, unsigned rlongest) {
+                             const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi) {
     if (lines == 0 || args.nsteps == 0) return;
-    const bool two = rargs && rlines && rargs->nsteps;
-    const unsigned lg = two ? std::max(longest, rlongest) : longest;
-    const unsigned threads = std::min<unsigned>(1024, (lg + 63) / 64 * 64);
-    const unsigned pad = two ? std::max(args.lw_pad, rargs->lw_pad) : args.lw_pad;
-    const size_t lds = (size_t)2 * E::W * pad * sizeof(double);
-    const bool lds_args = args_in_lds();
-    ObsRider r;
-    std::memset(&r, 0, sizeof r);
-    if (two) {
-        r.a = ra;
-        r.ap = ra_plane;
-        r.out = rout;
-        r.op = rout_plane;
-        r.g = *rargs;
+    const unsigned threads = std::min<unsigned>(1024, (longest + 63) / 64 * 64);
+    const size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
+    if (epi) {
+        ObsKArgs<true> ka;
+        ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = *epi;
+        GFT_LAUNCH((k_observe_chain_lds<E, true>), dim3(lines), dim3(threads), lds, st, ka);
+    } else {
+        ObsKArgs<false> ka;
+        ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = 0;
+        GFT_LAUNCH((k_observe_chain_lds<E, false>), dim3(lines), dim3(threads), lds, st, ka);
     }
-    if (lds_args) {
-        if (epi) {
-            ObsKArgs<true> ka;
-            ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = *epi; ka.lines0 = lines; ka.r = r;
-            if (two) GFT_LAUNCH((k_observe_chain_lds<E, true, true>), dim3(lines + rlines), dim3(threads), lds, st, ka);
-            else GFT_LAUNCH((k_observe_chain_lds<E, true, false>), dim3(lines), dim3(threads), lds, st, ka);
-        } else {
-            ObsKArgs<false> ka;
-            ka.a = a; ka.ap = a_plane; ka.out = out; ka.op = out_plane; ka.g = args; ka.epi = 0; ka.lines0 = lines; ka.r = r;
-            if (two) GFT_LAUNCH((k_observe_chain_lds<E, false, true>), dim3(lines + rlines), dim3(threads), lds, st, ka);
-            else GFT_LAUNCH((k_observe_chain_lds<E, false, false>), dim3(lines), dim3(threads), lds, st, ka);
-        }
-        return;
-    }
-    if (!two) {
-        if (epi) GFT_LAUNCH((k_observe_chain<E, true>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi);
-        else GFT_LAUNCH((k_observe_chain<E, false>), dim3(lines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0);
-        return;
-    }
-    if (epi) GFT_LAUNCH((k_observe_chain2<E, true>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, *epi, lines, r);
-    else GFT_LAUNCH((k_observe_chain2<E, false>), dim3(lines + rlines), dim3(threads), lds, st, a, a_plane, out, out_plane, args, 0, lines, r);
 }
 
 template <class E, bool EPI>
@@ -1775,20 +1689,6 @@ void K<E>::count_neq(hipStream_t st, const double* a, size_t a_plane, const doub
     GFT_LAUNCH(k_count_neq<E>, dim3(grid_for(n)), dim3(256), 0, st, a, a_plane, b, b_plane, n, count);
 }
 
-// dst[k][..] = src[k][..] / from(first + k) for nslabs leading slabs of `slab` elements: the "/ k0" of every slab of a
-// logarithm (mt:1384) in one launch (the blocked right-looking form, gft_api.hip Ops::log_right)
-template <class E>
-__global__ void __launch_bounds__(256) k_div_by_index(const double* __restrict__ src, size_t sp, double* __restrict__ dst, size_t dp, size_t slab,
-                                                      size_t total, unsigned first) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        E::st(dst, dp, i, E::div(E::ld(src, sp, i), E::from_u32(first + (unsigned)(i / slab))));
-}
-template <class E>
-void K<E>::div_by_index(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t nslabs, size_t slab, unsigned first) {
-    const size_t total = nslabs * slab;
-    if (total == 0) return;
-    GFT_LAUNCH(k_div_by_index<E>, dim3(grid_for(total)), dim3(256), 0, st, src, src_plane, dst, dst_plane, slab, total, first);
-}
 
 // Does the tensor hold a coefficient that is exactly zero ([0,0] for intervals)?  One launch, the answer through the mailbox
 // (payload[0] = 1 if so): the premise of the "no exact zero anywhere" proofs of gft_api.hip (Ops::nz_of).  state[0] collects
@@ -2051,10 +1951,7 @@ __global__ void __launch_bounds__(256) k_conv_shallow_lds(ShallowKArgs) {
 }
 
 // smallest result (elements) that takes the pair form of k_conv_shallow; negative: never ("shallow_pair_min", GFT_SHALLOW_PAIR_MIN)
-static double g_shallow_pair_min = [] {
-    const char* en = getenv("GFT_SHALLOW_PAIR_MIN");
-    return en ? atof(en) : 4096.0;
-}();
+static double g_shallow_pair_min = 4096.0;
 void shallow_set_pair_min(double v) { g_shallow_pair_min = v; }
 
 // The same with TWO outputs per thread, neighbours along the last axis, for stencils that are FLAT along it (ys[last] == 1:
@@ -2206,15 +2103,11 @@ bool K<E>::conv_shallow(hipStream_t st, const double* x, size_t x_plane, const d
     const bool u32 = nx < 0x7fffffffull && ny < 0x7fffffffull && aspan < 0x7fffffffull;
     ShallowKArgs ka;
     ka.x = x; ka.xp = x_plane; ka.y = y; ka.yp = y_plane; ka.out = out; ka.op = out_plane; ka.a = a; ka.e = e; ka.total = (unsigned)total;
-    const bool in_lds = args_in_lds();
 #define GFT_CASE(N)                                                                                                        \
     case N:                                                                                                                \
-        if (u32 && in_lds) {                                                                                               \
+        if (u32) {                                                                                                         \
             if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow_lds<E, N, true, unsigned>), g, b, 0, st, ka);                \
             else GFT_LAUNCH((k_conv_shallow_lds<E, N, false, unsigned>), g, b, 0, st, ka);                                 \
-        } else if (u32) {                                                                                                  \
-            if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
-            else GFT_LAUNCH((k_conv_shallow<E, N, false, unsigned>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
         } else {                                                                                                           \
             if (a.inner_from_zero) GFT_LAUNCH((k_conv_shallow<E, N, true, size_t>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total); \
             else GFT_LAUNCH((k_conv_shallow<E, N, false, size_t>), g, b, 0, st, x, x_plane, y, y_plane, out, out_plane, a, e, (unsigned)total);                 \
@@ -2287,10 +2180,7 @@ __global__ void __launch_bounds__(256) k_conv_line(const double* __restrict__ F,
 template <class E>
 bool K<E>::conv_line(hipStream_t st, const double* x, size_t x_plane, const double* y, size_t y_plane, double* z, size_t z_plane,
                      const ConvArgs& a) {
-    static const bool on = [] {
-        const char* e = getenv("GFT_CONV_LINE");  // A/B knob (0 = the one-thread-per-output kernel for these products too)
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool on = true;
     if (!on || a.nd < 2 || a.nd > MAXD || a.accumulate || a.j0_min || a.j0_excl || a.j0_desc || a.guard || !a.inner_from_zero) return false;
     if (a.slab_lo != 0 || a.slab_hi != a.zs[0]) return false;
     // which operand is the line, and along which axis
@@ -3145,36 +3035,12 @@ __global__ void __launch_bounds__(1024) k_horner_pipe_point(const double* __rest
     extern __shared__ double hp_lds[];
     horner_pipe_point_line<E>(res0, rp0, a, ap, out, plane, g, wit, blockIdx.x, blockDim.x >> 6, hp_lds);
 }
-// Two (three) independent loops in ONE launch (round 5: horizontal fusion).  A loop that was recorded instead of launched —
-// the first arm of an `if` substitutes into a memoised predecessor, nobody needs its result for a while — rides along with
-// the next loop the main chain launches: the lines of the riders are further workgroups of the same grid, each with its own
-// argument block; the carrier's guard word (a speculative launch queued behind its scan) only stops the carrier's lines.
-template <class E>
-__global__ void __launch_bounds__(1024) k_horner_pipe_point_multi(const double* __restrict__ res0, size_t rp0,
-                                                                  const double* __restrict__ a, size_t ap,
-                                                                  double* __restrict__ out, size_t plane, HornerLoopArgs g,
-                                                                  unsigned* __restrict__ wit, unsigned lines0, HornerRider r1, HornerRider r2) {
-    extern __shared__ double hp_lds[];
-    const unsigned b = blockIdx.x;
-    if (b < lines0) horner_pipe_point_line<E>(res0, rp0, a, ap, out, plane, g, wit, b, (g.fs[g.w] + 63u) >> 6, hp_lds);
-    else if (b - lines0 < r1.lines)
-        horner_pipe_point_line<E>(r1.res0, r1.rp0, r1.a, r1.ap, r1.out, r1.plane, r1.g, nullptr, b - lines0, (r1.g.fs[r1.g.w] + 63u) >> 6, hp_lds);
-    else
-        horner_pipe_point_line<E>(r2.res0, r2.rp0, r2.a, r2.ap, r2.out, r2.plane, r2.g, nullptr, b - lines0 - r1.lines, (r2.g.fs[r2.g.w] + 63u) >> 6, hp_lds);
-}
-
 // the LDS a loop needs on the POINT pipeline, or 0 if it does not run there (lines > 1024, non-point coefficient boxes, rings
 // beyond 60 KB, GFT_HORNER_PIPE / GFT_HORNER_LEAN = 0)
 template <class E>
 static size_t horner_pipe_point_lds(const HornerLoopArgs& args) {
-    static const bool pipe_on = [] {
-        const char* e = getenv("GFT_HORNER_PIPE");  // A/B knob (0 = the LDS ping-pong loop below)
-        return e ? atoi(e) != 0 : true;
-    }();
-    static const bool lean_on = [] {
-        const char* e = getenv("GFT_HORNER_LEAN");  // A/B knob (0 = the generic pipeline step for POINT lines too)
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool pipe_on = true;
+    static const bool lean_on = true;
     const unsigned lw = args.fs[args.w];
     if (!pipe_on || !lean_on || lw > 1024) return 0;
     const bool point = args.coeff_scalar || args.oc[args.w] == 1;
@@ -3182,10 +3048,6 @@ static size_t horner_pipe_point_lds(const HornerLoopArgs& args) {
     const unsigned nwv = (lw + 63) / 64;
     const size_t lds = (size_t)nwv * E::W * args.nsteps * sizeof(double) + (size_t)128 * 8 + 16;
     return lds <= 60 * 1024 ? lds : 0;
-}
-template <class E>
-bool K<E>::horner_can_carry(const HornerLoopArgs& args) {
-    return args.nsteps != 0 && horner_pipe_point_lds<E>(args) != 0;
 }
 template <class E>
 bool K<E>::horner_can_ride(const HornerLoopArgs& args) {
@@ -3215,39 +3077,15 @@ void K<E>::horner_batch(hipStream_t st, const HornerRider* items, unsigned n, co
 }
 template <class E>
 void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane, double* out,
-                              size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit, const HornerRider* riders, int nriders) {
-    if (args.nsteps == 0 || lines == 0) {
-        if (nriders > 0) throw std::runtime_error("internal: Horner riders on an empty carrier");
-        return;
-    }
+                              size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit) {
+    if (args.nsteps == 0 || lines == 0) return;
     const unsigned lw = args.fs[args.w];
     // wave pipeline (k_horner_linear_pipe): lines up to 1024 whose boundary rings fit LDS
-    static const bool pipe_on = [] {
-        const char* e = getenv("GFT_HORNER_PIPE");  // A/B knob (0 = the LDS ping-pong loop below)
-        return e ? atoi(e) != 0 : true;
-    }();
+    static const bool pipe_on = true;
     if (const size_t lds0 = horner_pipe_point_lds<E>(args)) {
-        if (nriders <= 0) {
-            GFT_LAUNCH((k_horner_pipe_point<E>), dim3(lines), dim3((lw + 63) / 64 * 64), lds0, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
-            return;
-        }
-        HornerRider r1 = riders[0], r2;
-        if (nriders > 1) r2 = riders[1];
-        else {
-            std::memset(&r2, 0, sizeof(r2));
-            r2.lines = 0;
-        }
-        size_t lds = std::max(lds0, horner_pipe_point_lds<E>(r1.g));
-        unsigned wmax = std::max(lw, r1.g.fs[r1.g.w]);
-        if (nriders > 1) {
-            lds = std::max(lds, horner_pipe_point_lds<E>(r2.g));
-            wmax = std::max(wmax, r2.g.fs[r2.g.w]);
-        }
-        GFT_LAUNCH((k_horner_pipe_point_multi<E>), dim3(lines + r1.lines + r2.lines), dim3((wmax + 63) / 64 * 64), lds, st, res0, res0_plane, a,
-                   a_plane, out, plane, args, wit, lines, r1, r2);
+        GFT_LAUNCH((k_horner_pipe_point<E>), dim3(lines), dim3((lw + 63) / 64 * 64), lds0, st, res0, res0_plane, a, a_plane, out, plane, args, wit);
         return;
     }
-    if (nriders > 0) throw std::runtime_error("internal: Horner riders on a carrier that is not a POINT pipeline");
     if (pipe_on && lw <= 1024) {
         const unsigned nwv = (lw + 63) / 64;
         const bool point = args.coeff_scalar || args.oc[args.w] == 1;
@@ -3262,10 +3100,7 @@ void K<E>::horner_linear_loop(hipStream_t st, const double* res0, size_t res0_pl
     }
     // one position per thread up to 1024-long lines (measured: two per thread is 10 % slower — the element chains
     // are not interleaved by the compiler, more waves hide the latency better)
-    static const unsigned per_thread = [] {
-        const char* e = getenv("GFT_HORNER_EPT");  // A/B knob: positions per thread the launch aims for (1 or 2)
-        return (unsigned)(e ? std::max(1, std::min(2, atoi(e))) : 1);
-    }();
+    static const unsigned per_thread = 1;
     unsigned threads = std::min<unsigned>(1024, ((lw + per_thread - 1) / per_thread + 63) / 64 * 64);
     size_t lds = (size_t)2 * E::W * args.lw_pad * sizeof(double);
     if (lw <= threads)

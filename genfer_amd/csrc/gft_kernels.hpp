@@ -202,7 +202,7 @@ struct HornerLoopArgs {
                                // before it said "the accumulator IS linear", i.e. the speculation this launch embodies failed
 };
 
-// A whole linear Horner loop that shares another loop's launch (K<E>::horner_linear_loop's riders).
+// A whole linear Horner loop as an item of a batch (K<E>::horner_batch): everything its launch needs.
 struct alignas(16) HornerRider {
     const double* res0;
     size_t rp0;
@@ -336,25 +336,19 @@ struct K {
                               size_t out_plane, const HornerArgs& args);
     static constexpr unsigned HORNER_LINE_MAX = 2048;  // longest line along the substitution axis of horner_linear_loop
     // `wit` (optional): wit[t] = 1 if the accumulator after in-kernel step t < nsteps-1 has a non-linearity witness
-    // `riders` (optional, at most 2): further loops that share the launch — only where horner_can_ride() says so for the
-    // carrier and for every rider (the POINT pipeline, no guard)
     static void horner_linear_loop(hipStream_t st, const double* res0, size_t res0_plane, const double* a, size_t a_plane,
-                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit,
-                                   const HornerRider* riders = nullptr, int nriders = 0);
+                                   double* out, size_t plane, const HornerLoopArgs& args, unsigned lines, unsigned* wit);
+    // the loop runs on the POINT pipeline without a guard word: it can be an item of a batch (horner_batch)
     static bool horner_can_ride(const HornerLoopArgs& args);
-    static bool horner_can_carry(const HornerLoopArgs& args);
     // *flag = 1 if `t` holds a non-zero coefficient at an index with two non-zero coordinates or a coordinate >= 2:
     // such a tensor is not of the form c + m*x_v (extract_linear, mt:275-294, would say None).  Sticky, no read-back.
     static void witness(hipStream_t st, const DView& t, unsigned* flag);
     static void observe_step(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                              const ObserveArgs& args);
     static constexpr unsigned OBSERVE_LINE_MAX = 2048;  // longest line along v of observe_chain
-    static void observe_chain_multi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
-                                    const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi,
-                                    const double* ra, size_t ra_plane, double* rout, size_t rout_plane, const ObserveChainArgs* rargs,
-                                    unsigned rlines, unsigned rlongest);
+    // `epi` (optional): the consumer's Add as the chain's epilogue
     static void observe_chain_epi(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
-                                  const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi& epi);
+                                  const ObserveChainArgs& args, unsigned lines, unsigned longest, const ObsEpi* epi);
     static void observe_chain(hipStream_t st, const double* a, size_t a_plane, double* out, size_t out_plane,
                               const ObserveChainArgs& args, unsigned lines, unsigned longest);
     // ---- batches (see ObsItem): `items` is DEVICE memory holding n items that share the launch geometry the *_geometry
@@ -429,7 +423,6 @@ struct K {
     static void sum_axis(hipStream_t st, const double* in, size_t in_plane, unsigned outer, unsigned len,
                          unsigned inner, size_t axis_stride_outer, double* out, size_t out_plane, int mode);
     // *count += number of positions where a != b  (n contiguous elements)
-    static void div_by_index(hipStream_t st, const double* src, size_t src_plane, double* dst, size_t dst_plane, size_t nslabs, size_t slab, unsigned first);
     static void any_zero(hipStream_t st, const double* p, size_t plane, size_t n, unsigned* state, const Mailbox& mb);
     // payload[0] = exact zeros among the n < 2^32 coefficients, payload[1 + u] = those in slab 0 of axis u < 6 of `sh`; state: 8 zeroed words
     static void zero_pattern(hipStream_t st, const double* p, size_t plane, const Shape& sh, size_t n, unsigned* state, const Mailbox& mb);

@@ -47,13 +47,6 @@ inline Lists& lists() {
     static thread_local Lists L;
     return L;
 }
-inline bool& enabled() {  // GFT_SMALL_ALLOC=0: every request goes to operator new / delete (A/B)
-    static bool on = [] {
-        const char* e = getenv("GFT_SMALL_ALLOC");
-        return !e || e[0] != '0';
-    }();
-    return on;
-}
 inline void* get(size_t bytes) {
     if (bytes == 0) bytes = 1;
     if (bytes > MAX_BYTES) return ::operator new(bytes);
@@ -75,7 +68,7 @@ inline void put(void* p, size_t bytes) noexcept {
         return;
     }
     const size_t c = (bytes + 15) >> 4;
-    if (dead() || !enabled()) {
+    if (dead()) {
         ::operator delete(p);
         return;
     }

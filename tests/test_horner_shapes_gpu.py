@@ -300,8 +300,8 @@ def test_recorded_chains_epilogues_and_riders_bit_exact(interval, OTP, GTP, OTPI
     # (tier "host" = the default dispatch, under which the substitutions `m * (x + eps_v) - m * x` stay lazy host handles as in
     # the interpreter's runs; tier "device" materialises them, which launches the recordings early: same bits, no fusion)
     try:
-        for opts in ({}, {"lazy_observe": 0}, {"obs_riders": 0}, {"lazy_sum": 0}, {"lazy_horner": 0}, {"horner_riders": 0}, {"nz_proofs": 0},
-                     {"lazy_observe": 0, "lazy_sum": 0, "lazy_horner": 0, "nz_proofs": 0}):
+        for opts in ({}, {"lazy_observe": 0}, {"batch_dag": 0}, {"lazy_sum": 0}, {"lazy_horner": 0}, {"nz_proofs": 0},
+                     {"lazy_observe": 0, "lazy_sum": 0, "lazy_horner": 0, "nz_proofs": 0}, {"batch_dag": 0, "lazy_sum": 0}):
             for k, v in opts.items():
                 assert L.gft_set_option(k.encode(), float(v)) == 0
             try:
@@ -310,8 +310,8 @@ def test_recorded_chains_epilogues_and_riders_bit_exact(interval, OTP, GTP, OTPI
                 check(want, got)
                 after = genfer_amd.op_stats()
                 d = {k: after[k] - before[k] for k in after}
-                switched = any(os.environ.get(k) for k in ("GFT_SIDE_STREAMS", "GFT_LAZY_OBSERVE", "GFT_LAZY_HORNER", "GFT_LAZY_SUM", "GFT_NZ_PROOFS",
-                                                           "GFT_OBS_RIDERS", "GFT_HORNER_RIDERS", "GFT_DEFER", "GFT_FUSE_HORNER", "GFT_HORNER_LOOP_MAX"))
+                switched = any(os.environ.get(k) for k in ("GFT_BATCH", "GFT_LAZY_OBSERVE", "GFT_LAZY_HORNER", "GFT_LAZY_SUM", "GFT_NZ_PROOFS",
+                                                           "GFT_DEFER", "GFT_HORNER_LOOP_MAX"))
                 if not opts and tier == "host" and not switched:  # (the verification matrix runs this test under every switch: bits only)
                     if not interval:
                         assert d["fused_observe_adds"] >= 3, d   # the Adds ran as the observation kernels' epilogues
@@ -359,18 +359,18 @@ def test_recorded_sums_nested_add_bit_exact(interval, OTP, GTP, OTPI, GTPI):
             for w, g_ in zip(want, got):
                 check(w, g_)
             d = genfer_amd.op_stats()
-            if lazy and not any(os.environ.get(k) for k in ("GFT_SIDE_STREAMS", "GFT_LAZY_SUM", "GFT_DEFER")):
+            if lazy and not any(os.environ.get(k) for k in ("GFT_BATCH", "GFT_LAZY_SUM", "GFT_DEFER")):
                 assert d["nested_adds"] - before["nested_adds"] >= 2, (d, before)
     finally:
         L.gft_set_option(b"lazy_sum", 1.0)
 
 
 @pytest.mark.parametrize("interval", [False, True])
-def test_dependent_recordings_do_not_ride_with_their_producer(interval, OTP, GTP, OTPI, GTPI, tier):
-    """A recording whose INPUT is another recording (B = observe(A), r2 = subst_var(r1)) must not ride in the launch that is
-    still writing that input: the rider's workgroups share the carrier's grid, nothing orders them after its stores (round-5
-    advisor finding; `Buf::writing`).  Reading the producer first, then the dependent, must give the oracle's bits — with
-    riders on and off."""
+def test_dependent_recordings_are_issued_after_their_producer(interval, OTP, GTP, OTPI, GTPI, tier):
+    """A recording whose INPUT is another recording (B = observe(A), r2 = subst_var(r1)) must never share a launch with the one
+    that writes that input (round-5 advisor finding on the riders of that round; in the launch graph of round 6 the two are on
+    different levels by construction).  Reading the producer first, then the dependents, must give the oracle's bits — with
+    the graph on and off."""
     import genfer_amd
 
     L = genfer_amd.lib()
@@ -400,7 +400,7 @@ def test_dependent_recordings_do_not_ride_with_their_producer(interval, OTP, GTP
 
     want = run(O)
     try:
-        for opts in ({}, {"obs_riders": 0, "horner_riders": 0}):
+        for opts in ({}, {"batch_dag": 0}):
             for k, v in opts.items():
                 assert L.gft_set_option(k.encode(), float(v)) == 0
             got = run(G)
@@ -408,5 +408,63 @@ def test_dependent_recordings_do_not_ride_with_their_producer(interval, OTP, GTP
                 assert w.shape == g_.shape, (i, w.shape, g_.shape)
                 assert np.array_equal(w, g_), (opts, i, float(np.max(np.abs(w - g_))))
     finally:
-        for k in ("obs_riders", "horner_riders"):
-            L.gft_set_option(k.encode(), 1.0)
+        L.gft_set_option(b"batch_dag", 1.0)
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_launch_graph_batches_bit_exact(interval, OTP, GTP, OTPI, GTPI):
+    """The deferred launch graph: B independent operations of one kind on same-shape tensors — what the evaluator
+    issues for the B input points of one depth — are recorded and issued as ONE launch per kind and level (blockIdx.y = item).
+    Every item must carry the bits of the oracle's own sequence for that item, with the graph on and off, and with it on the
+    counters must show batches: observation chains (plain, and with the Add of two arms as epilogue), two-chain Adds, nested
+    Adds of mul_linear sums, and (intervals) proven linear Horner loops."""
+    import genfer_amd
+
+    L = genfer_amd.lib()
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    n, B = 48, 9
+    base = rand((n, n), 601, 0.05, 1.0)
+    other = rand((n, n), 602, 0.05, 1.0)
+    mk = (lambda t: np.stack([t, t * (1 + 1e-15)])) if interval else (lambda t: t)
+    sc = (lambda v: (v, v)) if interval else (lambda v: v)
+    xs = [0.3 + 0.07 * k for k in range(B)]
+
+    def run(T):
+        g, h = T.new(mk(base), [n, n]), T.new(mk(other), [n, n])
+        out = []
+        # level 1: B plain observation chains on g, B on h (two axes)
+        a = [g.observe_chain(0, sc(x), [sc(0.1), sc(0.05)], n - 4) for x in xs]
+        b = [h.observe_chain(1, sc(x), [sc(0.2), sc(0.07)], n - 4) for x in xs]
+        # level 2: a chain on each result with the Add of the two arms as its epilogue (the `if` of mixture)
+        c = [a[k].observe_chain(0, sc(0.9), [sc(0.3)], n - 6) * T.from_scalar(sc(0.5)) +
+             b[k].observe_chain(1, sc(0.8), [sc(0.4)], n - 6) * T.from_scalar(sc(0.5)) for k in range(B)]
+        # two-chain Adds of scaled tensors
+        d = [a[k] * T.from_scalar(sc(0.25)) + b[k] * T.from_scalar(sc(0.75)) for k in range(B)]
+        # nested Adds of mul_linear sums (hmm's `State ~ Bernoulli(p)` on both arms)
+        lin1 = T.var_with_degrees_p1(0, sc(0.0), [n, n]) * T.from_scalar(sc(0.2)) + T.from_scalar(sc(0.8))
+        lin2 = T.var_with_degrees_p1(0, sc(0.0), [n, n]) * T.from_scalar(sc(0.7)) + T.from_scalar(sc(0.3))
+        e = [a[k] * lin1 + b[k] * lin2 for k in range(B)]
+        # linear Horner loops (recorded where the loop is proven: intervals with a non-zero constant)
+        f = [c[k].subst_var(0, T.var_with_degrees_p1(0, sc(0.25 + 0.01 * k), [n, n]) * T.from_scalar(sc(0.5))) for k in range(B)]
+        for lst in (c, d, e, f):
+            out += [t.array().copy() for t in lst]
+        return out
+
+    want = run(O)
+    try:
+        for batch in (1.0, 0.0):
+            assert L.gft_set_option(b"batch_dag", batch) == 0
+            before = genfer_amd.op_stats()
+            got = run(G)
+            for i, (w, g_) in enumerate(zip(want, got)):
+                assert w.shape == g_.shape, (batch, i, w.shape, g_.shape)
+                assert np.array_equal(w, g_), (batch, i, float(np.max(np.abs(w - g_))))
+            d = genfer_amd.op_stats()
+            delta = {k: d[k] - before[k] for k in d}
+            if batch and not any(os.environ.get(k) for k in ("GFT_BATCH", "GFT_LAZY_OBSERVE", "GFT_LAZY_SUM", "GFT_LAZY_HORNER", "GFT_DEFER", "GFT_NZ_PROOFS")):
+                assert delta["batch_launches"] >= 4 and delta["batch_items"] >= 4 * B, delta
+                assert delta["launches"] <= 60, delta  # (the same program without the graph: > 100 launches)
+            if not batch:
+                assert delta["batch_launches"] == 0, delta
+    finally:
+        L.gft_set_option(b"batch_dag", 1.0)

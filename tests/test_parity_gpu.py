@@ -1351,60 +1351,6 @@ def test_conv_tiled_rank5_and_up_matches_reference_order_kernel(xs, ys, zs):
     assert np.array_equal(_conv_raw_gpu(2, xi, y, zs), _conv_raw_gpu(1, xi, y, zs), equal_nan=True)
 
 
-BLOCKED_DIV_SHAPES = [(40, 40, 40), (64, 64, 64), (24, 24, 24, 24), (130, 130), (48, 40, 36)]
-
-
-@pytest.mark.parametrize("shape", BLOCKED_DIV_SHAPES)
-def test_div_log_blocked_right_looking_vs_oracle(shape, OTP, GTP):
-    """Large f64 quotients and logarithms as a BLOCKED right-looking recurrence (round 5, Ops::div_right_blocked / log_right):
-    diagonal blocks of leading slabs on the reference-order wavefront, the trailing updates as slab-range products on the
-    tiled FMA kernel.  Against the ORACLE (not the wavefront): 1e-10 per coefficient where the data do not cancel, the
-    normwise bound otherwise (the recurrence's own condition: |res| (*) |ys| / |ys_0| for the quotient), the non-finite
-    pattern identical; `div_right` = 0 gives the reference's bits back (test_div_row_wavefront_bit_exact)."""
-    import genfer_amd
-
-    L = genfer_amd.lib()
-    assert L.gft_set_option(b"host_max_elems", 0.0) == 0
-    assert L.gft_set_option(b"div_right", 1.0) == 0           # (off by default: the reference-order wavefronts)
-    assert L.gft_set_option(b"div_right_min_macs", 0.0) == 0  # (130^2 lies below the crossover)
-    assert L.gft_set_option(b"div_right_block", float(min(16, shape[0] // 2))) == 0
-    deg = list(shape)
-    try:
-        for sign, seed in (("positive", 401), ("mixed", 411)):
-            lo = 0.0 if sign == "positive" else -1.0
-            x, y = rand(shape, seed, lo, 1.0), rand(shape, seed + 1, lo * 0.05, 0.05)
-            y[(0,) * len(shape)] = 1.5
-            before = genfer_amd.op_stats()["tiled"]
-            got = (GTP.new(x, deg) / GTP.new(y, deg)).array()
-            assert genfer_amd.op_stats()["tiled"] > before, "the quotient did not take the blocked right-looking form"
-            want = (OTP.new(x, deg) / OTP.new(y, deg)).array()
-            # condition of the recurrence: what the terms of one coefficient add up to in absolute value
-            bound = (OTP.new(np.abs(want), deg) * OTP.new(np.abs(y), deg)).array() / abs(y.flat[0]) + np.abs(x) / abs(y.flat[0])
-            assert np.all(np.abs(got - want) <= 1e-10 * np.maximum(np.abs(want), bound)), (sign, np.abs((got - want) / bound).max())
-            if sign == "positive":
-                ylog = rand(shape, seed + 2, 0.0, 0.05)
-                ylog[(0,) * len(shape)] = 1.5
-                gl = GTP.new(ylog, deg).log().array()
-                wl = OTP.new(ylog, deg).log().array()
-                scale = np.maximum(np.abs(wl), np.abs(wl).max() * 1e-30)
-                lbound = (OTP.new(np.abs(wl), deg) * OTP.new(np.abs(ylog), deg)).array() / 1.5 + np.abs(ylog) / 1.5
-                assert np.all(np.abs(gl - wl) <= 1e-10 * np.maximum(scale, lbound)), np.abs((gl - wl) / np.maximum(scale, lbound)).max()
-        # non-finite operands: the trailing products fall back to the guarded reference-order launch, the pattern is the oracle's
-        x, y = rand(shape, 421, 0.0, 1.0), rand(shape, 422, 0.0, 0.05)
-        y[(0,) * len(shape)] = 1.5
-        x[tuple(min(2, s - 1) for s in shape)] = np.inf
-        got = (GTP.new(x, deg) / GTP.new(y, deg)).array()
-        want = (OTP.new(x, deg) / OTP.new(y, deg)).array()
-        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
-        fin = np.isfinite(want)
-        assert np.all(np.abs(got[fin] - want[fin]) <= 1e-9 * np.maximum(np.abs(want[fin]), 1e-300))
-    finally:
-        L.gft_set_option(b"div_right", 0.0)
-        L.gft_set_option(b"div_right_block", 0.0)
-        L.gft_set_option(b"div_right_min_macs", -1.0)
-        L.gft_set_option(b"host_max_elems", -1.0)
-
-
 WAVEFRONT_SHAPES = [
     # (quotient shape, divisor shape, dividend shape)
     ((40, 40, 40), (40, 40, 40), (40, 40, 40)),
@@ -1438,7 +1384,6 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier):
     L = genfer_amd.lib()
     # (the blocked right-looking form of large f64 quotients / logarithms — the tiled product's 1e-10 contract,
     # test_div_log_blocked_right_looking_vs_oracle — is an option, off by default; this test is about the reference-order kernels)
-    assert L.gft_set_option(b"div_right", 0.0) == 0
     _div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier, L, genfer_amd)
 
 
