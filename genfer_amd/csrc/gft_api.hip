@@ -2700,6 +2700,13 @@ struct Ops {
             zero_elems(false, fl->p, (words + 1) / 2 + 1);
             return K<E>::rows_wavefront(R.stream, 0, x.p, x.plane, xs, y.p, y.plane, ys, z.p, z.plane, zs, nullptr, 0, reinterpret_cast<unsigned*>(fl->p));
         }
+        if (nd >= 3 && zs[nd - 1] > 64 && zs[nd - 1] <= 4096 && rows >= 8) {
+            // long rows, rank 3 / 4 (round 6): the segment wavefront with leading axes — one launch instead of the slab-by-slab form
+            const size_t words = rows * ((zs[nd - 1] + 63) / 64) + 1;
+            std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
+            zero_elems(false, fl->p, (words + 1) / 2 + 1);
+            return K<E>::seg_wavefront(R.stream, 0, x.p, x.plane, xs, y.p, y.plane, ys, z.p, z.plane, zs, (int)nd, nullptr, 0, reinterpret_cast<unsigned*>(fl->p));
+        }
         if (zs[nd - 1] > 64 || zs[nd - 1] < 2 || rows < 64) return false;
         std::shared_ptr<Buf> fl = alloc_doubles((rows + 1 + 1) / 2 + 1);
         zero_elems(false, fl->p, (rows + 1 + 1) / 2 + 1);
@@ -2965,6 +2972,15 @@ struct Ops {
             zero_elems(false, fl->p, (words + 1) / 2 + 1);
             return K<E>::rows_wavefront(R.stream, 1, xs.p, xs.plane, xsh, xs.p, xs.plane, xsh, res.p, res.plane, rsh, qb->p, res.numel(),
                                         reinterpret_cast<unsigned*>(fl->p));
+        }
+        if (nd >= 3 && rsh[nd - 1] > 64 && rsh[nd - 1] <= 4096 && rows >= 8 && x0n >= 2 && nonunit_axes(xs.shape) >= 2) {
+            // long rows, rank 3 / 4 (round 6): the segment wavefront with leading axes
+            std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);
+            const size_t words = rows * ((rsh[nd - 1] + 63) / 64) + 1;
+            std::shared_ptr<Buf> fl = alloc_doubles((words + 1) / 2 + 1);
+            zero_elems(false, fl->p, (words + 1) / 2 + 1);
+            return K<E>::seg_wavefront(R.stream, 1, xs.p, xs.plane, xsh, xs.p, xs.plane, xsh, res.p, res.plane, rsh, (int)nd, qb->p, res.numel(),
+                                       reinterpret_cast<unsigned*>(fl->p));
         }
         if (rsh[nd - 1] > 64 || rows < 8 || x0n < 2 || nonunit_axes(xs.shape) < 2) return false;  // (the alternative is 2+ launches per slab)
         std::shared_ptr<Buf> qb = alloc_doubles(res.numel() * W);

@@ -1990,4 +1990,330 @@ template bool K<EF64>::rows_wavefront(hipStream_t, int, const double*, size_t, c
 template bool K<EIv>::rows_wavefront(hipStream_t, int, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
                                      const unsigned*, double*, size_t, unsigned*);
 
+// ------------------------------------------------------------------------------------------
+// Quotients / logarithms of rank 3 and 4 with LONG rows (round 6): the segment wavefront with leading axes
+// ------------------------------------------------------------------------------------------
+// k_div_wavefront takes rows of at most 64 coefficients, k_rows_wavefront rank 2 only: a rank-3 quotient with rows of 65 or
+// more fell back to the slab-by-slab blocked form of round 2 — 96^3 div 404 ms against 4.0 ms at 64^3, a 30x cliff at row 65.
+// Here the two are put together: a TASK is one 64-coefficient segment (K, s) of the quotient row K = (k_0 .. k_{L-1}); it
+// consumes its source rows level by level in the reference's order exactly as k_div_wavefront does (mt:1162-1192 over
+// mt:984-1012; see the comment there), but every source row contributes only the chunks of its row product that reach the
+// segment — chunk_mac over t = 0 .. s, k_rows_wavefront's scheme: the same additions in the same order — and the row's 1-d
+// division first takes the chunks its own earlier segments have published, then runs in lock step inside the segment.
+// Tasks are claimed in (row order, s) order: a task's sources — segments <= s of rows earlier in the row order, segments
+// < s of its own row — are all claimed before it.  Publication: EMPTY pattern + coherent 8-byte stores + per-segment flags.
+// log_mode 1: slabs k0 >= 1 of log(xs) (level 0: xs[k0 - j0] rows against j0 * res[j0] rows; levels >= 1 and the division:
+// by xs[0], on the slab's own quotient rows kept in `qb`; res = q / k0) — slab 0 is the caller's.
+struct SegWfArgs {
+    int L;
+    unsigned n[3], m[3], xn[3];
+    unsigned nr, mr, xnr;
+    size_t rstr[3], ystr[3], xstr[3];
+    unsigned nseg, ntasks;
+    unsigned* flags;              // [all rows of res][nseg], zeroed before the launch
+    unsigned* counter;
+    int log_mode;
+    const unsigned* order;        // task row t works on row order[t] of the task rows (dwf_order); null: t
+    double* qb;
+    size_t qbp;
+};
+template <class E, int L>
+__global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const double* __restrict__ xs, size_t xp, const double* __restrict__ ys, size_t yp,
+                                                               double* res, size_t rp, SegWfArgs g) {
+    typedef typename E::V V;
+    constexpr unsigned NW = DwfCfg<E>::NW;
+    __shared__ double part[2][E::W][NW][64];
+    __shared__ double stage[NW][E::W][192];
+    __shared__ unsigned s_task;
+    const unsigned lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* const my_stage = &stage[wave][0][0];
+    const bool lg = g.log_mode == 1;
+    // the divisor's first row: ys[0 .. 0, :] (log: xs[0 .. 0, :] — the caller passes xs as ys)
+    const V y0row = lane < g.mr ? E::ld(ys, yp, lane) : E::zero();
+    const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
+    auto plain_chunk = [&](const double* base, size_t plane, size_t rowoff, int chunk, unsigned len) -> V {
+        if (chunk < 0) return E::zero();
+        const unsigned idx = 64u * (unsigned)chunk + lane;
+        return idx < len ? E::ld(base, plane, rowoff + idx) : E::zero();
+    };
+    auto coherent_raw = [&](const double* base, size_t plane, size_t rowoff, int chunk) -> V {
+        if (chunk < 0) return E::zero();
+        const unsigned idx = 64u * (unsigned)chunk + lane;
+        return idx < g.nr ? ld_coherent<E>(base, plane, rowoff + idx) : E::zero();
+    };
+    auto coherent_confirm = [&](V v, const double* base, size_t plane, size_t rowoff, unsigned row_id, int chunk) -> V {
+        if (chunk < 0) return v;
+        const unsigned idx = 64u * (unsigned)chunk + lane;
+        const bool in = idx < g.nr;
+        bool confirmed = false;
+        for (unsigned spins = 1; !confirmed && any_lane(in && is_empty_bits(v)); ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins & 31u) == 0u && __hip_atomic_load(g.flags + (size_t)row_id * g.nseg + (unsigned)chunk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                confirmed = true;  // (what the reload below returns is the chunk)
+            v = in ? ld_coherent<E>(base, plane, rowoff + idx) : E::zero();
+        }
+        return v;
+    };
+    for (;;) {
+        if (threadIdx.x == 0) s_task = atomicAdd(g.counter, 1u);
+        __syncthreads();
+        const unsigned t = s_task;
+        __syncthreads();
+        if (t >= g.ntasks) break;
+        const unsigned s = t % g.nseg;
+        const unsigned c = 64u * s + lane;
+        unsigned k[3] = {0, 0, 0};
+        unsigned row_id = 0;
+        size_t qoff_row = 0;
+        {
+            unsigned r = g.order ? g.order[t / g.nseg] : t / g.nseg;
+#pragma unroll
+            for (int a = L - 1; a >= 1; --a) {
+                k[a] = r % g.n[a];
+                r /= g.n[a];
+            }
+            k[0] = r + (lg ? 1u : 0u);
+#pragma unroll
+            for (int a = 0; a < L; ++a) {
+                row_id = row_id * g.n[a] + k[a];
+                qoff_row += (size_t)k[a] * g.rstr[a];
+            }
+        }
+        V r_prev = E::zero();  // (meaningful in wave 0)
+        unsigned buf = 0;
+        auto level = [&](auto lev_c) {
+            constexpr int lev = decltype(lev_c)::value;
+            V S = E::zero();
+            const bool lg0 = lg && lev == 0;  // the other operand's rows come from xs, the odometer runs over ITS rows
+            unsigned lo[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
+            unsigned total = 1;
+#pragma unroll
+            for (int a = lev; a < L; ++a) {
+                if (lg0 && a > 0) {
+                    lo[a] = 0;
+                    cnt[a] = (k[a] < g.xn[a] ? k[a] : g.xn[a] - 1) + 1;
+                } else {
+                    const unsigned mm = lg0 ? g.xn[a] : g.m[a];
+                    lo[a] = k[a] + 1 > mm ? k[a] + 1 - mm : 0;
+                    if (lg0 && lo[a] < 1) lo[a] = 1;
+                    const unsigned hi = a == lev ? k[a] : k[a] + 1;  // exclusive
+                    cnt[a] = hi > lo[a] ? hi - lo[a] : 0;
+                }
+                total *= cnt[a];
+            }
+            const double* const coh_base = (lg && lev > 0) ? g.qb : res;  // where the result-side rows live
+            const size_t coh_plane = (lg && lev > 0) ? g.qbp : rp;
+            for (unsigned base = 0; base < total; base += NW) {
+                const unsigned i = base + wave;
+                if (i < total) {
+                    unsigned rem = i, j[3] = {0, 0, 0};
+#pragma unroll
+                    for (int a = L - 1; a >= lev; --a) {
+                        j[a] = rem % cnt[a];
+                        rem /= cnt[a];
+                    }
+#pragma unroll
+                    for (int a = lev; a < L; ++a) j[a] += lo[a];
+                    size_t roff = 0, ooff = 0;
+                    unsigned src = 0;
+#pragma unroll
+                    for (int a = 0; a < L; ++a) {
+                        unsigned ra;  // the result row's index on this axis
+                        if (a < lev) ra = k[a];
+                        else if (lg0 && a > 0) ra = k[a] - j[a];
+                        else ra = j[a];
+                        roff += (size_t)ra * g.rstr[a];
+                        src = src * g.n[a] + ra;
+                        if (a >= lev) {
+                            if (lg0) ooff += (size_t)(a == 0 ? k[0] - j[0] : j[a]) * g.xstr[a];
+                            else ooff += (size_t)(k[a] - j[a]) * g.ystr[a];
+                        }
+                    }
+                    const V scale = E::from_u32(j[0]);
+                    // A = the operand whose coefficient j is broadcast, B = the one read at c - j
+                    //   div, log levels >= 1: A = result row (coherent), B = divisor row (plain)
+                    //   log level 0:          A = xs row (plain),        B = j0 * result row (coherent)
+                    const unsigned alen = lg0 ? g.xnr : g.nr, blen = lg0 ? g.nr : g.mr;
+                    auto raw_a = [&](unsigned tt) -> V { return lg0 ? plain_chunk(xs, xp, ooff, (int)tt, g.xnr) : coherent_raw(coh_base, coh_plane, roff, (int)tt); };
+                    auto fix_a = [&](V v, unsigned tt) -> V { return lg0 ? v : coherent_confirm(v, coh_base, coh_plane, roff, src, (int)tt); };
+                    auto raw_b = [&](int ch) -> V {
+                        if (ch < 0) return E::zero();
+                        return lg0 ? coherent_raw(coh_base, coh_plane, roff, ch) : plain_chunk(ys, yp, ooff, ch, g.mr);
+                    };
+                    auto fix_b = [&](V v, int ch) -> V {
+                        if (ch < 0 || !lg0) return v;
+                        v = coherent_confirm(v, coh_base, coh_plane, roff, src, ch);
+                        if (64u * (unsigned)ch + lane < g.nr) v = E::mul(v, scale);
+                        return v;
+                    };
+                    const unsigned t_hi = (alen + 63u) / 64u - 1u < s ? (alen + 63u) / 64u - 1u : s;
+                    const unsigned t_lo = s > (blen + 62u) / 64u ? s - (blen + 62u) / 64u : 0u;
+                    V inner = E::zero();
+                    if (t_lo <= t_hi) {
+                        V bc = fix_b(raw_b((int)s - (int)t_lo), (int)s - (int)t_lo);
+                        V a_n = raw_a(t_lo), bp_n = raw_b((int)s - (int)t_lo - 1);
+                        for (unsigned tt = t_lo; tt <= t_hi; ++tt) {
+                            const V a = fix_a(a_n, tt);
+                            const V bp = fix_b(bp_n, (int)s - (int)tt - 1);
+                            if (tt < t_hi) {
+                                a_n = raw_a(tt + 1);
+                                bp_n = raw_b((int)s - (int)tt - 2);
+                            }
+                            inner = chunk_mac<E>(inner, a, bp, bc, lane, my_stage, 64u * tt, c, alen, blen);
+                            bc = bp;
+                        }
+                    }
+                    E::st(&part[buf][0][wave][0], (size_t)NW * 64, lane, inner);
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned nb = total - base < NW ? total - base : NW;
+                    const double* pb = &part[buf][0][0][0];
+                    if (nb == NW) {
+                        V pv[NW];
+#pragma unroll
+                        for (unsigned w = 0; w < NW; ++w) pv[w] = E::ld(pb, (size_t)NW * 64, (size_t)w * 64 + lane);
+#pragma unroll
+                        for (unsigned w = 0; w < NW; ++w) S = E::add(S, pv[w]);
+                    } else {
+                        for (unsigned w = 0; w < nb; ++w) S = E::add(S, E::ld(pb, (size_t)NW * 64, (size_t)w * 64 + lane));
+                    }
+                }
+                buf ^= 1u;
+            }
+            if (wave == 0) {
+                V r = E::neg(S);
+                if (lev == 0) {
+                    bool in_x = c < g.xnr;
+                    size_t xoff = 0;
+#pragma unroll
+                    for (int a = 0; a < L; ++a) {
+                        if (k[a] >= g.xn[a]) in_x = false;
+                        xoff += (size_t)k[a] * g.xstr[a];
+                    }
+                    if (in_x) {
+                        const V xin = E::ld(xs, xp, xoff + c);
+                        r = E::add(r, lg ? E::mul(E::from_u32(k[0]), xin) : xin);
+                    }
+                } else {
+                    r = E::add(r, r_prev);
+                }
+                r_prev = r;
+            }
+            __syncthreads();  // a level's last batch buffer is free again before the next level reuses it
+        };
+        level(std::integral_constant<int, 0>{});
+        if constexpr (L > 1) level(std::integral_constant<int, 1>{});
+        if constexpr (L > 2) level(std::integral_constant<int, 2>{});
+        if (wave == 0) {
+            const double* const qbase = lg ? g.qb : res;
+            const size_t qplane = lg ? g.qbp : rp;
+            V r = r_prev;
+            if (c >= g.nr) r = E::zero();
+            // the row's 1-d division (mt:1162-1185): cur[c] = sum_{j < c} q[j] * y0[c - j], ascending j — first the chunks of q the
+            // earlier segments of this row have published, then lock step inside the segment
+            V cur1 = E::zero();
+            {
+                const unsigned t_lo = s > (g.mr + 62u) / 64u ? s - (g.mr + 62u) / 64u : 0u;
+                if (t_lo < s) {
+                    V bc = plain_chunk(ys, yp, 0, (int)s - (int)t_lo, g.mr);
+                    V a_n = coherent_raw(qbase, qplane, qoff_row, (int)t_lo);
+                    for (unsigned tt = t_lo; tt < s; ++tt) {
+                        const V a = coherent_confirm(a_n, qbase, qplane, qoff_row, row_id, (int)tt);
+                        const V bp = plain_chunk(ys, yp, 0, (int)s - (int)tt - 1, g.mr);
+                        if (tt + 1 < s) a_n = coherent_raw(qbase, qplane, qoff_row, (int)tt + 1);
+                        cur1 = chunk_mac<E>(cur1, a, bp, bc, lane, my_stage, 64u * tt, c, g.nr, g.mr);
+                        bc = bp;
+                    }
+                }
+            }
+            V mine = E::zero(), ysl = y0row;  // ysl[l] = y0[l - jj] at step jj (zero for l < jj and beyond the divisor's row)
+            const bool fin = !any_lane(!elem_finite<E>(r)) && !any_lane(!elem_finite<E>(y0row)) && !any_lane(!elem_finite<E>(cur1));
+            const unsigned nsteps = g.nr - 64u * s < 64u ? g.nr - 64u * s : 64u;
+            for (unsigned jj = 0; jj < nsteps; ++jj) {
+                const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r), jj));
+                if (lane == jj) mine = q;
+                const V tnew = E::add(cur1, E::mul(q, ysl));
+                if (fin && elem_finite<E>(q)) {
+                    cur1 = tnew;  // positions outside the sum multiply a shifted-in zero
+                } else if (lane > jj && lane - jj < g.mr) {
+                    cur1 = tnew;
+                }
+                ysl = wave_shr1<E>(ysl);
+            }
+            if (c < g.nr) {
+                if (lg) {  // res[K] = q / k0 (mt:1384); the slab's own later rows and segments read q itself
+                    st_coherent(g.qb, g.qbp, qoff_row + c, mine);
+                    st_coherent(res, rp, qoff_row + c, E::div(mine, E::from_u32(k[0])));
+                } else {
+                    st_coherent(res, rp, qoff_row + c, mine);
+                }
+            }
+            __threadfence();  // the segment is visible device-wide before its flag is
+            if (lane == 0) __hip_atomic_store(g.flags + (size_t)row_id * g.nseg + s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// mode 0: res = xs / ys; mode 1: slabs k0 >= 1 of res = log(xs) (slab 0 is the caller's; qbuf: a tensor like res).  Ranks 3 and 4,
+// rows of 65 .. 4096 coefficients.  `flags_and_counter`: (rows of res) * ceil(row length / 64) + 1 zeroed words.  false: outside
+// the kernel's domain, nothing launched.
+template <class E>
+bool K<E>::seg_wavefront(hipStream_t st, int mode, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
+                         const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, int nd, double* qbuf, size_t q_plane,
+                         unsigned* flags_and_counter) {
+    if (nd < 3 || nd > 4 || (mode != 0 && mode != 1)) return false;
+    SegWfArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.L = nd - 1;
+    g.log_mode = mode;
+    g.nr = rshape[nd - 1];
+    g.xnr = xshape[nd - 1];
+    g.mr = mode == 0 ? yshape[nd - 1] : g.xnr;
+    if (g.nr <= 64 || g.nr > 4096 || g.mr == 0 || g.xnr == 0 || g.mr > g.nr || g.xnr > g.nr) return false;
+    if (mode == 1 && (!qbuf || rshape[0] < 2)) return false;
+    size_t rs = g.nr, ysd = g.mr, xsd = g.xnr, rows = 1;
+    for (int a = g.L - 1; a >= 0; --a) {
+        g.n[a] = rshape[a];
+        g.xn[a] = xshape[a];
+        g.m[a] = mode == 0 ? yshape[a] : xshape[a];
+        if (g.m[a] > g.n[a] || g.xn[a] > g.n[a] || g.n[a] == 0 || g.m[a] == 0 || g.xn[a] == 0) return false;
+        g.rstr[a] = rs;
+        g.ystr[a] = ysd;
+        g.xstr[a] = xsd;
+        rs *= rshape[a];
+        ysd *= g.m[a];
+        xsd *= xshape[a];
+        rows *= rshape[a];
+    }
+    g.nseg = (g.nr + 63u) / 64u;
+    const size_t slab_rows = rows / rshape[0];
+    const size_t task_rows = mode == 1 ? rows - slab_rows : rows;
+    const size_t ntasks = task_rows * g.nseg;
+    if (rows * g.nseg > 0x7fffffffu || task_rows == 0) return false;
+    g.ntasks = (unsigned)ntasks;
+    g.flags = flags_and_counter;
+    g.counter = flags_and_counter + rows * g.nseg;
+    g.order = dwf_order(g.L, g.n, mode == 1 ? 1u : 0u);
+    g.qb = qbuf;
+    g.qbp = q_plane;
+    const size_t skip = mode == 1 ? slab_rows * g.nr : 0, nel = task_rows * g.nr;
+    for (int pl = 0; pl < E::W; ++pl) {
+        const unsigned fb = (unsigned)std::min<size_t>((nel + 255) / 256, 2048);
+        GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, res + (size_t)pl * r_plane + skip, nel, DWF_EMPTY);
+        if (mode == 1) GFT_LAUNCH(k_fill_bits, dim3(fb), dim3(256), 0, st, qbuf + (size_t)pl * q_plane + skip, nel, DWF_EMPTY);
+    }
+    const dim3 grid((unsigned)std::min<size_t>(ntasks, (size_t)256 * 2)), block(64 * DwfCfg<E>::NW);
+    const double* yarg = mode == 0 ? ys : xs;
+    const size_t yplane = mode == 0 ? y_plane : x_plane;
+    if (g.L == 2) GFT_LAUNCH((k_seg_wavefront<E, 2>), grid, block, 0, st, xs, x_plane, yarg, yplane, res, r_plane, g);
+    else GFT_LAUNCH((k_seg_wavefront<E, 3>), grid, block, 0, st, xs, x_plane, yarg, yplane, res, r_plane, g);
+    return true;
+}
+template bool K<EF64>::seg_wavefront(hipStream_t, int, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                     const unsigned*, int, double*, size_t, unsigned*);
+template bool K<EIv>::seg_wavefront(hipStream_t, int, const double*, size_t, const unsigned*, const double*, size_t, const unsigned*, double*, size_t,
+                                    const unsigned*, int, double*, size_t, unsigned*);
+
+
 }  // namespace gft

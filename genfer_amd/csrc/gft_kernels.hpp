@@ -416,6 +416,12 @@ struct K {
     static bool rows_wavefront(hipStream_t st, int mode, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys,
                                size_t y_plane, const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, double* qbuf,
                                size_t q_plane, unsigned* flags_and_counter);
+    // Quotients (mode 0) and the slabs k0 >= 1 of logarithms (mode 1) of rank 3 / 4 with rows of 65 .. 4096 coefficients: the segment
+    // wavefront with leading axes (gft_div2d.hip k_seg_wavefront), bit-identical to the host-driven recursion.
+    // `flags_and_counter`: (rows of res) * ceil(row length / 64) + 1 zeroed words; `qbuf` (mode 1): a tensor like res.
+    static bool seg_wavefront(hipStream_t st, int mode, const double* xs, size_t x_plane, const unsigned* xshape, const double* ys, size_t y_plane,
+                              const unsigned* yshape, double* res, size_t r_plane, const unsigned* rshape, int nd, double* qbuf, size_t q_plane,
+                              unsigned* flags_and_counter);
     // factor tables computed on device in the reference's operation order (mt:472-478, 499-506, 557-565)
     static void factor_table(hipStream_t st, int op, unsigned n, unsigned len, const double* m, size_t m_plane,
                              double* tab, size_t tab_plane);

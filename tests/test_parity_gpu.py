@@ -1371,6 +1371,14 @@ WAVEFRONT_SHAPES = [
     ((150, 65), (150, 65), (150, 2)),                # one coefficient into the second segment; a thin dividend
     ((33, 256), (33, 100), (33, 256)),               # whole segments; divisor rows shorter than the quotient's
     ((130, 130), (130, 130), (130, 130)),
+    # rank 3 / 4 with rows > 64: the segment wavefront with leading axes (round 6; before: the slab-by-slab form, a 30x cliff at row 65)
+    ((6, 7, 70), (6, 7, 70), (6, 7, 70)),            # one coefficient run into the second segment (interval data too)
+    ((5, 9, 130), (2, 9, 70), (5, 4, 100)),          # compact divisor and dividend, three segments
+    ((4, 3, 5, 66), (4, 3, 5, 66), (4, 3, 5, 66)),   # rank 4
+    ((66, 66, 66), (66, 66, 66), (66, 66, 66)),      # just over the old cliff
+    ((10, 70, 130), (10, 70, 130), (10, 70, 130)),
+    ((6, 5, 100, 70), (6, 5, 100, 70), (6, 5, 100, 70)),
+    ((20, 96, 96), (20, 96, 96), (20, 96, 96)),
 ]
 
 
@@ -1382,8 +1390,6 @@ def test_div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier):
     import genfer_amd
 
     L = genfer_amd.lib()
-    # (the blocked right-looking form of large f64 quotients / logarithms — the tiled product's 1e-10 contract,
-    # test_div_log_blocked_right_looking_vs_oracle — is an option, off by default; this test is about the reference-order kernels)
     _div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier, L, genfer_amd)
 
 
