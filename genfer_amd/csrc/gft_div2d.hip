@@ -2004,12 +2004,36 @@ template bool K<EIv>::rows_wavefront(hipStream_t, int, const double*, size_t, co
 // < s of its own row — are all claimed before it.  Publication: EMPTY pattern + coherent 8-byte stores + per-segment flags.
 // log_mode 1: slabs k0 >= 1 of log(xs) (level 0: xs[k0 - j0] rows against j0 * res[j0] rows; levels >= 1 and the division:
 // by xs[0], on the slab's own quotient rows kept in `qb`; res = q / k0) — slab 0 is the caller's.
+// chunk_mac for segments of SL <= 64 coefficients: inner += sum_{i < SL} a[i] * bwin[SL + l - i]  (bwin = {bprev[SL], bcur[SL]}),
+// ascending i; lanes >= SL idle (they stage nothing and their sums are discarded).
+template <class E>
+__device__ inline typename E::V seg_chunk_mac(typename E::V inner, typename E::V a_l, typename E::V bp_l, typename E::V bc_l, unsigned l,
+                                              double* stage, unsigned SL, unsigned jbase, unsigned c, unsigned alen, unsigned blen) {
+    typedef typename E::V V;
+    if (l < SL) {
+        E::st(stage, 192, l, a_l);
+        E::st(stage, 192, SL + l, bp_l);
+        E::st(stage, 192, 2u * SL + l, bc_l);
+    }
+    const double* bl = stage + 2u * SL + (l < SL ? l : 0u);
+    if (!any_lane(!elem_finite<E>(a_l) || !elem_finite<E>(bp_l) || !elem_finite<E>(bc_l))) {
+#pragma unroll 4
+        for (unsigned i = 0; i < SL; ++i) inner = E::add(inner, E::mul(E::ld(stage, 192, i), E::ld(bl - i, 192, 0)));
+    } else {
+        for (unsigned i = 0; i < SL; ++i) {
+            const V t = E::add(inner, E::mul(E::ld(stage, 192, i), E::ld(bl - i, 192, 0)));
+            const unsigned j = jbase + i;
+            if (j <= c && j < alen && c - j < blen) inner = t;
+        }
+    }
+    return inner;
+}
 struct SegWfArgs {
     int L;
     unsigned n[3], m[3], xn[3];
     unsigned nr, mr, xnr;
     size_t rstr[3], ystr[3], xstr[3];
-    unsigned nseg, ntasks;
+    unsigned nseg, sl, ntasks;    // segments per row, coefficients per segment (<= 64: rows are cut EVENLY — a 65-long row is 33 + 32, not 64 + 1)
     unsigned* flags;              // [all rows of res][nseg], zeroed before the launch
     unsigned* counter;
     int log_mode;
@@ -2028,23 +2052,24 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
     const unsigned lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* const my_stage = &stage[wave][0][0];
     const bool lg = g.log_mode == 1;
+    const unsigned SL = g.sl;
     // the divisor's first row: ys[0 .. 0, :] (log: xs[0 .. 0, :] — the caller passes xs as ys)
     const V y0row = lane < g.mr ? E::ld(ys, yp, lane) : E::zero();
     const SlabDiv<E> div_y00(E::ld(ys, yp, 0));
     auto plain_chunk = [&](const double* base, size_t plane, size_t rowoff, int chunk, unsigned len) -> V {
-        if (chunk < 0) return E::zero();
-        const unsigned idx = 64u * (unsigned)chunk + lane;
+        if (chunk < 0 || lane >= SL) return E::zero();
+        const unsigned idx = SL * (unsigned)chunk + lane;
         return idx < len ? E::ld(base, plane, rowoff + idx) : E::zero();
     };
     auto coherent_raw = [&](const double* base, size_t plane, size_t rowoff, int chunk) -> V {
-        if (chunk < 0) return E::zero();
-        const unsigned idx = 64u * (unsigned)chunk + lane;
+        if (chunk < 0 || lane >= SL) return E::zero();
+        const unsigned idx = SL * (unsigned)chunk + lane;
         return idx < g.nr ? ld_coherent<E>(base, plane, rowoff + idx) : E::zero();
     };
     auto coherent_confirm = [&](V v, const double* base, size_t plane, size_t rowoff, unsigned row_id, int chunk) -> V {
         if (chunk < 0) return v;
-        const unsigned idx = 64u * (unsigned)chunk + lane;
-        const bool in = idx < g.nr;
+        const unsigned idx = SL * (unsigned)chunk + lane;
+        const bool in = lane < SL && idx < g.nr;
         bool confirmed = false;
         for (unsigned spins = 1; !confirmed && any_lane(in && is_empty_bits(v)); ++spins) {
             __builtin_amdgcn_s_sleep(2);
@@ -2061,7 +2086,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
         __syncthreads();
         if (t >= g.ntasks) break;
         const unsigned s = t % g.nseg;
-        const unsigned c = 64u * s + lane;
+        const unsigned c = SL * s + lane;  // (lanes >= SL idle: their values are zero and never stored)
         unsigned k[3] = {0, 0, 0};
         unsigned row_id = 0;
         size_t qoff_row = 0;
@@ -2143,11 +2168,11 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                     auto fix_b = [&](V v, int ch) -> V {
                         if (ch < 0 || !lg0) return v;
                         v = coherent_confirm(v, coh_base, coh_plane, roff, src, ch);
-                        if (64u * (unsigned)ch + lane < g.nr) v = E::mul(v, scale);
+                        if (lane < SL && SL * (unsigned)ch + lane < g.nr) v = E::mul(v, scale);
                         return v;
                     };
-                    const unsigned t_hi = (alen + 63u) / 64u - 1u < s ? (alen + 63u) / 64u - 1u : s;
-                    const unsigned t_lo = s > (blen + 62u) / 64u ? s - (blen + 62u) / 64u : 0u;
+                    const unsigned t_hi = (alen + SL - 1u) / SL - 1u < s ? (alen + SL - 1u) / SL - 1u : s;
+                    const unsigned t_lo = s > (blen + SL - 2u) / SL ? s - (blen + SL - 2u) / SL : 0u;
                     V inner = E::zero();
                     if (t_lo <= t_hi) {
                         V bc = fix_b(raw_b((int)s - (int)t_lo), (int)s - (int)t_lo);
@@ -2159,7 +2184,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                                 a_n = raw_a(tt + 1);
                                 bp_n = raw_b((int)s - (int)tt - 2);
                             }
-                            inner = chunk_mac<E>(inner, a, bp, bc, lane, my_stage, 64u * tt, c, alen, blen);
+                            inner = seg_chunk_mac<E>(inner, a, bp, bc, lane, my_stage, SL, SL * tt, c, alen, blen);
                             bc = bp;
                         }
                     }
@@ -2182,9 +2207,10 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                 buf ^= 1u;
             }
             if (wave == 0) {
+                if (lane >= SL) S = E::zero();
                 V r = E::neg(S);
                 if (lev == 0) {
-                    bool in_x = c < g.xnr;
+                    bool in_x = lane < SL && c < g.xnr;
                     size_t xoff = 0;
 #pragma unroll
                     for (int a = 0; a < L; ++a) {
@@ -2209,12 +2235,12 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
             const double* const qbase = lg ? g.qb : res;
             const size_t qplane = lg ? g.qbp : rp;
             V r = r_prev;
-            if (c >= g.nr) r = E::zero();
+            if (lane >= SL || c >= g.nr) r = E::zero();
             // the row's 1-d division (mt:1162-1185): cur[c] = sum_{j < c} q[j] * y0[c - j], ascending j — first the chunks of q the
             // earlier segments of this row have published, then lock step inside the segment
             V cur1 = E::zero();
             {
-                const unsigned t_lo = s > (g.mr + 62u) / 64u ? s - (g.mr + 62u) / 64u : 0u;
+                const unsigned t_lo = s > (g.mr + SL - 2u) / SL ? s - (g.mr + SL - 2u) / SL : 0u;
                 if (t_lo < s) {
                     V bc = plain_chunk(ys, yp, 0, (int)s - (int)t_lo, g.mr);
                     V a_n = coherent_raw(qbase, qplane, qoff_row, (int)t_lo);
@@ -2222,14 +2248,15 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                         const V a = coherent_confirm(a_n, qbase, qplane, qoff_row, row_id, (int)tt);
                         const V bp = plain_chunk(ys, yp, 0, (int)s - (int)tt - 1, g.mr);
                         if (tt + 1 < s) a_n = coherent_raw(qbase, qplane, qoff_row, (int)tt + 1);
-                        cur1 = chunk_mac<E>(cur1, a, bp, bc, lane, my_stage, 64u * tt, c, g.nr, g.mr);
+                        cur1 = seg_chunk_mac<E>(cur1, a, bp, bc, lane, my_stage, SL, SL * tt, c, g.nr, g.mr);
                         bc = bp;
                     }
                 }
             }
             V mine = E::zero(), ysl = y0row;  // ysl[l] = y0[l - jj] at step jj (zero for l < jj and beyond the divisor's row)
             const bool fin = !any_lane(!elem_finite<E>(r)) && !any_lane(!elem_finite<E>(y0row)) && !any_lane(!elem_finite<E>(cur1));
-            const unsigned nsteps = g.nr - 64u * s < 64u ? g.nr - 64u * s : 64u;
+            if (lane >= SL) cur1 = E::zero();
+            const unsigned nsteps = g.nr - SL * s < SL ? g.nr - SL * s : SL;
             for (unsigned jj = 0; jj < nsteps; ++jj) {
                 const V q = div_y00(bcast_lane<E>(E::add(E::neg(cur1), r), jj));
                 if (lane == jj) mine = q;
@@ -2241,7 +2268,7 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                 }
                 ysl = wave_shr1<E>(ysl);
             }
-            if (c < g.nr) {
+            if (lane < SL && c < g.nr) {
                 if (lg) {  // res[K] = q / k0 (mt:1384); the slab's own later rows and segments read q itself
                     st_coherent(g.qb, g.qbp, qoff_row + c, mine);
                     st_coherent(res, rp, qoff_row + c, E::div(mine, E::from_u32(k[0])));
@@ -2287,6 +2314,7 @@ bool K<E>::seg_wavefront(hipStream_t st, int mode, const double* xs, size_t x_pl
         rows *= rshape[a];
     }
     g.nseg = (g.nr + 63u) / 64u;
+    g.sl = (g.nr + g.nseg - 1u) / g.nseg;  // even cut: the work of a row is nseg (nseg + 1) / 2 chunk products of sl steps each
     const size_t slab_rows = rows / rshape[0];
     const size_t task_rows = mode == 1 ? rows - slab_rows : rows;
     const size_t ntasks = task_rows * g.nseg;

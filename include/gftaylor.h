@@ -73,14 +73,15 @@ void gft_pool_stats(size_t out[3]);
  * reference-order kernel, on the one-thread-per-output kernel, operations computed on the host tier,
  * host-resident tensors mirrored to the device}.  Diagnostics. */
 void gft_op_stats(size_t out[8]);
-/* More counters (returns how many exist, writes min(cap, that many)): {kernel launches of the library, elementwise
+/* More counters (returns how many exist — 18 — and writes min(cap, that many)): {kernel launches of the library, elementwise
  * operations deferred into a chain instead of launched, chains materialised by a consumer that needed the tensor in
  * memory, add/sub launches that evaluated deferred chains on the fly, launches whose argument block did not fit a
  * slot of the launch ring and were issued in place after a full drain, shallow (stencil) products on the fused
- * reference-order kernel, of which whole general Horner steps res * subst + slab in one launch, operations issued in a
- * side-stream scope, cross-stream event waits, recorded observation chains / Horner loops that rode along with another launch
- * of their kind, recorded observation chains launched with the consumer's Add as their epilogue, linearity scans answered by
- * a "no exact zero" proof (intervals)}.  Diagnostics; bench.py's e2e rows. */
+ * reference-order kernel, of which whole general Horner steps res * subst + slab in one launch, two unused words (0),
+ * one more unused word (0), recorded observation chains launched with the consumer's Add as their epilogue, linearity scans
+ * answered by a proof about exact zeros (intervals), Adds that evaluated recorded sums in their own launch, executions of the
+ * deferred launch graph, recordings issued through them, batched launches, items in them, microseconds of the calling thread
+ * inside graph executions}.  Diagnostics; bench.py's e2e rows. */
 size_t gft_op_stats_ex(size_t* out, size_t cap);
 /* hipEvent timing on the library's stream: record into slot 0..63, elapsed in ms (syncs on b). */
 int gft_event_record(int slot);
@@ -90,34 +91,32 @@ float gft_event_elapsed_ms(int slot_a, int slot_b);
  * LDS-staged reference-order kernel wherever its shape limits allow.  Modes 1 and 3 are bit-identical
  * to each other and to the CPU algorithm.  Test/bench knob. */
 int gft_set_conv_mode(int mode);
-/* Tuning / test knobs by name (returns -1 for an unknown name): "tiled_min_macs" (auto-mode crossover to the
- * tiled product), "conv_rb_min_macs" (smallest interval product, in multiply-adds, that takes the register-blocked rows kernel; negative: never), "conv_rb_pairs" (reference-order product, interval and f64, as independent row-pair sums with the ordered additions in a second pass: 0 never, 1 from 3e5 multiply-adds (rank 2: 1e6; rows of 8 .. 128) in slab ranges where the row sums exceed "conv_rb_pairs_cap" bytes [default 2 GiB], 2 whenever it applies, negative: the default), "pairs_first" (0: small plain f64 products go to the tiled kernel as before round 4 instead of asking the bit-exact row-pair form first), "fuse_horner" (0: generic Horner loop in subst_var), "horner_loop_max" (largest final tensor,
- * in elements, for which all Horner steps of a linear substitution run in one launch; 0 = one launch per step),
- * "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
- * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "div_wavefront" (0: the slab-by-slab blocked division instead of the one-launch row wavefront), "div2d" (0: host-driven division
- * recursion down to 1-d rows), "recur_overlap" (0: the blocked div / log recurrences keep every launch on one stream), "defer" (0: one launch per elementwise operation instead of deferred chains), "async_launch" (0: kernels are launched by the
- * calling thread instead of the library's launch thread), "tiled_tile" (0: the planner picks the tiled product's lane tile; 3..6 force 8x8, 4x16, 2x32,
- * 1x64 output rows per wave), "dist_min_macs" (smallest general product gft_mul shards over the GPUs of gft_dist_init),
- * "shallow_pair_min" (smallest result, in elements, for which a stencil that is flat along the last axis computes two
- * neighbouring outputs per thread with 16-byte accesses; 0: always, -1: the default 4096, below -1: never),
- * "shallow_max_terms" (plain products whose outputs receive at most this many terms each — one operand a stencil of a few
- * coefficients — run on the fused reference-order kernel, general Horner steps res * subst + slab in one launch; 0: never;
- * negative: the default, 256), "rows_wavefront" (0: rank-2 div / log / exp with rows longer than 64 coefficients row by row
- * instead of the one-launch coefficient-level wavefront), "exp_right" (0: exp's terms in the reference's order everywhere),
- * "recur_tiled_min_macs", "dist_event_slot", and the test knob "debug_fail_next_launch" (1: the next kernel launch requests
- * 1 MB of LDS and fails — on the launch thread; the failure is reported by the next gft_synchronize / value inspection).
- * Round 5: "lazy_observe", "lazy_sum", "lazy_horner" (0: observation chains / the Adds inside mul_linear /
- * proven linear Horner loops are launched where they are issued instead of being recorded on their result and launched
- * inside — or alongside — the launch that needs them), "obs_riders", "horner_riders" (0: a recorded chain / loop never shares
- * another one's launch), "nz_proofs" (0: interval Horner loops always scan their first accumulator for linearity, also where
- * the coefficient tensor is proven free of exact zeros), "side_streams" (0, the default: one stream; 1..4: operations on old
- * inputs run on side streams — slower on this part), "side_min_age", "div_right" (1: large f64 div / log as a
- * blocked right-looking recurrence on the tiled kernel — the tiled product's 1e-10 contract instead of the reference's bits;
- * off by default), "div_right_block", "div_right_min_macs", "conv_rb_pairs_cap" (bytes of row sums the row-pair form of the
- * reference-order product may hold at a time, default 2 GiB; 0 restores the default), "conv_rb_pairs_lanes" (the slab ranges of
- * a product over the cap on two lanes with half the cap each, one lane's additions under the other's row sums: 0 never, 1 always,
- * negative — the default — when half the cap leaves the ranges as they are), "conv_rb_pairs", "conv_rb_min_macs",
- * "pairs_first". */
+/* Switches and thresholds by name (returns -1 for an unknown name).  README lists them with their environment variables.
+ * SWITCHES (1 = on, the default; 0 = the simpler form, for A/B runs, bisecting and the verification matrix):
+ *   "batch_dag"     recordings form a deferred launch graph that is issued level by level as batched launches
+ *   "lazy_observe"  observation chains are recorded on their result instead of launched (and take the consumer's Add as epilogue)
+ *   "lazy_sum"      Adds of two deferred chains are recorded (nested Adds evaluate them in one launch)
+ *   "lazy_horner"   proven linear Horner loops are recorded (with "batch_dag")
+ *   "nz_proofs"     interval Horner loops skip the linearity scan where the operand's exact zeros are proven to be none, or whole
+ *                   leading slabs
+ *   "defer"         elementwise operations are deferred into chains instead of launched one by one
+ *   "async_launch"  kernels are issued by the library's launch thread instead of the calling thread
+ *   "div_wavefront" division / log / exp recurrences as one-launch wavefronts (0: the slab-by-slab blocked form)
+ *   "exp_right"     large f64 exponentials add their terms in arrival order (1e-10 contract; 0: the reference's order everywhere)
+ *   "recur_overlap" the blocked recurrences overlap their bulk updates on a second stream (test knob: same bits either way)
+ * THRESHOLDS: "host_max_elems" / "host_max_macs" (size-threshold dispatch: largest result, in elements, and largest general
+ * product, in multiply-adds, computed on the host tier; 0 = everything on the device), "tiled_min_macs" (auto-mode crossover to
+ * the tiled product), "horner_loop_max" (largest final tensor, in elements, whose linear Horner steps all run in one launch; 0 =
+ * one launch per step), "shallow_max_terms" (plain products whose outputs receive at most this many terms run on the fused
+ * reference-order kernel; 0: never; negative: the default, 256), "shallow_pair_min" (smallest result for which a flat stencil
+ * computes two outputs per thread; -1: the default 4096, below: never), "conv_rb_min_macs" (smallest interval product on the
+ * register-blocked rows kernel; negative: never), "conv_rb_pairs" (the reference-order product as row-pair sums: 0 never, 1 by
+ * size, 2 whenever it applies, negative: the default), "conv_rb_pairs_cap" (bytes of row sums that form may hold at a time;
+ * default 2 GiB), "conv_rb_pairs_lanes" (its slab ranges on two lanes: 0 never, 1 always, negative: the default rule),
+ * "tiled_tile" (3..6 force the tiled product's lane tile 8x8 .. 1x64; 0: the planner's choice), "dist_min_macs" (smallest
+ * general product gft_mul shards over the GPUs of gft_dist_init), "dist_event_slot".
+ * TEST KNOBS: "debug_fail_next_launch" (1: the next kernel launch requests 1 MB of LDS and fails — on the launch thread; the
+ * failure is reported by the next gft_synchronize / value inspection), "trace_lq_report". */
 int gft_set_option(const char* name, double value);
 /* Tiled-kernel variant for A/B measurements (-1 = library default).  Test/bench knob. */
 int gft_set_conv_variant(int variant);
