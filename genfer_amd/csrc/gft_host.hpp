@@ -18,6 +18,7 @@
 namespace gft {
 // GFT_TRACE_API: host-tier Horner steps by regime {positive constants, sign-known c, general} and elements that fell back
 extern unsigned long long g_host_horner_stats[4];
+extern bool g_host_horner_runs;  // the finite regime of the host Horner step in runs of equal terms (tests switch it off to compare)
 
 
 template <class E>
@@ -379,6 +380,69 @@ struct HK {
                 roff0 += (size_t)k * g.rstr[ax];
                 aoff0 += (size_t)k * g.astr[ax];
             }
+            if constexpr (E::HAS_POS) {
+                // (with a sign-known c the element form's first choice is the `semi` regime, which needs POSITIVE data: a line whose
+                // first accumulator element is not positive — switchpoint's error intervals around zero — goes straight to the runs)
+                bool runs = fin && g_host_horner_runs;
+                if (runs && semi) {
+                    const V x0 = in_r0 && g.rs[last] > 0 ? E::ld(res, rp, roff0) : E::one();
+                    if (E::pos_ok(x0)) runs = false;
+                }
+                if (runs) {
+                    // (round 6) the FINITE regime in RUNS: along the line the three terms of a position — res[k - 1] * m, c * res[k],
+                    // the coefficient — each exist on one interval of k, so the line is a handful of runs with the same terms, each a
+                    // plain loop over contiguous-stride operands (no per-element flags: switchpoint --bounds is 1.3e8 elements of this)
+                    const unsigned p_end = in_p0 ? (nlast < g.sh[last] ? nlast : g.sh[last]) : 0u;
+                    const unsigned t2_end = (in_r0 && !g.c_zero) ? (p_end < g.rs[last] ? p_end : g.rs[last]) : 0u;
+                    unsigned t1_lo = 0, t1_hi = 0;
+                    if (g.w == last) {
+                        t1_lo = 1;
+                        t1_hi = p_end < g.upper + 1u ? p_end : g.upper + 1u;
+                    } else if (kw0 >= 1 && kw0 - 1 < g.upper) {
+                        t1_hi = p_end;
+                    }
+                    if (t1_hi < t1_lo) t1_hi = t1_lo;
+                    unsigned t3_hi = 0;
+                    if (g.coeff_scalar) t3_hi = lin == 0 ? 1u : 0u;
+                    else if (in_c0) t3_hi = nlast < g.oc[last] ? nlast : g.oc[last];
+                    unsigned k = 0;
+                    while (k < nlast) {
+                        const bool t1 = k >= t1_lo && k < t1_hi, t2 = k < t2_end, t3 = k < t3_hi;
+                        unsigned q = nlast;  // the run ends where one of the three changes
+                        if (k < t1_lo && t1_lo < q) q = t1_lo;
+                        if (k < t1_hi && t1_hi < q) q = t1_hi;
+                        if (k < t2_end && t2_end < q) q = t2_end;
+                        if (k < t3_hi && t3_hi < q) q = t3_hi;
+                        const int sel = (t1 ? 1 : 0) | (t2 ? 2 : 0) | (t3 ? 4 : 0);
+                        const size_t roff = roff0 + (size_t)k * g.rstr[last], aoff = aoff0 + (size_t)k * g.astr[last];
+                        bool ok;
+                        switch (sel) {
+                            case 0: ok = horner_run_fin<false, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 1: ok = horner_run_fin<true, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 2: ok = horner_run_fin<false, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 3: ok = horner_run_fin<true, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 4: ok = horner_run_fin<false, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 5: ok = horner_run_fin<true, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            case 6: ok = horner_run_fin<false, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                            default: ok = horner_run_fin<true, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
+                        }
+                        if (!ok) {  // an operand outside the regime (or a result that left it): this run element by element, every regime tried
+                            for (unsigned kk = k; kk < q; ++kk) {
+                                const bool in_p = in_p0 && kk < g.sh[last], in_r = in_r0 && kk < g.rs[last], in_c = in_c0 && kk < g.oc[last];
+                                horner_linear_elem(res, rp, a, ap, out, op, g, lin + (kk - k), roff0 + (size_t)kk * g.rstr[last], aoff0 + (size_t)kk * g.astr[last],
+                                                   g.w == last ? kk : kw0, in_p, in_r, in_c, pos_consts, semi, fin);
+                            }
+                        }
+                        lin += q - k;
+                        k = q;
+                    }
+                    for (int ax = last - 1; ax >= 0; --ax) {
+                        if (++idx[ax] < g.out.d[ax]) break;
+                        idx[ax] = 0;
+                    }
+                    continue;
+                }
+            }
             for (unsigned k = 0; k < nlast; ++k, ++lin) {
                 const bool in_p = in_p0 && k < g.sh[last], in_r = in_r0 && k < g.rs[last], in_c = in_c0 && k < g.oc[last];
                 const unsigned kw = g.w == last ? k : kw0;
@@ -389,6 +453,45 @@ struct HK {
                 if (++idx[ax] < g.out.d[ax]) break;
                 idx[ax] = 0;
             }
+        }
+    }
+    // n consecutive positions of a line along the LAST axis that all have the terms T1 (res[k - 1] * m), T2 (c * res[k]), T3 (the
+    // coefficient), in the finite regime — element for element horner_linear_elem's `fin` branch.  false: some operand or result
+    // is outside the regime; nothing usable was stored (the caller redoes the run element by element).
+    template <bool T1, bool T2, bool T3>
+    static bool horner_run_fin(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g, size_t lin, size_t roff,
+                               size_t aoff, int last, unsigned n, int fin) {
+        if constexpr (E::HAS_POS) {
+            const V cv = E::from(g.c), mv = E::from(g.m);
+            const size_t rs = g.rstr[last], as = g.astr[last], wback = g.rstr[g.w];
+            const bool m_one = (fin & 32) != 0;
+            for (unsigned i = 0; i < n; ++i) {
+                V p = E::zero();
+                if constexpr (T1) {
+                    const V xm1 = E::ld(res, rp, roff + (size_t)i * rs - wback);
+                    if (!E::fin_ok(xm1)) return false;
+                    p = m_one ? xm1 : E::mul_fin(xm1, mv);
+                }
+                if constexpr (T2) {
+                    const V x = E::ld(res, rp, roff + (size_t)i * rs);
+                    if (!E::fin_ok(x)) return false;
+                    const V p2 = E::mul_fin(cv, x);
+                    if constexpr (T1) p = E::widen_fin(p.lo + p2.lo, p.hi + p2.hi);
+                    else p = p2;
+                }
+                V v = p;
+                if constexpr (T3) {
+                    const V cf = E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff + (size_t)i * as);
+                    if (!E::fin_ok(cf)) return false;
+                    if constexpr (T1 || T2) v = E::widen_fin(p.lo + cf.lo, p.hi + cf.hi);
+                    else v = cf;
+                }
+                if (E::is_nan(v)) return false;
+                E::st(out, op, lin + i, v);
+            }
+            return true;
+        } else {
+            return false;
         }
     }
     static inline void horner_linear_elem(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g,

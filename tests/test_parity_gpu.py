@@ -1414,8 +1414,9 @@ def _div_row_wavefront_bit_exact(zs, ys, xs, OTP, GTP, OTPI, GTPI, tier, L, genf
                 before = genfer_amd.op_stats()["launches"]
                 got[wf] = G.new(a, deg) / G.new(b, deg)
                 check(want, got[wf])
-                if wf and len(zs) == 2 and zs[1] > 64 and tier == "device" and os.environ.get("GFT_ROWS_WAVEFRONT") != "0":
-                    # one launch (+ the fill of the result with the EMPTY pattern, + the flags' memset): not one per row
+                if wf and zs[-1] > 64 and len(zs) <= 4 and tier == "device":
+                    # one launch (+ the fill of the result with the EMPTY pattern, + the flags' memset): not one per row or slab
+                    # (rank 2: k_rows_wavefront; rank 3 / 4, round 6: k_seg_wavefront)
                     assert genfer_amd.op_stats()["launches"] - before <= 8, "the long-row quotient did not take the one-launch wavefront"
             finally:
                 L.gft_set_option(b"div_wavefront", 1.0)

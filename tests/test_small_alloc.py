@@ -14,6 +14,3 @@ def test_small_block_lists_under_asan():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
         assert r.returncode == 0, r.stdout + r.stderr
         assert "small_alloc ok" in r.stdout
-        # and with the lists off (GFT_SMALL_ALLOC=0: every block straight back to operator delete)
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", GFT_SMALL_ALLOC="0"))
-        assert r.returncode == 0 and "small_alloc ok" in r.stdout, r.stdout + r.stderr
