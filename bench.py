@@ -136,7 +136,7 @@ def cpu_baseline_all_cores(shape, x, y, max_threads=64):
     }
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # newest first
 
 
 def pmc_traffic(world, workload):
@@ -188,7 +188,7 @@ E2E_PROGRAMS = (
 def e2e_seconds(gpu_runs=5, oracle_available=True):
     """BASELINE's second metric: end-to-end seconds ("Total inference time", best of N — the protocol of the
     reference's benchmarks/neurips2023/exact/bench.py:33-35,94-105) on NeurIPS'23 programs at --limit 100: the host
-    interpreter over libgftaylor (GPU, best of 5) and, beside it, the same interpreter over the CPU oracle on this
+    interpreter over libgftaylor (`backend_s`, best of 5; `host_tier_frac` says how much of it ran on the library's host tier) and, beside it, the same interpreter over the CPU oracle on this
     box's host (1 thread; best of 2, a single run for the long ones).  `parity`: the GPU report of the timed
     configuration against the oracle's report (genfer_amd/reports.py: 1e-10 on primary quantities) — "ok" or the first
     difference; a difference makes bench.py exit non-zero."""
@@ -208,27 +208,31 @@ def e2e_seconds(gpu_runs=5, oracle_available=True):
         texts = {}
         if not oracle_available:
             cpu_runs = 0
-        for key, lib, prefix, runs in (("gpu_s", genfer_amd.LIB_PATH, "gft_", gpu_runs if cpu_runs else min(gpu_runs, 3)),
+        for key, lib, prefix, runs in (("backend_s", genfer_amd.LIB_PATH, "gft_", gpu_runs if cpu_runs else min(gpu_runs, 3)),
                                        ("cpu_oracle_s", oracle, "orc_", cpu_runs)):
             best = None
             for _ in range(runs):
-                before = genfer_amd.op_stats() if key == "gpu_s" else None
+                before = genfer_amd.op_stats() if key == "backend_s" else None
                 pfx = prefix[:-1] + "i_" if "--bounds" in flags.split() else prefix  # the Interval<F64> entry points
                 rc, text, t = genfer_amd.run_sgcl_with_backend(src, run_flags, lib, pfx)
                 if rc != 0:
                     row[key + "_error"] = text[-200:]
                     best = None
-                    if key == "gpu_s":
+                    if key == "backend_s":
                         failed = True
                     break
                 texts[key] = text
                 best = t["time_infer"] if best is None else min(best, t["time_infer"])
                 if before is not None:  # what one run of the program costs (the same every run)
                     after = genfer_amd.op_stats()
-                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged", "per_output", "linear_scans", "fused_observe_adds", "riders", "nested_adds", "scans_proven"):
+                    for k in ("launches", "host_tier_ops", "deferred_ops", "tiled", "staged", "per_output", "linear_scans", "fused_observe_adds", "nested_adds", "scans_proven", "graph_executions", "batch_launches", "batch_items"):
                         row[k] = after[k] - before[k]
             row[key] = best
             row[key.replace("_s", "_runs")] = runs
+            if key == "backend_s" and "launches" in row:
+                # where the TaylorPoly operations of this program ran: a row that is (almost) all host tier — switchpoint, the
+                # exact/ programs — is a CPU number of the library's host tier, not a GPU result
+                row["host_tier_frac"] = round(row["host_tier_ops"] / max(1, row["host_tier_ops"] + row["launches"]), 4)
         if recorded and row.get("cpu_oracle_s") is None:
             row["cpu_oracle_s_recorded"] = {"value": recorded[0], "source": recorded[1]}
         # parity of the timed configuration, at the timed size
@@ -238,8 +242,8 @@ def e2e_seconds(gpu_runs=5, oracle_available=True):
         elif stored and os.path.exists(os.path.join(ROOT, "tests", "golden", "c3_limit100", stored)):
             want = open(os.path.join(ROOT, "tests", "golden", "c3_limit100", stored)).read()
             against = f"committed oracle report tests/golden/c3_limit100/{stored}"
-        if "gpu_s" in texts and want is not None:
-            diff = first_difference(texts["gpu_s"], want)
+        if "backend_s" in texts and want is not None:
+            diff = first_difference(texts["backend_s"], want)
             row["parity"] = "ok" if diff is None else diff
             row["parity_against"] = against
             if diff is not None:
