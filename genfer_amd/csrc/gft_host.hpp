@@ -18,6 +18,7 @@
 namespace gft {
 // GFT_TRACE_API: host-tier Horner steps by regime {positive constants, sign-known c, general} and elements that fell back
 extern unsigned long long g_host_horner_stats[4];
+extern int g_host_simd;  // the runs' AVX2 clones: -1 when the CPU has AVX2 (the default), 0 never (tests compare the two builds of the same loop)
 extern bool g_host_horner_runs;  // the finite regime of the host Horner step in runs of equal terms (tests switch it off to compare)
 
 
@@ -384,9 +385,13 @@ struct HK {
                 // (with a sign-known c the element form's first choice is the `semi` regime, which needs POSITIVE data: a line whose
                 // first accumulator element is not positive — switchpoint's error intervals around zero — goes straight to the runs)
                 bool runs = fin && g_host_horner_runs;
-                if (runs && semi) {
+                bool semi_runs = false;  // ... and a line of positive data under a sign-known c: the `semi` regime in the same runs
+                if (semi && g_host_horner_runs) {
                     const V x0 = in_r0 && g.rs[last] > 0 ? E::ld(res, rp, roff0) : E::one();
-                    if (E::pos_ok(x0)) runs = false;
+                    if (E::pos_ok(x0)) {
+                        runs = true;
+                        semi_runs = true;
+                    }
                 }
                 if (runs) {
                     // (round 6) the FINITE regime in RUNS: along the line the three terms of a position — res[k - 1] * m, c * res[k],
@@ -416,6 +421,18 @@ struct HK {
                         const int sel = (t1 ? 1 : 0) | (t2 ? 2 : 0) | (t3 ? 4 : 0);
                         const size_t roff = roff0 + (size_t)k * g.rstr[last], aoff = aoff0 + (size_t)k * g.astr[last];
                         bool ok;
+                        if (semi_runs) {
+                            switch (sel) {
+                                case 0: ok = horner_run_semi<false, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 1: ok = horner_run_semi<true, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 2: ok = horner_run_semi<false, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 3: ok = horner_run_semi<true, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 4: ok = horner_run_semi<false, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 5: ok = horner_run_semi<true, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                case 6: ok = horner_run_semi<false, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                                default: ok = horner_run_semi<true, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                            }
+                        } else
                         switch (sel) {
                             case 0: ok = horner_run_fin<false, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
                             case 1: ok = horner_run_fin<true, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
@@ -459,37 +476,159 @@ struct HK {
     // coefficient), in the finite regime — element for element horner_linear_elem's `fin` branch.  false: some operand or result
     // is outside the regime; nothing usable was stored (the caller redoes the run element by element).
     template <bool T1, bool T2, bool T3>
-    static bool horner_run_fin(const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g, size_t lin, size_t roff,
-                               size_t aoff, int last, unsigned n, int fin) {
+    static bool horner_run_fin(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                               const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
+        const size_t rs = g.rstr[last], as = g.coeff_scalar ? 0 : g.astr[last];  // (known strides: see horner_run_semi)
+        if (rs == 1 && as <= 1 && host_avx2()) {  // (the same loop compiled for 4-wide vectors: same operations per element, same bits)
+            if (as == 1) return horner_run_fin_avx2<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+            return horner_run_fin_avx2<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+        }
+        if (rs == 1 && as == 1) return horner_run_fin_s<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+        if (rs == 1 && as == 0) return horner_run_fin_s<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+        return horner_run_fin_s<T1, T2, T3, 0, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+    }
+    static bool host_avx2() {
+        static const bool has = __builtin_cpu_supports("avx2");
+        return has && g_host_simd != 0;
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    __attribute__((target("avx2"))) static bool horner_run_fin_avx2(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out,
+                                                                    size_t op, const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
+        return horner_run_fin_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    static bool horner_run_fin_s(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                                 const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
+        return horner_run_fin_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    __attribute__((always_inline)) static inline bool horner_run_fin_body(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                                 const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
         if constexpr (E::HAS_POS) {
             const V cv = E::from(g.c), mv = E::from(g.m);
-            const size_t rs = g.rstr[last], as = g.astr[last], wback = g.rstr[g.w];
+            const size_t rs = RS1 ? (size_t)1 : g.rstr[last], as = RS1 ? (size_t)AS1 : (g.coeff_scalar ? (size_t)0 : g.astr[last]), wback = g.rstr[g.w];
             const bool m_one = (fin & 32) != 0;
+            const double* const xl = res + roff, * const xh = res + rp + roff;
+            const double* const ml = xl - wback, * const mh = xh - wback;
+            const double* const al = a + (g.coeff_scalar ? g.a_base : aoff), * const ah = al + ap;
+            double* const ol = out + lin, * const oh = out + op + lin;
+            unsigned bad = 0;  // one verdict per run, no exit inside the loop (the caller redoes a failed run element by element)
             for (unsigned i = 0; i < n; ++i) {
                 V p = E::zero();
+                unsigned good = 1;
                 if constexpr (T1) {
-                    const V xm1 = E::ld(res, rp, roff + (size_t)i * rs - wback);
-                    if (!E::fin_ok(xm1)) return false;
+                    const V xm1 = Iv{ml[(size_t)i * rs], mh[(size_t)i * rs]};
+                    good &= (unsigned)E::fin_ok(xm1);
                     p = m_one ? xm1 : E::mul_fin(xm1, mv);
                 }
                 if constexpr (T2) {
-                    const V x = E::ld(res, rp, roff + (size_t)i * rs);
-                    if (!E::fin_ok(x)) return false;
+                    const V x = Iv{xl[(size_t)i * rs], xh[(size_t)i * rs]};
+                    good &= (unsigned)E::fin_ok(x);
                     const V p2 = E::mul_fin(cv, x);
                     if constexpr (T1) p = E::widen_fin(p.lo + p2.lo, p.hi + p2.hi);
                     else p = p2;
                 }
                 V v = p;
                 if constexpr (T3) {
-                    const V cf = E::ld(a, ap, g.coeff_scalar ? g.a_base : aoff + (size_t)i * as);
-                    if (!E::fin_ok(cf)) return false;
+                    const V cf = Iv{al[(size_t)i * as], ah[(size_t)i * as]};
+                    good &= (unsigned)E::fin_ok(cf);
                     if constexpr (T1 || T2) v = E::widen_fin(p.lo + cf.lo, p.hi + cf.hi);
                     else v = cf;
                 }
-                if (E::is_nan(v)) return false;
-                E::st(out, op, lin + i, v);
+                good &= (unsigned)!E::is_nan(v);
+                ol[i] = v.lo;
+                oh[i] = v.hi;
+                bad |= good ^ 1u;
             }
-            return true;
+            return bad == 0;
+        } else {
+            return false;
+        }
+    }
+    // ... and the same run in the `semi` regime (positive data, c with known signs): element for element horner_linear_elem's
+    // `semi` branch — no flags, no exits inside the loop (one verdict per run: a run with an element outside the regime is redone
+    // element by element by the caller, every regime tried), the planes read as planes.
+    template <bool T1, bool T2, bool T3>
+    static bool horner_run_semi(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                                const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int semi) {
+        // (the accumulator is compact: unit stride along the line; the coefficient's stride is 1, or 0 where the line runs along
+        // the substituted axis — known strides are what lets the compiler use vector loads)
+        const size_t rs = g.rstr[last], as = g.coeff_scalar ? 0 : g.astr[last];
+        if (rs == 1 && as <= 1 && host_avx2()) {
+            if (as == 1) return horner_run_semi_avx2<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+            return horner_run_semi_avx2<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+        }
+        if (rs == 1 && as == 1) return horner_run_semi_s<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+        if (rs == 1 && as == 0) return horner_run_semi_s<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+        return horner_run_semi_s<T1, T2, T3, 0, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    __attribute__((target("avx2"))) static bool horner_run_semi_avx2(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out,
+                                                                     size_t op, const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int semi) {
+        return horner_run_semi_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    static bool horner_run_semi_s(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                                  const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int semi) {
+        return horner_run_semi_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>  // RS1: the accumulator's stride along the line is 1 (else g's); AS1 likewise (with RS1: 1 or 0)
+    __attribute__((always_inline)) static inline bool horner_run_semi_body(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
+                                  const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int semi) {
+        if constexpr (E::HAS_POS) {
+            const V cv = E::from(g.c), mv = E::from(g.m);
+            const size_t rs = RS1 ? (size_t)1 : g.rstr[last], as = RS1 ? (size_t)AS1 : (g.coeff_scalar ? (size_t)0 : g.astr[last]), wback = g.rstr[g.w];
+            const bool m_one = (semi & 32) != 0;
+            const double inf = bits_f64(0x7ff0000000000000LL);
+            const long long dlo = (semi & 8) ? 1 : -1, dhi = (semi & 16) ? 1 : -1;
+            const double* const xl = res + roff, * const xh = res + rp + roff;             // x = res[k]
+            const double* const x_lo_src = (semi & 2) ? xh : xl, * const x_hi_src = (semi & 4) ? xl : xh;  // the bound of x each bound of c * x takes
+            const double* const ml = xl - wback, * const mh = xh - wback;                   // res[k - 1 along w]
+            const double* const al = a + (g.coeff_scalar ? g.a_base : aoff), * const ah = al + ap;
+            double* const ol = out + lin, * const oh = out + op + lin;
+            unsigned bad = 0;  // (ONE reduction, updated once per element: what the vectoriser recognises)
+            auto pos = [inf](double lo, double hi) { return (unsigned)((lo > 0.0) & (lo <= hi) & (hi < inf) & !((lo == 1.0) & (hi == 1.0))); };
+            for (unsigned i = 0; i < n; ++i) {
+                double plo = 0.0, phi = 0.0;
+                unsigned good = 1;
+                if constexpr (T1) {
+                    const double l = ml[(size_t)i * rs], h = mh[(size_t)i * rs];
+                    good &= pos(l, h);
+                    plo = m_one ? l : bits_f64(f64_bits(l * mv.lo) - 1);
+                    phi = m_one ? h : bits_f64(f64_bits(h * mv.hi) + 1);
+                    good &= (unsigned)((plo > 0.0) & (phi < inf));
+                }
+                if constexpr (T2) {
+                    good &= pos(xl[(size_t)i * rs], xh[(size_t)i * rs]);
+                    const double qlo = bits_f64(f64_bits(cv.lo * x_lo_src[(size_t)i * rs]) + dlo);
+                    const double qhi = bits_f64(f64_bits(cv.hi * x_hi_src[(size_t)i * rs]) + dhi);
+                    good &= (unsigned)((qlo > -inf) & (qhi < inf));
+                    if constexpr (T1) {
+                        plo = bits_f64(f64_bits(plo + qlo) - 1);
+                        phi = bits_f64(f64_bits(phi + qhi) + 1);
+                        good &= (unsigned)((plo > 0.0) & (phi < inf));
+                    } else {
+                        plo = qlo;
+                        phi = qhi;
+                    }
+                }
+                if constexpr (T3) {
+                    const double l = al[(size_t)i * as], h = ah[(size_t)i * as];
+                    good &= pos(l, h);
+                    if constexpr (T1 || T2) {
+                        plo = bits_f64(f64_bits(plo + l) - 1);
+                        phi = bits_f64(f64_bits(phi + h) + 1);
+                        good &= (unsigned)((plo > 0.0) & (phi < inf));
+                    } else {
+                        plo = l;
+                        phi = h;
+                    }
+                }
+                ol[i] = plo;
+                oh[i] = phi;
+                bad |= good ^ 1u;
+            }
+            return bad == 0;
         } else {
             return false;
         }

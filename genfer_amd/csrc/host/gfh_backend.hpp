@@ -127,6 +127,17 @@ struct SizeTrace {
 inline SizeTrace& size_trace() { static SizeTrace t; return t; }
 
 // The value type: shared immutable handle (clone = refcount, like the ABI's O(1) clone).
+// Reference counts of the interpreter's own objects (GenFun nodes, handle wrappers) are NOT atomic, like the reference's `Rc`
+// (generating_function.rs:14-16): an evaluation lives on one thread, and with the process's other threads around (the library's
+// launch thread, Python's) std::shared_ptr would pay a locked increment / decrement 10^7 times per program (13 % of switchpoint's
+// calling thread).  libstdc++'s shared_ptr with the single-threaded lock policy is exactly that type.
+template <class U>
+using Rc = std::__shared_ptr<U, __gnu_cxx::_S_single>;
+template <class U, class A, class... Args>
+inline Rc<U> rc_allocate(const A& a, Args&&... args) {
+    return std::__allocate_shared<U, __gnu_cxx::_S_single>(a, std::forward<Args>(args)...);
+}
+
 template <class T>
 class Poly {
     // (the wrapper keeps a plain pointer to its backend's table — tables live as long as the process, Api::load —, so a handle
@@ -140,13 +151,13 @@ class Poly {
         H& operator=(const H&) = delete;
         ~H() { if (h) api->free(h); }
     };
-    std::shared_ptr<H> p_;
+    Rc<H> p_;
     static std::shared_ptr<Api>& api_slot() { static std::shared_ptr<Api> a; return a; }
     static Poly wrap(void* h) {
         auto& a = api_slot();
         if (!h) throw std::runtime_error(std::string("TaylorPoly backend error: ") + a->last_error());
         Poly r;
-        r.p_ = std::allocate_shared<H>(gft_small::Alloc<H>());  // small-block lists: ../gft_small_alloc.hpp
+        r.p_ = rc_allocate<H>(gft_small::Alloc<H>());  // small-block lists: ../gft_small_alloc.hpp
         r.p_->api = a.get();
         r.p_->h = h;
         return r;

@@ -38,12 +38,12 @@ struct GenFun {
         mutable const Api* const_api = nullptr;
         mutable bool const_tp_set = false;
     };
-    std::shared_ptr<const Node> p;
+    Rc<const Node> p;
 
-    static GenFun mk(Node n) { GenFun g; g.p = std::allocate_shared<const Node>(gft_small::Alloc<Node>(), std::move(n)); return g; }  // (eval builds nodes too: gf.rs:684-706)
+    static GenFun mk(Node n) { GenFun g; g.p = rc_allocate<const Node>(gft_small::Alloc<Node>(), std::move(n)); return g; }  // (eval builds nodes too: gf.rs:684-706)
     // the node kinds eval itself builds by the thousand (observation chains): filled in where they live, no Node moved twice
     static GenFun mk_in_place(Kind k, const GenFun* a, const GenFun* b, size_t var_, size_t order_) {
-        auto sp = std::allocate_shared<Node>(gft_small::Alloc<Node>());
+        auto sp = rc_allocate<Node>(gft_small::Alloc<Node>());
         sp->kind = k;
         if (a) sp->a = *a;
         if (b) sp->b = *b;
