@@ -1152,6 +1152,9 @@ struct ApiTrace {
         for (auto& kv : tiny) fprintf(stderr, "[gft api] tiny device result from %-22s %zu\n", kv.first.c_str(), kv.second);
         fprintf(stderr, "[gft api] host-tier Horner steps: positive constants %llu, sign-known c %llu, other %llu; elements of a sign-known step that left its fast path %llu\n",
                 gft::g_host_horner_stats[0], gft::g_host_horner_stats[1], gft::g_host_horner_stats[2], gft::g_host_horner_stats[3]);
+        fprintf(stderr, "[gft api] host-tier Horner elements: sign-known runs %llu held / %llu failed, finite runs %llu / %llu, lines without runs %llu (sign-known c) + %llu; element form stored by: sign-known %llu, finite %llu, positive %llu, general %llu\n",
+                gft::g_host_horner_stats[4], gft::g_host_horner_stats[5], gft::g_host_horner_stats[6], gft::g_host_horner_stats[7], gft::g_host_horner_stats[8], gft::g_host_horner_stats[9],
+                gft::g_host_horner_stats[10], gft::g_host_horner_stats[11], gft::g_host_horner_stats[12], gft::g_host_horner_stats[13]);
         for (auto& kv : settles) fprintf(stderr, "[gft api] chains materialised for %-24s %zu\n", kv.first.c_str(), kv.second);
     }
 };

@@ -17,7 +17,7 @@
 #include <cstdio>
 namespace gft {
 // GFT_TRACE_API: host-tier Horner steps by regime {positive constants, sign-known c, general} and elements that fell back
-extern unsigned long long g_host_horner_stats[4];
+extern unsigned long long g_host_horner_stats[16];  // [0..3] steps by regime / semi misses; [4..7] elements of semi / fin runs that held / failed; [8..9] elements of lines without runs; [10..13] element form: stored by semi / fin / positive / general
 extern int g_host_simd;  // the runs' AVX2 clones: -1 when the CPU has AVX2 (the default), 0 never (tests compare the two builds of the same loop)
 extern bool g_host_horner_runs;  // the finite regime of the host Horner step in runs of equal terms (tests switch it off to compare)
 
@@ -420,34 +420,30 @@ struct HK {
                         if (k < t3_hi && t3_hi < q) q = t3_hi;
                         const int sel = (t1 ? 1 : 0) | (t2 ? 2 : 0) | (t3 ? 4 : 0);
                         const size_t roff = roff0 + (size_t)k * g.rstr[last], aoff = aoff0 + (size_t)k * g.astr[last];
-                        bool ok;
-                        if (semi_runs) {
-                            switch (sel) {
-                                case 0: ok = horner_run_semi<false, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 1: ok = horner_run_semi<true, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 2: ok = horner_run_semi<false, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 3: ok = horner_run_semi<true, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 4: ok = horner_run_semi<false, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 5: ok = horner_run_semi<true, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                case 6: ok = horner_run_semi<false, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
-                                default: ok = horner_run_semi<true, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, semi); break;
+                        // in chunks: one verdict per chunk, so a stray element outside the regime costs its chunk, not the line.  A line of
+                        // a sign-known step typically starts positive (probabilities) and ends in error intervals around zero: the
+                        // `semi` regime until a chunk fails it, the finite regime from there on (both are the reference's bits where
+                        // their tests pass), single elements with every regime tried only where a chunk fails both.
+                        constexpr unsigned CH = 16;
+                        for (unsigned kk = k; kk < q; kk += CH) {
+                            const unsigned n = q - kk < CH ? q - kk : CH;
+                            const size_t ro = roff + (size_t)(kk - k) * g.rstr[last], ao = aoff + (size_t)(kk - k) * g.astr[last], li = lin + (kk - k);
+                            bool ok = false;
+                            if (semi_runs) {
+                                ok = horner_run_sel<true>(sel, res, rp, a, ap, out, op, g, li, ro, ao, last, n, semi);
+                                g_host_horner_stats[ok ? 4 : 5] += n;
+                                if (!ok) semi_runs = false;  // (the rest of this line: straight to the finite regime)
                             }
-                        } else
-                        switch (sel) {
-                            case 0: ok = horner_run_fin<false, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 1: ok = horner_run_fin<true, false, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 2: ok = horner_run_fin<false, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 3: ok = horner_run_fin<true, true, false>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 4: ok = horner_run_fin<false, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 5: ok = horner_run_fin<true, false, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            case 6: ok = horner_run_fin<false, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                            default: ok = horner_run_fin<true, true, true>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, q - k, fin); break;
-                        }
-                        if (!ok) {  // an operand outside the regime (or a result that left it): this run element by element, every regime tried
-                            for (unsigned kk = k; kk < q; ++kk) {
-                                const bool in_p = in_p0 && kk < g.sh[last], in_r = in_r0 && kk < g.rs[last], in_c = in_c0 && kk < g.oc[last];
-                                horner_linear_elem(res, rp, a, ap, out, op, g, lin + (kk - k), roff0 + (size_t)kk * g.rstr[last], aoff0 + (size_t)kk * g.astr[last],
-                                                   g.w == last ? kk : kw0, in_p, in_r, in_c, pos_consts, semi, fin);
+                            if (!ok && fin) {
+                                ok = horner_run_sel<false>(sel, res, rp, a, ap, out, op, g, li, ro, ao, last, n, fin);
+                                g_host_horner_stats[ok ? 6 : 7] += n;
+                            }
+                            if (!ok) {
+                                for (unsigned e = kk; e < kk + n; ++e) {
+                                    const bool in_p = in_p0 && e < g.sh[last], in_r = in_r0 && e < g.rs[last], in_c = in_c0 && e < g.oc[last];
+                                    horner_linear_elem(res, rp, a, ap, out, op, g, lin + (e - k), roff0 + (size_t)e * g.rstr[last], aoff0 + (size_t)e * g.astr[last],
+                                                       g.w == last ? e : kw0, in_p, in_r, in_c, pos_consts, semi, fin);
+                                }
                             }
                         }
                         lin += q - k;
@@ -460,6 +456,7 @@ struct HK {
                     continue;
                 }
             }
+            g_host_horner_stats[semi ? 8 : 9] += nlast;
             for (unsigned k = 0; k < nlast; ++k, ++lin) {
                 const bool in_p = in_p0 && k < g.sh[last], in_r = in_r0 && k < g.rs[last], in_c = in_c0 && k < g.oc[last];
                 const unsigned kw = g.w == last ? k : kw0;
@@ -475,6 +472,24 @@ struct HK {
     // n consecutive positions of a line along the LAST axis that all have the terms T1 (res[k - 1] * m), T2 (c * res[k]), T3 (the
     // coefficient), in the finite regime — element for element horner_linear_elem's `fin` branch.  false: some operand or result
     // is outside the regime; nothing usable was stored (the caller redoes the run element by element).
+    template <bool SEMI>
+    static bool horner_run_sel(int sel, const double* res, size_t rp, const double* a, size_t ap, double* out, size_t op, const HornerArgs& g, size_t lin, size_t roff,
+                               size_t aoff, int last, unsigned n, int flags) {
+#define GFT_RUN(T1, T2, T3)                                                                                                  \
+    return SEMI ? horner_run_semi<T1, T2, T3>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, flags)                   \
+                : horner_run_fin<T1, T2, T3>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, flags)
+        switch (sel) {
+            case 0: GFT_RUN(false, false, false);
+            case 1: GFT_RUN(true, false, false);
+            case 2: GFT_RUN(false, true, false);
+            case 3: GFT_RUN(true, true, false);
+            case 4: GFT_RUN(false, false, true);
+            case 5: GFT_RUN(true, false, true);
+            case 6: GFT_RUN(false, true, true);
+            default: GFT_RUN(true, true, true);
+        }
+#undef GFT_RUN
+    }
     template <bool T1, bool T2, bool T3>
     static bool horner_run_fin(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
                                const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
@@ -674,6 +689,7 @@ struct HK {
                     }
                     if (!bad) {
                         E::st(out, op, lin, v);
+                        g_host_horner_stats[10]++;
                         return;
                     }
                 }
@@ -694,6 +710,7 @@ struct HK {
                     if (t3) v = (t1 || t2) ? E::widen_fin(p.lo + cf.lo, p.hi + cf.hi) : cf;
                     if (!E::is_nan(v)) {
                         E::st(out, op, lin, v);
+                        g_host_horner_stats[11]++;
                         return;
                     }
                 }
@@ -710,11 +727,13 @@ struct HK {
                     bad = bad || ((has_p || t3) && !E::pos_result_ok(v));
                     if (!bad) {
                         E::st(out, op, lin, v);
+                        g_host_horner_stats[12]++;
                         return;
                     }
                 }
             }
         }
+        g_host_horner_stats[13]++;
         V p = E::zero();
         if (in_p) {
             if (t1) p = E::mul(E::ld(res, rp, roff - g.rstr[g.w]), mv);

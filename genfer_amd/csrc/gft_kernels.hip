@@ -17,7 +17,7 @@
 namespace gft {
 
 unsigned long long g_launches = 0;
-unsigned long long g_host_horner_stats[4] = {0, 0, 0, 0};  // gft_host.hpp (GFT_TRACE_API)
+unsigned long long g_host_horner_stats[16] = {0};  // gft_host.hpp (GFT_TRACE_API)
 bool g_host_horner_runs = true;                             // gft_host.hpp: the finite regime of the host Horner step in runs (tests: false)
 int g_host_simd = -1;                                          // gft_host.hpp: the AVX2 clones of those runs (-1: when the CPU has AVX2, 0: never)
 unsigned long long g_launches_in_place = 0;

@@ -11,7 +11,7 @@
 #include "../genfer_amd/csrc/gft_host.hpp"
 
 namespace gft {
-unsigned long long g_host_horner_stats[4] = {0, 0, 0, 0};
+unsigned long long g_host_horner_stats[16] = {0};
 bool g_host_horner_runs = true;
 int g_host_simd = -1;
 }  // namespace gft
@@ -71,7 +71,7 @@ int main() {
         }
         g.coeff_scalar = coeff_scalar ? 1 : 0;
         g.upper = sh[g.w] - 1 < rs[g.w] ? sh[g.w] - 1 : rs[g.w];
-        const int cls = (int)irand(0, 6);  // 4-6: positive data under a sign-known c (the `semi` regime), 5 with values that underflow, 6 with stray non-positive elements
+        const int cls = (int)irand(0, 7);  // 4-6: positive data under a sign-known c (the `semi` regime), 5 with values that underflow, 6 with stray non-positive elements, 7 a positive head and a tail of error intervals around zero (switchpoint's lines)
         auto mk = [&](double centre, double width) {
             Iv r;
             r.lo = centre - width * urand();
@@ -87,6 +87,7 @@ int main() {
         auto fill = [&](std::vector<double>& t, size_t n) {
             for (size_t i = 0; i < n; ++i) {
                 Iv x = (cls == 1 || cls >= 4) ? mk(0.5, 0.4) : mk(0.0, cls == 2 ? 1e-300 : 1e-20);
+                if (cls == 7 && 2 * i >= n) x = mk(0.0, 1e-20);
                 if (cls == 5 && urand() < 0.05) x = Iv{4.9e-324 * (double)irand(1, 3), 1e-320};
                 if (cls == 6 && urand() < 0.05) x = urand() < 0.5 ? mk(0.0, 1e-3) : (urand() < 0.5 ? Iv{1.0, 1.0} : Iv{0.0, 0.0});
                 if (cls == 3 && urand() < 0.1) x = urand() < 0.5 ? Iv{0.0, 0.0} : Iv{1.0, 1.0};
