@@ -319,14 +319,27 @@ static void* host_alloc(size_t bytes, size_t* cls_out) {
 }
 static void host_free(void* p, size_t cls) { R.host_blocks[cls].push_back(p); }
 
+// Reference counts inside the library are NOT atomic: the header's contract is one calling thread, the launch thread's closures
+// capture raw device pointers (never a handle's buffer object), and a locked increment / decrement per handle copy was 7 % of the
+// calling thread on mixture.  libstdc++'s shared_ptr with the single-threaded lock policy is that type.
+template <class U>
+using Rc = std::__shared_ptr<U, __gnu_cxx::_S_single>;
+template <class U, class A, class... Args>
+static inline Rc<U> rc_allocate(const A& a, Args&&... args) {
+    return std::__allocate_shared<U, __gnu_cxx::_S_single>(a, std::forward<Args>(args)...);
+}
+template <class U, class... Args>
+static inline Rc<U> rc_make(Args&&... args) {
+    return std::__make_shared<U, __gnu_cxx::_S_single>(std::forward<Args>(args)...);
+}
 struct LazyOp;
-struct Buf : std::enable_shared_from_this<Buf> {
+struct Buf {
     double* p = nullptr;
     size_t cls = 0;
     bool borrowed = false;
     bool host = false;           // p is host memory (host tier); `dev` is its device mirror once a kernel needed it
     // the contents have not been launched yet (a recorded observation chain): use_buf() launches, or the consumer fuses
-    std::shared_ptr<LazyOp> lazy;
+    Rc<LazyOp> lazy;
     // interval tensors: 2 = PROVEN to hold no coefficient that is exactly [0,0] (Ops::nz_of), 1 = holds one / descends from a
     // tensor that does (nobody asks again), 0 = unknown
     unsigned char nz = 0;
@@ -339,10 +352,10 @@ struct Buf : std::enable_shared_from_this<Buf> {
     const char* origin = nullptr;  // the entry point whose result first owned this buffer (diagnostics: GFT_TRACE_SCANS)
     unsigned dag_mark = 0;       // run_dag: visited in this execution
     int dag_level = 0;           // ... and its level (longest path from tensors in memory)
-    std::shared_ptr<Buf> dev;
+    Rc<Buf> dev;
     // device tensors whose coefficients are read one by one (probs_taylor / moments_taylor read `limit` of them,
     // generating_function.rs:963,992): the second read mirrors the whole (immutable) buffer to the host once
-    std::shared_ptr<Buf> host_copy;
+    Rc<Buf> host_copy;
     unsigned coef_reads = 0;
     // memoised extract_linear() verdict: buffers are immutable once their polynomial is returned, and the
     // metadata-only reshapes that share a buffer (extend_to_dim, dropping a trailing unit axis) keep the
@@ -361,22 +374,22 @@ struct Buf : std::enable_shared_from_this<Buf> {
 struct DagRec;
 struct LazyOp {
     std::function<void(Buf*)> run;
-    std::shared_ptr<DagRec> rec;   // (round 6) the recording as a node of the deferred launch graph (gft_batch.hpp); null: launched by run() only
-    std::shared_ptr<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
-    std::shared_ptr<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
-    std::shared_ptr<void> sum;     // Ops<E>::LazySum: a recorded Add / Sub of two chains (an Add that consumes it launches both: K<E>::chain_nest)
+    Rc<DagRec> rec;   // (round 6) the recording as a node of the deferred launch graph (gft_batch.hpp); null: launched by run() only
+    Rc<void> obs;     // Ops<E>::LazyObs for the fused form (typed by the element class that recorded it)
+    Rc<void> horner;  // Ops<E>::LazyHorner: a recorded linear Horner loop (rides along with another loop's launch)
+    Rc<void> sum;     // Ops<E>::LazySum: a recorded Add / Sub of two chains (an Add that consumes it launches both: K<E>::chain_nest)
 };
 
 // (+ 8 doubles of slack: the tiled product reads operands in place and its pipelined x loads request one 64-byte chunk
 // beyond the last one they use — gft_conv_tiled.hip, ConvArgs::operands_slack)
-static std::shared_ptr<Buf> alloc_doubles(size_t n) {
-    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
+static Rc<Buf> alloc_doubles(size_t n) {
+    auto b = rc_allocate<Buf>(gft_small::Alloc<Buf>());
     b->p = (double*)pool_alloc((std::max<size_t>(n, 1) + 8) * sizeof(double), &b->cls);
     return b;
 }
 // a recording's result: no memory yet (ensure_alloc, when the recording is launched)
-static std::shared_ptr<Buf> alloc_recorded(size_t n) {
-    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
+static Rc<Buf> alloc_recorded(size_t n) {
+    auto b = rc_allocate<Buf>(gft_small::Alloc<Buf>());
     b->want = std::max<size_t>(n, 1);
     return b;
 }
@@ -384,13 +397,13 @@ static void ensure_alloc(Buf* b) {
     if (b->p || b->host) return;
     b->p = (double*)pool_alloc((std::max<size_t>(b->want, 1) + 8) * sizeof(double), &b->cls);
 }
-static std::shared_ptr<Buf> alloc_host_doubles(size_t n) {
-    auto b = std::allocate_shared<Buf>(gft_small::Alloc<Buf>());
+static Rc<Buf> alloc_host_doubles(size_t n) {
+    auto b = rc_allocate<Buf>(gft_small::Alloc<Buf>());
     b->host = true;
     b->p = (double*)host_alloc(std::max<size_t>(n, 1) * sizeof(double), &b->cls);
     return b;
 }
-static std::shared_ptr<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
+static Rc<Buf> alloc_tier(bool host, size_t n) { return host ? alloc_host_doubles(n) : alloc_doubles(n); }
 
 static void force_buf(Buf* b);
 static void ensure_alloc(Buf* b);
@@ -400,7 +413,7 @@ static inline void use_buf(Buf* b) {
     if (!b->host && b->lazy) force_buf(b);
 }
 static void force_buf(Buf* b) {
-    std::shared_ptr<LazyOp> op = b->lazy;
+    Rc<LazyOp> op = b->lazy;
     if (op->rec && R.batch_dag) {  // a node of the deferred launch graph: everything it depends on, level by level
         run_dag(b);
         return;
@@ -494,7 +507,7 @@ static void peek(double* out, const double* dev_src, size_t stride, unsigned n) 
 // product, mt:557-565), computed once per m on the host tier's functor and reused by every later substitution by the
 // same m (Genfer programs substitute the same few constants thousands of times).
 struct TabEntry {
-    std::shared_ptr<Buf> dev;   // W planes of `len` doubles
+    Rc<Buf> dev;   // W planes of `len` doubles
     std::vector<double> host;   // the same values (element 0 of a chain is host-computable)
     size_t len = 0;
     int nz = -1;                // (intervals) 1: no entry is exactly [0,0]; -1: not looked at yet
@@ -502,7 +515,7 @@ struct TabEntry {
 struct PendStage {
     int kind = 0, axis = 0;
     double s[2] = {0, 0};
-    std::shared_ptr<TabEntry> tab;
+    Rc<TabEntry> tab;
 };
 struct Pend {
     Dims base_shape;            // shape of the base tensor in `buf` (its axes align with the handle's leading axes)
@@ -515,11 +528,11 @@ struct Pend {
     Dims pad, src_box;
     int n = 0;
     PendStage st[gft::CHAIN_MAX];
-    std::shared_ptr<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
+    Rc<Buf> mat;   // the materialised tensor once some consumer needed it (shared by all copies of the handle)
     Dims mat_shape;
 };
 
-std::map<std::tuple<unsigned long long, unsigned long long>, std::shared_ptr<TabEntry>> g_pow_tabs[2];  // Ops<E>::pow_table
+std::map<std::tuple<unsigned long long, unsigned long long>, Rc<TabEntry>> g_pow_tabs[2];  // Ops<E>::pow_table
 
 }  // namespace
 
@@ -533,7 +546,7 @@ struct gft_poly {
     int width = 1;              // 1: F64, 2: Interval (lo plane, hi plane)
     Dims shape;                 // stored (compact) coefficient shape
     Dims deg;                   // degrees_p1
-    mutable std::shared_ptr<Buf> buf;   // width * numel doubles, plane stride == numel (null: lazy host-cached scalar)
+    mutable Rc<Buf> buf;   // width * numel doubles, plane stride == numel (null: lazy host-cached scalar)
     size_t numel = 1;
     // host cache of the value when numel == 1 (filled on construction from host scalars or lazily)
     mutable bool cached = false;
@@ -552,7 +565,7 @@ struct gft_poly {
     // deferred elementwise chain: the value is chain(buf restricted to the leading box `shape`); buf holds the BASE
     // tensor (device).  Consumers that understand chains read it directly, everyone else goes through dp(), which
     // materialises it once (settle).
-    mutable std::shared_ptr<Pend> pend;
+    mutable Rc<Pend> pend;
 };
 
 namespace {
@@ -786,7 +799,7 @@ static void settle(const gft_poly& p) {
     if (!p.pend) return;
     Pend& q = *p.pend;
     if (!(q.mat && same_dims_mod_trailing_ones(q.mat_shape, p.shape))) {
-        std::shared_ptr<Buf> out = alloc_doubles(p.numel * E::W);
+        Rc<Buf> out = alloc_doubles(p.numel * E::W);
         Dims keep = chain_keep(p.shape, {&p});
         if (keep.size() > (size_t)MAXD) throw Error("tensor rank exceeds GFT MAXD after collapsing");
         Shape sh;
@@ -966,7 +979,7 @@ struct Ops {
         out[v] = upper;
         Shifts shift(out.size(), 0);
         if (gather_tier(a, out)) return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, keep.data(), 1);
-        std::shared_ptr<Buf> kb = alloc_doubles((upper + 7) / 8 + 1);
+        Rc<Buf> kb = alloc_doubles((upper + 7) / 8 + 1);
         HIP_OK(hipMemcpyAsync(kb->p, keep.data(), upper, hipMemcpyHostToDevice, R.stream));
         HIP_OK(hipStreamSynchronize(R.stream));
         return gather(a, out, a.deg, shift, a.shape, OP_COPY, nullptr, (int)v, nullptr, 0, (const unsigned char*)kb->p, 0);
@@ -1044,7 +1057,7 @@ struct Ops {
         const double* d = dp<E>(a);
         Buf* b = a.buf.get();
         if (!b->host_copy && ++b->coef_reads >= 2 && a.numel * W * sizeof(double) <= ((size_t)32 << 20)) {
-            std::shared_ptr<Buf> m = alloc_host_doubles(a.numel * W);
+            Rc<Buf> m = alloc_host_doubles(a.numel * W);
             HIP_OK(hipMemcpyAsync(m->p, d, sizeof(double) * a.numel * W, hipMemcpyDeviceToHost, R.stream));
             HIP_OK(hipStreamSynchronize(R.stream));
             b->host_copy = m;

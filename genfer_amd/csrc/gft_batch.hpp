@@ -241,14 +241,14 @@ static void run_dag(Buf* root) {
     for (auto& nodes : levels) {
         // the recordings of this level stay alive (and with them their inputs: no pool block of an input is reused by an
         // output of the same level) until the level's launches have been issued
-        std::vector<std::shared_ptr<LazyOp>> keep;
+        std::vector<Rc<LazyOp>> keep;
         keep.reserve(nodes.size());
         ctx.prev = g_level;
         g_level = &ctx;
         try {
             for (Buf* b : nodes) {
                 if (!b->lazy) continue;  // (launched by a nested execution)
-                std::shared_ptr<LazyOp> op = b->lazy;
+                Rc<LazyOp> op = b->lazy;
                 keep.push_back(op);
                 if (!op->rec->emit(b)) {
                     ensure_alloc(b);
