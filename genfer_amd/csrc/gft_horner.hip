@@ -721,7 +721,22 @@ __device__ __forceinline__ void horner_pipe_point_line(const double* __restrict_
             }
         }
     };
-    for (unsigned t = 0; t <= nloop;) {
+    // (round 6) A wave joins the loop at the first step that reaches its positions.  The accumulator's extent along w grows by one
+    // per step (rsw(t) = min(rs0 + t, deg): a POINT coefficient box adds nothing beyond position 0), so until step
+    // t_s = 64 * wave - rs0 every position of the wave lies outside every box of the step — nothing computed, nothing stored, and
+    // what it would publish is read by a wave that joins later still.  Step t_s reads position 64 * wave - 1 as it is after step
+    // t_s - 1: slot t_s - 1 of the ring below.  A 101-wide line's second wave idles through 64 of its 101 steps — a third of the
+    // launch's instructions (mixture --bounds: k_horner_pipe_point_batch is 79 % of the device time).
+    unsigned t_join = 0;
+    if (wave) {
+        const unsigned first_pos = wave * 64u, rs0w = g.rs0[g.w];
+        if (first_pos > rs0w && first_pos < degw && first_pos - rs0w <= nloop && !(g.diag & 32)) {
+            t_join = first_pos - rs0w;
+            rsw = first_pos;  // = min(rs0 + t_join, deg)
+            below = ring_receive<E>(ring_b + (t_join - 1u), nslots, ring_request<E>(ring_b + (t_join - 1u), nslots));
+        }
+    }
+    for (unsigned t = t_join; t <= nloop;) {
         if (lean && t < nloop && !(g.diag & 16)) {
             const unsigned chunk_end = (t | 63u) + 1u;  // witness words are flushed per 64 steps
             const unsigned t_end = (wit && chunk_end < nloop) ? chunk_end : nloop;

@@ -2,13 +2,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 {
-for rep in 1 2; do
-for v in 3 1 0; do
-  echo "== GFT_SETTLE_REC=$v"
-  GFT_SETTLE_REC=$v timeout 600 python tools/bench_e2e.py --gpu-only --runs 5 --bounds --only approx/hmm 2>&1 | grep -v '^{' | cut -c1-200
-  GFT_SETTLE_REC=$v timeout 600 python tools/bench_e2e.py --gpu-only --runs 10 --only approx/hmm 2>&1 | grep -v '^{' | cut -c1-200
-  GFT_SETTLE_REC=$v timeout 600 python tools/bench_e2e.py --gpu-only --runs 5 --only approx/two 2>&1 | grep -v '^{' | cut -c1-200
-done
-done
+timeout 900 python -m pytest tests/test_horner_shapes_gpu.py tests/test_interval_pins.py tests/test_fuzz_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_e2e_snapshots.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python tools/bench_e2e.py --gpu-only --runs 5 --bounds --only approx/ 2>&1 | grep -v '^{' | cut -c1-200
 } > gpurun_out/r6ab.log 2>&1
 grep -v amdgpu gpurun_out/r6ab.log

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 600 python tools/profile_host.py mixture "--limit 100" 20 2>&1 | tail -1
-timeout 600 python tools/profile_host.py hmm "--limit 100" 40 2>&1 | tail -1
+timeout 600 python tools/profile_host.py mixture "--limit 100 --bounds" 5 2>&1 | tail -1
+timeout 600 python tools/profile_host.py hmm "--limit 100 --bounds" 5 2>&1 | tail -1
