@@ -440,6 +440,9 @@ def test_launch_graph_batches_bit_exact(interval, OTP, GTP, OTPI, GTPI, tier):
              b[k].observe_chain(1, sc(0.8), [sc(0.4)], n - 6) * T.from_scalar(sc(0.5)) for k in range(B)]
         # two-chain Adds of scaled tensors
         d = [a[k] * T.from_scalar(sc(0.25)) + b[k] * T.from_scalar(sc(0.75)) for k in range(B)]
+        # observation chains whose INPUT is a deferred chain (a scaled tensor): its materialisation is a node of the graph too
+        # (SettleRec: hmm's `if` arms) — B of them are one launch, then the B chains another
+        s_ = [(a[k] * T.from_scalar(sc(0.6))).observe_chain(0, sc(0.7), [sc(0.2)], n - 8) for k in range(B)]
         # nested Adds of mul_linear sums (hmm's `State ~ Bernoulli(p)` on both arms)
         lin1 = T.var_with_degrees_p1(0, sc(0.0), [n, n]) * T.from_scalar(sc(0.2)) + T.from_scalar(sc(0.8))
         lin2 = T.var_with_degrees_p1(0, sc(0.0), [n, n]) * T.from_scalar(sc(0.7)) + T.from_scalar(sc(0.3))
@@ -457,11 +460,12 @@ def test_launch_graph_batches_bit_exact(interval, OTP, GTP, OTPI, GTPI, tier):
             return r
         root = total(c + d + e)
         out.append(root.array().copy())
+        out.append(total(s_).array().copy())
         if f is None:
             f = mkf()
         froot = total(f)
         out.append(froot.array().copy())
-        for lst in (c, d, e, f):
+        for lst in (c, d, e, s_, f):
             out += [t.array().copy() for t in lst]
         return out
 
@@ -479,7 +483,8 @@ def test_launch_graph_batches_bit_exact(interval, OTP, GTP, OTPI, GTPI, tier):
             # (tier "host" = the default dispatch: scalars and affine substitutions stay host values, as in the interpreter's runs; with
             # everything forced onto the device their products read values back, which issues the recordings one by one)
             if batch and tier == "host" and not any(os.environ.get(k) for k in ("GFT_BATCH", "GFT_LAZY_OBSERVE", "GFT_LAZY_SUM", "GFT_LAZY_HORNER", "GFT_DEFER", "GFT_NZ_PROOFS")):
-                assert delta["batch_launches"] >= 3 and delta["batch_items"] >= 3 * B, delta
+                assert delta["batch_launches"] >= 4 and delta["batch_items"] >= 4 * B, delta
+                assert delta["chains_materialised"] >= B, delta  # (the B recorded materialisations)
             if not batch:
                 assert delta["batch_launches"] == 0, delta
     finally:
