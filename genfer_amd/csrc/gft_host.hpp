@@ -18,7 +18,7 @@
 namespace gft {
 // GFT_TRACE_API: host-tier Horner steps by regime {positive constants, sign-known c, general} and elements that fell back
 extern unsigned long long g_host_horner_stats[16];  // [0..3] steps by regime / semi misses; [4..7] elements of semi / fin runs that held / failed; [8..9] elements of lines without runs; [10..13] element form: stored by semi / fin / positive / general
-extern int g_host_simd;  // the runs' AVX2 clones: -1 when the CPU has AVX2 (the default), 0 never (tests compare the two builds of the same loop)
+extern int g_host_simd;  // the runs' vector clones: -1 the widest the CPU has (AVX-512, AVX2; the default), 1 AVX2 at most, 0 none (tests compare the builds of the same loop)
 extern bool g_host_horner_runs;  // the finite regime of the host Horner step in runs of equal terms (tests switch it off to compare)
 
 
@@ -494,7 +494,11 @@ struct HK {
     static bool horner_run_fin(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out, size_t op,
                                const HornerArgs& g, size_t lin, size_t roff, size_t aoff, int last, unsigned n, int fin) {
         const size_t rs = g.rstr[last], as = g.coeff_scalar ? 0 : g.astr[last];  // (known strides: see horner_run_semi)
-        if (rs == 1 && as <= 1 && host_avx2()) {  // (the same loop compiled for 4-wide vectors: same operations per element, same bits)
+        if (rs == 1 && as <= 1 && host_avx512()) {  // (the same loop compiled for 8-wide / 4-wide vectors: same operations per element, same bits)
+            if (as == 1) return horner_run_fin_avx512<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+            return horner_run_fin_avx512<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+        }
+        if (rs == 1 && as <= 1 && host_avx2()) {
             if (as == 1) return horner_run_fin_avx2<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
             return horner_run_fin_avx2<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
         }
@@ -505,6 +509,22 @@ struct HK {
     static bool host_avx2() {
         static const bool has = __builtin_cpu_supports("avx2");
         return has && g_host_simd != 0;
+    }
+    static bool host_avx512() {
+        static const bool has = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+        return has && g_host_simd < 0;
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    __attribute__((target("avx512f,avx512dq,avx512vl"))) static bool horner_run_fin_avx512(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap,
+                                                                                           double* __restrict out, size_t op, const HornerArgs& g, size_t lin, size_t roff,
+                                                                                           size_t aoff, int last, unsigned n, int fin) {
+        return horner_run_fin_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, fin);
+    }
+    template <bool T1, bool T2, bool T3, int RS1, int AS1>
+    __attribute__((target("avx512f,avx512dq,avx512vl"))) static bool horner_run_semi_avx512(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap,
+                                                                                            double* __restrict out, size_t op, const HornerArgs& g, size_t lin, size_t roff,
+                                                                                            size_t aoff, int last, unsigned n, int semi) {
+        return horner_run_semi_body<T1, T2, T3, RS1, AS1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
     }
     template <bool T1, bool T2, bool T3, int RS1, int AS1>
     __attribute__((target("avx2"))) static bool horner_run_fin_avx2(const double* __restrict res, size_t rp, const double* __restrict a, size_t ap, double* __restrict out,
@@ -569,6 +589,10 @@ struct HK {
         // (the accumulator is compact: unit stride along the line; the coefficient's stride is 1, or 0 where the line runs along
         // the substituted axis — known strides are what lets the compiler use vector loads)
         const size_t rs = g.rstr[last], as = g.coeff_scalar ? 0 : g.astr[last];
+        if (rs == 1 && as <= 1 && host_avx512()) {
+            if (as == 1) return horner_run_semi_avx512<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+            return horner_run_semi_avx512<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
+        }
         if (rs == 1 && as <= 1 && host_avx2()) {
             if (as == 1) return horner_run_semi_avx2<T1, T2, T3, 1, 1>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);
             return horner_run_semi_avx2<T1, T2, T3, 1, 0>(res, rp, a, ap, out, op, g, lin, roff, aoff, last, n, semi);

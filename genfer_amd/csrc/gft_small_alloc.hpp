@@ -22,18 +22,28 @@ constexpr size_t MAX_BYTES = 4096;          // larger requests: operator new / d
 constexpr size_t LIST_BYTES = 64u << 20;    // per size class and thread (a program's pending recordings: tens of thousands of 1-3 KB blocks)
 constexpr size_t NCLASS = MAX_BYTES / 16;
 
-// The thread is ending (or the process is, for the main thread): straight to operator new / delete.  A trivially
-// destructible thread_local of its own — later thread_local / static destructors that release handles read it after
-// `Lists` has been destroyed, which reading a member of the destroyed object would not allow.
-inline bool& dead() {
-    static thread_local bool d = false;
-    return d;
+// ONE constant-initialised thread_local per thread (a shared library reaches a thread_local through a __tls_get_addr call, and
+// one with a constructor through a guard test on top: 4 % of mixture's calling thread when `dead` and the lists were two of them):
+//   dead   the thread is ending (or the process is, for the main thread): straight to operator new / delete.  Later thread_local
+//          / static destructors that release handles read it after the lists have been destroyed;
+//   lists  this thread's free lists once it has used them (owned by the thread_local in lists_slow()).
+struct Lists;
+struct Tls {
+    bool dead;
+    Lists* lists;
+};
+inline Tls& tls() {
+    static thread_local Tls t = {false, nullptr};
+    return t;
 }
+inline bool& dead() { return tls().dead; }
 struct Lists {
     void* head[NCLASS + 1] = {};
     unsigned count[NCLASS + 1] = {};
     ~Lists() {
-        dead() = true;
+        Tls& t = tls();
+        t.dead = true;
+        t.lists = nullptr;
         for (size_t c = 0; c <= NCLASS; ++c) {
             while (void* p = head[c]) {
                 head[c] = *static_cast<void**>(p);
@@ -43,16 +53,19 @@ struct Lists {
         }
     }
 };
-inline Lists& lists() {
+inline Lists& lists_slow() {  // first use on this thread
     static thread_local Lists L;
+    tls().lists = &L;
     return L;
 }
+inline Lists& lists() { return tls().lists ? *tls().lists : lists_slow(); }
 inline void* get(size_t bytes) {
     if (bytes == 0) bytes = 1;
     if (bytes > MAX_BYTES) return ::operator new(bytes);
     const size_t c = (bytes + 15) >> 4;
-    if (dead()) return ::operator new(c << 4);
-    Lists& L = lists();
+    Tls& t = tls();
+    if (t.dead) return ::operator new(c << 4);
+    Lists& L = t.lists ? *t.lists : lists_slow();
     if (void* p = L.head[c]) {
         L.head[c] = *static_cast<void**>(p);
         --L.count[c];
@@ -68,11 +81,12 @@ inline void put(void* p, size_t bytes) noexcept {
         return;
     }
     const size_t c = (bytes + 15) >> 4;
-    if (dead()) {
+    Tls& t = tls();
+    if (t.dead) {
         ::operator delete(p);
         return;
     }
-    Lists& L = lists();
+    Lists& L = t.lists ? *t.lists : lists_slow();
     if ((size_t)L.count[c] * (c << 4) >= LIST_BYTES) {
         ::operator delete(p);
         return;

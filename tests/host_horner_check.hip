@@ -101,13 +101,13 @@ int main() {
         g_host_horner_runs = true;
         g_host_simd = -1;
         HK<E>::horner_linear(res.data(), nres, a.data(), na, o1.data(), nout, g);
-        {   // the baseline build of the same runs (what a CPU without AVX2 executes)
+        for (int simd = 0; simd <= 1; ++simd) {  // the narrower builds of the same runs (AVX2 at most; baseline x86-64)
             std::vector<double> o3(2 * nout, -7.0);
-            g_host_simd = 0;
+            g_host_simd = simd;
             HK<E>::horner_linear(res.data(), nres, a.data(), na, o3.data(), nout, g);
             g_host_simd = -1;
             if (std::memcmp(o1.data(), o3.data(), sizeof(double) * 2 * nout) != 0) {
-                std::printf("MISMATCH (avx2 vs baseline runs) trial %d\n", trial);
+                std::printf("MISMATCH (widest vs g_host_simd = %d) trial %d\n", simd, trial);
                 return 1;
             }
         }
@@ -144,9 +144,9 @@ int main() {
                 res[i] = 0.1 + 0.5 * urand(); res[nres + i] = res[i] + 0.1;
                 a[i] = 0.1 + 0.5 * urand(); a[nres + i] = a[i] + 0.1;
             }
-            for (int runs = 2; runs >= 0; --runs) {  // 2: runs with AVX2, 1: runs without, 0: element form
+            for (int runs = 3; runs >= 0; --runs) {  // 3: runs, widest vectors; 2: AVX2; 1: baseline; 0: element form
                 g_host_horner_runs = runs != 0;
-                g_host_simd = runs == 2 ? -1 : 0;
+                g_host_simd = runs == 3 ? -1 : (runs == 2 ? 1 : 0);
                 timespec t0, t1;
                 clock_gettime(CLOCK_MONOTONIC, &t0);
                 const int reps = 20000;
