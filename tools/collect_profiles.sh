@@ -103,6 +103,9 @@ GFT_BATCH=0 python3 tools/bench_e2e.py --limit 100 --runs 3 --only approx --gpu-
 GFT_BATCH=0 python3 tools/bench_e2e.py --limit 100 --runs 2 --only approx --gpu-only --bounds > "$OUT/e2e_bounds_batch_off.log" 2>&1; grep -v '^{' "$OUT/e2e_bounds_batch_off.log" > "$OUT/summary/e2e_neurips_limit100_bounds_batch_off.txt"
 GFT_TRACE_SCANS=1 python3 tools/bench_e2e.py --limit 100 --runs 1 --only approx/hmm --gpu-only --bounds 2>&1 | grep "gft scans" | sort > "$OUT/summary/e2e_hmm_bounds_scans.txt"
 python3 tools/profile_host.py approx/mixture "--limit 100" 8 > "$OUT/host_profile.log" 2>&1; python3 tools/symbolize_samples.py gpurun_out/host_profile_mixture.samples > "$OUT/summary/host_profile_mixture.txt" 2>&1
+python3 tools/profile_host.py switchpoint "--limit 100 --bounds" 3 > "$OUT/host_profile_swb.log" 2>&1; python3 tools/symbolize_samples.py gpurun_out/host_profile_switchpoint_bounds.samples 30 > "$OUT/summary/host_profile_switchpoint_bounds.txt" 2>&1
+python3 tools/profile_host.py switchpoint "--limit 100" 5 > "$OUT/host_profile_sw.log" 2>&1; python3 tools/symbolize_samples.py gpurun_out/host_profile_switchpoint.samples 30 > "$OUT/summary/host_profile_switchpoint.txt" 2>&1
+python3 tools/profile_host.py approx/hmm "--limit 100" 30 > "$OUT/host_profile_hmm.log" 2>&1; python3 tools/symbolize_samples.py gpurun_out/host_profile_hmm.samples 30 > "$OUT/summary/host_profile_hmm.txt" 2>&1
 python3 tools/bench_e2e.py --limit 100 --runs 3 > "$OUT/e2e.log" 2>&1; tail -1 "$OUT/e2e.log" > "$OUT/summary/e2e_neurips_limit100.json"
 grep -v '^{' "$OUT/e2e.log" > "$OUT/summary/e2e_neurips_limit100.txt"
 grep -v '^{' "$OUT/e2e_bounds.log" > "$OUT/summary/e2e_neurips_limit100_bounds.txt"
