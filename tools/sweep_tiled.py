@@ -10,7 +10,7 @@ import genfer_amd  # noqa: E402
 genfer_amd.init(0)
 L = genfer_amd.lib()
 F = genfer_amd.TaylorPoly
-L.gft_set_conv_mode(2)
+L.gft_set_conv_mode(int(os.environ.get("SWEEP_CONV_MODE", "2")))  # 2: forced tiled (the default of this tool); 0: what gft_mul does by itself
 rng = np.random.default_rng(0)
 shapes = [(32,) * 3, (40,) * 3, (48,) * 3, (56,) * 3, (64,) * 3, (80,) * 3, (96,) * 3, (112,) * 3, (128,) * 3, (16,) * 4, (24,) * 4,
           (32,) * 4, (48,) * 4, (64, 64, 128), (128, 128, 32), (256, 256, 16), (200, 200, 64),
