@@ -2028,6 +2028,48 @@ __device__ inline typename E::V seg_chunk_mac(typename E::V inner, typename E::V
     }
     return inner;
 }
+// The same chunk product with the BROADCAST operand read by scalar loads instead of from LDS (round 6: the segment wavefront is
+// LDS-bound — two 8-byte reads per multiply-add; 96^3 div 50 -> 38 ms in an experiment without the broadcast one).  A scalar load
+// needs memory nobody writes during the launch, i.e. a PLAIN operand — and the broadcast operand is A, the one whose index
+// ascends: that is xs's row at log's level 0 (where most of log's multiply-adds are: 96^3 log 51 -> 43 ms), but a result row other
+// workgroups publish everywhere else (div's every level).  Measured and not kept for those: broadcasting the divisor's chunks in
+// DESCENDING order against a window over the result row (the same terms in the same order, bit-exact) — 50 -> 57 ms at 96^3, with
+// the broadcast from SGPRs or from LDS alike: the loop over descending blocks costs more than the LDS read it saves.
+// `n` = elements of the broadcast chunk that exist (beyond them the staged form multiplies by zero: no term).  The staged copy of
+// the broadcast chunk (stage[0 .. SL)) serves the finiteness test and the masked, non-finite path.
+typedef const double __attribute__((address_space(4))) * seg_cptr_t;
+// a wave-uniform 64-bit value the compiler cannot see to be one (it came through LDS: the claimed task): into SGPRs
+__device__ __forceinline__ size_t seg_uniform(size_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((size_t)hi << 32) | lo;
+}
+template <class E>
+__device__ __forceinline__ typename E::V seg_sload(seg_cptr_t p, size_t plane, unsigned i) {
+    if constexpr (E::W == 2) return Iv{p[i], p[plane + i]};
+    else return p[i];
+}
+template <class E>
+__device__ inline typename E::V seg_chunk_mac_sa(typename E::V inner, typename E::V a_l, typename E::V bp_l, typename E::V bc_l, unsigned l, double* stage,
+                                                 unsigned SL, unsigned jbase, unsigned c, unsigned alen, unsigned blen, seg_cptr_t ap, size_t aplane, unsigned n) {
+    typedef typename E::V V;
+    if (l < SL) {
+        E::st(stage, 192, l, a_l);
+        E::st(stage, 192, SL + l, bp_l);
+        E::st(stage, 192, 2u * SL + l, bc_l);
+    }
+    const double* bl = stage + 2u * SL + (l < SL ? l : 0u);
+    if (!any_lane(!elem_finite<E>(a_l) || !elem_finite<E>(bp_l) || !elem_finite<E>(bc_l))) {
+#pragma unroll 8
+        for (unsigned i = 0; i < n; ++i) inner = E::add(inner, E::mul(seg_sload<E>(ap, aplane, i), E::ld(bl - i, 192, 0)));
+    } else {
+        for (unsigned i = 0; i < SL; ++i) {
+            const V t = E::add(inner, E::mul(E::ld(stage, 192, i), E::ld(bl - i, 192, 0)));
+            const unsigned j = jbase + i;
+            if (j <= c && j < alen && c - j < blen) inner = t;
+        }
+    }
+    return inner;
+}
 struct SegWfArgs {
     int L;
     unsigned n[3], m[3], xn[3];
@@ -2174,7 +2216,25 @@ __global__ void __launch_bounds__(64 * DwfCfg<E>::NW) k_seg_wavefront(const doub
                     const unsigned t_hi = (alen + SL - 1u) / SL - 1u < s ? (alen + SL - 1u) / SL - 1u : s;
                     const unsigned t_lo = s > (blen + SL - 2u) / SL ? s - (blen + SL - 2u) / SL : 0u;
                     V inner = E::zero();
-                    if (t_lo <= t_hi) {
+                    if (lg0) {
+                        // log level 0: A (xs's row) is the plain operand: broadcast by scalar loads, ascending as before
+                        if (t_lo <= t_hi) {
+                            const seg_cptr_t xrow = (seg_cptr_t)(xs + seg_uniform(ooff));
+                            V bc = fix_b(raw_b((int)s - (int)t_lo), (int)s - (int)t_lo);
+                            V a_n = raw_a(t_lo), bp_n = raw_b((int)s - (int)t_lo - 1);
+                            for (unsigned tt = t_lo; tt <= t_hi; ++tt) {
+                                const V a = fix_a(a_n, tt);
+                                const V bp = fix_b(bp_n, (int)s - (int)tt - 1);
+                                if (tt < t_hi) {
+                                    a_n = raw_a(tt + 1);
+                                    bp_n = raw_b((int)s - (int)tt - 2);
+                                }
+                                const unsigned na = alen - SL * tt < SL ? alen - SL * tt : SL;
+                                inner = seg_chunk_mac_sa<E>(inner, a, bp, bc, lane, my_stage, SL, SL * tt, c, alen, blen, xrow + SL * tt, xp, na);
+                                bc = bp;
+                            }
+                        }
+                    } else if (t_lo <= t_hi) {
                         V bc = fix_b(raw_b((int)s - (int)t_lo), (int)s - (int)t_lo);
                         V a_n = raw_a(t_lo), bp_n = raw_b((int)s - (int)t_lo - 1);
                         for (unsigned tt = t_lo; tt <= t_hi; ++tt) {
