@@ -1,5 +1,5 @@
 #!/bin/bash
-# after the matrix: the all-zero pattern's effect on hmm --bounds, host profiles of switchpoint, quick parity subset
+# A two-minute check on an MI355X box: the Horner-shape / interval-pin / e2e-snapshot tests, the approx programs at --limit 100 (f64 and --bounds), host profiles of switchpoint.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 {
