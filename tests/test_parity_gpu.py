@@ -354,6 +354,28 @@ def test_subst_var_linear_long_axis_and_wide_tensor(OTP, GTP):
         check(ow.subst_var(v, OTP.new(lin, deg)), gw.subst_var(v, GTP.new(lin, deg)))
 
 
+@pytest.mark.parametrize("interval", [False, True], ids=["f64", "interval"])
+@pytest.mark.parametrize("shape,deg,sdeg", [((70,), [70], [70]), ((130,), [140], [140]), ((200,), [200], [150]), ((300,), [300], [300]),
+                                            ((5, 130), [6, 130], [6, 130]), ((150, 3), [150, 4], [150, 4]), ((3, 200, 2), [3, 200, 2], [3, 190, 2])])
+def test_subst_var_point_pipeline_multi_wave(shape, deg, sdeg, interval, OTP, GTP, OTPI, GTPI):
+    """v -> c + m v on lines of 65 .. 1024 coefficients: the POINT wave pipeline with two to five waves per line.
+    A wave joins the loop at the first step that reaches its positions (round 6) — the result must be the oracle's bit for bit,
+    for positive data (the lean step), mixed signs (the generic step), a clipped degree and strided lines."""
+    O, G = (OTPI, GTPI) if interval else (OTP, GTP)
+    nd = len(shape)
+    v = max(range(nd), key=lambda ax: shape[ax])
+    for positive in (True, False):
+        base = rand(shape, 91, 0.05, 1.0) if positive else rand(shape, 92, -1.0, 1.0)
+        base = base * (0.97 ** np.arange(shape[v])).reshape([-1 if ax == v else 1 for ax in range(nd)])
+        mk = (lambda a: np.stack([a, a + np.abs(a) * 1e-12 + 1e-300])) if interval else (lambda a: a)
+        op, gp = O.new(mk(base), deg), G.new(mk(base), deg)
+        for c, m in ((0.3, 0.7), (-0.25, 0.9), (1e-13, 1.0)):
+            lin = np.zeros([2 if ax == v else 1 for ax in range(nd)])
+            lin.flat[0], lin.flat[1] = c, m
+            os_, gs_ = O.new(mk(lin), sdeg), G.new(mk(lin), sdeg)  # (a smaller degree of the substitution clips the result)
+            check(op.subst_var(v, os_), gp.subst_var(v, gs_))
+
+
 STAGED_SHAPES = [
     ((17,), (9,), (20,)),                                  # rank 1: rows only, axis 0 is the staged axis
     ((300,), (300,), (300,)),                              # more than one chunk per row
